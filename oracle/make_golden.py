@@ -1,0 +1,217 @@
+"""TEST INFRASTRUCTURE ONLY -- writes tests/golden/*.npz from the UNMODIFIED
+reference (``/root/reference``) run on CPU under the two shims of
+``oracle/ref_import.py``.  Run in the build container only:
+
+    python -m oracle.make_golden
+
+Inputs are re-creatable from seeds (``cc_amd/synthetic.py``, numpy streams), so
+the fixtures hold reference OUTPUTS only (fp32).  Two flavours of every
+grid_sample-dependent result are stored: ``acF`` = what the reference executes
+under this torch (align_corners=False) and ``acT`` = the authors'
+torch-1.0 semantics (grid_sample patched to align_corners=True).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ref_import, step as S          # noqa: E402
+from cc_amd import synthetic as syn               # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+# function-level case: a 6-level pyramid on a 64x96 base, B=2
+FB, FH, FW = 2, 64, 96
+# net/step-level case
+SB, SH, SW = 2, 128, 192
+
+
+def npy(t):
+    return t.detach().cpu().numpy().astype(np.float32) if torch.is_tensor(t) else np.float32(t)
+
+
+def pyramid_inputs(B, H, W, levels=6, seed=3):
+    """Per-level depth / flows / masks for function-level loss goldens (numpy-seeded)."""
+    out = []
+    for l in range(levels):
+        h, w = H >> l, W >> l
+        ki = syn.kernel_inputs(B, h, w, seed=seed + l)
+        s = 1.0 / (1 << l)
+        out.append(dict(depth=ki["depth"], flow_fwd=ki["flow_fwd"] * s, flow_bwd=ki["flow_bwd"] * s, mask=ki["mask"]))
+    return out
+
+
+def function_level(ac):
+    ref = ref_import.load(ac)
+    iw, lf, ss = ref.inverse_warp, ref.loss_functions, ref.ssim
+    tgt, refs, K, Kinv = syn.sample(FB, FH, FW, seed=1)
+    pyr = pyramid_inputs(FB, FH, FW)
+    pose = syn.kernel_inputs(FB, 8, 8, seed=2)["pose"] * 3.0
+    g = {}
+    d0 = pyr[0]["depth"][:, 0]
+    g["P"] = npy(K.bmm(iw.pose_vec2mat(pose[:, 0])))
+    g["pose_mat_euler"] = npy(iw.pose_vec2mat(pose[:, 0], "euler"))
+    g["pose_mat_quat"] = npy(iw.pose_vec2mat(pose[:, 0] * 10, "quat"))
+    cam = iw.pixel2cam(d0, Kinv)
+    P = K.bmm(iw.pose_vec2mat(pose[:, 0]))
+    g["grid_zeros"] = npy(iw.cam2pixel(cam, P[:, :, :3], P[:, :, -1:], "zeros"))
+    g["inverse_warp"] = npy(iw.inverse_warp(refs[0], d0, pose[:, 0], K, Kinv))
+    g["inverse_warp_quat"] = npy(iw.inverse_warp(refs[0], d0, pose[:, 0], K, Kinv, "quat"))
+    g["pose2flow"] = npy(iw.pose2flow(d0, pose[:, 0], K, Kinv))
+    g["flow_warp"] = npy(iw.flow_warp(refs[1], pyr[0]["flow_fwd"]))
+    g["flow2oob"] = iw.flow2oob(pyr[0]["flow_fwd"] * 4).numpy().astype(np.uint8)
+    g["ssim"] = npy(ss.ssim(tgt, refs[1]))
+    g["ssim_self"] = npy(ss.ssim(tgt, tgt))
+    bf = ref.back2future.Model(6)
+    feat = syn.frames(FB, 16, 24, seed=7, n_frames=1)[0]
+    feat = torch.cat([feat, feat.flip(1), feat * 0.5], 1)[:, :8].contiguous()
+    flo = syn.kernel_inputs(FB, 16, 24, seed=8)["flow_fwd"]
+    g["feature_warp"] = npy(bf.warp(feat, flo))
+    g["corr9"] = npy(ref.back2future.correlate(feat, feat.flip(3)))
+
+    # losses with gradients w.r.t. their differentiable inputs
+    depth = [p["depth"].clone().requires_grad_(True) for p in pyr]
+    mask = [p["mask"].clone().requires_grad_(True) for p in pyr]
+    ffw = [p["flow_fwd"].clone().requires_grad_(True) for p in pyr]
+    fbw = [p["flow_bwd"].clone().requires_grad_(True) for p in pyr]
+    posev = pose.clone().requires_grad_(True)
+
+    def record(name, loss, wrt):
+        g[name] = npy(loss)
+        grads = torch.autograd.grad(loss, [w for w in wrt.values()], allow_unused=True)
+        for (k, _), gr in zip(wrt.items(), grads):
+            if gr is not None:
+                g[name + ".grad." + k] = npy(gr)
+
+    wrt = {("depth%d" % i): d for i, d in enumerate(depth)}
+    wrt.update({("mask%d" % i): m for i, m in enumerate(mask)})
+    wrt["pose"] = posev
+    record("photometric_reconstruction_loss",
+           lf.photometric_reconstruction_loss(tgt, refs, K, Kinv, depth, mask, posev, wssim=0.997, qch=0.5), wrt)
+    wrt = {("depth%d" % i): d for i, d in enumerate(depth)}
+    wrt["pose"] = posev
+    record("photometric_reconstruction_loss_nomask",
+           lf.photometric_reconstruction_loss(tgt, refs, K, Kinv, depth, [None] * 6, posev, wssim=0.5, qch=0.5,
+                                              lambda_oob=0.3), wrt)
+    fmask = [1 - m[:, 1:3] for m in mask]
+    wrt = {("flow_fwd%d" % i): f for i, f in enumerate(ffw)}
+    wrt.update({("flow_bwd%d" % i): f for i, f in enumerate(fbw)})
+    wrt.update({("mask%d" % i): m for i, m in enumerate(mask)})
+    record("photometric_flow_loss",
+           lf.photometric_flow_loss(tgt, refs[1:3], [fbw, ffw], fmask, wssim=0.997, qch=0.5), wrt)
+    record("explainability_loss", lf.explainability_loss(mask), {("mask%d" % i): m for i, m in enumerate(mask)})
+    record("gaussian_explainability_loss", lf.gaussian_explainability_loss(mask),
+           {("mask%d" % i): m for i, m in enumerate(mask)})
+    for nm, lst in (("depth", depth), ("flow_fwd", ffw), ("mask", mask)):
+        record("smooth_loss." + nm, lf.smooth_loss(lst), {("%s%d" % (nm, i)): t for i, t in enumerate(lst)})
+        record("edge_aware_smoothness_loss." + nm, lf.edge_aware_smoothness_loss(tgt, lst),
+               {("%s%d" % (nm, i)): t for i, t in enumerate(lst)})
+    with torch.no_grad():
+        cam_f = [iw.pose2flow(d[:, 0], pose[:, 2], K, Kinv) for d in depth]
+        cam_b = [iw.pose2flow(d[:, 0], pose[:, 1], K, Kinv) for d in depth]
+        target = lf.consensus_exp_masks(cam_f, cam_b, ffw, fbw, tgt, refs[2], refs[1], wssim=0.997, wrig=1.0, ws=0.1)
+        for i, t in enumerate(target):
+            g["consensus_exp_masks.%d" % i] = t.numpy().astype(np.uint8)
+        for i in range(6):
+            g["pose2flow_fullK.%d" % i] = npy(cam_f[i])
+        occ = lf.depth_occlusion_masks(depth[0], pose, K, Kinv)
+        g["depth_occlusion_masks.0"] = occ.numpy().astype(np.uint8)
+        rig_f = [(a - b).abs() for a, b in zip(cam_f, ffw)]
+        rig_b = [(a - b).abs() for a, b in zip(cam_b, fbw)]
+    record("consensus_depth_flow_mask",
+           lf.consensus_depth_flow_mask(mask, rig_b, rig_f, target, target, THRESH=0.5, wbce=0.5),
+           {("mask%d" % i): m for i, m in enumerate(mask)})
+    return g
+
+
+def _coarse(name, tensors, g, limit=4096):
+    """store small tensors fully, large ones as (sum, abs-sum, strided sample)."""
+    for i, t in enumerate(tensors):
+        if t is None:
+            continue
+        k = "%s.%d" % (name, i)
+        if t.numel() <= limit:
+            g[k] = npy(t)
+        else:
+            flat = t.detach().reshape(-1)
+            g[k + ".stats"] = np.array([float(flat.double().sum()), float(flat.double().abs().sum())], dtype=np.float64)
+            g[k + ".sample"] = npy(flat[:: max(1, flat.numel() // 2048)])
+
+
+def net_and_step_level(ac):
+    ref = ref_import.load(ac)
+    g = {}
+    batch = syn.sample(SB, SH, SW, seed=1)
+    tgt, refs, K, Kinv = batch
+    nets = S.build_nets("ref", ref)
+    for n in nets:
+        n.load_state_dict(syn.seeded_state_dict(n, 0))
+        n.train()
+    cfg = S.StepConfig()
+    out = S.cc_forward(nets, batch, cfg, impl=ref, keep=True)
+    for k in ("loss", "loss_1", "loss_2", "loss_3", "loss_4", "loss_5"):
+        g[k] = npy(out[k])
+    _coarse("disparities", out["disparities"], g)
+    g["pose"] = npy(out["pose"])
+    _coarse("exp_mask", out["exp_mask"], g)
+    _coarse("flow_fwd", out["flow_fwd"], g)
+    _coarse("flow_bwd", out["flow_bwd"], g)
+    _coarse("cam_fwd", out["cam_fwd"], g)
+    for i, t in enumerate(out["target"]):
+        g["target.%d.mean" % i] = np.float32(t.mean())
+    out["loss"].backward()
+    for name, n in zip(("disp", "pose", "mask", "flow"), nets):
+        sq = 0.0
+        for pn, p in n.named_parameters():
+            if p.grad is None:
+                continue
+            sq += float(p.grad.double().pow(2).sum())
+            if p.numel() <= 64:
+                g["grad.%s.%s" % (name, pn)] = npy(p.grad)
+        g["gradnorm." + name] = np.float64(sq ** 0.5)
+    # one Adam step, then the loss again: pins train.py:566-568
+    opt = S.make_optimizer(nets, cfg)
+    opt.step()
+    out2 = S.cc_forward(nets, batch, cfg, impl=ref)
+    g["loss_after_adam"] = npy(out2["loss"])
+
+    # BASELINE config 2 (DispResNet6 + PoseNetB6 only, mask None)
+    nets2 = S.build_nets("ref", ref, flow=False, mask=False)
+    for n in nets2:
+        if n is not None:
+            n.load_state_dict(syn.seeded_state_dict(n, 0))
+            n.train()
+    o2 = S.cc_forward(nets2, batch, cfg, impl=ref)
+    g["c2.loss"], g["c2.loss_1"], g["c2.loss_3"] = npy(o2["loss"]), npy(o2["loss_1"]), npy(o2["loss_3"])
+
+    # BASELINE config 1 (DispNetS + PoseExpNet, 1 scale, wssim=0, photometric + smooth)
+    dn, pn = ref.DispNetS.DispNetS(), ref.PoseExpNet.PoseExpNet(nb_ref_imgs=4, output_exp=False)
+    for n in (dn, pn):
+        n.load_state_dict(syn.seeded_state_dict(n, 0))
+        n.train()
+    disp = dn(tgt)
+    _, pose = pn(tgt, refs)
+    depth = 1 / disp[0]
+    # depth_occlusion_masks squeezes the depth itself (loss_functions.py:133)
+    l1 = ref.loss_functions.photometric_reconstruction_loss(tgt, refs, K, Kinv, depth, None, pose, wssim=0)
+    l3 = ref.loss_functions.smooth_loss(depth)
+    g["c1.loss_1"], g["c1.loss_3"] = npy(l1), npy(l3)
+    _coarse("c1.disp", disp, g)
+    g["c1.pose"] = npy(pose)
+    return g
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(1)   # run-to-run bit reproducibility of the fixtures
+    for tag, ac in (("acF", None), ("acT", True)):
+        np.savez_compressed(os.path.join(OUT, "functions_%s.npz" % tag), **function_level(ac))
+        np.savez_compressed(os.path.join(OUT, "step_%s.npz" % tag), **net_and_step_level(ac))
+        print("wrote", tag)
+    ref_import.set_align_corners(None)
+
+
+if __name__ == "__main__":
+    main()

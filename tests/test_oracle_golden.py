@@ -1,0 +1,187 @@
+"""The oracle (oracle/*.py, torch-CPU restatement) against the fixtures the
+UNMODIFIED reference produced (tests/golden/*.npz, written by oracle/make_golden.py).
+Same ATen kernels in the same order -> the bar here is (near) bit equality."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cc_amd import synthetic as syn
+from oracle import geometry as G, losses as L, nets as N, step as S
+from oracle.make_golden import FB, FH, FW, SB, SH, SW, pyramid_inputs
+
+TAGS = [("acF", False), ("acT", True)]
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def _close(a, ref, atol=1e-6, rtol=1e-5):
+    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    np.testing.assert_allclose(a, ref, atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("tag,ac", TAGS)
+def test_geometry_and_ssim(golden_dir, tag, ac):
+    g = _load(golden_dir, "functions_%s.npz" % tag)
+    torch.set_num_threads(1)
+    tgt, refs, K, Kinv = syn.sample(FB, FH, FW, seed=1)
+    pyr = pyramid_inputs(FB, FH, FW)
+    pose = syn.kernel_inputs(FB, 8, 8, seed=2)["pose"] * 3.0
+    d0 = pyr[0]["depth"][:, 0]
+    _close(G.projection(pose[:, 0], K), g["P"], 0, 0)
+    _close(G.pose_vec2mat(pose[:, 0] * 10, "quat"), g["pose_mat_quat"], 0, 0)
+    _close(G.warp_grid(d0, pose[:, 0], K, Kinv), g["grid_zeros"], 0, 0)
+    _close(G.inverse_warp(refs[0], d0, pose[:, 0], K, Kinv, align_corners=ac), g["inverse_warp"], 0, 0)
+    _close(G.inverse_warp(refs[0], d0, pose[:, 0], K, Kinv, "quat", align_corners=ac), g["inverse_warp_quat"], 0, 0)
+    _close(G.pose2flow(d0, pose[:, 0], K, Kinv), g["pose2flow"], 0, 0)
+    _close(G.flow_warp(refs[1], pyr[0]["flow_fwd"], align_corners=ac), g["flow_warp"], 0, 0)
+    assert np.array_equal(G.flow2oob(pyr[0]["flow_fwd"] * 4).numpy().astype(np.uint8), g["flow2oob"])
+    _close(L.ssim(tgt, refs[1]), g["ssim"], 0, 0)
+    assert np.allclose(g["ssim_self"], 1.0, atol=1e-5)          # SURVEY.md section 4 property
+    feat = syn.frames(FB, 16, 24, seed=7, n_frames=1)[0]
+    feat = torch.cat([feat, feat.flip(1), feat * 0.5], 1)[:, :8].contiguous()
+    flo = syn.kernel_inputs(FB, 16, 24, seed=8)["flow_fwd"]
+    _close(G.feature_warp(feat, flo, align_corners=ac), g["feature_warp"], 0, 0)
+    from oracle.corr import correlate9
+    _close(correlate9(feat, feat.flip(3)), g["corr9"], 0, 0)
+
+
+def test_known_answers():
+    """SURVEY.md section 4 KATs measured on the reference."""
+    e = G.euler2mat(torch.tensor([[0.1, 0.2, 0.3]])).reshape(-1).numpy()
+    np.testing.assert_allclose(e, [0.93629342, -0.28962949, 0.19866933, 0.31299183, 0.94470257, -0.09784340,
+                                   -0.15934508, 0.15379199, 0.97517037], atol=2e-7)
+    q = G.quat2mat(torch.tensor([[0.1, 0.2, 0.3]])).reshape(-1).numpy()
+    np.testing.assert_allclose(q, [0.77192992, -0.49122807, 0.40350881, 0.56140351, 0.82456142, -0.07017544,
+                                   -0.29824564, 0.28070179, 0.91228074], atol=2e-7)
+    assert abs(float(L.ssim_window(13, 3).sum()) - 3.0) < 1e-5
+    x = torch.rand(2, 3, 20, 30)
+    assert float((L.ssim(x, x) - 1).abs().max()) < 1e-5
+    d = torch.rand(2, 16, 24) + 0.5
+    K, Kinv = syn.kitti_intrinsics(2, 16, 24)
+    assert float(G.pose2flow(d, torch.zeros(2, 6), K, Kinv).abs().max()) < 2e-4   # zero pose -> zero flow
+
+
+@pytest.mark.parametrize("tag,ac", TAGS)
+def test_losses_and_grads(golden_dir, tag, ac):
+    g = _load(golden_dir, "functions_%s.npz" % tag)
+    torch.set_num_threads(1)
+    tgt, refs, K, Kinv = syn.sample(FB, FH, FW, seed=1)
+    pyr = pyramid_inputs(FB, FH, FW)
+    pose = (syn.kernel_inputs(FB, 8, 8, seed=2)["pose"] * 3.0).requires_grad_(True)
+    depth = [p["depth"].clone().requires_grad_(True) for p in pyr]
+    mask = [p["mask"].clone().requires_grad_(True) for p in pyr]
+    ffw = [p["flow_fwd"].clone().requires_grad_(True) for p in pyr]
+    fbw = [p["flow_bwd"].clone().requires_grad_(True) for p in pyr]
+
+    def check(name, loss, wrt):
+        _close(loss, g[name], 1e-7, 1e-6)
+        grads = torch.autograd.grad(loss, list(wrt.values()), allow_unused=True)
+        for (k, _), gr in zip(wrt.items(), grads):
+            key = name + ".grad." + k
+            if gr is None:
+                assert key not in g
+            else:
+                _close(gr, g[key], 1e-9, 1e-5)
+
+    wrt = {("depth%d" % i): d for i, d in enumerate(depth)}
+    wrt.update({("mask%d" % i): m for i, m in enumerate(mask)})
+    wrt["pose"] = pose
+    check("photometric_reconstruction_loss",
+          L.photometric_reconstruction_loss(tgt, refs, K, Kinv, depth, mask, pose, wssim=0.997, qch=0.5,
+                                            align_corners=ac), wrt)
+    wrt = {("depth%d" % i): d for i, d in enumerate(depth)}
+    wrt["pose"] = pose
+    check("photometric_reconstruction_loss_nomask",
+          L.photometric_reconstruction_loss(tgt, refs, K, Kinv, depth, [None] * 6, pose, wssim=0.5, qch=0.5,
+                                            lambda_oob=0.3, align_corners=ac), wrt)
+    fmask = [1 - m[:, 1:3] for m in mask]
+    wrt = {("flow_fwd%d" % i): f for i, f in enumerate(ffw)}
+    wrt.update({("flow_bwd%d" % i): f for i, f in enumerate(fbw)})
+    wrt.update({("mask%d" % i): m for i, m in enumerate(mask)})
+    check("photometric_flow_loss",
+          L.photometric_flow_loss(tgt, refs[1:3], [fbw, ffw], fmask, wssim=0.997, qch=0.5, align_corners=ac), wrt)
+    mk = {("mask%d" % i): m for i, m in enumerate(mask)}
+    check("explainability_loss", L.explainability_loss(mask), mk)
+    check("gaussian_explainability_loss", L.gaussian_explainability_loss(mask), mk)
+    for nm, lst in (("depth", depth), ("flow_fwd", ffw), ("mask", mask)):
+        w = {("%s%d" % (nm, i)): t for i, t in enumerate(lst)}
+        check("smooth_loss." + nm, L.smooth_loss(lst), w)
+        check("edge_aware_smoothness_loss." + nm, L.edge_aware_smoothness_loss(tgt, lst), w)
+    with torch.no_grad():
+        p = pose.detach()
+        cam_f = [G.pose2flow(d[:, 0], p[:, 2], K, Kinv) for d in depth]
+        cam_b = [G.pose2flow(d[:, 0], p[:, 1], K, Kinv) for d in depth]
+        target = L.consensus_exp_masks(cam_f, cam_b, ffw, fbw, tgt, refs[2], refs[1], wssim=0.997, wrig=1.0,
+                                       align_corners=ac)
+        for i, t in enumerate(target):
+            assert np.array_equal(t.numpy().astype(np.uint8), g["consensus_exp_masks.%d" % i])
+            _close(cam_f[i], g["pose2flow_fullK.%d" % i], 0, 0)
+        occ = L.depth_occlusion_masks(depth[0], p, K, Kinv)
+        assert np.array_equal(occ.numpy().astype(np.uint8), g["depth_occlusion_masks.0"])
+        rig_f = [(a - b).abs() for a, b in zip(cam_f, ffw)]
+        rig_b = [(a - b).abs() for a, b in zip(cam_b, fbw)]
+    check("consensus_depth_flow_mask",
+          L.consensus_depth_flow_mask(mask, rig_b, rig_f, target, target, THRESH=0.5, wbce=0.5), mk)
+
+
+@pytest.mark.parametrize("tag,ac", TAGS)
+def test_full_step(golden_dir, tag, ac):
+    """train.py:454-509,566-568 replay: losses, net outputs, gradient norms, one Adam step."""
+    g = _load(golden_dir, "step_%s.npz" % tag)
+    torch.set_num_threads(1)
+    batch = syn.sample(SB, SH, SW, seed=1)
+    nets = S.build_nets("oracle", align_corners=ac)
+    for n in nets:
+        n.load_state_dict(syn.seeded_state_dict(n, 0))
+        n.train()
+    cfg = S.StepConfig()
+    impl = S.oracle_impl(ac)
+    out = S.cc_forward(nets, batch, cfg, impl=impl, keep=True)
+    for k in ("loss", "loss_1", "loss_2", "loss_3", "loss_4", "loss_5"):
+        _close(out[k], g[k], 0, 2e-6)
+    _close(out["pose"], g["pose"], 1e-9, 1e-6)
+    for name in ("disparities", "exp_mask", "flow_fwd", "flow_bwd", "cam_fwd"):
+        for i, t in enumerate(out[name]):
+            k = "%s.%d" % (name, i)
+            if k in g:
+                _close(t, g[k], 1e-6, 1e-5)
+            else:
+                flat = t.detach().reshape(-1)
+                _close(flat[:: max(1, flat.numel() // 2048)], g[k + ".sample"], 1e-6, 1e-5)
+    out["loss"].backward()
+    for name, n in zip(("disp", "pose", "mask", "flow"), nets):
+        sq = sum(float(p.grad.double().pow(2).sum()) for p in n.parameters() if p.grad is not None)
+        assert abs(sq ** 0.5 - float(g["gradnorm." + name])) <= 1e-5 * float(g["gradnorm." + name]) + 1e-12
+    opt = S.make_optimizer(nets, cfg)
+    opt.step()
+    out2 = S.cc_forward(nets, batch, cfg, impl=impl)
+    _close(out2["loss"], g["loss_after_adam"], 0, 5e-6)
+
+
+def test_config1_and_config2(golden_dir):
+    """BASELINE.json configs[0] (DispNetS+PoseExpNet, 1 scale, CPU plumbing) and configs[1]."""
+    g = _load(golden_dir, "step_acF.npz")
+    torch.set_num_threads(1)
+    batch = syn.sample(SB, SH, SW, seed=1)
+    tgt, refs, K, Kinv = batch
+    nets2 = S.build_nets("oracle", flow=False, mask=False)
+    for n in nets2:
+        if n is not None:
+            n.load_state_dict(syn.seeded_state_dict(n, 0))
+            n.train()
+    o2 = S.cc_forward(nets2, batch, S.StepConfig(), impl=S.oracle_impl(False))
+    _close(o2["loss"], g["c2.loss"], 0, 2e-6)
+    dn, pn = N.DispNetS(), N.PoseExpNet(nb_ref_imgs=4, output_exp=False)
+    for n in (dn, pn):
+        n.load_state_dict(syn.seeded_state_dict(n, 0))
+        n.train()
+    disp = dn(tgt)
+    _, pose = pn(tgt, refs)
+    depth = 1 / disp[0]
+    _close(L.photometric_reconstruction_loss(tgt, refs, K, Kinv, depth, None, pose, wssim=0), g["c1.loss_1"], 0, 2e-6)
+    _close(L.smooth_loss(depth), g["c1.loss_3"], 0, 2e-6)
+    _close(pose, g["c1.pose"], 1e-9, 1e-6)
