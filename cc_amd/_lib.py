@@ -1,0 +1,113 @@
+"""ctypes binding of libccengine.so -- the C-ABI boundary (include/ccengine.h).
+
+The signatures are parsed from the header itself, so the header is the single
+source of truth.  There is NO fallback: if the shared library is missing or a
+tensor is not a contiguous fp32 tensor on a HIP device, the call raises.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "ccengine.h")
+LIB_PATH = os.path.join(_HERE, "libccengine.so")
+
+_CT = {"int": ctypes.c_int, "float": ctypes.c_float, "size_t": ctypes.c_size_t, "double": ctypes.c_double}
+
+STREAM = object()      # placeholder argument: "the current torch stream"
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [argtypes], [arg names])} for every `cc_*` declaration."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(int|size_t|void)\s+(cc_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        types, names = [], []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    types.append(ctypes.c_void_p)
+                else:
+                    base = a.replace("const ", "").split(" ")[0]
+                    types.append(_CT[base])
+                names.append(a.split(" ")[-1].lstrip("*"))
+        out[name] = ({"int": ctypes.c_int, "size_t": ctypes.c_size_t, "void": None}[ret], types, names)
+    return out
+
+
+class Engine:
+    def __init__(self, path=LIB_PATH, require_device=True):
+        if not os.path.isfile(path):
+            raise RuntimeError(
+                "ccengine: %s not found -- build it with `python -m cc_amd.build` (hipcc, gfx950). "
+                "There is no CPU fallback." % path)
+        self.path = path
+        self.require_device = require_device
+        self.lib = ctypes.CDLL(path)
+        self.sigs = parse_header()
+        self.fn = {}
+        for name, (ret, types, _) in self.sigs.items():
+            f = getattr(self.lib, name)      # AttributeError if the library lacks a declared symbol
+            f.restype = ret
+            f.argtypes = types
+            self.fn[name] = f
+
+    def _ptr(self, t, name, i):
+        if t is None:
+            return None
+        if not torch.is_tensor(t):
+            raise TypeError("%s arg %d: expected a tensor or None, got %r" % (name, i, type(t)))
+        if self.require_device and not t.is_cuda:
+            raise RuntimeError("%s arg %d: tensor is on %s; the ccengine kernels need a HIP device (no CPU path)"
+                               % (name, i, t.device))
+        if t.dtype != torch.float32 and t.dtype != torch.int32 and t.dtype != torch.uint8:
+            raise TypeError("%s arg %d: unsupported dtype %s" % (name, i, t.dtype))
+        if not t.is_contiguous():
+            raise ValueError("%s arg %d: tensor must be contiguous" % (name, i))
+        return t.data_ptr()
+
+    def stream_ptr(self):
+        if self.require_device:
+            return torch.cuda.current_stream().cuda_stream
+        return None
+
+    def call(self, name, *args):
+        f = self.fn[name]
+        types = self.sigs[name][1]
+        if len(args) != len(types):
+            raise TypeError("%s expects %d arguments, got %d" % (name, len(types), len(args)))
+        conv = []
+        for i, (a, ty) in enumerate(zip(args, types)):
+            if a is STREAM:
+                conv.append(self.stream_ptr())
+            elif ty is ctypes.c_void_p:
+                # ints are raw addresses (only used for the documented host pointer gauss13_host)
+                conv.append(a if isinstance(a, int) else self._ptr(a, name, i))
+            else:
+                conv.append(a)
+        r = f(*conv)
+        if self.sigs[name][0] is ctypes.c_int and r != 0:
+            raise RuntimeError("%s failed with code %d" % (name, r))
+        return r
+
+
+_engine = None
+
+
+def engine():
+    global _engine
+    if _engine is None:
+        _engine = Engine()
+    return _engine
+
+
+def _set_engine_for_tests(e):
+    """Test hook (tests/hipemu): inject an Engine bound to the x86 emulation build of the SAME kernel
+    sources.  Never called by the package itself."""
+    global _engine
+    _engine = e

@@ -1,0 +1,7 @@
+"""Engine-wide switches.
+
+align_corners: grid_sample semantics of every warp.  False = what the unmodified
+reference executes under torch >= 1.3 (default, the as-run parity target); True = the authors'
+torch-1.0 semantics.
+"""
+align_corners = False

@@ -1,0 +1,44 @@
+// Shared device helpers for the ccengine HIP kernels (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CC_OK 0
+#define CC_ERR_ARG (-1)
+#define CC_ERR_LAUNCH (-2)
+
+#define CC_CHECK_LAUNCH()                                   \
+    do {                                                    \
+        if (hipGetLastError() != hipSuccess) return CC_ERR_LAUNCH; \
+    } while (0)
+
+namespace cc {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// Sum `N` per-thread values over a 256-thread workgroup; the totals land in
+// out[0..N) of thread 0 (valid for threadIdx.x == 0 only).  `scratch` needs 4*N floats.
+template <int N>
+__device__ __forceinline__ void block_sum_256(float (&v)[N], float* scratch) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = wave_sum(v[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; i++) scratch[wid * N + i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] = (scratch[i] + scratch[N + i]) + (scratch[2 * N + i] + scratch[3 * N + i]);
+    }
+    __syncthreads();
+}
+
+}  // namespace cc

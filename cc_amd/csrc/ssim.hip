@@ -1,0 +1,472 @@
+// Fused 13x13-Gaussian SSIM + robust-L1 + mask photometric kernels (gfx950).
+//
+// Replaces, per (scale, reference frame), ssim.py:19-36 (five depth-wise 13x13 conv2d) plus the
+// ~40 elementwise ATen ops of loss_functions.py:44-58 / :100-114 / :181-193 with
+//   k_ssim_tile<MODE>   one pass: LDS tile (+6 px halo) -> separable 13-tap filter of the five
+//                       moments (mu_x, mu_y, E[xx], E[yy], E[xy]) -> SSIM -> valid / masks /
+//                       robust-L1 -> block-reduced partial sums (+ the three adjoint maps)
+//   k_ssim_adjoint      separable filter of the adjoint maps = d(loss)/d(warped image)
+//   k_photo_finalize    deterministic reduction of the partial sums -> loss term, OOB normaliser
+// The window is separable (outer product of the 1-D Gaussian, ssim.py:13-17), so a tile costs
+// 2 x 13 taps instead of 169.  Zero padding 6 as in the reference.
+//
+// Tile: 32x32 outputs per 256-thread workgroup, one channel at a time through LDS
+// (2 x 44x44 inputs + 5 x 44x32 row-filtered moments = 43 KB -> 3 workgroups / CU).
+//   H pass: work item = (row, 4 consecutive columns): 16 inputs per image via ds_read_b128,
+//           4 outputs x 13 taps x 5 moments in registers, ds_write_b128.
+//   V pass: thread = (column, 4 consecutive rows): 16 ds_read_b32 per moment (conflict-free:
+//           a 32-lane group reads 32 consecutive columns).
+#include "cc_common.h"
+#include "../../include/ccengine.h"
+
+namespace {
+
+constexpr int TS = 32;          // output tile edge
+constexpr int HALO = 6;         // window_size // 2
+constexpr int TIN = TS + 2 * HALO;   // 44
+constexpr float C1 = 0.0001f;   // 0.01^2  (ssim.py:31)
+constexpr float C2 = 0.0009f;   // 0.03^2  (ssim.py:32)
+
+struct Gauss13 { float g[13]; };
+
+enum { MODE_MAP = 0, MODE_PHOTO = 1, MODE_ERR = 2, MODE_GRAD = 3 };
+
+struct PhotoArgs {
+    const float* x;        // tgt   [B,3,H,W]
+    const float* y;        // warped[B,3,H,W]
+    const float* mask_a;   // non-differentiable factor (1-occ), element (b, y, x) at mask_a[b*a_bs + p], or null
+    const float* mask_b;   // differentiable factor (explainability), at mask_b[b*b_bs + p], or null
+    int a_bs, b_bs;
+    int b_complement;      // use (1 - mask_b)  (train.py:488 flow_exp_mask)
+    const float* upstream; // MODE_GRAD: d(loss)/d(ssim map) [B,3,H,W]
+    float* out_map;        // MODE_MAP: ssim [B,3,H,W];  MODE_ERR: err [B,1,H,W]
+    float* out_valid;      // MODE_ERR: valid [B,1,H,W]
+    float* partials;       // MODE_PHOTO: [nblk][4]
+    float* adjA; float* adjB; float* adjC;   // MODE_PHOTO (grad): [B,3,H,W] each
+    float* g0;             // MODE_PHOTO (grad): direct robust-L1 adjoint [B,3,H,W]
+    float* gmask;          // MODE_PHOTO (grad): d/d mask_b (unscaled), at gmask[b*gm_bs + p], or null
+    int gm_bs;
+    int want_grad;
+    float wssim, q;
+    int H, W;
+};
+
+__device__ __forceinline__ float robust_pow(float v, float q) {
+    // (x^2 + 0.01)^q  (loss_functions.py:18-25); q = 0.5 is the only value the reference trains with
+    return (q == 0.5f) ? sqrtf(v) : powf(v, q);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_ssim_tile(PhotoArgs a, Gauss13 gw) {
+    __shared__ __attribute__((aligned(16))) float tx[TIN * TIN];
+    __shared__ __attribute__((aligned(16))) float ty[TIN * TIN];
+    __shared__ __attribute__((aligned(16))) float hb[5][TIN * TS];
+    __shared__ float red[4 * 3];
+
+    const int H = a.H, W = a.W, HW = H * W;
+    const int b = blockIdx.z;
+    const int ox0 = blockIdx.x * TS, oy0 = blockIdx.y * TS;
+    const int tid = threadIdx.x;
+    const int cx = tid & 31, rg = tid >> 5;
+    const int gx = ox0 + cx;
+
+    // per-thread pixels: column gx, rows oy0 + 4*rg + j
+    float valid[4], m[4], ma[4], acc_gm[4], err_rob[4], err_ss[4];
+    bool inimg[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int gy = oy0 + 4 * rg + j;
+        inimg[j] = (gx < W) && (gy < H);
+        valid[j] = 0.f; m[j] = 0.f; ma[j] = 1.f; acc_gm[j] = 0.f; err_rob[j] = 0.f; err_ss[j] = 0.f;
+        if (inimg[j]) {
+            const int p = gy * W + gx;
+            if (MODE == MODE_PHOTO || MODE == MODE_ERR) {
+                const float* yp = a.y + (size_t)b * 3 * HW + p;
+                // loss_functions.py:45,100: 1 - prod_c(warped == 0)
+                valid[j] = (yp[0] == 0.f && yp[HW] == 0.f && yp[2 * HW] == 0.f) ? 0.f : 1.f;
+            }
+            if (MODE == MODE_PHOTO) {
+                float mm = 1.f;
+                if (a.mask_a) { ma[j] = a.mask_a[(size_t)b * a.a_bs + p]; mm = ma[j]; }
+                if (a.mask_b) {
+                    float mb = a.mask_b[(size_t)b * a.b_bs + p];
+                    if (a.b_complement) mb = 1.f - mb;
+                    // reference order: diff * (1-occ) * exp  (rigid, :107-108) / diff * exp * (1-occ) (flow, :51-56);
+                    // both are one product of two factors -> commutative in fp32
+                    mm = mm * mb;
+                }
+                m[j] = mm;
+            }
+        }
+    }
+
+    float s_rob = 0.f, s_sl = 0.f;
+
+    for (int c = 0; c < 3; c++) {
+        const float* xp = a.x + ((size_t)b * 3 + c) * HW;
+        const float* yp = a.y + ((size_t)b * 3 + c) * HW;
+        if (c > 0) __syncthreads();          // everyone is done with the previous channel's V pass
+        for (int i = tid; i < TIN * TIN; i += 256) {
+            const int r = i / TIN, col = i - r * TIN;
+            const int yy = oy0 - HALO + r, xx = ox0 - HALO + col;
+            const bool in = (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
+            tx[i] = in ? xp[yy * W + xx] : 0.f;
+            ty[i] = in ? yp[yy * W + xx] : 0.f;
+        }
+        __syncthreads();
+        // ---- H pass
+        for (int it = tid; it < TIN * (TS / 4); it += 256) {
+            const int r = it >> 3, cg = it & 7;
+            float xv[16], yv[16];
+            const float4* px = reinterpret_cast<const float4*>(&tx[r * TIN + 4 * cg]);
+            const float4* py = reinterpret_cast<const float4*>(&ty[r * TIN + 4 * cg]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float4 vx = px[k], vy = py[k];
+                xv[4 * k] = vx.x; xv[4 * k + 1] = vx.y; xv[4 * k + 2] = vx.z; xv[4 * k + 3] = vx.w;
+                yv[4 * k] = vy.x; yv[4 * k + 1] = vy.y; yv[4 * k + 2] = vy.z; yv[4 * k + 3] = vy.w;
+            }
+            float o[5][4];
+#pragma unroll
+            for (int mi = 0; mi < 5; mi++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) o[mi][j] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const float vx = xv[k], vy = yv[k];
+                const float pxx = vx * vx, pyy = vy * vy, pxy = vx * vy;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int t = k - j;
+                    if (t >= 0 && t < 13) {
+                        const float g = gw.g[t];
+                        o[0][j] = fmaf(g, vx, o[0][j]);
+                        o[1][j] = fmaf(g, vy, o[1][j]);
+                        o[2][j] = fmaf(g, pxx, o[2][j]);
+                        o[3][j] = fmaf(g, pyy, o[3][j]);
+                        o[4][j] = fmaf(g, pxy, o[4][j]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < 5; mi++)
+                *reinterpret_cast<float4*>(&hb[mi][r * TS + 4 * cg]) = make_float4(o[mi][0], o[mi][1], o[mi][2], o[mi][3]);
+        }
+        __syncthreads();
+        // ---- V pass
+        float mo[5][4];
+#pragma unroll
+        for (int mi = 0; mi < 5; mi++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) mo[mi][j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const float v = hb[mi][(4 * rg + i) * TS + cx];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int t = i - j;
+                    if (t >= 0 && t < 13) mo[mi][j] = fmaf(gw.g[t], v, mo[mi][j]);
+                }
+            }
+        }
+        // ---- per-pixel SSIM (ssim.py:20-34) and loss pieces
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (!inimg[j]) continue;
+            const int p = (oy0 + 4 * rg + j) * W + gx;
+            const float mu1 = mo[0][j], mu2 = mo[1][j];
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float s1 = mo[2][j] - mu1_sq, s2 = mo[3][j] - mu2_sq, s12 = mo[4][j] - mu12;
+            const float num1 = 2.f * mu12 + C1, num2 = 2.f * s12 + C2;
+            const float den1 = mu1_sq + mu2_sq + C1, den2 = s1 + s2 + C2;
+            const float S = (num1 * num2) / (den1 * den2);
+            if (MODE == MODE_MAP) {
+                a.out_map[((size_t)b * 3 + c) * HW + p] = S;
+                continue;
+            }
+            if (MODE == MODE_GRAD) {
+                // adjoint maps of the SSIM map w.r.t. the SECOND image (call with swapped roles for the first)
+                const size_t o = ((size_t)b * 3 + c) * HW + p;
+                const float gS = a.upstream[o];
+                const float D = den1 * den2;
+                a.adjC[o] = gS * (2.f * num1 / D);
+                a.adjB[o] = gS * (-S / den2);
+                a.adjA[o] = gS * (2.f * mu1 * (num2 - num1) / D - 2.f * mu2 * S * (1.f / den1 - 1.f / den2));
+                continue;
+            }
+            const float xc = tx[(4 * rg + j + HALO) * TIN + cx + HALO];
+            const float yc = ty[(4 * rg + j + HALO) * TIN + cx + HALO];
+            if (MODE == MODE_ERR) {
+                // loss_functions.py:181-188: robust_l1_per_pix(tgt - warped) and (1 - ssim), channel means
+                const float d = xc - yc;
+                err_rob[j] += sqrtf(d * d + 0.01f);
+                err_ss[j] += 1.f - S;
+                continue;
+            }
+            // MODE_PHOTO
+            const float vm = valid[j] * m[j];
+            const float d = (xc - yc) * vm;                    // diff * valid * masks
+            const float base = d * d + 0.01f;
+            const float rob = robust_pow(base, a.q);
+            const float sl = (1.f - S * valid[j]) * m[j];       // ssim_loss
+            s_rob += rob;
+            s_sl += sl;
+            if (a.want_grad) {
+                // d rob / d d = q * base^(q-1) * 2 d
+                const float drob = (a.q == 0.5f) ? (d / rob) : (a.q * powf(base, a.q - 1.f) * 2.f * d);
+                const size_t o = ((size_t)b * 3 + c) * HW + p;
+                a.g0[o] = -drob * vm;                           // d/dy through diff
+                const float D = den1 * den2;
+                const float gS = -vm * a.wssim;                 // d(wssim * sl)/dS
+                a.adjC[o] = gS * (2.f * num1 / D);              // dS/dE[xy]
+                a.adjB[o] = gS * (-S / den2);                   // dS/dE[yy]
+                a.adjA[o] = gS * (2.f * mu1 * (num2 - num1) / D - 2.f * mu2 * S * (1.f / den1 - 1.f / den2));  // dS/dmu_y
+                // d/d mask_b: diff and ssim_loss are both linear in the mask product
+                acc_gm[j] += drob * (xc - yc) * valid[j] * ma[j] + a.wssim * (1.f - S * valid[j]) * ma[j];
+            }
+        }
+    }
+
+    if (MODE == MODE_ERR) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (!inimg[j]) continue;
+            const int p = (oy0 + 4 * rg + j) * W + gx;
+            // (1-wssim) * mean_c(robust) + wssim * mean_c(1 - ssim)   (torch mean over 3 channels = sum / 3)
+            a.out_map[(size_t)b * HW + p] = (1.f - a.wssim) * (err_rob[j] / 3.f) + a.wssim * (err_ss[j] / 3.f);
+            a.out_valid[(size_t)b * HW + p] = valid[j];
+        }
+    }
+    if (MODE == MODE_PHOTO) {
+        float s_valid = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (!inimg[j]) continue;
+            s_valid += valid[j];
+            if (a.want_grad && a.gmask) {
+                const int p = (oy0 + 4 * rg + j) * W + gx;
+                a.gmask[(size_t)b * a.gm_bs + p] = a.b_complement ? -acc_gm[j] : acc_gm[j];
+            }
+        }
+        float v[3] = {s_rob, s_sl, s_valid};
+        __syncthreads();
+        cc::block_sum_256<3>(v, red);
+        if (tid == 0) {
+            const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            a.partials[blk * 4 + 0] = v[0];
+            a.partials[blk * 4 + 1] = v[1];
+            a.partials[blk * 4 + 2] = v[2];
+            a.partials[blk * 4 + 3] = 0.f;
+        }
+    }
+}
+
+// gy = scale * (g0 + G*adjA + 2*y*(G*adjB) + x*(G*adjC)),  G* = zero-padded 13x13 Gaussian filter
+__global__ __launch_bounds__(256) void k_ssim_adjoint(const float* __restrict__ adjA, const float* __restrict__ adjB,
+                                                      const float* __restrict__ adjC, const float* __restrict__ g0,
+                                                      const float* __restrict__ x, const float* __restrict__ y,
+                                                      const float* __restrict__ scale, float* __restrict__ gy, int H,
+                                                      int W, int accumulate, Gauss13 gw) {
+    __shared__ __attribute__((aligned(16))) float tin[3][TIN * TIN];
+    __shared__ __attribute__((aligned(16))) float hb[3][TIN * TS];
+    const int HW = H * W, b = blockIdx.z;
+    const int ox0 = blockIdx.x * TS, oy0 = blockIdx.y * TS;
+    const int tid = threadIdx.x, cx = tid & 31, rg = tid >> 5, gx = ox0 + cx;
+    const float sc = scale ? scale[0] : 1.f;
+    for (int c = 0; c < 3; c++) {
+        const size_t plane = ((size_t)b * 3 + c) * HW;
+        if (c > 0) __syncthreads();
+        for (int i = tid; i < TIN * TIN; i += 256) {
+            const int r = i / TIN, col = i - r * TIN;
+            const int yy = oy0 - HALO + r, xx = ox0 - HALO + col;
+            const bool in = (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
+            const size_t o = plane + (size_t)yy * W + xx;
+            tin[0][i] = in ? adjA[o] : 0.f;
+            tin[1][i] = in ? adjB[o] : 0.f;
+            tin[2][i] = in ? adjC[o] : 0.f;
+        }
+        __syncthreads();
+        for (int it = tid; it < TIN * (TS / 4); it += 256) {
+            const int r = it >> 3, cg = it & 7;
+#pragma unroll
+            for (int mi = 0; mi < 3; mi++) {
+                float v[16];
+                const float4* pv = reinterpret_cast<const float4*>(&tin[mi][r * TIN + 4 * cg]);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float4 q = pv[k];
+                    v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+                }
+                float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int t = k - j;
+                        if (t >= 0 && t < 13) o[j] = fmaf(gw.g[t], v[k], o[j]);
+                    }
+                *reinterpret_cast<float4*>(&hb[mi][r * TS + 4 * cg]) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        __syncthreads();
+        float mo[3][4];
+#pragma unroll
+        for (int mi = 0; mi < 3; mi++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) mo[mi][j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const float v = hb[mi][(4 * rg + i) * TS + cx];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int t = i - j;
+                    if (t >= 0 && t < 13) mo[mi][j] = fmaf(gw.g[t], v, mo[mi][j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int gyy = oy0 + 4 * rg + j;
+            if (gx < W && gyy < H) {
+                const size_t o = plane + (size_t)gyy * W + gx;
+                const float r = sc * ((g0 ? g0[o] : 0.f) + mo[0][j] + 2.f * y[o] * mo[1][j] + x[o] * mo[2][j]);
+                gy[o] = accumulate ? gy[o] + r : r;
+            }
+        }
+    }
+}
+
+// loss_functions.py:48,58 / :103,114: oob = N/sum(valid);  term = (1-wssim)*oob*(mean(rob) + wssim*mean(sl))
+//                                     + lambda_oob * robust_l1(1 - valid)
+// out[0] += term;  out[1] = (1-wssim)*oob/N3 (the common scale of every adjoint of this term);
+// out[2] = 1 if the term is NaN (deferred version of the reference's `assert loss == loss`)
+__global__ __launch_bounds__(256) void k_photo_finalize(const float* __restrict__ partials, int nblk, float n1, float n3,
+                                                        float wssim, float q, float lambda_oob,
+                                                        float* __restrict__ loss_accum, float* __restrict__ scale_out,
+                                                        float* __restrict__ nan_flag) {
+    __shared__ float red[4 * 3];
+    float v[3] = {0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+        v[0] += partials[i * 4 + 0];
+        v[1] += partials[i * 4 + 1];
+        v[2] += partials[i * 4 + 2];
+    }
+    cc::block_sum_256<3>(v, red);
+    if (threadIdx.x == 0) {
+        const float oob = n1 / v[2];
+        float term = (1.f - wssim) * oob * (v[0] / n3 + wssim * (v[1] / n3));
+        if (lambda_oob != 0.f) {
+            const float hi = powf(1.01f, q), lo = powf(0.01f, q);
+            term += lambda_oob * (((n1 - v[2]) * hi + v[2] * lo) / n1);
+        }
+        loss_accum[0] += term;
+        scale_out[0] = (1.f - wssim) * oob / n3;
+        if (!(term == term)) nan_flag[0] = 1.f;
+    }
+}
+
+// loss_functions.py:189-193: target = (wrig * min(err_cf, err_cb) * (valid_cf OR valid_cb) <= err_ff + 1e-8)
+__global__ __launch_bounds__(256) void k_consensus_combine(const float* __restrict__ err_cf, const float* __restrict__ err_cb,
+                                                           const float* __restrict__ err_ff, const float* __restrict__ v_cf,
+                                                           const float* __restrict__ v_cb, float* __restrict__ target,
+                                                           float wrig, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float valid = 1.f - (1.f - v_cf[i]) * (1.f - v_cb[i]);
+    const float cam_err = fminf(err_cf[i], err_cb[i]) * valid;
+    target[i] = (wrig * cam_err <= (err_ff[i] + 1e-8f)) ? 1.f : 0.f;
+}
+
+inline dim3 tile_grid(int B, int H, int W) { return dim3((W + TS - 1) / TS, (H + TS - 1) / TS, B); }
+
+inline Gauss13 make_gauss(const float* g13) {
+    Gauss13 g;
+    for (int i = 0; i < 13; i++) g.g[i] = g13[i];
+    return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cc_ssim_num_blocks(int B, int H, int W) { return B * ((W + TS - 1) / TS) * ((H + TS - 1) / TS); }
+
+int cc_ssim_fwd(const float* img1, const float* img2, float* out, const float* gauss13_host, int B, int H, int W,
+                void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return CC_ERR_ARG;
+    PhotoArgs a = {};
+    a.x = img1; a.y = img2; a.out_map = out; a.H = H; a.W = W;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ssim_tile<MODE_MAP>), tile_grid(B, H, W), dim3(256), 0, (hipStream_t)stream, a,
+                       make_gauss(gauss13_host));
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_ssim_photo_fwd(const float* tgt, const float* warped, const float* mask_a, int mask_a_bstride,
+                      const float* mask_b, int mask_b_bstride, int mask_b_complement, float* partials, float* adjA,
+                      float* adjB, float* adjC, float* g0, float* gmask, int gmask_bstride, int want_grad,
+                      float wssim, float q, float lambda_oob, float* loss_accum, float* scale_out, float* nan_flag,
+                      const float* gauss13_host, int B, int H, int W, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    PhotoArgs a = {};
+    a.x = tgt; a.y = warped; a.mask_a = mask_a; a.a_bs = mask_a_bstride; a.mask_b = mask_b; a.b_bs = mask_b_bstride;
+    a.b_complement = mask_b_complement; a.partials = partials; a.adjA = adjA; a.adjB = adjB; a.adjC = adjC; a.g0 = g0;
+    a.gmask = gmask; a.gm_bs = gmask_bstride; a.want_grad = want_grad; a.wssim = wssim; a.q = q; a.H = H; a.W = W;
+    dim3 g = tile_grid(B, H, W);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ssim_tile<MODE_PHOTO>), g, dim3(256), 0, s, a, make_gauss(gauss13_host));
+    const float n1 = (float)B * (float)H * (float)W;
+    hipLaunchKernelGGL(k_photo_finalize, dim3(1), dim3(256), 0, s, (const float*)partials, (int)(g.x * g.y * g.z), n1,
+                       3.f * n1, wssim, q, lambda_oob, loss_accum, scale_out, nan_flag);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_ssim_photo_bwd(const float* adjA, const float* adjB, const float* adjC, const float* g0, const float* tgt,
+                      const float* warped, const float* scale, float* gwarped, int accumulate,
+                      const float* gauss13_host, int B, int H, int W, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_ssim_adjoint, tile_grid(B, H, W), dim3(256), 0, (hipStream_t)stream, adjA, adjB, adjC, g0, tgt,
+                       warped, scale, gwarped, H, W, accumulate, make_gauss(gauss13_host));
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+/* generic autograd of cc_ssim_fwd: given d(loss)/d(ssim) computes d(loss)/d(img2); call again with
+ * img1/img2 swapped for d(loss)/d(img1) (SSIM is symmetric).  adjA/B/C: scratch [B,3,H,W] each. */
+int cc_ssim_bwd(const float* img1, const float* img2, const float* gout, float* adjA, float* adjB, float* adjC,
+                float* gimg2, const float* gauss13_host, int B, int H, int W, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    PhotoArgs a = {};
+    a.x = img1; a.y = img2; a.upstream = gout; a.adjA = adjA; a.adjB = adjB; a.adjC = adjC; a.H = H; a.W = W;
+    Gauss13 g = make_gauss(gauss13_host);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ssim_tile<MODE_GRAD>), tile_grid(B, H, W), dim3(256), 0, s, a, g);
+    hipLaunchKernelGGL(k_ssim_adjoint, tile_grid(B, H, W), dim3(256), 0, s, (const float*)adjA, (const float*)adjB,
+                       (const float*)adjC, (const float*)nullptr, img1, img2, (const float*)nullptr, gimg2, H, W, 0, g);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_ssim_err_fwd(const float* tgt, const float* warped, float* err, float* valid, float wssim,
+                    const float* gauss13_host, int B, int H, int W, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return CC_ERR_ARG;
+    PhotoArgs a = {};
+    a.x = tgt; a.y = warped; a.out_map = err; a.out_valid = valid; a.wssim = wssim; a.H = H; a.W = W;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ssim_tile<MODE_ERR>), tile_grid(B, H, W), dim3(256), 0, (hipStream_t)stream, a,
+                       make_gauss(gauss13_host));
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_consensus_target(const float* err_cam_fwd, const float* err_cam_bwd, const float* err_flow_fwd,
+                        const float* valid_cam_fwd, const float* valid_cam_bwd, float* target, float wrig, int n,
+                        void* stream) {
+    if (n <= 0) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_consensus_combine, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, err_cam_fwd,
+                       err_cam_bwd, err_flow_fwd, valid_cam_fwd, valid_cam_bwd, target, wrig, n);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+}  // extern "C"

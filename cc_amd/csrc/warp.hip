@@ -1,0 +1,441 @@
+// Geometry layer of the CC hot path as fused gfx950 kernels:
+//   depth -> 3-D point (K^-1) -> SE(3)+project (P = K.[R|t]) -> normalise -> OOB rule
+//   -> bilinear gather, in ONE pass per pixel, plus the analytic backward to
+//   depth / P (rigid) or flow, with an atomic-free block reduction for dL/dP.
+// Replaces inverse_warp.py:31-79,164-220,250-283 and models/back2future.py:287-321
+// (reference = a bmm + ~25 elementwise ATen ops + grid_sampler_2d per call).
+//
+// Coordinate arithmetic follows SURVEY.md appendix D exactly (explicit fmaf where
+// the CPU reference's bmm fuses, nowhere else; build with -ffp-contract=off), so
+// that tap indices are bit-identical to the reference given identical P / Kinv.
+// All kernels are HBM-bound (<= ~10 flop/B): one work-item per pixel, x fastest,
+// so depth/flow/out accesses are fully coalesced and the 4-tap gathers hit
+// neighbouring lines (L1/L2-resident for the small motions of this workload).
+#include "cc_common.h"
+#include "../../include/ccengine.h"
+
+namespace {
+
+struct Bilinear {
+    float w, e, n, s;     // distances to the west/east/north/south tap (ATen cpu/GridSamplerKernel naming)
+    int x0, y0;
+    bool vx0, vx1, vy0, vy1;
+    float gmx, gmy;       // d(ix)/d(xn), d(iy)/d(yn) incl. border-clip mask
+};
+
+template <bool AC, bool BORDER>
+__device__ __forceinline__ void bilinear_setup(float xn, float yn, int W, int H, Bilinear& t) {
+    float ix, iy;
+    if (AC) {
+        ix = ((xn + 1.f) * 0.5f) * (float)(W - 1);
+        iy = ((yn + 1.f) * 0.5f) * (float)(H - 1);
+        t.gmx = (float)(W - 1) * 0.5f;
+        t.gmy = (float)(H - 1) * 0.5f;
+    } else {
+        // ATen's vectorised CPU kernel evaluates (x+1)*(W/2) - 0.5 as ONE fma (measured: 100 % of
+        // 2e5 random coordinates bit-identical with this form, 77 % without the fma)
+        ix = fmaf(xn + 1.f, (float)W * 0.5f, -0.5f);
+        iy = fmaf(yn + 1.f, (float)H * 0.5f, -0.5f);
+        t.gmx = (float)W * 0.5f;
+        t.gmy = (float)H * 0.5f;
+    }
+    if (BORDER) {
+        const float mx = (float)(W - 1), my = (float)(H - 1);
+        if (!(ix > 0.f)) { ix = 0.f; t.gmx = 0.f; } else if (!(ix < mx)) { ix = mx; t.gmx = 0.f; }
+        if (!(iy > 0.f)) { iy = 0.f; t.gmy = 0.f; } else if (!(iy < my)) { iy = my; t.gmy = 0.f; }
+    }
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    t.w = ix - x0f;
+    t.e = 1.f - t.w;
+    t.n = iy - y0f;
+    t.s = 1.f - t.n;
+    t.vx0 = (x0f >= 0.f) && (x0f <= (float)(W - 1));
+    t.vx1 = (x0f + 1.f >= 0.f) && (x0f + 1.f <= (float)(W - 1));
+    t.vy0 = (y0f >= 0.f) && (y0f <= (float)(H - 1));
+    t.vy1 = (y0f + 1.f >= 0.f) && (y0f + 1.f <= (float)(H - 1));
+    t.x0 = (int)fminf(fmaxf(x0f, -2.f), (float)W);
+    t.y0 = (int)fminf(fmaxf(y0f, -2.f), (float)H);
+}
+
+__device__ __forceinline__ void gather4(const float* __restrict__ plane, int W, const Bilinear& t,
+                                        float& nw, float& ne, float& sw, float& se) {
+    const int o = t.y0 * W + t.x0;
+    nw = (t.vy0 && t.vx0) ? plane[o] : 0.f;
+    ne = (t.vy0 && t.vx1) ? plane[o + 1] : 0.f;
+    sw = (t.vy1 && t.vx0) ? plane[o + W] : 0.f;
+    se = (t.vy1 && t.vx1) ? plane[o + W + 1] : 0.f;
+}
+
+__device__ __forceinline__ float blend(const Bilinear& t, float nw, float ne, float sw, float se) {
+    // same contraction as the CPU reference (bit-identical on 2e5 random samples)
+    return fmaf(se, t.n * t.w, fmaf(sw, t.n * t.e, fmaf(ne, t.s * t.w, nw * (t.s * t.e))));
+}
+
+struct Rigid {
+    float ray[3], cam[3], p0, p1, p2, Z, xn, yn;
+    bool xo, yo;   // coordinate rewritten to 2 (zeros mode): no gradient
+};
+
+// inverse_warp.py:43-45 (pixel2cam) + :60-76 (cam2pixel); SURVEY.md appendix D recipe.
+__device__ __forceinline__ void rigid_project(const float* __restrict__ P, const float* __restrict__ Ki, float x,
+                                              float y, float d, int W, int H, bool rewrite, Rigid& r) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        r.ray[i] = fmaf(Ki[3 * i + 2], 1.0f, fmaf(Ki[3 * i + 1], y, Ki[3 * i] * x));
+        r.cam[i] = r.ray[i] * d;
+    }
+    r.p0 = fmaf(P[2], r.cam[2], fmaf(P[1], r.cam[1], P[0] * r.cam[0])) + P[3];
+    r.p1 = fmaf(P[6], r.cam[2], fmaf(P[5], r.cam[1], P[4] * r.cam[0])) + P[7];
+    r.p2 = fmaf(P[10], r.cam[2], fmaf(P[9], r.cam[1], P[8] * r.cam[0])) + P[11];
+    r.Z = fmaxf(r.p2, 1e-3f);
+    r.xn = (2.0f * (r.p0 / r.Z)) / (float)(W - 1) - 1.0f;
+    r.yn = (2.0f * (r.p1 / r.Z)) / (float)(H - 1) - 1.0f;
+    r.xo = rewrite && (r.xn > 1.f || r.xn < -1.f);
+    r.yo = rewrite && (r.yn > 1.f || r.yn < -1.f);
+    if (r.xo) r.xn = 2.f;
+    if (r.yo) r.yn = 2.f;
+}
+
+// chain d(loss)/d(xn,yn) back to depth and to the 12 entries of P
+__device__ __forceinline__ void rigid_backward(const float* __restrict__ P, const Rigid& r, float gxn, float gyn, int W,
+                                               int H, float& gdepth, float (&gP)[12]) {
+    if (r.xo) gxn = 0.f;
+    if (r.yo) gyn = 0.f;
+    const float gu = gxn * (2.0f / (float)(W - 1));
+    const float gv = gyn * (2.0f / (float)(H - 1));
+    const float iz = 1.0f / r.Z;
+    const float gp0 = gu * iz, gp1 = gv * iz;
+    const float gz = -(gu * r.p0 + gv * r.p1) * iz * iz;
+    const float gp2 = (r.p2 < 1e-3f) ? 0.f : gz;
+    const float gp[3] = {gp0, gp1, gp2};
+    float gcam[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            gP[4 * i + j] = gp[i] * r.cam[j];
+            gcam[j] += gp[i] * P[4 * i + j];
+        }
+        gP[4 * i + 3] = gp[i];
+    }
+    gdepth = gcam[0] * r.ray[0] + gcam[1] * r.ray[1] + gcam[2] * r.ray[2];
+}
+
+// ------------------------------------------------------------------ rigid (inverse_warp / pose2flow)
+template <bool AC, bool BORDER>
+__global__ __launch_bounds__(256) void k_inverse_warp_fwd(const float* __restrict__ img, const float* __restrict__ depth,
+                                                          const float* __restrict__ P, const float* __restrict__ Kinv,
+                                                          float* __restrict__ out, int C, int H, int W) {
+    const int b = blockIdx.y, HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    Rigid r;
+    rigid_project(P + 12 * b, Kinv + 9 * b, (float)x, (float)y, depth[(size_t)b * HW + p], W, H, !BORDER, r);
+    Bilinear t;
+    bilinear_setup<AC, BORDER>(r.xn, r.yn, W, H, t);
+    const float* src = img + (size_t)b * C * HW;
+    float* dst = out + (size_t)b * C * HW + p;
+    for (int c = 0; c < C; c++) {
+        float nw, ne, sw, se;
+        gather4(src + (size_t)c * HW, W, t, nw, ne, sw, se);
+        dst[(size_t)c * HW] = blend(t, nw, ne, sw, se);
+    }
+}
+
+// d(sum_c gout_c * sample_c)/d(ix, iy) (ATen grid_sampler_2d_backward, bilinear)
+__device__ __forceinline__ void sample_grad(const float* __restrict__ src, const float* __restrict__ gout, int C, int HW,
+                                            int W, const Bilinear& t, float* __restrict__ gimg, float& gix, float& giy) {
+    gix = 0.f;
+    giy = 0.f;
+    for (int c = 0; c < C; c++) {
+        float nw, ne, sw, se;
+        gather4(src + (size_t)c * HW, W, t, nw, ne, sw, se);
+        const float g = gout[(size_t)c * HW];
+        gix += ((ne - nw) * t.s + (se - sw) * t.n) * g;
+        giy += ((sw - nw) * t.e + (se - ne) * t.w) * g;
+        if (gimg) {
+            float* gp = gimg + (size_t)c * HW + t.y0 * W + t.x0;
+            if (t.vy0 && t.vx0) atomicAdd(gp, g * (t.s * t.e));
+            if (t.vy0 && t.vx1) atomicAdd(gp + 1, g * (t.s * t.w));
+            if (t.vy1 && t.vx0) atomicAdd(gp + W, g * (t.n * t.e));
+            if (t.vy1 && t.vx1) atomicAdd(gp + W + 1, g * (t.n * t.w));
+        }
+    }
+}
+
+template <bool AC, bool BORDER>
+__global__ __launch_bounds__(256) void k_inverse_warp_bwd(const float* __restrict__ gout, const float* __restrict__ img,
+                                                          const float* __restrict__ depth, const float* __restrict__ P,
+                                                          const float* __restrict__ Kinv, float* __restrict__ gdepth,
+                                                          float* __restrict__ gP_part, float* __restrict__ gimg, int C,
+                                                          int H, int W) {
+    __shared__ float red[4 * 12];
+    const int b = blockIdx.y, HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    float gP[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) gP[i] = 0.f;
+    if (p < HW) {
+        const int y = p / W, x = p - y * W;
+        Rigid r;
+        rigid_project(P + 12 * b, Kinv + 9 * b, (float)x, (float)y, depth[(size_t)b * HW + p], W, H, !BORDER, r);
+        Bilinear t;
+        bilinear_setup<AC, BORDER>(r.xn, r.yn, W, H, t);
+        float gix, giy, gd;
+        sample_grad(img + (size_t)b * C * HW, gout + (size_t)b * C * HW + p, C, HW, W, t,
+                    gimg ? gimg + (size_t)b * C * HW : nullptr, gix, giy);
+        rigid_backward(P + 12 * b, r, gix * t.gmx, giy * t.gmy, W, H, gd, gP);
+        gdepth[(size_t)b * HW + p] = gd;
+    }
+    cc::block_sum_256<12>(gP, red);
+    if (threadIdx.x == 0) {
+        float* o = gP_part + ((size_t)b * gridDim.x + blockIdx.x) * 12;
+#pragma unroll
+        for (int i = 0; i < 12; i++) o[i] = gP[i];
+    }
+}
+
+// deterministic second stage of the dL/dP reduction: one wave per batch item
+__global__ __launch_bounds__(64) void k_reduce_gP(const float* __restrict__ part, float* __restrict__ gP, int nblk,
+                                                  int accumulate) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) acc[i] = 0.f;
+    for (int k = lane; k < nblk; k += 64) {
+        const float* s = part + ((size_t)b * nblk + k) * 12;
+#pragma unroll
+        for (int i = 0; i < 12; i++) acc[i] += s[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) acc[i] = cc::wave_sum(acc[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) gP[12 * b + i] = accumulate ? gP[12 * b + i] + acc[i] : acc[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pose2flow_fwd(const float* __restrict__ depth, const float* __restrict__ P,
+                                                       const float* __restrict__ Kinv, float* __restrict__ flow, int H,
+                                                       int W, int rewrite) {
+    const int b = blockIdx.y, HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    Rigid r;
+    rigid_project(P + 12 * b, Kinv + 9 * b, (float)x, (float)y, depth[(size_t)b * HW + p], W, H, rewrite != 0, r);
+    // inverse_warp.py:217-218
+    flow[((size_t)b * 2 + 0) * HW + p] = (float)(W - 1) * (r.xn / 2.0f + 0.5f) - (float)x;
+    flow[((size_t)b * 2 + 1) * HW + p] = (float)(H - 1) * (r.yn / 2.0f + 0.5f) - (float)y;
+}
+
+__global__ __launch_bounds__(256) void k_pose2flow_bwd(const float* __restrict__ gflow, const float* __restrict__ depth,
+                                                       const float* __restrict__ P, const float* __restrict__ Kinv,
+                                                       float* __restrict__ gdepth, float* __restrict__ gP_part, int H,
+                                                       int W, int rewrite) {
+    __shared__ float red[4 * 12];
+    const int b = blockIdx.y, HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    float gP[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) gP[i] = 0.f;
+    if (p < HW) {
+        const int y = p / W, x = p - y * W;
+        Rigid r;
+        rigid_project(P + 12 * b, Kinv + 9 * b, (float)x, (float)y, depth[(size_t)b * HW + p], W, H, rewrite != 0, r);
+        const float gxn = gflow[((size_t)b * 2 + 0) * HW + p] * ((float)(W - 1) * 0.5f);
+        const float gyn = gflow[((size_t)b * 2 + 1) * HW + p] * ((float)(H - 1) * 0.5f);
+        float gd;
+        rigid_backward(P + 12 * b, r, gxn, gyn, W, H, gd, gP);
+        gdepth[(size_t)b * HW + p] = gd;
+    }
+    cc::block_sum_256<12>(gP, red);
+    if (threadIdx.x == 0) {
+        float* o = gP_part + ((size_t)b * gridDim.x + blockIdx.x) * 12;
+#pragma unroll
+        for (int i = 0; i < 12; i++) o[i] = gP[i];
+    }
+}
+
+// ------------------------------------------------------------------ flow-driven warps
+// FEATURE=false: inverse_warp.py:185-188 flow_warp grid; FEATURE=true: back2future.py:306-307 grid
+template <bool FEATURE>
+__device__ __forceinline__ void flow_coords(float x, float y, float u, float v, int W, int H, float& xn, float& yn,
+                                            float& dxn, float& dyn) {
+    if (FEATURE) {
+        const float mw = (float)(W - 1 > 1 ? W - 1 : 1), mh = (float)(H - 1 > 1 ? H - 1 : 1);
+        xn = (2.0f * (x + u)) / mw - 1.0f;
+        yn = (2.0f * (y + v)) / mh - 1.0f;
+        dxn = 2.0f / mw;
+        dyn = 2.0f / mh;
+    } else {
+        xn = 2.0f * ((x + u) / ((float)W - 1.0f) - 0.5f);
+        yn = 2.0f * ((y + v) / ((float)H - 1.0f) - 0.5f);
+        dxn = 2.0f / ((float)W - 1.0f);
+        dyn = 2.0f / ((float)H - 1.0f);
+    }
+}
+
+template <bool AC, bool BORDER, bool FEATURE>
+__global__ __launch_bounds__(256) void k_flow_warp_fwd(const float* __restrict__ img, const float* __restrict__ flow,
+                                                       float* __restrict__ out, int C, int H, int W) {
+    const int b = blockIdx.y, HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    float xn, yn, dxn, dyn;
+    flow_coords<FEATURE>((float)x, (float)y, flow[((size_t)b * 2) * HW + p], flow[((size_t)b * 2 + 1) * HW + p], W, H, xn,
+                         yn, dxn, dyn);
+    Bilinear t;
+    bilinear_setup<AC, BORDER>(xn, yn, W, H, t);
+    const float* src = img + (size_t)b * C * HW;
+    float* dst = out + (size_t)b * C * HW + p;
+    for (int c = 0; c < C; c++) {
+        float nw, ne, sw, se;
+        gather4(src + (size_t)c * HW, W, t, nw, ne, sw, se);
+        dst[(size_t)c * HW] = blend(t, nw, ne, sw, se);
+    }
+}
+
+template <bool AC, bool BORDER, bool FEATURE>
+__global__ __launch_bounds__(256) void k_flow_warp_bwd(const float* __restrict__ gout, const float* __restrict__ img,
+                                                       const float* __restrict__ flow, float* __restrict__ gflow,
+                                                       float* __restrict__ gimg, int C, int H, int W) {
+    const int b = blockIdx.y, HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    float xn, yn, dxn, dyn;
+    flow_coords<FEATURE>((float)x, (float)y, flow[((size_t)b * 2) * HW + p], flow[((size_t)b * 2 + 1) * HW + p], W, H, xn,
+                         yn, dxn, dyn);
+    Bilinear t;
+    bilinear_setup<AC, BORDER>(xn, yn, W, H, t);
+    float gix, giy;
+    sample_grad(img + (size_t)b * C * HW, gout + (size_t)b * C * HW + p, C, HW, W, t,
+                gimg ? gimg + (size_t)b * C * HW : nullptr, gix, giy);
+    if (gflow) {
+        gflow[((size_t)b * 2) * HW + p] = gix * t.gmx * dxn;
+        gflow[((size_t)b * 2 + 1) * HW + p] = giy * t.gmy * dyn;
+    }
+}
+
+inline dim3 pix_grid(int B, int H, int W) { return dim3((unsigned)((H * W + 255) / 256), (unsigned)B); }
+
+}  // namespace
+
+#define CC_DISPATCH_AC_PAD(KERN, ac, border, ...)                                                            \
+    do {                                                                                                     \
+        if (ac) {                                                                                            \
+            if (border) hipLaunchKernelGGL(HIP_KERNEL_NAME(KERN<true, true>), __VA_ARGS__);                  \
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(KERN<true, false>), __VA_ARGS__);                        \
+        } else {                                                                                             \
+            if (border) hipLaunchKernelGGL(HIP_KERNEL_NAME(KERN<false, true>), __VA_ARGS__);                 \
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(KERN<false, false>), __VA_ARGS__);                       \
+        }                                                                                                    \
+    } while (0)
+
+extern "C" {
+
+size_t cc_warp_partials_bytes(int B, int H, int W) { return (size_t)B * ((H * W + 255) / 256) * 12 * sizeof(float); }
+
+int cc_inverse_warp_fwd(const float* img, const float* depth, const float* P, const float* Kinv, float* out, int B, int C,
+                        int H, int W, int padding_border, int align_corners, void* stream) {
+    if (B <= 0 || C <= 0 || H < 2 || W < 2) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    CC_DISPATCH_AC_PAD(k_inverse_warp_fwd, align_corners, padding_border, pix_grid(B, H, W), dim3(256), 0, s, img, depth,
+                       P, Kinv, out, C, H, W);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_inverse_warp_bwd(const float* gout, const float* img, const float* depth, const float* P, const float* Kinv,
+                        float* gdepth, float* gP, float* gimg_or_null, float* ws_partials, int B, int C, int H, int W,
+                        int padding_border, int align_corners, void* stream) {
+    if (B <= 0 || C <= 0 || H < 2 || W < 2) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g = pix_grid(B, H, W);
+    CC_DISPATCH_AC_PAD(k_inverse_warp_bwd, align_corners, padding_border, g, dim3(256), 0, s, gout, img, depth, P, Kinv,
+                       gdepth, ws_partials, gimg_or_null, C, H, W);
+    hipLaunchKernelGGL(k_reduce_gP, dim3(B), dim3(64), 0, s, (const float*)ws_partials, gP, (int)g.x, 0);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_pose2flow_fwd(const float* depth, const float* P, const float* Kinv, float* flow, int B, int H, int W,
+                     int rewrite_oob, void* stream) {
+    if (B <= 0 || H < 2 || W < 2) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_pose2flow_fwd, pix_grid(B, H, W), dim3(256), 0, (hipStream_t)stream, depth, P, Kinv, flow, H, W,
+                       rewrite_oob);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_pose2flow_bwd(const float* gflow, const float* depth, const float* P, const float* Kinv, float* gdepth, float* gP,
+                     float* ws_partials, int B, int H, int W, int rewrite_oob, void* stream) {
+    if (B <= 0 || H < 2 || W < 2) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g = pix_grid(B, H, W);
+    hipLaunchKernelGGL(k_pose2flow_bwd, g, dim3(256), 0, s, gflow, depth, P, Kinv, gdepth, ws_partials, H, W, rewrite_oob);
+    hipLaunchKernelGGL(k_reduce_gP, dim3(B), dim3(64), 0, s, (const float*)ws_partials, gP, (int)g.x, 0);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_flow_warp_fwd(const float* img, const float* flow, float* out, int B, int C, int H, int W, int padding_border,
+                     int align_corners, void* stream) {
+    if (B <= 0 || C <= 0 || H < 2 || W < 2) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g = pix_grid(B, H, W);
+    if (align_corners) {
+        if (padding_border) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_fwd<true, true, false>), g, dim3(256), 0, s, img, flow, out, C, H, W);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_fwd<true, false, false>), g, dim3(256), 0, s, img, flow, out, C, H, W);
+    } else {
+        if (padding_border) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_fwd<false, true, false>), g, dim3(256), 0, s, img, flow, out, C, H, W);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_fwd<false, false, false>), g, dim3(256), 0, s, img, flow, out, C, H, W);
+    }
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_flow_warp_bwd(const float* gout, const float* img, const float* flow, float* gflow_or_null, float* gimg_or_null,
+                     int B, int C, int H, int W, int padding_border, int align_corners, void* stream) {
+    if (B <= 0 || C <= 0 || H < 2 || W < 2) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g = pix_grid(B, H, W);
+    if (align_corners) {
+        if (padding_border) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<true, true, false>), g, dim3(256), 0, s, gout, img, flow, gflow_or_null, gimg_or_null, C, H, W);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<true, false, false>), g, dim3(256), 0, s, gout, img, flow, gflow_or_null, gimg_or_null, C, H, W);
+    } else {
+        if (padding_border) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<false, true, false>), g, dim3(256), 0, s, gout, img, flow, gflow_or_null, gimg_or_null, C, H, W);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<false, false, false>), g, dim3(256), 0, s, gout, img, flow, gflow_or_null, gimg_or_null, C, H, W);
+    }
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+// models/back2future.py:287-321 Model.warp (border padding, grid = 2(x+u)/max(W-1,1) - 1)
+int cc_feature_warp_fwd(const float* feat, const float* flow, float* out, int B, int C, int H, int W, int align_corners,
+                        void* stream) {
+    if (B <= 0 || C <= 0 || H < 1 || W < 1) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g = pix_grid(B, H, W);
+    if (align_corners) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_fwd<true, true, true>), g, dim3(256), 0, s, feat, flow, out, C, H, W);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_fwd<false, true, true>), g, dim3(256), 0, s, feat, flow, out, C, H, W);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+// gfeat must be zero-filled by the caller (scatter-add with float atomics)
+int cc_feature_warp_bwd(const float* gout, const float* feat, const float* flow, float* gflow_or_null,
+                        float* gfeat_or_null, int B, int C, int H, int W, int align_corners, void* stream) {
+    if (B <= 0 || C <= 0 || H < 1 || W < 1) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g = pix_grid(B, H, W);
+    if (align_corners) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<true, true, true>), g, dim3(256), 0, s, gout, feat, flow, gflow_or_null, gfeat_or_null, C, H, W);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<false, true, true>), g, dim3(256), 0, s, gout, feat, flow, gflow_or_null, gfeat_or_null, C, H, W);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,115 @@
+/* ccengine -- C ABI of the MI355X-native Competitive-Collaboration training hot path.
+ *
+ * libccengine.so (built by hipcc for gfx950 from the .hip sources under cc_amd/csrc) is the drop-in boundary
+ * underneath the reference's Python call surface.  The reference itself has
+ * no FFI on this path -- it calls ATen/cuDNN ops and one third-party CUDA extension -- so every
+ * entry point below names the reference call it replaces (file:line under anuragranj/cc).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 NCHW data owned by the caller
+ *     (torch tensors); nothing is allocated or freed inside, there is no global state, all entry
+ *     points are thread-safe and capturable into a hipGraph;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *   - return value: 0 = launched; CC_ERR_ARG (-1) bad argument; CC_ERR_LAUNCH (-2) launch failed;
+ *   - P is the 3x4 projection K.[R|t] (inverse_warp.py:214,278), Kinv the 3x3 inverse
+ *     intrinsics, both row-major per batch item;
+ *   - align_corners selects grid_sample semantics (0 = what the reference executes under
+ *     torch >= 1.3, 1 = the authors' torch-1.0 behaviour);
+ *   - *_ws_* / *_bytes functions size caller-provided scratch.
+ */
+#ifndef CCENGINE_H
+#define CCENGINE_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int cc_version(void);
+
+/* ---------------------------------------------------------------- geometry (inverse_warp.py) */
+
+/* scratch for the per-workgroup partial sums of dL/dP: B * ceil(H*W/256) * 12 floats */
+size_t cc_warp_partials_bytes(int B, int H, int W);
+
+/* inverse_warp.py:250-283 inverse_warp (pixel2cam :31-45, cam2pixel :48-79, F.grid_sample :281):
+ * out[B,C,H,W] = bilinear sample of img[B,C,H,W] at the projection of every target pixel.
+ * padding_border: 0 = 'zeros' (OOB coordinates rewritten to 2, :72-76), 1 = 'border'. */
+int cc_inverse_warp_fwd(const float* img, const float* depth, const float* P, const float* Kinv, float* out,
+                        int B, int C, int H, int W, int padding_border, int align_corners, void* stream);
+
+/* autograd of the above w.r.t. depth[B,H,W] and P[B,12] (and, optionally, img via atomics:
+ * gimg must be zero-filled).  ws_partials: cc_warp_partials_bytes(). */
+int cc_inverse_warp_bwd(const float* gout, const float* img, const float* depth, const float* P,
+                        const float* Kinv, float* gdepth, float* gP, float* gimg_or_null, float* ws_partials,
+                        int B, int C, int H, int W, int padding_border, int align_corners, void* stream);
+
+/* inverse_warp.py:195-220 pose2flow: rigid flow [B,2,H,W] in pixels.  rewrite_oob = 1 only for
+ * padding_mode='zeros' (the reference's callers all use padding_mode=None -> 0). */
+int cc_pose2flow_fwd(const float* depth, const float* P, const float* Kinv, float* flow, int B, int H, int W,
+                     int rewrite_oob, void* stream);
+int cc_pose2flow_bwd(const float* gflow, const float* depth, const float* P, const float* Kinv, float* gdepth,
+                     float* gP, float* ws_partials, int B, int H, int W, int rewrite_oob, void* stream);
+
+/* inverse_warp.py:164-192 flow_warp: sample img at (x+u, y+v). */
+int cc_flow_warp_fwd(const float* img, const float* flow, float* out, int B, int C, int H, int W,
+                     int padding_border, int align_corners, void* stream);
+int cc_flow_warp_bwd(const float* gout, const float* img, const float* flow, float* gflow_or_null,
+                     float* gimg_or_null, int B, int C, int H, int W, int padding_border, int align_corners,
+                     void* stream);
+
+/* models/back2future.py:287-321 Model.warp: border-padded feature warp, grads to features
+ * (atomics, gfeat zero-filled by the caller) and flow. */
+int cc_feature_warp_fwd(const float* feat, const float* flow, float* out, int B, int C, int H, int W,
+                        int align_corners, void* stream);
+int cc_feature_warp_bwd(const float* gout, const float* feat, const float* flow, float* gflow_or_null,
+                        float* gfeat_or_null, int B, int C, int H, int W, int align_corners, void* stream);
+
+/* ---------------------------------------------------------------- SSIM / photometric (ssim.py, loss_functions.py)
+ * gauss13_host is the ONE host pointer of this ABI: the 13 taps of the normalised 1-D Gaussian
+ * (ssim.py:9-11, sigma 1.5), copied into the kernel arguments at launch. */
+
+/* number of 32x32 tiles = length of the partial-sum buffer of cc_ssim_photo_fwd (x4 floats) */
+int cc_ssim_num_blocks(int B, int H, int W);
+
+/* ssim.py:68-76 ssim(img1, img2, window_size=13): per-pixel, per-channel map [B,3,H,W], zero padding 6 */
+int cc_ssim_fwd(const float* img1, const float* img2, float* out, const float* gauss13_host, int B, int H, int W,
+                void* stream);
+int cc_ssim_bwd(const float* img1, const float* img2, const float* gout, float* adjA, float* adjB, float* adjC,
+                float* gimg2, const float* gauss13_host, int B, int H, int W, void* stream);
+
+/* The body of one (scale, reference-frame) term of photometric_reconstruction_loss
+ * (loss_functions.py:99-114) / photometric_flow_loss (:44-58), fused:
+ *   valid = 1 - prod_c(warped == 0); m = mask_a * mask_b (either may be null; mask_b may be used as 1 - mask_b);
+ *   diff = (tgt - warped) * valid * m;  ssim_loss = (1 - ssim(tgt, warped) * valid) * m;
+ *   loss_accum[0] += (1-wssim) * N/sum(valid) * (mean (diff^2+0.01)^q + wssim * mean ssim_loss)
+ *                    + lambda_oob * robust_l1(1 - valid);
+ *   scale_out[0]   = (1-wssim) * N/sum(valid) / (3N)   (common factor of all adjoints of this term);
+ *   nan_flag[0]    = 1 if the term is NaN (deferred form of the reference's asserts :60,105,115).
+ * With want_grad it also writes the adjoint maps consumed by cc_ssim_photo_bwd (adjA/B/C, g0: [B,3,H,W])
+ * and gmask = d(term)/d(mask_b) / scale  (element (b,p) at gmask[b*gmask_bstride + p]).
+ * partials: cc_ssim_num_blocks()*4 floats. */
+int cc_ssim_photo_fwd(const float* tgt, const float* warped, const float* mask_a, int mask_a_bstride,
+                      const float* mask_b, int mask_b_bstride, int mask_b_complement, float* partials, float* adjA,
+                      float* adjB, float* adjC, float* g0, float* gmask, int gmask_bstride, int want_grad,
+                      float wssim, float q, float lambda_oob, float* loss_accum, float* scale_out, float* nan_flag,
+                      const float* gauss13_host, int B, int H, int W, void* stream);
+
+/* gwarped (+)= scale[0] * (g0 + G*adjA + 2*warped*(G*adjB) + tgt*(G*adjC)): d(term)/d(warped) */
+int cc_ssim_photo_bwd(const float* adjA, const float* adjB, const float* adjC, const float* g0, const float* tgt,
+                      const float* warped, const float* scale, float* gwarped, int accumulate,
+                      const float* gauss13_host, int B, int H, int W, void* stream);
+
+/* loss_functions.py:181-188 (consensus_exp_masks error maps): err[B,1,H,W] = (1-wssim)*mean_c sqrt((tgt-w)^2+0.01)
+ * + wssim*mean_c(1 - ssim(tgt,w)); valid[B,1,H,W] = 1 - prod_c(w == 0) */
+int cc_ssim_err_fwd(const float* tgt, const float* warped, float* err, float* valid, float wssim,
+                    const float* gauss13_host, int B, int H, int W, void* stream);
+
+/* loss_functions.py:173-175,189-193: target = (wrig * min(err_cf, err_cb) * OR(valid_cf, valid_cb) <= err_ff + 1e-8) */
+int cc_consensus_target(const float* err_cam_fwd, const float* err_cam_bwd, const float* err_flow_fwd,
+                        const float* valid_cam_fwd, const float* valid_cam_bwd, float* target, float wrig, int n,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
