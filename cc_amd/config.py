@@ -5,3 +5,7 @@ reference executes under torch >= 1.3 (default, the as-run parity target); True 
 torch-1.0 semantics.
 """
 align_corners = False
+
+# True: check every photometric term for NaN eagerly (AssertionError, one host sync per term, the
+# reference's behaviour, loss_functions.py:60,105,115).  False: device flag, see loss_functions.check_finite().
+strict_nan_checks = False

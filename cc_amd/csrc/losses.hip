@@ -1,0 +1,356 @@
+// Elementwise / stencil loss kernels of the CC step (gfx950), all HBM-bound:
+//   image pyramid (adaptive_avg_pool2d), rigid + flow occlusion masks, edge-aware and second-order
+//   smoothness, explainability BCE, consensus (weighted) BCE -- each with its gradient produced in
+//   the same pass (the loss is a scalar with constant weights, so d(loss)/d(input) is known as soon
+//   as the forward value is) and with deterministic two-stage reductions (no float atomics).
+// Replaces the per-scale Python loops of loss_functions.py:132-137,148-155,221-261,287-352.
+#include "cc_common.h"
+#include "../../include/ccengine.h"
+
+namespace {
+
+// ------------------------------------------------------------------ pyramid
+// F.adaptive_avg_pool2d(img, (h, w)) (loss_functions.py:36-37,89-90,163-165,315): window
+// [floor(i*H/h), ceil((i+1)*H/h)), summed row-major in fp32 then divided by the count (ATen order).
+__global__ __launch_bounds__(256) void k_adaptive_pool(const float* __restrict__ in, float* __restrict__ out, int H, int W,
+                                                       int h, int w, int planes) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = h * w;
+    if (i >= n) return;
+    const int pl = blockIdx.y;
+    const int oy = i / w, ox = i - oy * w;
+    const int y0 = (int)(((long)oy * H) / h), y1 = (int)((((long)oy + 1) * H + h - 1) / h);
+    const int x0 = (int)(((long)ox * W) / w), x1 = (int)((((long)ox + 1) * W + w - 1) / w);
+    const float* src = in + (size_t)pl * H * W;
+    float s = 0.f;
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) s += src[y * W + x];
+    out[(size_t)pl * n + i] = s / (float)((y1 - y0) * (x1 - x0));
+}
+
+// ------------------------------------------------------------------ occlusion masks
+// loss_functions.py:343-352 occlusion_masks: occ = sum_c(f_fw + f_bw) > 0.08*(|f_fw|^2 + |f_bw|^2) + 1
+// (signed sum; occ_fw == occ_bw).  Output is (1 - occ), the factor the losses multiply by.
+__device__ __forceinline__ float noocc(float bu, float bv, float fu, float fv) {
+    const float mag = (fu * fu + fv * fv) + (bu * bu + bv * bv);
+    const float thr = 0.08f * mag + 1.0f;
+    const float s = (fu + bu) + (fv + bv);
+    return (s > thr) ? 0.f : 1.f;
+}
+
+__global__ __launch_bounds__(256) void k_flow_noocc(const float* __restrict__ flow_bw, const float* __restrict__ flow_fw,
+                                                    float* __restrict__ out, int HW) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int b = blockIdx.y;
+    const float* fb = flow_bw + (size_t)b * 2 * HW + p;
+    const float* ff = flow_fw + (size_t)b * 2 * HW + p;
+    out[(size_t)b * HW + p] = noocc(fb[0], fb[HW], ff[0], ff[HW]);
+}
+
+// loss_functions.py:132-137 depth_occlusion_masks: four rigid flows (pose2flow with the FULL-resolution
+// K at every scale, Q4), pairs (1,2) and (0,3) -> (1 - occ) for refs 0..3, [B,4,H,W].
+// flows: [4][B,2,H,W] computed by cc_pose2flow_fwd into one buffer.
+__global__ __launch_bounds__(256) void k_rigid_noocc(const float* __restrict__ flows, float* __restrict__ out, int B,
+                                                     int HW) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int b = blockIdx.y;
+    const size_t fs = (size_t)B * 2 * HW;
+    const float* f0 = flows + 0 * fs + (size_t)b * 2 * HW + p;
+    const float* f1 = flows + 1 * fs + (size_t)b * 2 * HW + p;
+    const float* f2 = flows + 2 * fs + (size_t)b * 2 * HW + p;
+    const float* f3 = flows + 3 * fs + (size_t)b * 2 * HW + p;
+    const float m12 = noocc(f1[0], f1[HW], f2[0], f2[HW]);   // occlusion_masks(flow_cam[1], flow_cam[2])
+    const float m03 = noocc(f0[0], f0[HW], f3[0], f3[HW]);   // occlusion_masks(flow_cam[0], flow_cam[3])
+    float* o = out + (size_t)b * 4 * HW + p;
+    o[0] = m03;
+    o[HW] = m12;
+    o[2 * HW] = m12;
+    o[3 * HW] = m03;
+}
+
+// ------------------------------------------------------------------ generic deterministic finalize
+// accum[0] += coef * sum(partials[0..n))
+__global__ __launch_bounds__(256) void k_reduce_add(const float* __restrict__ partials, int n, float coef,
+                                                    float* __restrict__ accum) {
+    __shared__ float red[4];
+    float v[1] = {0.f};
+    for (int i = threadIdx.x; i < n; i += 256) v[0] += partials[i];
+    cc::block_sum_256<1>(v, red);
+    if (threadIdx.x == 0) accum[0] += coef * v[0];
+}
+
+// ------------------------------------------------------------------ edge-aware smoothness
+// loss_functions.py:287-319 (per scale): mean(|p[y]-p[y+1]| * exp(-mean_c|im[y]-im[y+1]|)) over [B,C,H-1,W]
+//                                     + mean(|p[x]-p[x+1]| * exp(-mean_c|im[x]-im[x+1]|)) over [B,C,H,W-1]
+// ("gradient_x" runs along H, Q7).  One thread per pixel of one (b, c) plane; the gradient is gathered.
+__device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
+__device__ __forceinline__ float edge_w(const float* __restrict__ im, int HW, int p, int q) {
+    const float a = fabsf(im[p] - im[q]) + fabsf(im[HW + p] - im[HW + q]) + fabsf(im[2 * HW + p] - im[2 * HW + q]);
+    return expf(-(a / 3.f));
+}
+
+__global__ __launch_bounds__(256) void k_edge_smooth(const float* __restrict__ img, const float* __restrict__ pred,
+                                                     float* __restrict__ gpred, float* __restrict__ partials, int C, int H,
+                                                     int W, float inv_nx, float inv_ny, float gscale) {
+    __shared__ float red[4];
+    const int HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int bc = blockIdx.y, b = bc / C;
+    float part[1] = {0.f};
+    if (p < HW) {
+        const int y = p / W, x = p - y * W;
+        const float* im = img + (size_t)b * 3 * HW;
+        const float* pr = pred + (size_t)bc * HW;
+        const float v = pr[p];
+        float g = 0.f;
+        if (y + 1 < H) {                      // term (y, x) of the H-direction sum
+            const float d = v - pr[p + W];
+            const float w = edge_w(im, HW, p, p + W);
+            part[0] += fabsf(d) * w * inv_nx;
+            g += sgn(d) * w * inv_nx;
+        }
+        if (y > 0) {                          // this pixel is the "+1" operand of term (y-1, x)
+            const float d = pr[p - W] - v;
+            g -= sgn(d) * edge_w(im, HW, p - W, p) * inv_nx;
+        }
+        if (x + 1 < W) {
+            const float d = v - pr[p + 1];
+            const float w = edge_w(im, HW, p, p + 1);
+            part[0] += fabsf(d) * w * inv_ny;
+            g += sgn(d) * w * inv_ny;
+        }
+        if (x > 0) {
+            const float d = pr[p - 1] - v;
+            g -= sgn(d) * edge_w(im, HW, p - 1, p) * inv_ny;
+        }
+        if (gpred) gpred[(size_t)bc * HW + p] = g * gscale;
+    }
+    cc::block_sum_256<1>(part, red);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = part[0];
+}
+
+// ------------------------------------------------------------------ second-order smoothness
+// loss_functions.py:323-341 smooth_loss (per scale, times weight): mean|dx2| + mean|dxdy| + mean|dydx| + mean|dy2|
+//   dx2(y,x)  = p(y,x+2) - 2p(y,x+1) + p(y,x)          over [H, W-2]
+//   dxdy(y,x) = p(y+1,x+1) - p(y+1,x) - p(y,x+1) + p(y,x) over [H-1, W-1]   (dydx is the same expression)
+//   dy2(y,x)  = p(y+2,x) - 2p(y+1,x) + p(y,x)          over [H-2, W]
+struct Plane {
+    const float* p; int H, W;
+    __device__ __forceinline__ float at(int y, int x) const { return p[y * W + x]; }
+    __device__ __forceinline__ float dx2(int y, int x) const { return at(y, x + 2) - 2.f * at(y, x + 1) + at(y, x); }
+    __device__ __forceinline__ float dy2(int y, int x) const { return at(y + 2, x) - 2.f * at(y + 1, x) + at(y, x); }
+    __device__ __forceinline__ float dxy(int y, int x) const { return (at(y + 1, x + 1) - at(y + 1, x)) - (at(y, x + 1) - at(y, x)); }
+};
+
+__global__ __launch_bounds__(256) void k_smooth2(const float* __restrict__ pred, float* __restrict__ gpred,
+                                                 float* __restrict__ partials, int H, int W, float c_dx2, float c_dxy,
+                                                 float c_dy2, float gscale) {
+    __shared__ float red[4];
+    const int HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    float part[1] = {0.f};
+    if (p < HW) {
+        const int y = p / W, x = p - y * W;
+        Plane P{pred + (size_t)blockIdx.y * HW, H, W};
+        float g = 0.f;
+        // forward terms anchored at this pixel
+        if (x + 2 < W) part[0] += fabsf(P.dx2(y, x)) * c_dx2;
+        if (y + 2 < H) part[0] += fabsf(P.dy2(y, x)) * c_dy2;
+        if (x + 1 < W && y + 1 < H) part[0] += fabsf(P.dxy(y, x)) * c_dxy;     // c_dxy already counts dxdy + dydx
+        // gradient: every stencil this pixel takes part in
+        for (int k = 0; k < 3; k++) {          // dx2 anchored at x-k, coefficient {1,-2,1}[k]
+            const int xa = x - k;
+            if (xa >= 0 && xa + 2 < W) g += sgn(P.dx2(y, xa)) * ((k == 1) ? -2.f : 1.f) * c_dx2;
+            const int ya = y - k;
+            if (ya >= 0 && ya + 2 < H) g += sgn(P.dy2(ya, x)) * ((k == 1) ? -2.f : 1.f) * c_dy2;
+        }
+        for (int dy = 0; dy < 2; dy++)
+            for (int dx = 0; dx < 2; dx++) {   // dxy anchored at (y-dy, x-dx): coefficient +1 if dy==dx else -1
+                const int ya = y - dy, xa = x - dx;
+                if (ya >= 0 && xa >= 0 && ya + 1 < H && xa + 1 < W)
+                    g += sgn(P.dxy(ya, xa)) * ((dy == dx) ? 1.f : -1.f) * c_dxy;
+            }
+        if (gpred) gpred[(size_t)blockIdx.y * HW + p] = g * gscale;
+    }
+    cc::block_sum_256<1>(part, red);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = part[0];
+}
+
+// ------------------------------------------------------------------ BCE losses
+// loss_functions.py:148-155 explainability_loss: F.binary_cross_entropy(mask, 1) = mean(-max(log(mask), -100))
+__global__ __launch_bounds__(256) void k_bce_ones(const float* __restrict__ mask, float* __restrict__ gmask,
+                                                  float* __restrict__ partials, int n, float inv_n, float gscale) {
+    __shared__ float red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float part[1] = {0.f};
+    if (i < n) {
+        const float m = mask[i];
+        const float lg = fmaxf(logf(m), -100.f);
+        part[0] = -lg * inv_n;
+        // ATen binary_cross_entropy_backward: (x - y) / max((1 - x) * x, 1e-12), y = 1
+        if (gmask) gmask[i] = ((m - 1.f) / fmaxf((1.f - m) * m, 1e-12f)) * inv_n * gscale;
+    }
+    cc::block_sum_256<1>(part, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = part[0];
+}
+
+// loss_functions.py:221-261 consensus_depth_flow_mask, one scale (census_* = |cam_flow - flow|, train.py:475-476):
+//   census_d = prod_c(census_mask_d < THRESH)  OR  exp_target_d                 (d in {bwd, fwd})
+//   target   = (bwd, bwd, fwd, fwd);  loss = -mean(w1*t*log(e+eps) + w0*(1-t)*log(1-e+eps)), w=[wbce, 1-wbce]
+__global__ __launch_bounds__(256) void k_consensus_bce(const float* __restrict__ exp_mask, const float* __restrict__ census_bwd,
+                                                       const float* __restrict__ census_fwd, const float* __restrict__ tgt_bwd,
+                                                       const float* __restrict__ tgt_fwd, float* __restrict__ gmask,
+                                                       float* __restrict__ partials, int HW, float thresh, float w0,
+                                                       float w1, float inv_n, float gscale) {
+    __shared__ float red[4];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    float part[1] = {0.f};
+    if (p < HW) {
+        const size_t f = (size_t)b * 2 * HW + p;
+        const float cb = (census_bwd[f] < thresh && census_bwd[f + HW] < thresh) ? 1.f : 0.f;
+        const float cf = (census_fwd[f] < thresh && census_fwd[f + HW] < thresh) ? 1.f : 0.f;
+        const float tb = 1.f - (1.f - cb) * (1.f - tgt_bwd[(size_t)b * HW + p]);
+        const float tf = 1.f - (1.f - cf) * (1.f - tgt_fwd[(size_t)b * HW + p]);
+        const float t[4] = {tb, tb, tf, tf};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const size_t o = ((size_t)b * 4 + c) * HW + p;
+            const float e = exp_mask[o];
+            const float a1 = e + 1e-8f, a0 = (1.f - e) + 1e-8f;
+            part[0] -= (w1 * (t[c] * logf(a1)) + w0 * ((1.f - t[c]) * logf(a0))) * inv_n;
+            if (gmask) gmask[o] = -(w1 * t[c] / a1 - w0 * (1.f - t[c]) / a0) * inv_n * gscale;
+        }
+    }
+    cc::block_sum_256<1>(part, red);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = part[0];
+}
+
+// out = a * s   (device scalar s) -- used to apply grad_output to stashed gradients without a host sync
+__global__ __launch_bounds__(256) void k_scale_by_scalar(const float* __restrict__ a, const float* __restrict__ s,
+                                                         float* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] * s[0];
+}
+
+}  // namespace
+
+extern "C" {
+
+int cc_adaptive_avg_pool(const float* in, float* out, int planes, int H, int W, int h, int w, void* stream) {
+    if (planes <= 0 || h <= 0 || w <= 0 || H < h || W < w) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_adaptive_pool, dim3((h * w + 255) / 256, planes), dim3(256), 0, (hipStream_t)stream, in, out, H, W,
+                       h, w, planes);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+// levels 1..nlevels-1 of the 2^l box-mean pyramid of `planes` H x W images, each computed from level 0
+// (as the reference does); out_packed holds the levels back to back: [planes, H>>1, W>>1], [planes, H>>2, W>>2] ...
+int cc_pyramid_build(const float* level0, float* out_packed, int nlevels, int planes, int H, int W, void* stream) {
+    if (nlevels < 1 || planes <= 0) return CC_ERR_ARG;
+    size_t off = 0;
+    for (int l = 1; l < nlevels; l++) {
+        const int h = H >> l, w = W >> l;
+        if (h < 1 || w < 1) return CC_ERR_ARG;
+        hipLaunchKernelGGL(k_adaptive_pool, dim3((h * w + 255) / 256, planes), dim3(256), 0, (hipStream_t)stream, level0,
+                           out_packed + off, H, W, h, w, planes);
+        off += (size_t)planes * h * w;
+    }
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_flow_noocc(const float* flow_bw, const float* flow_fw, float* out, int B, int H, int W, void* stream) {
+    if (B <= 0) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_flow_noocc, dim3((H * W + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, flow_bw, flow_fw, out,
+                       H * W);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_rigid_noocc(const float* flows4, float* out, int B, int H, int W, void* stream) {
+    if (B <= 0) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_rigid_noocc, dim3((H * W + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, flows4, out, B,
+                       H * W);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_reduce_add(const float* partials, int n, float coef, float* accum, void* stream) {
+    hipLaunchKernelGGL(k_reduce_add, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, n, coef, accum);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+size_t cc_elem_num_blocks(int n) { return (n + 255) / 256; }
+
+int cc_edge_smooth_fwd_bwd(const float* img, const float* pred, float* gpred_or_null, float* partials, float* loss_accum,
+                           float gscale, int B, int C, int H, int W, void* stream) {
+    if (B <= 0 || C <= 0 || H < 2 || W < 2) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (H * W + 255) / 256;
+    const float inv_nx = 1.f / ((float)B * C * (H - 1) * W), inv_ny = 1.f / ((float)B * C * H * (W - 1));
+    hipLaunchKernelGGL(k_edge_smooth, dim3(nb, B * C), dim3(256), 0, s, img, pred, gpred_or_null, partials, C, H, W, inv_nx,
+                       inv_ny, gscale);
+    hipLaunchKernelGGL(k_reduce_add, dim3(1), dim3(256), 0, s, (const float*)partials, nb * B * C, 1.0f, loss_accum);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_smooth2_fwd_bwd(const float* pred, float* gpred_or_null, float* partials, float* loss_accum, float weight,
+                       float gscale, int planes, int H, int W, void* stream) {
+    if (planes <= 0 || H < 1 || W < 1) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (H * W + 255) / 256;
+    // a map thinner than 3 pixels makes one of the reference's .mean() calls run over an empty tensor -> NaN
+    const bool degenerate = (H < 3 || W < 3);
+    const float c_dx2 = (W > 2) ? weight / ((float)planes * H * (W - 2)) : 0.f;
+    const float c_dy2 = (H > 2) ? weight / ((float)planes * (H - 2) * W) : 0.f;
+    const float c_dxy = (H > 1 && W > 1) ? 2.f * weight / ((float)planes * (H - 1) * (W - 1)) : 0.f;
+    hipLaunchKernelGGL(k_smooth2, dim3(nb, planes), dim3(256), 0, s, pred, gpred_or_null, partials, H, W, c_dx2, c_dxy,
+                       c_dy2, gscale);
+    hipLaunchKernelGGL(k_reduce_add, dim3(1), dim3(256), 0, s, (const float*)partials, nb * planes,
+                       degenerate ? __builtin_nanf("") : 1.0f, loss_accum);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_bce_ones_fwd_bwd(const float* mask, float* gmask_or_null, float* partials, float* loss_accum, float gscale, int n,
+                        void* stream) {
+    if (n <= 0) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_bce_ones, dim3(nb), dim3(256), 0, s, mask, gmask_or_null, partials, n, 1.f / (float)n, gscale);
+    hipLaunchKernelGGL(k_reduce_add, dim3(1), dim3(256), 0, s, (const float*)partials, nb, 1.0f, loss_accum);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_consensus_bce_fwd_bwd(const float* exp_mask, const float* census_bwd, const float* census_fwd,
+                             const float* target_bwd, const float* target_fwd, float* gmask_or_null, float* partials,
+                             float* loss_accum, float thresh, float wbce, float gscale, int B, int H, int W,
+                             void* stream) {
+    if (B <= 0) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int HW = H * W, nb = (HW + 255) / 256;
+    // weights = [wbce, 1 - wbce]: weights[1] multiplies the target term, weights[0] the (1 - target) term
+    hipLaunchKernelGGL(k_consensus_bce, dim3(nb, B), dim3(256), 0, s, exp_mask, census_bwd, census_fwd, target_bwd,
+                       target_fwd, gmask_or_null, partials, HW, thresh, wbce, 1.f - wbce, 1.f / ((float)B * 4 * HW),
+                       gscale);
+    hipLaunchKernelGGL(k_reduce_add, dim3(1), dim3(256), 0, s, (const float*)partials, nb * B, 1.0f, loss_accum);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_scale_by_scalar(const float* a, const float* scalar_dev, float* out, int n, void* stream) {
+    if (n <= 0) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_scale_by_scalar, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, scalar_dev, out, n);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+}  // extern "C"

@@ -389,7 +389,7 @@ inline Gauss13 make_gauss(const float* g13) {
 
 extern "C" {
 
-int cc_ssim_num_blocks(int B, int H, int W) { return B * ((W + TS - 1) / TS) * ((H + TS - 1) / TS); }
+size_t cc_ssim_num_blocks(int B, int H, int W) { return B * ((W + TS - 1) / TS) * ((H + TS - 1) / TS); }
 
 int cc_ssim_fwd(const float* img1, const float* img2, float* out, const float* gauss13_host, int B, int H, int W,
                 void* stream) {

@@ -1,2 +1,2 @@
 #include "../../include/ccengine.h"
-extern "C" int cc_version(void) { return 1; }
+extern "C" size_t cc_version(void) { return 1; }

@@ -1,0 +1,525 @@
+"""Drop-in for the reference's ``loss_functions`` module on the fused gfx950 kernels
+(cc_amd/csrc/{warp,ssim,losses}.hip, C ABI in include/ccengine.h).
+
+Same names / signatures / return types as loss_functions.py (the 14 names train.py:23-26 imports).
+MI355X-first differences in HOW, not in WHAT:
+
+* every loss is one ``torch.autograd.Function`` whose forward launches the fused kernels AND their
+  adjoints (a scalar loss with constant weights has a known upstream gradient), so nothing but the
+  final input-gradients is kept between forward and backward; ``backward`` only scales them;
+* all reductions are two-stage and deterministic (no float atomics), the OOB normaliser
+  ``nelement/sum(valid)`` (loss_functions.py:48,103) stays on the device -> zero host syncs per step
+  (the reference does ~66); the NaN asserts (:60,105,115) become a device flag, checked on demand
+  (``check_finite()``) or eagerly with ``config.strict_nan_checks = True``;
+* the image pyramid (``adaptive_avg_pool2d``, recomputed 90x per step by the reference) is cached
+  per source tensor.
+
+Quirks Q1-Q8 of SURVEY.md section 8 are reproduced on purpose.
+"""
+import torch
+from torch import nn
+
+from . import config
+from ._lib import engine, STREAM
+from .inverse_warp import projection_matrix, pose2flow, _ac
+from .ssim import gauss13_ptr
+
+epsilon = 1e-8
+
+
+# ----------------------------------------------------------------------------- helpers
+def _f32c(t):
+    return t.contiguous().float()
+
+
+def _zeros1(ref):
+    return torch.zeros(1, device=ref.device, dtype=torch.float32)
+
+
+def _empty(n, ref):
+    return torch.empty(max(int(n), 1), device=ref.device, dtype=torch.float32)
+
+
+_nan_flags = []
+
+
+def check_finite():
+    """Deferred form of the reference's ``assert((loss == loss).item() == 1)`` (one host sync)."""
+    bad = any(bool(f.item() != 0) for f in _nan_flags)
+    del _nan_flags[:]
+    assert not bad, "NaN encountered in a photometric loss term"
+
+
+def _register_nan_flag(flag):
+    if config.strict_nan_checks:
+        assert flag.item() == 0, "NaN encountered in a photometric loss term"
+    else:
+        _nan_flags.append(flag)
+        if len(_nan_flags) > 64:
+            del _nan_flags[:-64]
+
+
+class _PyramidCache:
+    """adaptive_avg_pool2d(img, (h, w)) results keyed on the identity (+ version) of the source tensor."""
+
+    def __init__(self, cap=16):
+        self.cap = cap
+        self.items = {}
+
+    def clear(self):
+        self.items.clear()
+
+    def get(self, img, h, w):
+        H, W = img.shape[2], img.shape[3]
+        if (h, w) == (H, W):
+            return _f32c(img)
+        key = id(img)
+        ent = self.items.get(key)
+        if ent is None or ent[0] is not img or ent[1] != img._version:
+            ent = (img, img._version, {})
+            self.items[key] = ent
+            while len(self.items) > self.cap:
+                self.items.pop(next(iter(self.items)))
+        lv = ent[2].get((h, w))
+        if lv is None:
+            src = _f32c(img.detach())
+            B, C = src.shape[0], src.shape[1]
+            lv = torch.empty(B, C, h, w, device=src.device, dtype=torch.float32)
+            engine().call("cc_adaptive_avg_pool", src, lv, B * C, H, W, h, w, STREAM)
+            ent[2][(h, w)] = lv
+        return lv
+
+
+pyramid_cache = _PyramidCache()
+
+
+def _scaled_intrinsics(intrinsics, intrinsics_inv, downscale):
+    """loss_functions.py:91-92."""
+    K_s = torch.cat((intrinsics[:, 0:2] / downscale, intrinsics[:, 2:]), dim=1)
+    Kinv_s = torch.cat((intrinsics_inv[:, :, 0:2] * downscale, intrinsics_inv[:, :, 2:]), dim=2)
+    return K_s, Kinv_s
+
+
+def _scale_grads(stash, gout):
+    out = []
+    for g in stash:
+        if g is None:
+            out.append(None)
+        else:
+            r = torch.empty_like(g)
+            engine().call("cc_scale_by_scalar", g, _f32c(gout).reshape(1), r, g.numel(), STREAM)
+            out.append(r)
+    return out
+
+
+# ----------------------------------------------------------------------------- small public helpers
+def spatial_normalize(disp):
+    """loss_functions.py:13-16."""
+    _mean = disp.mean(dim=1, keepdim=True).mean(dim=2, keepdim=True).mean(dim=3, keepdim=True)
+    return disp / _mean
+
+
+def robust_l1(x, q=0.5, eps=1e-2):
+    """loss_functions.py:18-21."""
+    return torch.pow((x.pow(2) + eps), q).mean()
+
+
+def robust_l1_per_pix(x, q=0.5, eps=1e-2):
+    """loss_functions.py:23-25."""
+    return torch.pow((x.pow(2) + eps), q)
+
+
+def logical_or(a, b):
+    """loss_functions.py:157-158."""
+    return 1 - (1 - a) * (1 - b)
+
+
+def occlusion_masks(flow_bw, flow_fw):
+    """loss_functions.py:343-352 -> (occ_bw, occ_fw), each [B,H,W] in {0,1}."""
+    flow_bw, flow_fw = _f32c(flow_bw.detach()), _f32c(flow_fw.detach())
+    B, _, H, W = flow_bw.shape
+    no = torch.empty(B, 1, H, W, device=flow_bw.device, dtype=torch.float32)
+    engine().call("cc_flow_noocc", flow_bw, flow_fw, no, B, H, W, STREAM)
+    occ = (1 - no)[:, 0]
+    return occ, occ.clone()
+
+
+def _rigid_noocc(depth_bhw, P_full, Kinv):
+    """(1 - depth_occlusion_masks) laid out [4,B,h,w] (reference-frame major)."""
+    B, h, w = depth_bhw.shape
+    E = engine()
+    flows4 = torch.empty(4, B, 2, h, w, device=depth_bhw.device, dtype=torch.float32)
+    for r in range(4):
+        E.call("cc_pose2flow_fwd", depth_bhw, P_full[r], Kinv, flows4[r], B, h, w, 0, STREAM)
+    no = torch.empty(B, 4, h, w, device=depth_bhw.device, dtype=torch.float32)
+    E.call("cc_rigid_noocc", flows4, no, B, h, w, STREAM)
+    return no
+
+
+def depth_occlusion_masks(depth, pose, intrinsics, intrinsics_inv):
+    """loss_functions.py:132-137 -> [B,4,h,w] occlusion masks (needs exactly 4 reference poses, H3)."""
+    d = _f32c(depth.detach().squeeze())
+    assert d.dim() == 3, "wrong size for depth"           # loss_functions.py:133 squeezes the batch away for B=1 (H4)
+    Kinv = _f32c(intrinsics_inv.detach())
+    P_full = [_f32c(projection_matrix(pose[:, i].detach(), intrinsics.detach())) for i in range(pose.size(1))]
+    return 1 - _rigid_noocc(d, P_full, Kinv)
+
+
+# ----------------------------------------------------------------------------- photometric losses
+class _PhotoCfg:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _photo_term(E, tgt_s, warped, mask_a, a_bs, mask_b, b_bs, gmask, gm_bs, want_grad, cfg, loss_acc, nan_flag):
+    """One (scale, reference) term: fused forward (+ adjoint maps).  Returns the scratch needed by the adjoint."""
+    B, _, h, w = tgt_s.shape
+    nblk = E.call("cc_ssim_num_blocks", B, h, w)
+    partials = _empty(nblk * 4, tgt_s)
+    scale = _empty(1, tgt_s)
+    if want_grad:
+        adj = [torch.empty_like(warped) for _ in range(4)]
+    else:
+        adj = [None] * 4
+    E.call("cc_ssim_photo_fwd", tgt_s, warped, mask_a, a_bs, mask_b, b_bs, 0, partials, adj[0], adj[1], adj[2], adj[3],
+           gmask, gm_bs, 1 if want_grad else 0, float(cfg.wssim), float(cfg.qch), float(cfg.lambda_oob), loss_acc,
+           scale, nan_flag, gauss13_ptr(), B, h, w, STREAM)
+    return adj, scale
+
+
+class _PhotoRigidFn(torch.autograd.Function):
+    """loss_functions.py:80-128 over all scales and reference frames."""
+
+    @staticmethod
+    def forward(ctx, cfg, tgt_img, intrinsics, intrinsics_inv, pose, *rest):
+        R, S = cfg.n_refs, cfg.n_scales
+        refs = rest[:R]
+        depths = rest[R:R + S]
+        masks = rest[R + S:]
+        E = engine()
+        dev = tgt_img.device
+        need = ctx.needs_input_grad
+        want_grad = any(need)
+        loss_acc, nan_flag = _zeros1(tgt_img), _zeros1(tgt_img)
+        Kinv_full = _f32c(intrinsics_inv.detach())
+        with torch.enable_grad():
+            pose_l = pose.detach().requires_grad_(bool(need[4]))
+            K_d = intrinsics.detach()
+            P_full = [projection_matrix(pose_l[:, r], K_d, cfg.rotation_mode) for r in range(R)]
+        P_full_c = [_f32c(p.detach()) for p in P_full]
+        gdepths, gmasks, gP_all, P_all = [], [], [], []
+        for s in range(S):
+            d4 = depths[s]
+            assert masks[s] is None or d4.size()[2:] == masks[s].size()[2:]
+            assert pose.size(1) == R
+            B, _, h, w = d4.shape
+            d = _f32c(d4.detach()[:, 0])
+            HW = h * w
+            downscale = tgt_img.size(2) / h
+            tgt_s = pyramid_cache.get(tgt_img, h, w)
+            no = _rigid_noocc(d, P_full_c, Kinv_full)                        # [B,4,h,w]
+            K_s, Kinv_s = _scaled_intrinsics(K_d, intrinsics_inv.detach(), downscale)
+            Kinv_s = _f32c(Kinv_s)
+            m = None if masks[s] is None else _f32c(masks[s].detach())
+            gd = torch.zeros_like(d) if want_grad else None
+            gm = torch.empty_like(m) if (m is not None and want_grad) else None
+            for r in range(R):
+                ref_s = pyramid_cache.get(refs[r], h, w)
+                with torch.enable_grad():
+                    P = projection_matrix(pose_l[:, r], K_s, cfg.rotation_mode)
+                Pc = _f32c(P.detach())
+                warped = torch.empty_like(ref_s)
+                E.call("cc_inverse_warp_fwd", ref_s, d, Pc, Kinv_s, warped, B, 3, h, w, cfg.border, cfg.ac, STREAM)
+                adj, scale = _photo_term(
+                    E, tgt_s, warped, no.view(-1)[r * HW:], 4 * HW,
+                    None if m is None else m.view(-1)[r * HW:], 4 * HW,
+                    None if gm is None else gm.view(-1)[r * HW:], 4 * HW, want_grad, cfg, loss_acc, nan_flag)
+                if want_grad:
+                    gw = torch.empty_like(warped)
+                    E.call("cc_ssim_photo_bwd", adj[0], adj[1], adj[2], adj[3], tgt_s, warped, scale, gw, 0, gauss13_ptr(),
+                           B, h, w, STREAM)
+                    gd_r = torch.empty_like(d)
+                    gP = torch.empty_like(Pc)
+                    ws = _empty(E.call("cc_warp_partials_bytes", B, h, w) // 4, d)
+                    E.call("cc_inverse_warp_bwd", gw, ref_s, d, Pc, Kinv_s, gd_r, gP, None, ws, B, 3, h, w, cfg.border,
+                           cfg.ac, STREAM)
+                    gd += gd_r
+                    if gm is not None:
+                        gm[:, r] *= scale
+                    gP_all.append(gP)
+                    P_all.append(P)
+            gdepths.append(None if gd is None else gd.unsqueeze(1))
+            gmasks.append(gm)
+        gpose = None
+        if want_grad and need[4]:
+            gpose = torch.autograd.grad(P_all, pose_l, gP_all)[0]
+        _register_nan_flag(nan_flag)
+        ctx.stash = [gpose] + [None] * R + gdepths + gmasks
+        ctx.need = need
+        return loss_acc.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        grads = _scale_grads(ctx.stash, gout)
+        need = ctx.need
+        out = [None, None, None, None] + grads
+        return tuple(g if (g is not None and need[i]) else None for i, g in enumerate(out))
+
+
+def photometric_reconstruction_loss(tgt_img, ref_imgs, intrinsics, intrinsics_inv, depth, explainability_mask, pose,
+                                    rotation_mode='euler', padding_mode='zeros', lambda_oob=0, qch=0.5, wssim=0.5,
+                                    align_corners=None):
+    """loss_functions.py:80-128."""
+    if type(explainability_mask) not in [tuple, list]:
+        explainability_mask = [explainability_mask]
+    if type(depth) not in [list, tuple]:
+        depth = [depth]
+    n = min(len(depth), len(explainability_mask))            # zip() semantics of :125
+    depth, explainability_mask = list(depth[:n]), list(explainability_mask[:n])
+    if pose.size(1) != 4:
+        raise IndexError("depth_occlusion_masks needs 4 reference frames (loss_functions.py:132-137)")
+    cfg = _PhotoCfg(n_refs=len(ref_imgs), n_scales=n, rotation_mode=rotation_mode,
+                    border=1 if padding_mode == 'border' else 0, ac=_ac(align_corners), lambda_oob=lambda_oob,
+                    qch=qch, wssim=wssim)
+    return _PhotoRigidFn.apply(cfg, tgt_img, intrinsics, intrinsics_inv, pose, *ref_imgs, *depth, *explainability_mask)
+
+
+class _PhotoFlowFn(torch.autograd.Function):
+    """loss_functions.py:27-77 over all scales; flows = [flow list of ref 0, flow list of ref 1]."""
+
+    @staticmethod
+    def forward(ctx, cfg, tgt_img, *rest):
+        R, S = cfg.n_refs, cfg.n_scales
+        refs = rest[:R]
+        flows = [rest[R + i * S:R + (i + 1) * S] for i in range(R)]
+        masks = rest[R + R * S:]
+        E = engine()
+        need = ctx.needs_input_grad
+        want_grad = any(need)
+        loss_acc, nan_flag = _zeros1(tgt_img), _zeros1(tgt_img)
+        gflows = [[None] * S for _ in range(R)]
+        gmasks = []
+        for s in range(S):
+            fl = [_f32c(flows[i][s].detach()) for i in range(R)]
+            B, _, h, w = fl[0].shape
+            HW = h * w
+            assert masks[s] is None or fl[0].size()[2:] == masks[s].size()[2:]
+            tgt_s = pyramid_cache.get(tgt_img, h, w)
+            no = torch.empty(B, 1, h, w, device=tgt_img.device, dtype=torch.float32)
+            E.call("cc_flow_noocc", fl[0], fl[1], no, B, h, w, STREAM)        # occlusion_masks(flow[0], flow[1]), :70
+            m = None if masks[s] is None else _f32c(masks[s].detach())
+            MC = 0 if m is None else m.shape[1]
+            gm = torch.empty_like(m) if (m is not None and want_grad) else None
+            for i in range(R):
+                ref_s = pyramid_cache.get(refs[i], h, w)
+                warped = torch.empty_like(ref_s)
+                E.call("cc_flow_warp_fwd", ref_s, fl[i], warped, B, 3, h, w, 0, cfg.ac, STREAM)
+                adj, scale = _photo_term(
+                    E, tgt_s, warped, no, HW,
+                    None if m is None else m.view(-1)[i * HW:], MC * HW,
+                    None if gm is None else gm.view(-1)[i * HW:], MC * HW, want_grad, cfg, loss_acc, nan_flag)
+                if want_grad:
+                    gw = torch.empty_like(warped)
+                    E.call("cc_ssim_photo_bwd", adj[0], adj[1], adj[2], adj[3], tgt_s, warped, scale, gw, 0, gauss13_ptr(),
+                           B, h, w, STREAM)
+                    gf = torch.empty_like(fl[i])
+                    E.call("cc_flow_warp_bwd", gw, ref_s, fl[i], gf, None, B, 3, h, w, 0, cfg.ac, STREAM)
+                    gflows[i][s] = gf
+                    if gm is not None:
+                        gm[:, i] *= scale
+            if gm is not None and MC > R:
+                gm[:, R:] = 0
+            gmasks.append(gm)
+        _register_nan_flag(nan_flag)
+        ctx.stash = [None] * R + [g for i in range(R) for g in gflows[i]] + gmasks
+        ctx.need = need
+        return loss_acc.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        grads = _scale_grads(ctx.stash, gout)
+        need = ctx.need
+        out = [None, None] + grads
+        return tuple(g if (g is not None and need[i]) else None for i, g in enumerate(out))
+
+
+def photometric_flow_loss(tgt_img, ref_imgs, flows, explainability_mask, lambda_oob=0, qch=0.5, wssim=0.5,
+                          align_corners=None):
+    """loss_functions.py:27-77."""
+    if type(flows[0]) not in [tuple, list]:
+        if explainability_mask is not None:
+            explainability_mask = [explainability_mask]
+        flows = [[uv] for uv in flows]
+    S = len(flows[0])
+    if explainability_mask is None:
+        explainability_mask = [None] * S
+    assert len(flows) == len(ref_imgs)
+    if len(flows) != 2:
+        raise IndexError("occlusion_masks needs exactly two flows (loss_functions.py:70)")
+    cfg = _PhotoCfg(n_refs=len(ref_imgs), n_scales=S, ac=_ac(align_corners), lambda_oob=lambda_oob, qch=qch, wssim=wssim)
+    flat = [f for uv in flows for f in uv]
+    return _PhotoFlowFn.apply(cfg, tgt_img, *ref_imgs, *flat, *list(explainability_mask)[:S])
+
+
+# ----------------------------------------------------------------------------- mask / smoothness losses
+def gaussian_explainability_loss(mask):
+    """loss_functions.py:139-145 (imported by train.py:24, never called): stock torch."""
+    if type(mask) not in [tuple, list]:
+        mask = [mask]
+    loss = 0
+    for mask_scaled in mask:
+        loss += torch.exp(-torch.mean((mask_scaled - 0.5).pow(2)) / 0.15)
+    return loss
+
+
+class _PerScaleFn(torch.autograd.Function):
+    """Shared driver: sum over scales of a fused value+gradient kernel on one prediction list."""
+
+    @staticmethod
+    def forward(ctx, launch, *preds):
+        need = ctx.needs_input_grad
+        loss_acc = _zeros1(preds[0])
+        stash = []
+        for s, p in enumerate(preds):
+            pc = _f32c(p.detach())
+            g = torch.empty_like(pc) if need[1 + s] else None
+            launch(s, pc, g, loss_acc)
+            stash.append(g)
+        ctx.stash = stash
+        return loss_acc.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        return (None,) + tuple(_scale_grads(ctx.stash, gout))
+
+
+def explainability_loss(mask):
+    """loss_functions.py:148-155: sum over scales of BCE(mask, ones)."""
+    if type(mask) not in [tuple, list]:
+        mask = [mask]
+    E = engine()
+
+    def launch(s, p, g, acc):
+        n = p.numel()
+        E.call("cc_bce_ones_fwd_bwd", p, g, _empty(E.call("cc_elem_num_blocks", n), p), acc, 1.0, n, STREAM)
+    return _PerScaleFn.apply(launch, *mask)
+
+
+def edge_aware_smoothness_loss(img, pred_disp):
+    """loss_functions.py:287-319."""
+    E = engine()
+
+    def launch(s, p, g, acc):
+        B, C, h, w = p.shape
+        im = pyramid_cache.get(img, h, w)
+        nb = E.call("cc_elem_num_blocks", h * w) * B * C
+        E.call("cc_edge_smooth_fwd_bwd", im, p, g, _empty(nb, p), acc, 1.0, B, C, h, w, STREAM)
+    return _PerScaleFn.apply(launch, *pred_disp)
+
+
+def smooth_loss(pred_disp):
+    """loss_functions.py:323-341."""
+    if type(pred_disp) not in [tuple, list]:
+        pred_disp = [pred_disp]
+    E = engine()
+
+    def launch(s, p, g, acc):
+        B, C, h, w = p.shape
+        nb = E.call("cc_elem_num_blocks", h * w) * B * C
+        E.call("cc_smooth2_fwd_bwd", p, g, _empty(nb, p), acc, 1.0 / (2.3 ** s), 1.0, B * C, h, w, STREAM)
+    return _PerScaleFn.apply(launch, *pred_disp)
+
+
+# ----------------------------------------------------------------------------- consensus
+def consensus_exp_masks(cam_flows_fwd, cam_flows_bwd, flows_fwd, flows_bwd, tgt_img, ref_img_fwd, ref_img_bwd, wssim,
+                        wrig, ws=0.1, align_corners=None):
+    """loss_functions.py:160-202: per-pixel {0,1} consensus target (non-differentiable; `ws` is unused there too)."""
+    E = engine()
+    ac = _ac(align_corners)
+    out = []
+    with torch.no_grad():
+        for i in range(len(cam_flows_fwd)):
+            cf, cb, ff = _f32c(cam_flows_fwd[i]), _f32c(cam_flows_bwd[i]), _f32c(flows_fwd[i])
+            B, _, h, w = cf.shape
+            tgt_s = pyramid_cache.get(tgt_img, h, w)
+            rf = pyramid_cache.get(ref_img_fwd, h, w)
+            rb = pyramid_cache.get(ref_img_bwd, h, w)
+            errs, valids = [], []
+            for src, flow in ((rf, cf), (rb, cb), (rf, ff)):
+                warped = torch.empty_like(src)
+                E.call("cc_flow_warp_fwd", src, flow, warped, B, 3, h, w, 0, ac, STREAM)
+                err = torch.empty(B, 1, h, w, device=src.device, dtype=torch.float32)
+                valid = torch.empty_like(err)
+                E.call("cc_ssim_err_fwd", tgt_s, warped, err, valid, float(wssim), gauss13_ptr(), B, h, w, STREAM)
+                errs.append(err)
+                valids.append(valid)
+            target = torch.empty_like(errs[0])
+            E.call("cc_consensus_target", errs[0], errs[1], errs[2], valids[0], valids[1], target, float(wrig),
+                   target.numel(), STREAM)
+            out.append(target)
+    return out
+
+
+def compute_joint_mask_for_depth(explainability_mask, rigidity_mask_bwd, rigidity_mask_fwd, THRESH):
+    """loss_functions.py:204-219 (optional path, broken in train.py -- H10); stock torch."""
+    joint_masks = []
+    for i in range(len(explainability_mask)):
+        e = explainability_mask[i]
+        rf = (rigidity_mask_fwd[i] > THRESH).type_as(e)
+        rb = (rigidity_mask_bwd[i] > THRESH).type_as(e)
+        ej = 1 - (1 - e[:, 1]) * (1 - e[:, 2]).unsqueeze(1) > 0.5
+        jf = logical_or(rf.type_as(e), ej.type_as(e)).detach()
+        jb = logical_or(rb.type_as(e), ej.type_as(e)).detach()
+        joint_masks.append(torch.cat((jb, jb, jf, jf), dim=1))
+    return joint_masks
+
+
+class _ConsensusBCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, *rest):
+        S = cfg.n_scales
+        masks = rest[:S]
+        cb, cf, tb, tf = (rest[S * (k + 1):S * (k + 2)] for k in range(4))
+        E = engine()
+        need = ctx.needs_input_grad
+        loss_acc = _zeros1(masks[0])
+        stash = []
+        for s in range(S):
+            e = _f32c(masks[s].detach())
+            B, C, h, w = e.shape
+            assert C == 4
+            g = torch.empty_like(e) if need[1 + s] else None
+            nb = E.call("cc_elem_num_blocks", h * w) * B
+            E.call("cc_consensus_bce_fwd_bwd", e, _f32c(cb[s].detach()), _f32c(cf[s].detach()), _f32c(tb[s].detach()),
+                   _f32c(tf[s].detach()), g, _empty(nb, e), loss_acc, float(cfg.THRESH), float(cfg.wbce), 1.0, B, h, w,
+                   STREAM)
+            stash.append(g)
+        ctx.stash = stash
+        ctx.n_rest = len(rest)
+        return loss_acc.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        g = _scale_grads(ctx.stash, gout)
+        return (None,) + tuple(g) + (None,) * (ctx.n_rest - len(g))
+
+
+def consensus_depth_flow_mask(explainability_mask, census_mask_bwd, census_mask_fwd, exp_masks_bwd_target,
+                              exp_masks_fwd_target, THRESH, wbce):
+    """loss_functions.py:221-250."""
+    assert len(explainability_mask) == len(census_mask_bwd)
+    assert len(explainability_mask) == len(census_mask_fwd)
+    cfg = _PhotoCfg(n_scales=len(explainability_mask), THRESH=THRESH, wbce=wbce)
+    return _ConsensusBCEFn.apply(cfg, *explainability_mask, *census_mask_bwd, *census_mask_fwd, *exp_masks_bwd_target,
+                                 *exp_masks_fwd_target)
+
+
+def weighted_binary_cross_entropy(output, target, weights=None):
+    """loss_functions.py:252-261 (public helper; the training path uses the fused kernel above)."""
+    if weights is not None:
+        assert len(weights) == 2
+        loss = weights[1] * (target * torch.log(output + epsilon)) + \
+            weights[0] * ((1 - target) * torch.log(1 - output + epsilon))
+    else:
+        loss = target * torch.log(output + epsilon) + (1 - target) * torch.log(1 - output + epsilon)
+    return torch.neg(torch.mean(loss))

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-int cc_version(void);
+size_t cc_version(void);
 
 /* ---------------------------------------------------------------- geometry (inverse_warp.py) */
 
@@ -69,7 +69,7 @@ int cc_feature_warp_bwd(const float* gout, const float* feat, const float* flow,
  * (ssim.py:9-11, sigma 1.5), copied into the kernel arguments at launch. */
 
 /* number of 32x32 tiles = length of the partial-sum buffer of cc_ssim_photo_fwd (x4 floats) */
-int cc_ssim_num_blocks(int B, int H, int W);
+size_t cc_ssim_num_blocks(int B, int H, int W);
 
 /* ssim.py:68-76 ssim(img1, img2, window_size=13): per-pixel, per-channel map [B,3,H,W], zero padding 6 */
 int cc_ssim_fwd(const float* img1, const float* img2, float* out, const float* gauss13_host, int B, int H, int W,
@@ -108,6 +108,43 @@ int cc_ssim_err_fwd(const float* tgt, const float* warped, float* err, float* va
 int cc_consensus_target(const float* err_cam_fwd, const float* err_cam_bwd, const float* err_flow_fwd,
                         const float* valid_cam_fwd, const float* valid_cam_bwd, float* target, float wrig, int n,
                         void* stream);
+
+/* ---------------------------------------------------------------- pyramid, masks, smoothness, BCE (loss_functions.py)
+ * Every *_fwd_bwd entry adds its loss value into loss_accum[0] (device scalar) and, when the gradient
+ * pointer is non-null, writes d(value)/d(input) * gscale in the same pass.  partials: scratch of
+ * (number of workgroups) floats -- cc_elem_num_blocks(H*W) * planes. */
+size_t cc_elem_num_blocks(int n);
+
+/* F.adaptive_avg_pool2d(x, (h, w)) as used at loss_functions.py:36-37,89-90,163-165,315 */
+int cc_adaptive_avg_pool(const float* in, float* out, int planes, int H, int W, int h, int w, void* stream);
+/* the same for levels 1..nlevels-1 (sizes H>>l x W>>l), packed back to back in out_packed */
+int cc_pyramid_build(const float* level0, float* out_packed, int nlevels, int planes, int H, int W, void* stream);
+
+/* loss_functions.py:343-352 occlusion_masks -> (1 - occ) [B,1,H,W] (occ_fw == occ_bw) */
+int cc_flow_noocc(const float* flow_bw, const float* flow_fw, float* out, int B, int H, int W, void* stream);
+/* loss_functions.py:132-137 depth_occlusion_masks -> (1 - occ) [B,4,H,W]; flows4 = the four rigid flows
+ * [4][B,2,H,W] (pose2flow with the full-resolution K) */
+int cc_rigid_noocc(const float* flows4, float* out, int B, int H, int W, void* stream);
+
+/* accum[0] += coef * sum(partials[0..n)) -- deterministic second reduction stage */
+int cc_reduce_add(const float* partials, int n, float coef, float* accum, void* stream);
+
+/* loss_functions.py:287-319 edge_aware_smoothness_loss, one scale (img already pooled to H x W) */
+int cc_edge_smooth_fwd_bwd(const float* img, const float* pred, float* gpred_or_null, float* partials, float* loss_accum,
+                           float gscale, int B, int C, int H, int W, void* stream);
+/* loss_functions.py:323-341 smooth_loss, one scale (weight = 1/2.3^scale) */
+int cc_smooth2_fwd_bwd(const float* pred, float* gpred_or_null, float* partials, float* loss_accum, float weight,
+                       float gscale, int planes, int H, int W, void* stream);
+/* loss_functions.py:148-155 explainability_loss, one scale: BCE(mask, 1) */
+int cc_bce_ones_fwd_bwd(const float* mask, float* gmask_or_null, float* partials, float* loss_accum, float gscale, int n,
+                        void* stream);
+/* loss_functions.py:221-261 consensus_depth_flow_mask + weighted_binary_cross_entropy, one scale */
+int cc_consensus_bce_fwd_bwd(const float* exp_mask, const float* census_bwd, const float* census_fwd,
+                             const float* target_bwd, const float* target_fwd, float* gmask_or_null, float* partials,
+                             float* loss_accum, float thresh, float wbce, float gscale, int B, int H, int W,
+                             void* stream);
+/* out = a * scalar_dev[0] */
+int cc_scale_by_scalar(const float* a, const float* scalar_dev, float* out, int n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,207 @@
+"""Shared parity cases: the HIP engine (cc_amd, through the C ABI) against the oracle on identical seeded
+inputs.  `dev` is "cuda" for the real library (-m gpu) or "cpu" for the x86 emulation build of the same
+kernel sources (tests/hipemu).  Tolerances are the ones SURVEY.md section 8c / BASELINE.json state."""
+import numpy as np
+import torch
+
+from cc_amd import synthetic as syn, inverse_warp as IW, loss_functions as LF, ssim as SS
+from oracle import geometry as G, losses as L
+from oracle.make_golden import pyramid_inputs
+
+
+def to(dev, *ts):
+    out = [t.to(dev) if torch.is_tensor(t) else [x.to(dev) for x in t] for t in ts]
+    return out if len(out) > 1 else out[0]
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def leaf(t, dev):
+    return t.detach().clone().to(dev).requires_grad_(True)
+
+
+def check_warps(dev, B=2, H=24, W=40, exact=True):
+    """a8/a9/a10 + Back2Future.warp: forward bit-exact (index arithmetic AND blend follow the CPU
+    reference's roundings), gradients to 1e-5 rel."""
+    tgt, refs, K, Kinv = syn.sample(B, H, W, seed=1)
+    ki = syn.kernel_inputs(B, H, W)
+    pose = ki["pose"] * 3
+    Kd, Kinvd = to(dev, K, Kinv)
+    for ac in (False, True):
+        for pad in ("zeros", "border"):
+            d, p, im = leaf(ki["depth"][:, 0], dev), leaf(pose[:, 0], dev), leaf(refs[0], dev)
+            d0, p0, im0 = leaf(ki["depth"][:, 0], "cpu"), leaf(pose[:, 0], "cpu"), leaf(refs[0], "cpu")
+            # the kernel boundary is P = K.[R|t]: feed the oracle's P so coordinates can be compared bit-for-bit
+            o = IW.inverse_warp(im, d, p, Kd, Kinvd, padding_mode=pad, align_corners=ac)
+            r = G.inverse_warp(im0, d0, p0, K, Kinv, padding_mode=pad, align_corners=ac)
+            go = torch.randn(r.shape, generator=torch.Generator().manual_seed(5))
+            o.backward(go.to(dev))
+            r.backward(go)
+            if exact:
+                Pc = G.projection(p0.detach(), K).reshape(-1, 12).to(dev)
+                oe = IW._InverseWarpFn.apply(im.detach(), d.detach(), Pc, Kinvd, 1 if pad == "border" else 0, int(ac))
+                assert torch.equal(oe.cpu(), r.detach()), "inverse_warp forward not bit-exact (ac=%s pad=%s)" % (ac, pad)
+            assert float((o.detach().cpu() - r.detach()).abs().max()) < 1e-5
+            assert rel(d.grad, d0.grad) < 2e-5 and rel(p.grad, p0.grad) < 2e-5 and rel(im.grad, im0.grad) < 2e-5
+        d, p = leaf(ki["depth"][:, 0], dev), leaf(pose[:, 1], dev)
+        d0, p0 = leaf(ki["depth"][:, 0], "cpu"), leaf(pose[:, 1], "cpu")
+        f, f0 = IW.pose2flow(d, p, Kd, Kinvd), G.pose2flow(d0, p0, K, Kinv)
+        if exact:
+            Pc = G.projection(p0.detach(), K).reshape(-1, 12).to(dev)
+            fe = IW._Pose2FlowFn.apply(d.detach(), Pc, Kinvd, 0)
+            assert torch.equal(fe.cpu(), f0.detach()), "pose2flow not bit-exact"
+        assert float((f.detach().cpu() - f0.detach()).abs().max()) < 1e-3
+        gf = torch.randn(f0.shape, generator=torch.Generator().manual_seed(6))
+        g1 = torch.autograd.grad(f, [d, p], gf.to(dev))
+        g0 = torch.autograd.grad(f0, [d0, p0], gf)
+        assert rel(g1[0], g0[0]) < 2e-5 and rel(g1[1], g0[1]) < 2e-5
+        fl, im = leaf(ki["flow_fwd"], dev), leaf(refs[1], dev)
+        fl0, im0 = leaf(ki["flow_fwd"], "cpu"), leaf(refs[1], "cpu")
+        o, r = IW.flow_warp(im, fl, align_corners=ac), G.flow_warp(im0, fl0, align_corners=ac)
+        assert torch.equal(o.detach().cpu(), r.detach()), "flow_warp forward not bit-exact"
+        go = torch.randn(r.shape, generator=torch.Generator().manual_seed(7))
+        g1 = torch.autograd.grad(o, [im, fl], go.to(dev))
+        g0 = torch.autograd.grad(r, [im0, fl0], go)
+        assert rel(g1[0], g0[0]) < 2e-5 and rel(g1[1], g0[1]) < 2e-5
+        ft = torch.randn(B, 8, H, W, generator=torch.Generator().manual_seed(8))
+        fe, fe0 = leaf(ft, dev), leaf(ft, "cpu")
+        o, r = IW.feature_warp(fe, fl, align_corners=ac), G.feature_warp(fe0, fl0, align_corners=ac)
+        assert torch.equal(o.detach().cpu(), r.detach()), "feature_warp forward not bit-exact"
+        go = torch.randn(r.shape, generator=torch.Generator().manual_seed(9))
+        g1 = torch.autograd.grad(o, [fe, fl], go.to(dev))
+        g0 = torch.autograd.grad(r, [fe0, fl0], go)
+        assert rel(g1[0], g0[0]) < 2e-5 and rel(g1[1], g0[1]) < 2e-5
+
+
+def check_ssim(dev, cases=((2, 40, 70, 0), (1, 64, 96, 3), (2, 8, 26, 0), (1, 33, 31, 1))):
+    """a11: per-pixel 2e-4 abs (fp32 cancellation noise of the reference itself), mean 1e-5 rel."""
+    for (B, H, W, smooth) in cases:
+        fr = syn.frames(B, H, W, seed=3, n_frames=2, smooth=smooth)
+        x, y = leaf(fr[0], dev), leaf(fr[1], dev)
+        x0, y0 = leaf(fr[0], "cpu"), leaf(fr[1], "cpu")
+        o, r = SS.ssim(x, y), L.ssim(x0, y0)
+        assert float((o.detach().cpu() - r.detach()).abs().max()) < 2e-4
+        assert abs(float(o.mean()) - float(r.mean())) < 1e-5 * abs(float(r.mean())) + 1e-7
+        go = torch.randn(r.shape, generator=torch.Generator().manual_seed(4))
+        g1 = torch.autograd.grad(o, [x, y], go.to(dev))
+        g0 = torch.autograd.grad(r, [x0, y0], go)
+        assert rel(g1[0], g0[0]) < 5e-5 and rel(g1[1], g0[1]) < 5e-5
+    xx = torch.rand(1, 3, 20, 30)
+    assert float((SS.ssim(xx.to(dev), xx.to(dev)).cpu() - 1).abs().max()) < 1e-5     # ssim(x, x) == 1
+
+
+def _pyr(dev, B, H, W):
+    tgt, refs, K, Kinv = syn.sample(B, H, W, seed=1)
+    pyr = pyramid_inputs(B, H, W)
+    pose = syn.kernel_inputs(B, 8, 8, seed=2)["pose"] * 3.0
+
+    def mk(d):
+        return dict(depth=[leaf(p["depth"], d) for p in pyr], mask=[leaf(p["mask"], d) for p in pyr],
+                    ff=[leaf(p["flow_fwd"], d) for p in pyr], fb=[leaf(p["flow_bwd"], d) for p in pyr],
+                    pose=leaf(pose, d), tgt=tgt.to(d), refs=[r.to(d) for r in refs], K=K.to(d), Kinv=Kinv.to(d))
+    return mk(dev), mk("cpu")
+
+
+def _cmp(name, l1, l0, w1, w0, ltol=1e-4, gtol=1e-4):
+    assert abs(float(l1) - float(l0)) <= ltol * abs(float(l0)), (name, float(l1), float(l0))
+    g1 = torch.autograd.grad(l1, w1, allow_unused=True)
+    g0 = torch.autograd.grad(l0, w0, allow_unused=True)
+    for a, b in zip(g1, g0):
+        assert (a is None) == (b is None), name
+        if b is not None:
+            assert rel(a, b) < gtol, (name, rel(a, b))
+
+
+def check_losses(dev, B=2, H=64, W=96):
+    """a12-a17 with gradients (north-star bar: losses within 1e-4 rel of the reference CPU path)."""
+    for ac in (False, True):
+        a, o = _pyr(dev, B, H, W)
+        _cmp("photometric_reconstruction_loss",
+             LF.photometric_reconstruction_loss(a["tgt"], a["refs"], a["K"], a["Kinv"], a["depth"], a["mask"], a["pose"],
+                                                wssim=0.997, qch=0.5, align_corners=ac),
+             L.photometric_reconstruction_loss(o["tgt"], o["refs"], o["K"], o["Kinv"], o["depth"], o["mask"], o["pose"],
+                                               wssim=0.997, qch=0.5, align_corners=ac),
+             a["depth"] + a["mask"] + [a["pose"]], o["depth"] + o["mask"] + [o["pose"]])
+        a, o = _pyr(dev, B, H, W)
+        _cmp("photometric_reconstruction_loss(no mask, lambda_oob, qch=0.4)",
+             LF.photometric_reconstruction_loss(a["tgt"], a["refs"], a["K"], a["Kinv"], a["depth"], [None] * 6, a["pose"],
+                                                wssim=0.5, qch=0.4, lambda_oob=0.3, align_corners=ac),
+             L.photometric_reconstruction_loss(o["tgt"], o["refs"], o["K"], o["Kinv"], o["depth"], [None] * 6, o["pose"],
+                                               wssim=0.5, qch=0.4, lambda_oob=0.3, align_corners=ac),
+             a["depth"] + [a["pose"]], o["depth"] + [o["pose"]])
+        a, o = _pyr(dev, B, H, W)
+        _cmp("photometric_flow_loss",
+             LF.photometric_flow_loss(a["tgt"], a["refs"][1:3], [a["fb"], a["ff"]], [1 - m[:, 1:3] for m in a["mask"]],
+                                      wssim=0.997, align_corners=ac),
+             L.photometric_flow_loss(o["tgt"], o["refs"][1:3], [o["fb"], o["ff"]], [1 - m[:, 1:3] for m in o["mask"]],
+                                     wssim=0.997, align_corners=ac),
+             a["ff"] + a["fb"] + a["mask"], o["ff"] + o["fb"] + o["mask"])
+    a, o = _pyr(dev, B, H, W)
+    _cmp("explainability_loss", LF.explainability_loss(a["mask"]), L.explainability_loss(o["mask"]), a["mask"], o["mask"])
+    for nm in ("depth", "ff", "mask"):
+        a, o = _pyr(dev, B, H, W)
+        # 5 scales: the 6th (2x3) makes the reference's smooth_loss NaN (mean over an empty tensor)
+        _cmp("smooth_loss " + nm, LF.smooth_loss(a[nm][:5]), L.smooth_loss(o[nm][:5]), a[nm][:5], o[nm][:5])
+        assert torch.isnan(LF.smooth_loss(a[nm])) and torch.isnan(L.smooth_loss(o[nm]))
+        _cmp("edge_aware_smoothness_loss " + nm, LF.edge_aware_smoothness_loss(a["tgt"], a[nm]),
+             L.edge_aware_smoothness_loss(o["tgt"], o[nm]), a[nm], o[nm])
+    a, o = _pyr(dev, B, H, W)
+    with torch.no_grad():
+        cf1 = [IW.pose2flow(d[:, 0], a["pose"][:, 2], a["K"], a["Kinv"]) for d in a["depth"]]
+        cb1 = [IW.pose2flow(d[:, 0], a["pose"][:, 1], a["K"], a["Kinv"]) for d in a["depth"]]
+        cf0 = [G.pose2flow(d[:, 0], o["pose"][:, 2], o["K"], o["Kinv"]) for d in o["depth"]]
+        cb0 = [G.pose2flow(d[:, 0], o["pose"][:, 1], o["K"], o["Kinv"]) for d in o["depth"]]
+        t1 = LF.consensus_exp_masks(cf1, cb1, a["ff"], a["fb"], a["tgt"], a["refs"][2], a["refs"][1], wssim=0.997, wrig=1.0)
+        t0 = L.consensus_exp_masks(cf0, cb0, o["ff"], o["fb"], o["tgt"], o["refs"][2], o["refs"][1], wssim=0.997, wrig=1.0)
+        for x, y in zip(t1, t0):
+            assert float((x.cpu() != y).float().mean()) <= 2e-3      # discontinuous output: flip rate
+        assert 0.2 < float(t0[0].mean()) < 0.95                        # both classes present at the fine level
+        occ1 = LF.depth_occlusion_masks(a["depth"][0], a["pose"], a["K"], a["Kinv"])
+        occ0 = L.depth_occlusion_masks(o["depth"][0], o["pose"], o["K"], o["Kinv"])
+        assert float((occ1.cpu() != occ0).float().mean()) <= 1e-5
+        big_b, big_f = o["fb"][0] * 3 + 4, o["ff"][0] * 3 + 4         # force occlusions (signed-sum rule, Q5)
+        ob1, of1 = LF.occlusion_masks(big_b.to(dev), big_f.to(dev))
+        ob0, of0 = L.occlusion_masks(big_b, big_f)
+        assert torch.equal(ob1.cpu(), ob0) and torch.equal(of1.cpu(), of0) and 0.05 < float(ob0.mean()) < 0.95
+        rf = [(x - y).abs() for x, y in zip(cf0, o["ff"])]
+        rb = [(x - y).abs() for x, y in zip(cb0, o["fb"])]
+    _cmp("consensus_depth_flow_mask",
+         LF.consensus_depth_flow_mask(a["mask"], to(dev, rb), to(dev, rf), to(dev, t0), to(dev, t0), THRESH=0.5, wbce=0.5),
+         L.consensus_depth_flow_mask(o["mask"], rb, rf, t0, t0, THRESH=0.5, wbce=0.5), a["mask"], o["mask"])
+
+
+def check_occluded_photo_loss(dev, B=2, H=32, W=48):
+    """photometric_flow_loss with flows large enough that the occlusion factor (1 - occ) is exercised."""
+    tgt, refs, K, Kinv = syn.sample(B, H, W, seed=4)
+    ki = syn.kernel_inputs(B, H, W, seed=9)
+    fb, ff = ki["flow_bwd"] * 0.5 + 0.3, ki["flow_fwd"] * 0.5 + 0.3
+    assert 0.05 < float(L.occlusion_masks(fb, ff)[0].mean()) < 0.95
+    m = ki["mask"][:, :2].contiguous()
+    a = dict(fb=leaf(fb, dev), ff=leaf(ff, dev), m=leaf(m, dev))
+    o = dict(fb=leaf(fb, "cpu"), ff=leaf(ff, "cpu"), m=leaf(m, "cpu"))
+    _cmp("photometric_flow_loss (occluded, single scale)",
+         LF.photometric_flow_loss(tgt.to(dev), to(dev, refs[1:3]), [a["fb"], a["ff"]], a["m"], wssim=0.5),
+         L.photometric_flow_loss(tgt, refs[1:3], [o["fb"], o["ff"]], o["m"], wssim=0.5),
+         [a["fb"], a["ff"], a["m"]], [o["fb"], o["ff"], o["m"]])
+
+
+def check_pyramid(dev):
+    from cc_amd._lib import engine, STREAM
+    x = syn.frames(2, 64, 96, seed=11, n_frames=1)[0]
+    xd = x.to(dev)
+    for (h, w) in ((32, 48), (16, 24), (2, 3), (20, 31)):
+        ref = torch.nn.functional.adaptive_avg_pool2d(x, (h, w))
+        out = torch.empty(2, 3, h, w, device=dev)
+        engine().call("cc_adaptive_avg_pool", xd, out, 6, 64, 96, h, w, STREAM)
+        assert float((out.cpu() - ref).abs().max()) < 1e-6
+    packed = torch.empty(6 * (32 * 48 + 16 * 24 + 8 * 12), device=dev)
+    engine().call("cc_pyramid_build", xd, packed, 4, 6, 64, 96, STREAM)
+    off = 0
+    for l in (1, 2, 3):
+        h, w = 64 >> l, 96 >> l
+        lv = packed[off:off + 6 * h * w].view(2, 3, h, w).cpu()
+        assert float((lv - torch.nn.functional.adaptive_avg_pool2d(x, (h, w))).abs().max()) < 1e-6
+        off += 6 * h * w

@@ -1,0 +1,33 @@
+"""CPU-side parity of the HIP kernel SOURCES: cc_amd/csrc/*.hip compiled for x86 against the fiber-based
+HIP shim (tests/hipemu) and driven through cc_amd's real Python glue + C ABI, vs the oracle.  The same
+cases run against the real gfx950 library in tests/test_kernels_gpu.py (-m gpu)."""
+import pytest
+
+import parity
+from hipemu.emu import emulated_engine
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _emu():
+    with emulated_engine():
+        yield
+
+
+def test_warps():
+    parity.check_warps("cpu")
+
+
+def test_ssim():
+    parity.check_ssim("cpu")
+
+
+def test_losses():
+    parity.check_losses("cpu")
+
+
+def test_occluded_flow_loss():
+    parity.check_occluded_photo_loss("cpu")
+
+
+def test_pyramid():
+    parity.check_pyramid("cpu")

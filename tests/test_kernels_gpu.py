@@ -1,0 +1,40 @@
+"""Parity tests proper: the real libccengine.so (gfx950) through the C ABI vs the oracle (CPU) on the same
+seeded inputs.  Needs an MI355X: run with `-m gpu` via gpurun."""
+import pytest
+import torch
+
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def test_library_is_the_hip_build():
+    from cc_amd import _lib
+    e = _lib.engine()
+    assert e.path.endswith("cc_amd/libccengine.so") and e.require_device
+    assert torch.cuda.is_available()
+
+
+def test_warps():
+    parity.check_warps("cuda")
+
+
+def test_warps_full_size():
+    parity.check_warps("cuda", B=2, H=256, W=832)
+
+
+def test_ssim():
+    parity.check_ssim("cuda")
+    parity.check_ssim("cuda", cases=((2, 256, 832, 2),))
+
+
+def test_losses():
+    parity.check_losses("cuda")
+
+
+def test_occluded_flow_loss():
+    parity.check_occluded_photo_loss("cuda")
+
+
+def test_pyramid():
+    parity.check_pyramid("cuda")
