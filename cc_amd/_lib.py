@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "ccengine.h")
 LIB_PATH = os.path.join(_HERE, "libccengine.so")
 
-_CT = {"int": ctypes.c_int, "float": ctypes.c_float, "size_t": ctypes.c_size_t, "double": ctypes.c_double}
+_CT = {"long": ctypes.c_long, "int": ctypes.c_int, "float": ctypes.c_float, "size_t": ctypes.c_size_t, "double": ctypes.c_double}
 
 STREAM = object()      # placeholder argument: "the current torch stream"
 

@@ -1,0 +1,531 @@
+// fp32 convolutions of the four CC networks on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32:
+// exact fp32, bit-equal to an fmaf chain, 157 TFLOP/s peak).  Replaces cuDNN/MIOpen's conv2d,
+// conv_transpose2d and convolution_backward (219 forward + 297 backward calls per step).
+//
+// ONE implicit-GEMM "gather-GEMM" kernel covers conv forward, conv data-gradient, transposed-conv forward
+// and transposed-conv data-gradient:
+//      Y[n, m, P(t)] = epilogue( sum_{c, i, j}  A[m, (c,i,j)] * X[n, c, si*ty + dy(i), si*tx + dx(j)] )
+//   * output pixels t = (ty, tx) live on a lattice  P(t) = (oy0 + so*ty, ox0 + so*tx)   (so = 2 selects one
+//     parity class of a stride-2 transposed conv / stride-2 data-gradient, so no MFMA work is spent on
+//     structurally-zero taps);
+//   * the taps form a regular Rt x St grid: dy(i) = dy0 + i*dstep, dx(j) = dx0 + j*dstep, and the weight of
+//     (m, c, i, j) sits at  w[w0 + m*w_sm + c*w_sc + i*w_ri + j*w_sj]  -- strides express [K,C,R,S] weights,
+//     their transpose/flip for data-gradients, and ConvTranspose2d's [Cin,Cout,R,S] layout without repacking.
+// GEMM view: M = output channels, N = B*OHt*OWt lattice pixels (contiguous in NCHW -> coalesced stores, and
+// MFMA D columns map to lanes = pixels), K = Cin*Rt*St gathered on the fly (im2col never materialised).
+// Tile: BM x 128 pixels x 16 (K) per 256-thread workgroup, 4 waves of (BM/2 or 32) x (64 or 32) built from
+// 32x32x2 MFMAs; register-staged double-buffered LDS, one barrier per K chunk.  B-tile loads are
+// lane = pixel (coalesced along x) with a wave-uniform k so the (c,i,j) decode runs on the scalar unit.
+// Epilogue fuses bias, residual add, ReLU / LeakyReLU(0.2) / a*sigmoid+b.
+//
+// Weight gradient: second kernel, M = channels of dY, N = (c,i,j), K = pixels, split over pixel ranges with a
+// deterministic second-stage reduction (no atomics).
+#include "cc_common.h"
+#include "../../include/ccengine.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BN = 128;   // pixels per workgroup tile
+constexpr int BK = 16;    // reduction chunk
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_SIGMOID = 3 };
+
+struct GG {
+    const float* x; const float* w; const float* bias; const float* res; float* y;
+    int B, Cin, IH, IW; long x_bs;
+    int M; long w_sm, w_sc; int w0, w_ri, w_sj;
+    int Rt, St, dy0, dx0, dstep, si;
+    int OHt, OWt, so, oy0, ox0, OH, OW; long y_bs, res_bs;
+    int act; float act_a, act_b;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act, float a, float b) {
+    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ACT_LRELU) return v > 0.f ? v : 0.2f * v;
+    if (act == ACT_SIGMOID) return a * (1.f / (1.f + expf(-v))) + b;
+    return v;
+}
+
+template <int BM>
+__global__ __launch_bounds__(256) void k_gather_gemm(GG g) {
+    constexpr int WM = (BM >= 64) ? BM / 2 : 32;     // wave tile rows
+    constexpr int WN = (BM >= 64) ? 64 : 32;         // wave tile cols
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int AP = BM + 4;                        // padded A row (k-major: As[k][m])
+    constexpr int AQ = BM / 16;                       // A elements per thread per chunk
+    __shared__ float As[2][BK * AP];
+    __shared__ float Bs[2][BK * BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (BM >= 64) ? (wid >> 1) : 0;
+    const int wn = (BM >= 64) ? (wid & 1) : wid;
+    const int m0 = blockIdx.y * BM;
+    const long p0 = (long)blockIdx.x * BN;
+    const int HWt = g.OHt * g.OWt;
+    const long Ntot = (long)g.B * HWt;
+    const int RS = g.Rt * g.St;
+    const int Ktot = g.Cin * RS;
+    const int x_cs = g.IH * g.IW;
+
+    // ---- loader roles
+    // B: pixel column jb, k rows kr0 + 2q
+    const int jb = tid & (BN - 1);
+    const int kr0 = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const long pb = p0 + jb;
+    const bool pvalid = pb < Ntot;
+    int iy0 = 0, ix0 = 0;
+    long xbase = 0;
+    if (pvalid) {
+        const int n = (int)(pb / HWt);
+        const int t = (int)(pb - (long)n * HWt);
+        const int ty = t / g.OWt, tx = t - ty * g.OWt;
+        iy0 = g.si * ty;
+        ix0 = g.si * tx;
+        xbase = (long)n * g.x_bs;
+    }
+    float ra[AQ], rb[8];
+
+    auto load_chunk = [&](int kbase) {
+        // A tile: element e = tid + 256q -> (m = e>>4, kk = e&15 = tid&15): one (c,i,j) decode per chunk
+        {
+            const int k = kbase + (tid & 15);
+            const bool kv = k < Ktot;
+            const int c = k / RS, rem = k - c * RS;
+            const int i = rem / g.St, j = rem - i * g.St;
+            const long woff = (long)g.w0 + (long)c * g.w_sc + i * g.w_ri + j * g.w_sj;
+#pragma unroll
+            for (int q = 0; q < AQ; q++) {
+                const int m = m0 + (tid >> 4) + 16 * q;
+                ra[q] = (kv && m < g.M) ? g.w[woff + (long)m * g.w_sm] : 0.f;
+            }
+        }
+        // B tile: k wave-uniform
+        int k = kbase + kr0;
+        int c = k / RS, rem = k - c * RS;
+        int i = rem / g.St, j = rem - i * g.St;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            float v = 0.f;
+            if (pvalid && k < Ktot) {
+                const int iy = iy0 + g.dy0 + i * g.dstep, ix = ix0 + g.dx0 + j * g.dstep;
+                if ((unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW)
+                    v = g.x[xbase + (long)c * x_cs + iy * g.IW + ix];
+            }
+            rb[q] = v;
+            k += 2;
+            j += 2;
+            while (j >= g.St) { j -= g.St; i++; }
+            while (i >= g.Rt) { i -= g.Rt; c++; }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < AQ; q++) {
+            const int e = tid + 256 * q;
+            As[buf][(e & 15) * AP + (e >> 4)] = ra[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) Bs[buf][(kr0 + 2 * q) * BN + jb] = rb[q];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; a++)
+#pragma unroll
+        for (int b = 0; b < TN; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    const int nchunks = (Ktot + BK - 1) / BK;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    const int l31 = lane & 31, lk = lane >> 5;
+    for (int ch = 0; ch < nchunks; ch++) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) load_chunk((ch + 1) * BK);
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ks++) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int a = 0; a < TM; a++) af[a] = As[buf][(2 * ks + lk) * AP + wm * WM + a * 32 + l31];
+#pragma unroll
+            for (int b = 0; b < TN; b++) bf[b] = Bs[buf][(2 * ks + lk) * BN + wn * WN + b * 32 + l31];
+#pragma unroll
+            for (int a = 0; a < TM; a++)
+#pragma unroll
+                for (int b = 0; b < TN; b++)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (ch + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D col = lane&31 -> pixel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> channel
+    const int y_cs = g.OH * g.OW;
+#pragma unroll
+    for (int b = 0; b < TN; b++) {
+        const long p = p0 + wn * WN + b * 32 + l31;
+        if (p >= Ntot) continue;
+        const int n = (int)(p / HWt);
+        const int t = (int)(p - (long)n * HWt);
+        const int ty = t / g.OWt, tx = t - ty * g.OWt;
+        const long pix = (long)(g.oy0 + g.so * ty) * g.OW + (g.ox0 + g.so * tx);
+        float* yb = g.y + (long)n * g.y_bs + pix;
+        const float* rbp = g.res ? g.res + (long)n * g.res_bs + pix : nullptr;
+#pragma unroll
+        for (int a = 0; a < TM; a++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m < g.M) {
+                    float v = acc[a][b][r];
+                    if (g.bias) v += g.bias[m];
+                    if (rbp) v += rbp[(long)m * y_cs];
+                    yb[(long)m * y_cs] = apply_act(v, g.act, g.act_a, g.act_b);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ weight gradient
+struct WG {
+    const float* a;   // "dY-like" tensor [B, M, AH, AW] (batch stride a_bs), sampled on the full lattice (ty, tx)
+    const float* x;   // gathered tensor [B, Cin, IH, IW]
+    float* out;       // partial tiles ws[split][M][N] (or the final gradient when nsplit == 1 -> strided store)
+    int B, M, AH, AW; long a_bs;
+    int Cin, IH, IW; long x_bs;
+    int Rt, St, dy0, dx0, dstep, si;
+    long o_sm, o_sc; int o_ri, o_sj;     // gradient strides (used when direct == 1)
+    int direct;
+    int pix_per_split;
+};
+
+template <int BM>
+__global__ __launch_bounds__(256) void k_wgrad(WG g) {
+    constexpr int WM = (BM >= 64) ? BM / 2 : 32;
+    constexpr int WN = (BM >= 64) ? 64 : 32;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int AP = BM + 4, BP = BN + 4;
+    constexpr int AQ = BM / 16;
+    __shared__ float As[2][BK * AP];   // As[pp][m]
+    __shared__ float Bs[2][BK * BP];   // Bs[pp][jn]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (BM >= 64) ? (wid >> 1) : 0;
+    const int wn = (BM >= 64) ? (wid & 1) : wid;
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int RS = g.Rt * g.St;
+    const int Ntot = g.Cin * RS;
+    const int HWa = g.AH * g.AW;
+    const long Ptot = (long)g.B * HWa;
+    const long pbeg = (long)blockIdx.z * g.pix_per_split;
+    long pend = pbeg + g.pix_per_split;
+    if (pend > Ptot) pend = Ptot;
+    const int x_cs = g.IH * g.IW;
+
+    // loader roles: pp = tid & 15 (pixel within the chunk), row group = tid >> 4 (16 groups)
+    const int pp = tid & 15, rgp = tid >> 4;
+    // B columns handled by this thread: jn = rgp + 16*q  -> constant over the pixel loop
+    int xoff[8], tdy[8], tdx[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int jn = n0 + rgp + 16 * q;
+        if (jn < Ntot) {
+            const int c = jn / RS, rem = jn - c * RS;
+            const int i = rem / g.St, j = rem - i * g.St;
+            tdy[q] = g.dy0 + i * g.dstep;
+            tdx[q] = g.dx0 + j * g.dstep;
+            xoff[q] = c * x_cs + tdy[q] * g.IW + tdx[q];
+        } else {
+            tdy[q] = -(1 << 28);
+            tdx[q] = 0;
+            xoff[q] = 0;
+        }
+    }
+    float ra[AQ], rb[8];
+    auto load_chunk = [&](long pbase) {
+        const long p = pbase + pp;
+        const bool pv = p < pend;
+        int n = 0, ty = 0, tx = 0;
+        if (pv) {
+            n = (int)(p / HWa);
+            const int t = (int)(p - (long)n * HWa);
+            ty = t / g.AW;
+            tx = t - ty * g.AW;
+        }
+#pragma unroll
+        for (int q = 0; q < AQ; q++) {
+            const int m = m0 + rgp + 16 * q;
+            ra[q] = (pv && m < g.M) ? g.a[(long)n * g.a_bs + (long)m * HWa + ty * g.AW + tx] : 0.f;
+        }
+        const int iy0 = g.si * ty, ix0 = g.si * tx;
+        const long xb = (long)n * g.x_bs + (long)iy0 * g.IW + ix0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int iy = iy0 + tdy[q], ix = ix0 + tdx[q];
+            rb[q] = (pv && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW) ? g.x[xb + xoff[q]] : 0.f;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < AQ; q++) As[buf][pp * AP + rgp + 16 * q] = ra[q];
+#pragma unroll
+        for (int q = 0; q < 8; q++) Bs[buf][pp * BP + rgp + 16 * q] = rb[q];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; a++)
+#pragma unroll
+        for (int b = 0; b < TN; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    const int l31 = lane & 31, lk = lane >> 5;
+    const long nchunks = (pend > pbeg) ? (pend - pbeg + BK - 1) / BK : 0;
+    if (nchunks > 0) {
+        load_chunk(pbeg);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (long ch = 0; ch < nchunks; ch++) {
+        const int buf = (int)(ch & 1);
+        if (ch + 1 < nchunks) load_chunk(pbeg + (ch + 1) * BK);
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ks++) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int a = 0; a < TM; a++) af[a] = As[buf][(2 * ks + lk) * AP + wm * WM + a * 32 + l31];
+#pragma unroll
+            for (int b = 0; b < TN; b++) bf[b] = Bs[buf][(2 * ks + lk) * BP + wn * WN + b * 32 + l31];
+#pragma unroll
+            for (int a = 0; a < TM; a++)
+#pragma unroll
+                for (int b = 0; b < TN; b++)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (ch + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue: D col = lane&31 -> (c,i,j) column, row -> channel m
+#pragma unroll
+    for (int b = 0; b < TN; b++) {
+        const int jn = n0 + wn * WN + b * 32 + l31;
+        if (jn >= Ntot) continue;
+        long obase;
+        if (g.direct) {
+            const int c = jn / RS, rem = jn - c * RS;
+            const int i = rem / g.St, j = rem - i * g.St;
+            obase = (long)c * g.o_sc + i * g.o_ri + j * g.o_sj;
+        } else {
+            obase = (long)blockIdx.z * g.M * Ntot + jn;
+        }
+#pragma unroll
+        for (int a = 0; a < TM; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m < g.M) g.out[obase + (g.direct ? (long)m * g.o_sm : (long)m * Ntot)] = acc[a][b][r];
+            }
+    }
+}
+
+// second stage: gw[m, (c,i,j)] = sum_split ws[split][m][(c,i,j)]
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ gw, int nsplit,
+                                                      int M, int Ntot, int RS, int St, long o_sm, long o_sc, int o_ri,
+                                                      int o_sj) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const long tot = (long)M * Ntot;
+    if (e >= tot) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; k++) s += ws[(long)k * tot + e];
+    const int m = (int)(e / Ntot), jn = (int)(e - (long)m * Ntot);
+    const int c = jn / RS, rem = jn - c * RS;
+    const int i = rem / St, j = rem - i * St;
+    gw[(long)m * o_sm + (long)c * o_sc + i * o_ri + j * o_sj] = s;
+}
+
+// ------------------------------------------------------------------ activation backward + bias gradient
+// geff = gy * act'(y) (in place allowed);  partial[m][chunk] = sum over the chunk of geff
+__global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ gy, const float* __restrict__ y,
+                                                 float* __restrict__ geff, float* __restrict__ partial, int C, int HW,
+                                                 long gy_bs, long y_bs, long ge_bs, int act, float act_a, float act_b,
+                                                 int B) {
+    __shared__ float red[4];
+    const int m = blockIdx.y;
+    const int nchunk = gridDim.x;
+    float s[1] = {0.f};
+    const long tot = (long)B * HW;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)nchunk * 256) {
+        const int n = (int)(e / HW);
+        const int p = (int)(e - (long)n * HW);
+        float g = gy[(long)n * gy_bs + (long)m * HW + p];
+        if (act != ACT_NONE) {
+            const float v = y[(long)n * y_bs + (long)m * HW + p];
+            if (act == ACT_RELU) g = v > 0.f ? g : 0.f;
+            else if (act == ACT_LRELU) g = v > 0.f ? g : 0.2f * g;
+            else { const float sg = (v - act_b) / act_a; g = g * act_a * sg * (1.f - sg); }
+        }
+        if (geff) geff[(long)n * ge_bs + (long)m * HW + p] = g;
+        s[0] += g;
+    }
+    cc::block_sum_256<1>(s, red);
+    if (threadIdx.x == 0 && partial) partial[(long)m * nchunk + blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__(64) void k_bias_reduce(const float* __restrict__ partial, float* __restrict__ gbias, int nchunk) {
+    const int m = blockIdx.x;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < nchunk; k += 64) s += partial[(long)m * nchunk + k];
+    s = cc::wave_sum(s);
+    if (threadIdx.x == 0) gbias[m] = s;
+}
+
+inline int pick_bm(int M) { return M > 64 ? 128 : (M > 32 ? 64 : 32); }
+
+inline void launch_gg(const GG& g, hipStream_t s) {
+    const long Ntot = (long)g.B * g.OHt * g.OWt;
+    const int bm = pick_bm(g.M);
+    dim3 grid((unsigned)((Ntot + BN - 1) / BN), (unsigned)((g.M + bm - 1) / bm));
+    if (bm == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_gemm<128>), grid, dim3(256), 0, s, g);
+    else if (bm == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_gemm<64>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_gemm<32>), grid, dim3(256), 0, s, g);
+}
+
+}  // namespace
+
+extern "C" {
+
+/* y = act(conv2d(x, w, stride, pad) + bias + res).  x: [B,Cin,IH,IW] (batch stride x_bs), w: [Cout,Cin,R,S],
+ * y: [B,Cout,OH,OW] (batch stride y_bs; may be a channel slice of a wider tensor). */
+int cc_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, const float* res_or_null, float* y, int B,
+                  int Cin, int IH, int IW, long x_bs, int Cout, int R, int S, int stride, int pad, int OH, int OW,
+                  long y_bs, long res_bs, int act, float act_a, float act_b, void* stream) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0) return CC_ERR_ARG;
+    GG g = {};
+    g.x = x; g.w = w; g.bias = bias_or_null; g.res = res_or_null; g.y = y;
+    g.B = B; g.Cin = Cin; g.IH = IH; g.IW = IW; g.x_bs = x_bs;
+    g.M = Cout; g.w_sm = (long)Cin * R * S; g.w_sc = (long)R * S; g.w0 = 0; g.w_ri = S; g.w_sj = 1;
+    g.Rt = R; g.St = S; g.dy0 = -pad; g.dx0 = -pad; g.dstep = 1; g.si = stride;
+    g.OHt = OH; g.OWt = OW; g.so = 1; g.oy0 = 0; g.ox0 = 0; g.OH = OH; g.OW = OW; g.y_bs = y_bs; g.res_bs = res_bs;
+    g.act = act; g.act_a = act_a; g.act_b = act_b;
+    launch_gg(g, (hipStream_t)stream);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+/* Transposed-convolution arithmetic  gx[n, c, iy, ix] = sum_{k,r,s} wT(k,c,r,s) * gy[n, k, oy, ox],  iy = oy*stride - pad + r.
+ * Used for (a) the data-gradient of conv2d (w: [K,C,R,S] -> w_k_stride = C*R*S, w_c_stride = R*S) and
+ * (b) ConvTranspose2d forward (w: [Cin=K, Cout=C, R, S] -> w_k_stride = C*R*S, w_c_stride = R*S as well),
+ * one launch per output parity class so that no structurally-zero tap is multiplied.
+ * gy: [B,K,OH,OW]; gx: [B,C,IH,IW]. */
+int cc_conv2d_dgrad(const float* gy, const float* w, const float* bias_or_null, float* gx, int B, int K, int OH, int OW,
+                    long gy_bs, int C, int R, int S, int stride, int pad, int IH, int IW, long gx_bs, long w_k_stride,
+                    long w_c_stride, int act, float act_a, float act_b, void* stream) {
+    if (B <= 0 || K <= 0 || C <= 0 || stride <= 0) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    for (int py = 0; py < stride; py++) {
+        for (int px = 0; px < stride; px++) {
+            // taps r with (py + pad - r) % stride == 0, r ascending: r = r0 + stride*i
+            int r0 = (py + pad) % stride, s0 = (px + pad) % stride;
+            const int Rt = (r0 < R) ? (R - r0 + stride - 1) / stride : 0;
+            const int St = (s0 < S) ? (S - s0 + stride - 1) / stride : 0;
+            const int OHt = (IH - py + stride - 1) / stride, OWt = (IW - px + stride - 1) / stride;
+            if (OHt <= 0 || OWt <= 0) continue;
+            GG g = {};
+            g.x = gy; g.w = w; g.bias = bias_or_null; g.res = nullptr; g.y = gx;
+            g.B = B; g.Cin = K; g.IH = OH; g.IW = OW; g.x_bs = gy_bs;
+            g.M = C; g.w_sm = w_c_stride; g.w_sc = w_k_stride;
+            g.w0 = r0 * S + s0; g.w_ri = stride * S; g.w_sj = stride;
+            g.Rt = Rt > 0 ? Rt : 1; g.St = St > 0 ? St : 1;
+            // oy = (iy + pad - r)/stride with iy = py + stride*ty, r = r0 + stride*i  ->  oy = ty + (py + pad - r0)/stride - i
+            g.dy0 = (py + pad - r0) / stride; g.dx0 = (px + pad - s0) / stride; g.dstep = -1; g.si = 1;
+            if (Rt == 0 || St == 0) { g.Cin = 0; }   // no tap reaches this parity class: output = act(bias)
+            g.OHt = OHt; g.OWt = OWt; g.so = stride; g.oy0 = py; g.ox0 = px; g.OH = IH; g.OW = IW; g.y_bs = gx_bs;
+            g.act = act; g.act_a = act_a; g.act_b = act_b;
+            launch_gg(g, s);
+        }
+    }
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+size_t cc_conv2d_wgrad_ws_bytes(int B, int M, int AH, int AW, int Cin, int R, int S) {
+    const long Ntot = (long)Cin * R * S;
+    const long P = (long)B * AH * AW;
+    const int bm = pick_bm(M);
+    const long tiles = ((Ntot + BN - 1) / BN) * ((M + bm - 1) / bm);
+    long nsplit = (1024 + tiles - 1) / tiles;
+    const long maxsplit = (P + 255) / 256;
+    if (nsplit > maxsplit) nsplit = maxsplit;
+    if (nsplit < 1) nsplit = 1;
+    return nsplit <= 1 ? 16 : (size_t)nsplit * M * Ntot * sizeof(float);
+}
+
+/* gw[m, c, r, s] (strides o_*) = sum_{n,ty,tx} a[n, m, ty, tx] * x[n, c, si*ty - pad + r, si*tx - pad + s].
+ * conv2d weight-gradient: a = dY [B,Cout,OH,OW], x = input, si = stride, o strides of [Cout,Cin,R,S];
+ * ConvTranspose2d weight-gradient: a = input [B,Cin,IH,IW], x = dY, si = stride, o strides of [Cin,Cout,R,S]. */
+int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B, int M, int AH, int AW, long a_bs, int Cin,
+                    int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, void* stream) {
+    if (B <= 0 || M <= 0 || Cin <= 0) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const long Ntot = (long)Cin * R * S;
+    const long P = (long)B * AH * AW;
+    const int bm = pick_bm(M);
+    const long tiles = ((Ntot + BN - 1) / BN) * ((M + bm - 1) / bm);
+    long nsplit = (1024 + tiles - 1) / tiles;
+    const long maxsplit = (P + 255) / 256;
+    if (nsplit > maxsplit) nsplit = maxsplit;
+    if (nsplit < 1) nsplit = 1;
+    long pps = (P + nsplit - 1) / nsplit;
+    pps = ((pps + BK - 1) / BK) * BK;
+    nsplit = (P + pps - 1) / pps;
+    WG g = {};
+    g.a = a; g.x = x; g.B = B; g.M = M; g.AH = AH; g.AW = AW; g.a_bs = a_bs;
+    g.Cin = Cin; g.IH = IH; g.IW = IW; g.x_bs = x_bs;
+    g.Rt = R; g.St = S; g.dy0 = -pad; g.dx0 = -pad; g.dstep = 1; g.si = si;
+    g.o_sm = o_sm; g.o_sc = o_sc; g.o_ri = S; g.o_sj = 1;
+    g.direct = (nsplit == 1);
+    g.out = g.direct ? gw : ws;
+    g.pix_per_split = (int)pps;
+    dim3 grid((unsigned)((Ntot + BN - 1) / BN), (unsigned)((M + bm - 1) / bm), (unsigned)nsplit);
+    if (bm == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<128>), grid, dim3(256), 0, s, g);
+    else if (bm == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<64>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<32>), grid, dim3(256), 0, s, g);
+    if (!g.direct) {
+        const long tot = (long)M * Ntot;
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const float*)ws, gw,
+                           (int)nsplit, M, (int)Ntot, R * S, S, o_sm, o_sc, S, 1);
+    }
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+size_t cc_act_bwd_ws_bytes(int C) { return (size_t)C * 64 * sizeof(float); }
+
+/* geff = gy * act'(y) (geff may alias gy or be null), gbias[c] = sum_{n,p} geff (gbias may be null) */
+int cc_act_bwd_bias(const float* gy, const float* y_or_null, float* geff_or_null, float* gbias_or_null, float* ws, int B,
+                    int C, int H, int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b,
+                    void* stream) {
+    if (B <= 0 || C <= 0) return CC_ERR_ARG;
+    if (act != ACT_NONE && !y_or_null) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int HW = H * W;
+    long want = ((long)B * HW + 4095) / 4096;
+    int nchunk = (int)(want < 1 ? 1 : (want > 64 ? 64 : want));
+    hipLaunchKernelGGL(k_act_bwd, dim3(nchunk, C), dim3(256), 0, s, gy, y_or_null, geff_or_null,
+                       gbias_or_null ? ws : (float*)nullptr, C, HW, gy_bs, y_bs, geff_bs, act, act_a, act_b, B);
+    if (gbias_or_null) hipLaunchKernelGGL(k_bias_reduce, dim3(C), dim3(64), 0, s, (const float*)ws, gbias_or_null, nchunk);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,136 @@
+// 9x9-displacement cost volume of Back2Future (models/back2future.py:15-25 `correlate`):
+//   vol[b, d, y, x] = (1/C) * sum_c f1[b,c,y,x] * f2[b,c,y+dy-4,x+dx-4],  d = dy*9+dx, zero outside f2
+// i.e. the third-party spatial_correlation_sampler CUDA extension (requirements.txt:13, kernel_size=1,
+// patch_size=9, stride=1) + the /C of :24 + the channel permutation idx_fwd/idx_bwd of :56-59,175-177
+// folded into the store (chan_of_disp[d] = output channel of displacement d; null = identity).
+// Gather-form forward AND backward (deterministic, no atomics).  Maps are tiny (4x13 .. 64x208) and the
+// op is ~0.2 % of the step's MACs, so the kernels are kept simple: one work-item per output element,
+// f2 window reads served by L1/L2.
+#include "cc_common.h"
+#include "../../include/ccengine.h"
+
+namespace {
+
+constexpr int R = 4, PATCH = 9, ND = 81;
+
+__global__ __launch_bounds__(256) void k_corr_fwd(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                  float* __restrict__ out, const int* __restrict__ chan_of_disp, int C,
+                                                  int H, int W, int out_cstride_total, int out_coffset) {
+    // one thread per (pixel, dy): 9 dx accumulators
+    const int HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int dy = blockIdx.y, b = blockIdx.z;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    const int yy = y + dy - R;
+    float acc[PATCH];
+#pragma unroll
+    for (int j = 0; j < PATCH; j++) acc[j] = 0.f;
+    if (yy >= 0 && yy < H) {
+        const float* a = f1 + (size_t)b * C * HW + p;
+        const float* bb = f2 + (size_t)b * C * HW + yy * W;
+        for (int c = 0; c < C; c++) {
+            const float av = a[(size_t)c * HW];
+            const float* row = bb + (size_t)c * HW;
+#pragma unroll
+            for (int j = 0; j < PATCH; j++) {
+                const int xx = x + j - R;
+                if (xx >= 0 && xx < W) acc[j] = fmaf(av, row[xx], acc[j]);
+            }
+        }
+    }
+    const float inv = 1.f / (float)C;
+#pragma unroll
+    for (int j = 0; j < PATCH; j++) {
+        const int d = dy * PATCH + j;
+        const int ch = (chan_of_disp ? chan_of_disp[d] : d) + out_coffset;
+        out[((size_t)b * out_cstride_total + ch) * HW + p] = acc[j] * inv;
+    }
+}
+
+// g1[b,c,y,x] = (1/C) sum_d gout[b,ch(d),y,x] * f2[b,c,y+dy-4,x+dx-4]
+__global__ __launch_bounds__(256) void k_corr_bwd_f1(const float* __restrict__ gout, const float* __restrict__ f2,
+                                                     float* __restrict__ g1, const int* __restrict__ chan_of_disp, int C,
+                                                     int H, int W, int g_cstride_total, int g_coffset, int accumulate) {
+    const int HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    const float* g = gout + ((size_t)b * g_cstride_total + g_coffset) * HW + p;
+    const float* src = f2 + ((size_t)b * C + c) * HW;
+    float acc = 0.f;
+    for (int dy = 0; dy < PATCH; dy++) {
+        const int yy = y + dy - R;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < PATCH; dx++) {
+            const int xx = x + dx - R;
+            if (xx < 0 || xx >= W) continue;
+            const int d = dy * PATCH + dx;
+            const int ch = chan_of_disp ? chan_of_disp[d] : d;
+            acc = fmaf(g[(size_t)ch * HW], src[yy * W + xx], acc);
+        }
+    }
+    const size_t o = ((size_t)b * C + c) * HW + p;
+    const float r = acc / (float)C;
+    g1[o] = accumulate ? g1[o] + r : r;
+}
+
+// g2[b,c,y',x'] = (1/C) sum_d gout[b,ch(d),y'-dy+4,x'-dx+4] * f1[b,c,y'-dy+4,x'-dx+4]
+__global__ __launch_bounds__(256) void k_corr_bwd_f2(const float* __restrict__ gout, const float* __restrict__ f1,
+                                                     float* __restrict__ g2, const int* __restrict__ chan_of_disp, int C,
+                                                     int H, int W, int g_cstride_total, int g_coffset) {
+    const int HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    const float* g = gout + ((size_t)b * g_cstride_total + g_coffset) * HW;
+    const float* src = f1 + ((size_t)b * C + c) * HW;
+    float acc = 0.f;
+    for (int dy = 0; dy < PATCH; dy++) {
+        const int ys = y - dy + R;
+        if (ys < 0 || ys >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < PATCH; dx++) {
+            const int xs = x - dx + R;
+            if (xs < 0 || xs >= W) continue;
+            const int d = dy * PATCH + dx;
+            const int ch = chan_of_disp ? chan_of_disp[d] : d;
+            const int q = ys * W + xs;
+            acc = fmaf(g[(size_t)ch * HW + q], src[q], acc);
+        }
+    }
+    g2[((size_t)b * C + c) * HW + p] = acc / (float)C;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cc_corr9x9_fwd(const float* f1, const float* f2, float* out, const int* chan_of_disp_or_null, int B, int C, int H,
+                   int W, int out_channels_total, int out_channel_offset, void* stream) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || out_channel_offset + ND > out_channels_total) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_corr_fwd, dim3((H * W + 255) / 256, PATCH, B), dim3(256), 0, (hipStream_t)stream, f1, f2, out,
+                       chan_of_disp_or_null, C, H, W, out_channels_total, out_channel_offset);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_corr9x9_bwd(const float* gout, const float* f1, const float* f2, float* g1, float* g2_or_null,
+                   const int* chan_of_disp_or_null, int B, int C, int H, int W, int g_channels_total,
+                   int g_channel_offset, int accumulate_g1, void* stream) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || g_channel_offset + ND > g_channels_total) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g((H * W + 255) / 256, C, B);
+    hipLaunchKernelGGL(k_corr_bwd_f1, g, dim3(256), 0, s, gout, f2, g1, chan_of_disp_or_null, C, H, W, g_channels_total,
+                       g_channel_offset, accumulate_g1);
+    if (g2_or_null)
+        hipLaunchKernelGGL(k_corr_bwd_f2, g, dim3(256), 0, s, gout, f1, g2_or_null, chan_of_disp_or_null, C, H, W,
+                           g_channels_total, g_channel_offset);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+}  // extern "C"

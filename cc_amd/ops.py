@@ -1,0 +1,228 @@
+"""Network-layer operators of the engine: thin ``torch.autograd.Function`` bindings of the gfx950 kernels
+(convolutions on fp32 MFMA, the 9x9 cost volume, feature warp) behind the C ABI.
+
+Everything heavy is a HIP kernel.  What is still stock ATen (tiny tensors, listed in DESIGN.md as "torch
+plumbing"): BatchNorm of the 13 residual shortcuts, x2 bilinear / nearest upsampling of 1-2 channel maps,
+channel softmax of the (unused-by-training) occlusion head, torch.cat.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import config
+from ._lib import engine, STREAM
+
+ACT = {None: 0, "relu": 1, "lrelu": 2, "sigmoid": 3}
+
+
+def _c(t):
+    return t.contiguous().float()
+
+
+def _ws(nbytes, ref):
+    return torch.empty(max(int(nbytes) // 4, 4), device=ref.device, dtype=torch.float32)
+
+
+# ----------------------------------------------------------------------------- convolution
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, res, stride, pad, act, act_a, act_b):
+        x, w = _c(x), _c(w)
+        B, Cin, IH, IW = x.shape
+        Cout, _, R, S = w.shape
+        OH = (IH + 2 * pad - R) // stride + 1
+        OW = (IW + 2 * pad - S) // stride + 1
+        y = torch.empty(B, Cout, OH, OW, device=x.device, dtype=torch.float32)
+        bias_c = None if bias is None else _c(bias)
+        res_c = None if res is None else _c(res)
+        engine().call("cc_conv2d_fwd", x, w, bias_c, res_c, y, B, Cin, IH, IW, Cin * IH * IW, Cout, R, S, stride, pad,
+                      OH, OW, Cout * OH * OW, Cout * OH * OW, act, act_a, act_b, STREAM)
+        ctx.save_for_backward(x, w, y if act != 0 else None)
+        ctx.cfg = (stride, pad, act, act_a, act_b, bias is not None, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, act, act_a, act_b, has_bias, has_res = ctx.cfg
+        E = engine()
+        gy = _c(gy)
+        B, Cin, IH, IW = x.shape
+        Cout, _, R, S = w.shape
+        OH, OW = gy.shape[2], gy.shape[3]
+        need = ctx.needs_input_grad
+        gbias = torch.empty(Cout, device=x.device, dtype=torch.float32) if (has_bias and need[2]) else None
+        if act != 0 or gbias is not None:
+            geff = torch.empty_like(gy) if act != 0 else None
+            E.call("cc_act_bwd_bias", gy, y, geff, gbias, _ws(E.call("cc_act_bwd_ws_bytes", Cout), x), B, Cout, OH, OW,
+                   Cout * OH * OW, Cout * OH * OW, Cout * OH * OW, act, act_a, act_b, STREAM)
+            if geff is not None:
+                gy = geff
+        gx = gw = None
+        if need[0]:
+            gx = torch.empty_like(x)
+            E.call("cc_conv2d_dgrad", gy, w, None, gx, B, Cout, OH, OW, Cout * OH * OW, Cin, R, S, stride, pad, IH, IW,
+                   Cin * IH * IW, Cin * R * S, R * S, 0, 1.0, 0.0, STREAM)
+        if need[1]:
+            gw = torch.empty_like(w)
+            ws = _ws(E.call("cc_conv2d_wgrad_ws_bytes", B, Cout, OH, OW, Cin, R, S), x)
+            E.call("cc_conv2d_wgrad", gy, x, gw, ws, B, Cout, OH, OW, Cout * OH * OW, Cin, IH, IW, Cin * IH * IW, R, S,
+                   stride, pad, Cin * R * S, R * S, STREAM)
+        gres = gy if (has_res and need[3]) else None
+        return gx, gw, gbias, gres, None, None, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, padding=0, act=None, residual=None, act_a=1.0, act_b=0.0):
+    """act(conv2d(x, w, bias) + residual): nn.Conv2d (+ fused ReLU/LeakyReLU(0.2)/a*sigmoid+b epilogue)."""
+    if config.conv_backend == "miopen":
+        y = F.conv2d(x, w, bias, stride, padding)
+        if residual is not None:
+            y = y + residual
+        return _torch_act(y, act, act_a, act_b)
+    return _Conv2dFn.apply(x, w, bias, residual, int(stride), int(padding), ACT[act], float(act_a), float(act_b))
+
+
+class _ConvT2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, out_pad, act):
+        x, w = _c(x), _c(w)
+        B, Cin, IH, IW = x.shape
+        _, Cout, R, S = w.shape
+        OH = (IH - 1) * stride - 2 * pad + R + out_pad
+        OW = (IW - 1) * stride - 2 * pad + S + out_pad
+        y = torch.empty(B, Cout, OH, OW, device=x.device, dtype=torch.float32)
+        bias_c = None if bias is None else _c(bias)
+        # ConvTranspose2d forward == the transposed-conv arithmetic of cc_conv2d_dgrad with K = Cin, C = Cout
+        engine().call("cc_conv2d_dgrad", x, w, bias_c, y, B, Cin, IH, IW, Cin * IH * IW, Cout, R, S, stride, pad, OH, OW,
+                      Cout * OH * OW, Cout * R * S, R * S, act, 1.0, 0.0, STREAM)
+        ctx.save_for_backward(x, w, y if act != 0 else None)
+        ctx.cfg = (stride, pad, act, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, act, has_bias = ctx.cfg
+        E = engine()
+        gy = _c(gy)
+        B, Cin, IH, IW = x.shape
+        _, Cout, R, S = w.shape
+        OH, OW = gy.shape[2], gy.shape[3]
+        need = ctx.needs_input_grad
+        gbias = torch.empty(Cout, device=x.device, dtype=torch.float32) if (has_bias and need[2]) else None
+        if act != 0 or gbias is not None:
+            geff = torch.empty_like(gy) if act != 0 else None
+            E.call("cc_act_bwd_bias", gy, y, geff, gbias, _ws(E.call("cc_act_bwd_ws_bytes", Cout), x), B, Cout, OH, OW,
+                   Cout * OH * OW, Cout * OH * OW, Cout * OH * OW, act, 1.0, 0.0, STREAM)
+            if geff is not None:
+                gy = geff
+        gx = gw = None
+        if need[0]:
+            # d/dx of a transposed conv is a plain strided conv of gy; the [Cin,Cout,R,S] weight IS its [M,C,R,S] weight
+            gx = torch.empty_like(x)
+            E.call("cc_conv2d_fwd", gy, w, None, None, gx, B, Cout, OH, OW, Cout * OH * OW, Cin, R, S, stride, pad, IH, IW,
+                   Cin * IH * IW, 0, 0, 1.0, 0.0, STREAM)
+        if need[1]:
+            gw = torch.empty_like(w)
+            ws = _ws(E.call("cc_conv2d_wgrad_ws_bytes", B, Cin, IH, IW, Cout, R, S), x)
+            E.call("cc_conv2d_wgrad", x, gy, gw, ws, B, Cin, IH, IW, Cin * IH * IW, Cout, OH, OW, Cout * OH * OW, R, S,
+                   stride, pad, Cout * R * S, R * S, STREAM)
+        return gx, gw, gbias, None, None, None, None
+
+
+def conv_transpose2d(x, w, bias=None, stride=1, padding=0, output_padding=0, act=None):
+    if config.conv_backend == "miopen":
+        return _torch_act(F.conv_transpose2d(x, w, bias, stride, padding, output_padding), act, 1.0, 0.0)
+    return _ConvT2dFn.apply(x, w, bias, int(stride), int(padding), int(output_padding), ACT[act])
+
+
+def _torch_act(y, act, a, b):
+    if act == "relu":
+        return F.relu(y)
+    if act == "lrelu":
+        return F.leaky_relu(y, 0.2)
+    if act == "sigmoid":
+        return a * torch.sigmoid(y) + b
+    return y
+
+
+# ----------------------------------------------------------------------------- small ATen-backed pieces
+def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps):
+    if training and num_batches_tracked is not None:
+        num_batches_tracked.add_(1)
+    return F.batch_norm(x, running_mean, running_var, weight, bias, training, momentum, eps)
+
+
+def upsample_bilinear2x(x):
+    return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+
+
+# ----------------------------------------------------------------------------- cost volume
+_perm_cache = {}
+
+
+def _inv_perm(perm, device):
+    key = (tuple(perm), str(device))
+    t = _perm_cache.get(key)
+    if t is None:
+        inv = [0] * len(perm)
+        for k, d in enumerate(perm):
+            inv[d] = k                       # displacement d is stored in output channel k
+        t = torch.tensor(inv, dtype=torch.int32, device=device)
+        _perm_cache[key] = t
+    return t
+
+
+class _CorrPairFn(torch.autograd.Function):
+    """cat(correlate(a, b)[:, perm_b], correlate(a, c)[:, perm_c]) -> [B,162,H,W] (back2future.py:173-177)."""
+
+    @staticmethod
+    def forward(ctx, a, b, c, inv_b, inv_c):
+        a, b, c = _c(a), _c(b), _c(c)
+        B, C, H, W = a.shape
+        out = torch.empty(B, 162, H, W, device=a.device, dtype=torch.float32)
+        E = engine()
+        E.call("cc_corr9x9_fwd", a, b, out, inv_b, B, C, H, W, 162, 0, STREAM)
+        E.call("cc_corr9x9_fwd", a, c, out, inv_c, B, C, H, W, 162, 81, STREAM)
+        ctx.save_for_backward(a, b, c, inv_b, inv_c)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, c, inv_b, inv_c = ctx.saved_tensors
+        g = _c(g)
+        B, C, H, W = a.shape
+        E = engine()
+        ga = torch.empty_like(a)
+        gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        gc = torch.empty_like(c) if ctx.needs_input_grad[2] else None
+        E.call("cc_corr9x9_bwd", g, a, b, ga, gb, inv_b, B, C, H, W, 162, 0, 0, STREAM)
+        E.call("cc_corr9x9_bwd", g, a, c, ga, gc, inv_c, B, C, H, W, 162, 81, 1, STREAM)
+        return ga, gb, gc, None, None
+
+
+def correlation_pair(a, b, c, perm_b, perm_c):
+    return _CorrPairFn.apply(a, b, c, _inv_perm(perm_b, a.device), _inv_perm(perm_c, a.device))
+
+
+def correlate(input1, input2):
+    """models/back2future.py:15-25 `correlate` (no permutation): [B,81,H,W]."""
+    a, b = _c(input1), _c(input2)
+    return _CorrFn.apply(a, b)
+
+
+class _CorrFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        B, C, H, W = a.shape
+        out = torch.empty(B, 81, H, W, device=a.device, dtype=torch.float32)
+        engine().call("cc_corr9x9_fwd", a, b, out, None, B, C, H, W, 81, 0, STREAM)
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        B, C, H, W = a.shape
+        ga, gb = torch.empty_like(a), torch.empty_like(b)
+        engine().call("cc_corr9x9_bwd", _c(g), a, b, ga, gb, None, B, C, H, W, 81, 0, 0, STREAM)
+        return ga, gb

@@ -146,6 +146,40 @@ int cc_consensus_bce_fwd_bwd(const float* exp_mask, const float* census_bwd, con
 /* out = a * scalar_dev[0] */
 int cc_scale_by_scalar(const float* a, const float* scalar_dev, float* out, int n, void* stream);
 
+/* ---------------------------------------------------------------- cost volume (models/back2future.py:15-25)
+ * vol[b, ch(d), y, x] = (1/C) sum_c f1[b,c,y,x] * f2[b,c,y+dy-4,x+dx-4], d = dy*9+dx: the spatial_correlation_sampler
+ * call (kernel_size=1, patch_size=9, stride=1) + the division by C (:24) + index_select(idx_fwd/idx_bwd) (:175-177,
+ * chan_of_disp = inverse permutation, int32 device array or null) + torch.cat (written at out_channel_offset of a
+ * tensor with out_channels_total channels). */
+int cc_corr9x9_fwd(const float* f1, const float* f2, float* out, const int* chan_of_disp_or_null, int B, int C, int H,
+                   int W, int out_channels_total, int out_channel_offset, void* stream);
+int cc_corr9x9_bwd(const float* gout, const float* f1, const float* f2, float* g1, float* g2_or_null,
+                   const int* chan_of_disp_or_null, int B, int C, int H, int W, int g_channels_total,
+                   int g_channel_offset, int accumulate_g1, void* stream);
+
+/* ---------------------------------------------------------------- convolutions (nn.Conv2d / nn.ConvTranspose2d of models/ *.py)
+ * fp32 implicit GEMM on v_mfma_f32_32x32x2_f32.  act: 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 act_a*sigmoid+act_b.
+ * Batch strides (elements) let inputs/outputs be channel slices of wider NCHW tensors (no torch.cat copies). */
+int cc_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, const float* res_or_null, float* y, int B,
+                  int Cin, int IH, int IW, long x_bs, int Cout, int R, int S, int stride, int pad, int OH, int OW,
+                  long y_bs, long res_bs, int act, float act_a, float act_b, void* stream);
+/* gx[n,c,iy,ix] = act(bias[c] + sum_{k,r,s} w(k,c,r,s) * gy[n,k,oy,ox]), iy = oy*stride - pad + r: the data-gradient of
+ * conv2d (act 0, bias null) and the forward of ConvTranspose2d (weight [Cin=K, Cout=C, R, S]); one launch per
+ * output parity class.  w(k,c,r,s) = w[k*w_k_stride + c*w_c_stride + r*S + s]. */
+int cc_conv2d_dgrad(const float* gy, const float* w, const float* bias_or_null, float* gx, int B, int K, int OH, int OW,
+                    long gy_bs, int C, int R, int S, int stride, int pad, int IH, int IW, long gx_bs, long w_k_stride,
+                    long w_c_stride, int act, float act_a, float act_b, void* stream);
+size_t cc_conv2d_wgrad_ws_bytes(int B, int M, int AH, int AW, int Cin, int R, int S);
+/* gw[m*o_sm + c*o_sc + r*S + s] = sum_{n,ty,tx} a[n,m,ty,tx] * x[n,c,si*ty-pad+r,si*tx-pad+s] (split over pixels,
+ * deterministic second-stage reduction through ws). */
+int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B, int M, int AH, int AW, long a_bs, int Cin,
+                    int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, void* stream);
+size_t cc_act_bwd_ws_bytes(int C);
+/* geff = gy * act'(y);  gbias[c] = sum geff  (either output may be null; geff may alias gy) */
+int cc_act_bwd_bias(const float* gy, const float* y_or_null, float* geff_or_null, float* gbias_or_null, float* ws, int B,
+                    int C, int H, int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif
