@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""Headline benchmark: train images/sec of the Competitive-Collaboration step (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL gradient all-reduce)
+
+One "step" = one full CC training step (train.py:445-568: DispResNet6 + PoseNetB6 + MaskNet6 + Back2Future
+forward, 6-scale losses, backward, gradient all-reduce, Adam) on a synthetic per-GPU mini-batch of 4 five-frame
+832x256 samples already resident in HBM.  value = N * 4 * K / time (whole-job images/sec, weak scaling).
+
+Extra objects on the JSON line:
+  roofline      the dominant kernel family (fp32 MFMA implicit-GEMM convolutions): algorithmic FLOPs of every
+                launch of one instrumented step / their HIP-event durations, against the 157.3 TFLOP/s fp32 MFMA peak
+  kernels       the same for each C-ABI entry point (conv: TFLOP/s; warp/SSIM: algorithmic GB/s vs 8 TB/s HBM)
+  cpu_baseline  the oracle (CPU port of the reference path, oracle/step.py) timed on this box's host cores
+                (rank 0, N=1 only, bounded sample)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch                      # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_MFMA_F32 = 157.3   # TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM = 8000.0       # GB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="per-GPU mini-batch")
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=832)
+    ap.add_argument("--config", default="c3", choices=["c2", "c3"],
+                    help="c3 = full CC (BASELINE configs[2], the metric's config); c2 = DispResNet6+PoseNetB6 only")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--conv-backend", default="hip", choices=["hip", "miopen"])
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------- per-call instrumentation
+def _px(args, names, *keys):
+    d = dict(zip(names, args))
+    r = 1
+    for k in keys:
+        r *= d[k]
+    return r
+
+
+WORK = {   # entry point -> (kind, fn(args dict) -> algorithmic flops or bytes)
+    "cc_conv2d_fwd": ("flop", lambda d: 2.0 * d["B"] * d["OH"] * d["OW"] * d["Cout"] * d["Cin"] * d["R"] * d["S"]),
+    "cc_conv2d_dgrad": ("flop", lambda d: 2.0 * d["B"] * d["OH"] * d["OW"] * d["K"] * d["C"] * d["R"] * d["S"]),
+    "cc_conv2d_wgrad": ("flop", lambda d: 2.0 * d["B"] * d["AH"] * d["AW"] * d["M"] * d["Cin"] * d["R"] * d["S"]),
+    # algorithmic bytes per pixel (SURVEY.md 8d conventions: each distinct tensor argument once, fp32)
+    "cc_inverse_warp_fwd": ("byte", lambda d: 28.0 * d["B"] * d["H"] * d["W"]),
+    "cc_inverse_warp_bwd": ("byte", lambda d: 32.0 * d["B"] * d["H"] * d["W"]),
+    "cc_flow_warp_fwd": ("byte", lambda d: 32.0 * d["B"] * d["H"] * d["W"]),
+    "cc_flow_warp_bwd": ("byte", lambda d: 40.0 * d["B"] * d["H"] * d["W"]),
+    "cc_pose2flow_fwd": ("byte", lambda d: 12.0 * d["B"] * d["H"] * d["W"]),
+    # fused photometric body: reads tgt, warped (24) + two masks (8); with gradients writes 4 adjoint maps (48) + gmask (4)
+    "cc_ssim_photo_fwd": ("byte", lambda d: (32.0 + (52.0 if d["want_grad"] else 0.0)) * d["B"] * d["H"] * d["W"]),
+    # adjoint: reads 4 maps + tgt + warped (72), writes gwarped (12)
+    "cc_ssim_photo_bwd": ("byte", lambda d: 84.0 * d["B"] * d["H"] * d["W"]),
+    "cc_ssim_err_fwd": ("byte", lambda d: 32.0 * d["B"] * d["H"] * d["W"]),
+    "cc_adam_step": ("byte", lambda d: 28.0 * d["n"]),
+}
+
+
+class CallTimer:
+    """Brackets selected C-ABI calls with HIP events on the launch stream (torch's current stream)."""
+
+    def __init__(self, eng):
+        self.eng = eng
+        self.records = []
+        self._orig = eng.call
+
+    def __enter__(self):
+        def call(name, *args):
+            if name in WORK:
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = self._orig(name, *args)
+                e.record()
+                d = dict(zip(self.eng.sigs[name][2], args))
+                self.records.append((name, WORK[name][1](d), s, e))
+                return r
+            return self._orig(name, *args)
+        self.eng.call = call
+        return self
+
+    def __exit__(self, *a):
+        self.eng.call = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, work, s, e in self.records:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += work
+            a[2] += s.elapsed_time(e)
+        out = {}
+        for name, (n, work, ms) in agg.items():
+            kind = WORK[name][0]
+            rate = work / (ms * 1e-3) / (1e12 if kind == "flop" else 1e9) if ms > 0 else 0.0
+            out[name] = {"calls": n, "ms": round(ms, 4), "avg_us": round(1e3 * ms / n, 2),
+                         ("tflops" if kind == "flop" else "gbps"): round(rate, 2),
+                         "frac": round(rate / (PEAK_MFMA_F32 if kind == "flop" else PEAK_HBM), 4)}
+        return out
+
+
+def cpu_baseline(batch_cpu, args):
+    """The oracle (CPU port of the reference step) on this box's host cores -- reported beside, never the target."""
+    from oracle import step as S
+    n = os.cpu_count() or 1
+    torch.set_num_threads(n)
+    torch.manual_seed(0)
+    nets = S.build_nets("oracle", flow=(args.config == "c3"), mask=(args.config == "c3"))
+    for m in nets:
+        if m is not None:
+            m.init_weights()
+    cfg = S.StepConfig()
+    opt = S.make_optimizer(nets, cfg)
+    S.cc_step(nets, opt, batch_cpu, cfg)          # warm-up
+    t0 = time.time()
+    for _ in range(args.cpu_steps):
+        S.cc_step(nets, opt, batch_cpu, cfg)
+    dt = (time.time() - t0) / args.cpu_steps
+    return {"value": round(batch_cpu[0].shape[0] / dt, 4), "unit": "images/s", "cores": n, "kind": "port",
+            "sample": "%d full CC steps (fwd+bwd+Adam) after 1 warm-up, B=%d %dx%d, torch %s CPU, %d threads"
+                      % (args.cpu_steps, batch_cpu[0].shape[0], batch_cpu[0].shape[3], batch_cpu[0].shape[2],
+                         torch.__version__, n),
+            "s_per_step": round(dt, 3)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs HIP devices (there is no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)     # nccl == RCCL on ROCm
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from cc_amd import config, synthetic as syn, trainer as T, _lib
+    config.conv_backend = args.conv_backend
+    eng = _lib.engine()
+
+    torch.manual_seed(0)                                             # train.py:152
+    nets = T.build_nets(dev, flow=(args.config == "c3"), mask=(args.config == "c3"))
+    cfg = T.StepConfig()
+    B, H, W = args.batch, args.height, args.width
+    batch_cpu = syn.sample(B, H, W, seed=1 + rank, smooth=3)
+    batch = (batch_cpu[0].to(dev), [r.to(dev) for r in batch_cpu[1]], batch_cpu[2].to(dev), batch_cpu[3].to(dev))
+    tr = T.CCTrainer(nets, cfg, use_graph=not args.no_graph)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        losses = tr.step(batch)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = tr.step(batch)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(losses["loss"])
+    from cc_amd import loss_functions as LF
+    LF.check_finite()
+
+    kernels, roof = None, None
+    if not args.no_kernel_timing:
+        tr_e = tr
+        tr_e.use_graph = False
+        with CallTimer(eng) as ct:
+            tr_e.step(batch)
+        kernels = ct.summary()
+        convs = {k: v for k, v in kernels.items() if "tflops" in v}
+        if convs:
+            tot_ms = sum(v["ms"] for v in convs.values())
+            tot_fl = sum(v["tflops"] * v["ms"] for v in convs.values())           # TFLOP/s * ms = GFLOP
+            ach = tot_fl / tot_ms if tot_ms > 0 else 0.0
+            roof = {"bound": "mfma", "kernel": "k_gather_gemm/k_wgrad (cc_conv2d_fwd+dgrad+wgrad)",
+                    "achieved": round(ach, 2), "peak": PEAK_MFMA_F32, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_MFMA_F32, 4), "traffic": None,
+                    "launches": sum(v["calls"] for v in convs.values()), "ms_per_step": round(tot_ms, 3)}
+
+    if rank == 0:
+        imgs = B * world * args.steps
+        line = {
+            "metric": "train images/sec (832x256, 5-frame sample, 6-scale CC step)",
+            "value": round(imgs / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("full CC: DispResNet6+PoseNetB6+MaskNet6+Back2Future, all losses"
+                                    if args.config == "c3" else "DispResNet6+PoseNetB6, photometric+smoothness"),
+                       "per_gpu_batch": B, "global_batch": B * world, "height": H, "width": W, "scales": 6,
+                       "frames": 5, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph,
+                       "conv_backend": args.conv_backend, "loss": round(loss_val, 6)},
+            "roofline": roof, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(syn.sample(B, H, W, seed=1, smooth=3), args)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

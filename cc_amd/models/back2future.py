@@ -1,0 +1,115 @@
+"""models.Back2Future (reference models/back2future.py ``Model``) on the gfx950 kernels: MFMA convs, the HIP 9x9
+cost volume (replacing the spatial_correlation_sampler CUDA extension) with idx_fwd/idx_bwd + cat folded into its
+store, and the HIP border-padded feature warp.  Device-agnostic construction (no ``.cuda()`` in __init__)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import nn as L
+from .. import ops
+from ..inverse_warp import feature_warp
+
+
+def conv_feat_block(nIn, nOut):
+    """back2future.py:27-33: conv s2 + LeakyReLU(0.2), conv s1 + LeakyReLU(0.2) (parameters at .0 and .2)."""
+    return nn.Sequential(L.Conv2d(nIn, nOut, 3, 2, 1, act="lrelu"), L.Act(),
+                         L.Conv2d(nOut, nOut, 3, 1, 1, act="lrelu"), L.Act())
+
+
+def conv_dec_block(nIn):
+    """back2future.py:35-48: nIn->128->128->96->64->32->2, LeakyReLU(0.2) between (parameters at .0,.2,...,.10)."""
+    chans = [nIn, 128, 128, 96, 64, 32]
+    layers = []
+    for a, b in zip(chans[:-1], chans[1:]):
+        layers += [L.Conv2d(a, b, 3, 1, 1, act="lrelu"), L.Act()]
+    layers.append(L.Conv2d(32, 2, 3, 1, 1))
+    return nn.Sequential(*layers)
+
+
+def correlate(input1, input2):
+    """back2future.py:15-25."""
+    return ops.correlate(input1, input2)
+
+
+class Model(nn.Module):
+    FEAT = [3, 16, 32, 64, 96, 128, 192]
+    DEC_IN = {6: 162, 5: 292, 4: 260, 3: 228, 2: 196}
+    WARP_SCALE = {6: 0.625, 5: 1.25, 4: 2.5, 3: 5.0}
+    FULL_SCALE = {2: 20, 3: 10, 4: 5, 5: 2.5, 6: 1.25}
+
+    def __init__(self, nlevels):
+        super().__init__()
+        self.nlevels = nlevels
+        idx = [k for n in range(80, 71, -1) for k in range(n, -1, -9)]          # back2future.py:56-57
+        self.idx_fwd = idx
+        self.idx_bwd = list(reversed(idx))
+        for lvl in range(1, 7):
+            for s in "abc":
+                setattr(self, "conv%d%s" % (lvl, s), conv_feat_block(self.FEAT[lvl - 1], self.FEAT[lvl]))
+        self.corr = correlate
+        # ImageNet statistics of normalize(); non-persistent buffers: not part of the state_dict contract
+        self.register_buffer("_im_mean", torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), persistent=False)
+        self.register_buffer("_im_std", torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1), persistent=False)
+        for lvl in range(6, 1, -1):
+            setattr(self, "decoder_fwd%d" % lvl, conv_dec_block(self.DEC_IN[lvl]))
+            setattr(self, "decoder_bwd%d" % lvl, conv_dec_block(self.DEC_IN[lvl]))
+        self.decoder_occ6 = conv_dec_block(354)
+        for lvl in range(5, 1, -1):
+            setattr(self, "decoder_occ%d" % lvl, conv_dec_block(self.DEC_IN[lvl]))
+
+    def init_weights(self):
+        """back2future.py:106-116: U(0,1) bias first, then xavier weight."""
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                if m.bias is not None:
+                    nn.init.uniform_(m.bias)
+                nn.init.xavier_uniform_(m.weight)
+
+    def normalize(self, ims):
+        """back2future.py:118-132: [-1,1] -> ImageNet-normalised, on copies."""
+        return [((im * 0.5 + 0.5) - self._im_mean) / self._im_std for im in ims]
+
+    def warp(self, x, flo):
+        """back2future.py:287-321."""
+        return feature_warp(x, flo)
+
+    def forward(self, im_tar, im_refs):
+        n = self.normalize([im_tar] + list(im_refs))
+        feats = {}
+        for s, im in (("a", n[0]), ("b", n[2]), ("c", n[1])):      # b = I+, c = I-  (back2future.py:159,166)
+            x = im
+            for lvl in range(1, 7):
+                x = getattr(self, "conv%d%s" % (lvl, s))(x)
+                feats[(lvl, s)] = x
+        flow_f, flow_b, up_f, up_b, occ = {}, {}, {}, {}, {}
+        bw, cw = feats[(6, "b")], feats[(6, "c")]
+        up = ops.upsample_bilinear2x
+        for lvl in range(6, 1, -1):
+            a = feats[(lvl, "a")]
+            corr = ops.correlation_pair(a, bw, cw, self.idx_fwd, self.idx_bwd)
+            if lvl == 6:
+                in_f = in_b = corr
+                in_o = torch.cat((corr, a), 1)
+            else:
+                in_f = torch.cat((corr, a, up_f[lvl + 1]), 1)
+                in_b = torch.cat((corr, a, up_b[lvl + 1]), 1)
+                in_o = in_f
+            flow_f[lvl] = getattr(self, "decoder_fwd%d" % lvl)(in_f)
+            up_f[lvl] = up(flow_f[lvl])
+            flow_b[lvl] = getattr(self, "decoder_bwd%d" % lvl)(in_b)
+            up_b[lvl] = up(flow_b[lvl])
+            occ[lvl] = torch.softmax(getattr(self, "decoder_occ%d" % lvl)(in_o), dim=1)
+            if lvl > 2:
+                s = self.WARP_SCALE[lvl]
+                bw = self.warp(feats[(lvl - 1, "b")], s * up_f[lvl])
+                cw = self.warp(feats[(lvl - 1, "c")], -s * up_f[lvl])      # the FORWARD flow for both (Q9)
+        ff = [self.FULL_SCALE[l] * up(up_f[l]) for l in range(2, 7)]
+        fb = [-self.FULL_SCALE[l] * up(up_b[l]) for l in range(2, 7)]
+        oc = [F.interpolate(occ[l], scale_factor=4) for l in range(2, 7)]
+        if self.training:
+            if self.nlevels == 6:
+                ff.append(0.625 * up_f[6])
+                fb.append(-0.625 * up_b[6])
+                oc.append(F.interpolate(occ[6], scale_factor=2))
+            return ff, fb, oc
+        return ff[0], fb[0], oc[0]

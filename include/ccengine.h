@@ -180,6 +180,13 @@ int cc_act_bwd_bias(const float* gy, const float* y_or_null, float* geff_or_null
                     int C, int H, int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b,
                     void* stream);
 
+/* ---------------------------------------------------------------- optimizer (train.py:307-310,568)
+ * torch.optim.Adam(betas, eps, weight_decay=0) on the flat fp32 bucket; grads are multiplied by grad_scale first
+ * (1/world_size after the RCCL all-reduce).  step_dev: device float, incremented by the call. */
+int cc_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* step_dev, long n, float lr,
+                 float beta1, float beta2, float eps, float grad_scale, void* stream);
+int cc_fill(float* p, long n, float value, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

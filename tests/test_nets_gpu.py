@@ -1,0 +1,90 @@
+"""Networks and the full CC step on the MI355X against (a) the oracle on CPU and (b) the golden fixture the
+UNMODIFIED reference produced (tests/golden/step_acF.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cc_amd import models, synthetic as syn, trainer as T
+from oracle import nets as N, step as S
+from oracle.make_golden import SB, SH, SW
+
+pytestmark = pytest.mark.gpu
+
+
+def _flat(o):
+    if torch.is_tensor(o):
+        return [o]
+    r = []
+    for x in o:
+        if x is not None:
+            r += _flat(x)
+    return r
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("name", ["disp", "pose", "mask", "flow", "dispS", "poseexp"])
+def test_net_forward_backward(name):
+    dev = "cuda"
+    tgt, refs, K, Kinv = syn.sample(2, 128, 192, seed=1)
+    mk = {"disp": (models.DispResNet6, N.DispResNet6, (), "t"), "pose": (models.PoseNetB6, N.PoseNetB6, (4,), "tr"),
+          "mask": (models.MaskNet6, N.MaskNet6, (4,), "tr"), "flow": (models.Back2Future, N.Back2Future, (6,), "t2"),
+          "dispS": (models.DispNetS, N.DispNetS, (), "t"), "poseexp": (models.PoseExpNet, N.PoseExpNet, (4, True), "tr")}[name]
+    mine, orc = mk[0](*mk[2]), mk[1](*mk[2])
+    assert list(mine.state_dict().keys()) == list(orc.state_dict().keys())
+    sd = syn.seeded_state_dict(orc, 0)
+    mine.load_state_dict(sd)
+    orc.load_state_dict(sd)
+    mine.to(dev)
+    a_cpu = {"t": (tgt,), "tr": (tgt, refs), "t2": (tgt, refs[1:3])}[mk[3]]
+    a_dev = {"t": (tgt.to(dev),), "tr": (tgt.to(dev), [r.to(dev) for r in refs]),
+             "t2": (tgt.to(dev), [r.to(dev) for r in refs[1:3]])}[mk[3]]
+    o1, o0 = _flat(mine(*a_dev)), _flat(orc(*a_cpu))
+    for a, b in zip(o1, o0):
+        assert _rel(a, b) < 1e-4
+    sum((a * a).sum() for a in o1).backward()
+    sum((a * a).sum() for a in o0).backward()
+    num = den = 0.0
+    for (n1, p1), (n2, p2) in zip(mine.named_parameters(), orc.named_parameters()):
+        if p2.grad is None:
+            continue
+        num += float((p1.grad.cpu().double() - p2.grad.double()).pow(2).sum())
+        den += float(p2.grad.double().pow(2).sum())
+    assert (num / den) ** 0.5 < 1e-4
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_full_step_against_reference_golden(golden_dir, use_graph):
+    """losses within 1e-4 rel of the reference CPU path (BASELINE.json north star), one Adam step included."""
+    g = dict(np.load(os.path.join(golden_dir, "step_acF.npz")))
+    dev = torch.device("cuda")
+    bc = syn.sample(SB, SH, SW, seed=1)
+    batch = (bc[0].to(dev), [r.to(dev) for r in bc[1]], bc[2].to(dev), bc[3].to(dev))
+    nets = T.build_nets(dev, init=False)
+    for n in nets:
+        n.load_state_dict(syn.seeded_state_dict(n, 0))
+    tr = T.CCTrainer(nets, T.StepConfig(), use_graph=use_graph)
+    got = {k: float(v) for k, v in tr.step(batch).items()}
+    for k in ("loss", "loss_1", "loss_2", "loss_3", "loss_4", "loss_5"):
+        assert abs(got[k] - float(g[k])) <= 1e-4 * abs(float(g[k])), (k, got[k], float(g[k]))
+    got2 = {k: float(v) for k, v in tr.step(batch).items()}
+    assert abs(got2["loss"] - float(g["loss_after_adam"])) <= 1e-4 * abs(float(g["loss_after_adam"]))
+
+
+def test_config2_against_reference_golden(golden_dir):
+    g = dict(np.load(os.path.join(golden_dir, "step_acF.npz")))
+    dev = torch.device("cuda")
+    bc = syn.sample(SB, SH, SW, seed=1)
+    batch = (bc[0].to(dev), [r.to(dev) for r in bc[1]], bc[2].to(dev), bc[3].to(dev))
+    nets = T.build_nets(dev, flow=False, mask=False, init=False)
+    for n in nets:
+        if n is not None:
+            n.load_state_dict(syn.seeded_state_dict(n, 0))
+            n.train()
+    out = T.cc_forward(nets, batch, T.StepConfig())
+    assert abs(float(out["loss"]) - float(g["c2.loss"])) <= 1e-4 * abs(float(g["c2.loss"]))
