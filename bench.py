@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--conv-backend", default="hip", choices=["hip", "miopen"])
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=64)
     return ap.parse_args()
 
 
@@ -120,10 +121,14 @@ class CallTimer:
         return out
 
 
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
 def cpu_baseline(batch_cpu, args):
     """The oracle (CPU port of the reference step) on this box's host cores -- reported beside, never the target."""
     from oracle import step as S
-    n = os.cpu_count() or 1
+    n = min(os.cpu_count() or 1, args.cpu_threads)
     torch.set_num_threads(n)
     torch.manual_seed(0)
     nets = S.build_nets("oracle", flow=(args.config == "c3"), mask=(args.config == "c3"))
@@ -132,7 +137,9 @@ def cpu_baseline(batch_cpu, args):
             m.init_weights()
     cfg = S.StepConfig()
     opt = S.make_optimizer(nets, cfg)
+    t0 = time.time()
     S.cc_step(nets, opt, batch_cpu, cfg)          # warm-up
+    log("cpu baseline warm-up step %.1f s (%d threads)" % (time.time() - t0, n))
     t0 = time.time()
     for _ in range(args.cpu_steps):
         S.cc_step(nets, opt, batch_cpu, cfg)
@@ -175,8 +182,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    t_w = time.perf_counter()
+    for i in range(args.warmup):
         losses = tr.step(batch)
+        if rank == 0:
+            torch.cuda.synchronize()
+            log("warm-up step %d done at %.1f s" % (i, time.perf_counter() - t_w))
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -188,6 +199,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_val = float(losses["loss"])
+    if rank == 0:
+        log("timed %d steps: %.2f ms/step, loss %.6f" % (args.steps, 1e3 * dt / args.steps, loss_val))
     from cc_amd import loss_functions as LF
     LF.check_finite()
 

@@ -31,3 +31,11 @@ def test_occluded_flow_loss():
 
 def test_pyramid():
     parity.check_pyramid("cpu")
+
+
+def test_warps_bit_exact_vs_reference_golden(golden_dir):
+    r = parity.check_warps_bit_exact_vs_golden("cpu", golden_dir)
+    print(r)
+    for tag, d in r.items():
+        for k in ("inverse_warp", "pose2flow", "flow_warp", "feature_warp"):
+            assert d[k] == 1.0, (tag, k, d)
