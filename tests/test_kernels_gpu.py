@@ -46,3 +46,7 @@ def test_warps_bit_exact_vs_reference_golden(golden_dir):
     for tag, d in r.items():
         for k in ("inverse_warp", "pose2flow", "flow_warp", "feature_warp"):
             assert d[k] == 1.0, (tag, k, d)
+
+
+def test_losses_vs_reference_golden(golden_dir):
+    print(parity.check_losses_vs_golden("cuda", golden_dir))
