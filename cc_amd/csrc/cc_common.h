@@ -12,6 +12,14 @@
         if (hipGetLastError() != hipSuccess) return CC_ERR_LAUNCH; \
     } while (0)
 
+// address-space casts for __builtin_amdgcn_global_load_lds (LDS-DMA)
+#ifndef CC_LDS_PTR
+#define CC_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define CC_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#endif
+// s_waitcnt vmcnt(0) with expcnt/lgkmcnt left at their maxima (gfx9 encoding)
+#define CC_WAIT_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)
+
 namespace cc {
 
 constexpr int kWave = 64;

@@ -27,6 +27,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+inline int pick_bm_fwd(int M) { return M > 64 ? 128 : (M > 32 ? 64 : 32); }
+
 constexpr int BN = 128;   // pixels per workgroup tile
 constexpr int BK = 16;    // reduction chunk
 
@@ -192,6 +194,256 @@ __global__ __launch_bounds__(256) void k_gather_gemm(GG g) {
         }
     }
 }
+
+// ------------------------------------------------------------------ patch-staged implicit GEMM (main path)
+// Same GEMM as k_gather_gemm, restructured so that neither operand needs per-element index math:
+//   * the output tile is a 4 x 32 block of lattice pixels of ONE image; for a chunk of CK input channels the
+//     input PATCH that all Rt x St taps of that tile touch is staged in LDS once (zero-filled outside the
+//     image) and every tap's B fragment is a shifted ds_read of it -> global->LDS traffic / tap count;
+//   * weights are repacked per call to wp[tap][c][m] (m contiguous, zero padded to CK / BM multiples), so an
+//     A tile is CK contiguous rows;
+//   * both are moved by LDS-DMA (global_load_lds: no staging VGPRs, no ds_write, fully asynchronous) and
+//     double-buffered: A per (chunk, tap) stage, patch per chunk; one barrier per stage (= CK/2 MFMA k-steps
+//     x TM x TN MFMAs per wave);
+//   * deep layers on small maps get split-K over channel chunks (grid.z) with a deterministic second pass.
+constexpr int TH = 4, TW = 32;
+
+struct CP {
+    const float* x; const float* wp; const float* zeros; const float* bias; const float* res; float* y; float* part;
+    int B, Cin, IH, IW; long x_bs;
+    int M, Mpad, Cpad;
+    int Rt, St, si, dstep, dy_base, dx_base, ymin, xmin;
+    int PH, PWr, PS;
+    int OHt, OWt, so, oy0, ox0, OH, OW; long y_bs, res_bs;
+    int tiles_x, tiles_y;
+    int nsplit, cps; long part_stride;
+    int act; float act_a, act_b;
+};
+
+// wp[(t*Cpad + c)*Mpad + m] = w[w0 + m*w_sm + c*w_sc + i*w_ri + j*w_sj]  (0 beyond Cin / M), t = i*St + j
+__global__ __launch_bounds__(256) void k_repack_w(const float* __restrict__ w, float* __restrict__ wp, float* __restrict__ zeros,
+                                                  int M, int Cin, int Mpad, int Cpad, int T, int St, long w_sm, long w_sc,
+                                                  int w0, int w_ri, int w_sj) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < 64) zeros[threadIdx.x] = 0.f;
+    const long tot = (long)T * Cpad * Mpad;
+    if (e >= tot) return;
+    const int m = (int)(e % Mpad);
+    const long r = e / Mpad;
+    const int c = (int)(r % Cpad), t = (int)(r / Cpad);
+    const int i = t / St, j = t - i * St;
+    wp[e] = (m < M && c < Cin) ? w[(long)w0 + (long)m * w_sm + (long)c * w_sc + i * w_ri + j * w_sj] : 0.f;
+}
+
+template <int BM, int CK>
+__global__ __launch_bounds__(256) void k_conv_patch(CP g) {
+    constexpr int WM = (BM >= 64) ? BM / 2 : 32;
+    constexpr int TM = WM / 32;
+    constexpr int TN = (BM >= 64) ? 2 : 1;           // lattice rows of the tile per wave
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* As = smem;                    // [2][CK][BM]
+    float* Ps = smem + 2 * CK * BM;      // [2][CK][PS]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (BM >= 64) ? (wid >> 1) : 0;
+    const int row0 = (BM >= 64) ? 2 * (wid & 1) : wid;       // first lattice row (0..3) of this wave
+    const int l31 = lane & 31, lk = lane >> 5;
+
+    int bx = blockIdx.x;
+    const int tile_x = bx % g.tiles_x;
+    bx /= g.tiles_x;
+    const int tile_y = bx % g.tiles_y;
+    const int n = bx / g.tiles_y;
+    const int ty0 = tile_y * TH, tx0 = tile_x * TW;
+    const int gy0 = g.si * ty0 + g.ymin, gx0 = g.si * tx0 + g.xmin;
+    const int m0 = blockIdx.y * BM;
+    const int T = g.Rt * g.St;
+    const int nchunk = g.Cpad / CK;
+    const int c_beg = blockIdx.z * g.cps;
+    int c_end = c_beg + g.cps;
+    if (c_end > nchunk) c_end = nchunk;
+    const int x_cs = g.IH * g.IW;
+    const int R = g.PS >> 6;
+    const float* xn = g.x + (long)n * g.x_bs;
+
+    auto load_patch = [&](int chunk, int buf) {
+        float* dst = Ps + buf * CK * g.PS;
+        for (int r = 0; r < R; r++) {
+            const int pos = lane + 64 * r;
+            const int py = pos / g.PWr, px = pos - py * g.PWr;
+            const int iy = gy0 + py, ix = gx0 + px;
+            const bool ok = (py < g.PH) && ((unsigned)iy < (unsigned)g.IH) && ((unsigned)ix < (unsigned)g.IW);
+            const long go = (long)iy * g.IW + ix;
+#pragma unroll
+            for (int k = 0; k < CK / 4; k++) {
+                const int cl = wid + 4 * k;
+                const int c = chunk * CK + cl;
+                const float* src = (ok && c < g.Cin) ? xn + (long)c * x_cs + go : g.zeros + lane;
+                __builtin_amdgcn_global_load_lds(CC_GLOBAL_PTR(src), CC_LDS_PTR(dst + cl * g.PS + 64 * r), 4, 0, 0);
+            }
+        }
+    };
+    auto load_A = [&](int chunk, int tap, int buf) {
+        // CK rows of BM contiguous floats: wp[((tap*Cpad + chunk*CK + kk) * Mpad) + m0 + mm]
+        const float* base = g.wp + ((long)tap * g.Cpad + (long)chunk * CK) * g.Mpad + m0;
+        float* dst = As + buf * CK * BM;
+        constexpr int N4 = CK * BM / 4;                        // float4 count
+#pragma unroll
+        for (int q = 0; q < (N4 + 255) / 256; q++) {
+            const int w4 = q * 256 + wid * 64;                 // first float4 of this wave (uniform)
+            if (w4 < N4) {
+                const int f = 4 * (w4 + lane);
+                const int kk = f / BM, mm = f - kk * BM;
+                __builtin_amdgcn_global_load_lds(CC_GLOBAL_PTR(base + (long)kk * g.Mpad + mm), CC_LDS_PTR(dst + 4 * w4), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; a++)
+#pragma unroll
+        for (int b = 0; b < TN; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    if (c_beg < c_end) {
+        load_patch(c_beg, c_beg & 1);
+        load_A(c_beg, 0, 0);
+        CC_WAIT_VMCNT0();
+        __syncthreads();
+        int s = 0;
+        for (int chunk = c_beg; chunk < c_end; chunk++) {
+            const float* Pb = Ps + (chunk & 1) * CK * g.PS;
+            int ti = 0, tj = 0;
+            for (int tap = 0; tap < T; tap++, s++) {
+                // prefetch the next stage's operands (other buffers; their last readers passed the previous barrier)
+                if (tap + 1 < T) load_A(chunk, tap + 1, (s + 1) & 1);
+                else if (chunk + 1 < c_end) load_A(chunk + 1, 0, (s + 1) & 1);
+                if (tap == 0 && chunk + 1 < c_end) load_patch(chunk + 1, (chunk + 1) & 1);
+                const float* Ab = As + (s & 1) * CK * BM;
+                const int tapoff = (g.dy_base + ti * g.dstep) * g.PWr + (g.dx_base + tj * g.dstep);
+                const float* Pl = Pb + lk * g.PS + (g.si * row0) * g.PWr + g.si * l31 + tapoff;
+                const float* Al = Ab + lk * BM + wm * WM + l31;
+#pragma unroll
+                for (int ks = 0; ks < CK / 2; ks++) {
+                    float af[TM], bf[TN];
+#pragma unroll
+                    for (int a = 0; a < TM; a++) af[a] = Al[(2 * ks) * BM + a * 32];
+#pragma unroll
+                    for (int b = 0; b < TN; b++) bf[b] = Pl[(2 * ks) * g.PS + (g.si * b) * g.PWr];
+#pragma unroll
+                    for (int a = 0; a < TM; a++)
+#pragma unroll
+                        for (int b = 0; b < TN; b++)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+                }
+                if (++tj == g.St) { tj = 0; ti++; }
+                CC_WAIT_VMCNT0();
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue: D col = lane&31 -> tx, row -> channel
+    const int y_cs = g.OH * g.OW;
+    const int tx = tx0 + l31;
+#pragma unroll
+    for (int b = 0; b < TN; b++) {
+        const int ty = ty0 + row0 + b;
+        if (ty >= g.OHt || tx >= g.OWt) continue;
+        const long pix = (long)(g.oy0 + g.so * ty) * g.OW + (g.ox0 + g.so * tx);
+        if (g.nsplit > 1) {
+            float* pb = g.part + (long)blockIdx.z * g.part_stride + ((long)n * g.M) * y_cs + pix;
+#pragma unroll
+            for (int a = 0; a < TM; a++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (m < g.M) pb[(long)m * y_cs] = acc[a][b][r];
+                }
+        } else {
+            float* yb = g.y + (long)n * g.y_bs + pix;
+            const float* rbp = g.res ? g.res + (long)n * g.res_bs + pix : nullptr;
+#pragma unroll
+            for (int a = 0; a < TM; a++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (m < g.M) {
+                        float v = acc[a][b][r];
+                        if (g.bias) v += g.bias[m];
+                        if (rbp) v += rbp[(long)m * y_cs];
+                        yb[(long)m * y_cs] = apply_act(v, g.act, g.act_a, g.act_b);
+                    }
+                }
+        }
+    }
+}
+
+// y = act(bias + res + sum_k part[k])   (so == 1 lattices only: the partial slabs are dense [B][M][OH*OW])
+__global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict__ part, int nsplit, long part_stride,
+                                                         const float* __restrict__ bias, const float* __restrict__ res,
+                                                         float* __restrict__ y, int M, int HW, long y_bs, long res_bs,
+                                                         long total, int act, float act_a, float act_b) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    float v = 0.f;
+    for (int k = 0; k < nsplit; k++) v += part[(long)k * part_stride + e];
+    const long per = (long)M * HW;
+    const int n = (int)(e / per);
+    const long r = e - (long)n * per;
+    const int m = (int)(r / HW);
+    if (bias) v += bias[m];
+    if (res) v += res[(long)n * res_bs + r];
+    y[(long)n * y_bs + r] = apply_act(v, act, act_a, act_b);
+}
+
+struct ConvPlan {
+    bool use_patch;
+    int bm, ck, Mpad, Cpad, PH, PWr, PS, ymin, xmin, tiles_x, tiles_y, nsplit, cps;
+    size_t smem, wp_floats, part_floats;
+};
+
+inline ConvPlan plan_conv(const GG& g) {
+    ConvPlan p = {};
+    p.bm = pick_bm_fwd(g.M);
+    const int ylast = g.dy0 + (g.Rt - 1) * g.dstep, xlast = g.dx0 + (g.St - 1) * g.dstep;
+    p.ymin = g.dy0 < ylast ? g.dy0 : ylast;
+    p.xmin = g.dx0 < xlast ? g.dx0 : xlast;
+    const int ymax = g.dy0 < ylast ? ylast : g.dy0, xmax = g.dx0 < xlast ? xlast : g.dx0;
+    p.PH = (TH - 1) * g.si + (ymax - p.ymin) + 1;
+    p.PWr = (TW - 1) * g.si + (xmax - p.xmin) + 1;
+    p.PS = ((p.PH * p.PWr + 63) / 64) * 64;
+    p.ck = 16;
+    auto smem_of = [&](int ck) { return (size_t)(2 * ck * p.bm + 2 * ck * p.PS) * sizeof(float); };
+    if (smem_of(16) > 64 * 1024) p.ck = 8;
+    p.smem = smem_of(p.ck);
+    p.use_patch = (p.smem <= 150 * 1024) && g.Cin > 0;
+    p.Mpad = ((g.M + p.bm - 1) / p.bm) * p.bm;
+    p.Cpad = ((g.Cin + p.ck - 1) / p.ck) * p.ck;
+    p.tiles_x = (g.OWt + TW - 1) / TW;
+    p.tiles_y = (g.OHt + TH - 1) / TH;
+    p.wp_floats = (size_t)g.Rt * g.St * p.Cpad * p.Mpad;
+    const long blocks = (long)g.B * p.tiles_x * p.tiles_y * (p.Mpad / p.bm);
+    const int nchunk = p.Cpad / p.ck;
+    p.nsplit = 1;
+    p.cps = nchunk;
+    if (g.so == 1 && blocks < 256 && nchunk >= 4) {
+        long want = (512 + blocks - 1) / blocks;
+        if (want > nchunk / 2) want = nchunk / 2;
+        if (want > 32) want = 32;
+        if (want >= 2) {
+            p.cps = (int)((nchunk + want - 1) / want);
+            p.nsplit = (nchunk + p.cps - 1) / p.cps;
+        }
+    }
+    p.part_floats = p.nsplit > 1 ? (size_t)p.nsplit * g.B * g.M * g.OH * g.OW : 0;
+    return p;
+}
+
+inline size_t conv_ws_floats(const ConvPlan& p) { return 64 + p.wp_floats + p.part_floats; }
 
 // ------------------------------------------------------------------ weight gradient
 struct WG {
@@ -391,7 +643,7 @@ __global__ __launch_bounds__(64) void k_bias_reduce(const float* __restrict__ pa
 
 inline int pick_bm(int M) { return M > 64 ? 128 : (M > 32 ? 64 : 32); }
 
-inline void launch_gg(const GG& g, hipStream_t s) {
+inline void launch_gg_flat(const GG& g, hipStream_t s) {
     const long Ntot = (long)g.B * g.OHt * g.OWt;
     const int bm = pick_bm(g.M);
     dim3 grid((unsigned)((Ntot + BN - 1) / BN), (unsigned)((g.M + bm - 1) / bm));
@@ -400,24 +652,83 @@ inline void launch_gg(const GG& g, hipStream_t s) {
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_gemm<32>), grid, dim3(256), 0, s, g);
 }
 
+template <int BM, int CK>
+inline void launch_patch(const CP& c, dim3 grid, size_t smem, hipStream_t s) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_patch<BM, CK>), grid, dim3(256), smem, s, c);
+}
+
+// ws: [64 zeros][repacked weights][split-K partial slabs]; sized by conv_ws_floats(plan_conv(g))
+inline void launch_gg(const GG& g, float* ws, hipStream_t s) {
+    const ConvPlan p = plan_conv(g);
+    if (!p.use_patch || ws == nullptr) { launch_gg_flat(g, s); return; }
+    float* zeros = ws;
+    float* wp = ws + 64;
+    float* part = wp + p.wp_floats;
+    const int T = g.Rt * g.St;
+    hipLaunchKernelGGL(k_repack_w, dim3((unsigned)((p.wp_floats + 255) / 256)), dim3(256), 0, s, g.w, wp, zeros, g.M, g.Cin,
+                       p.Mpad, p.Cpad, T, g.St, g.w_sm, g.w_sc, g.w0, g.w_ri, g.w_sj);
+    CP c = {};
+    c.x = g.x; c.wp = wp; c.zeros = zeros; c.bias = g.bias; c.res = g.res; c.y = g.y; c.part = part;
+    c.B = g.B; c.Cin = g.Cin; c.IH = g.IH; c.IW = g.IW; c.x_bs = g.x_bs;
+    c.M = g.M; c.Mpad = p.Mpad; c.Cpad = p.Cpad;
+    c.Rt = g.Rt; c.St = g.St; c.si = g.si; c.dstep = g.dstep;
+    c.dy_base = g.dy0 - p.ymin; c.dx_base = g.dx0 - p.xmin; c.ymin = p.ymin; c.xmin = p.xmin;
+    c.PH = p.PH; c.PWr = p.PWr; c.PS = p.PS;
+    c.OHt = g.OHt; c.OWt = g.OWt; c.so = g.so; c.oy0 = g.oy0; c.ox0 = g.ox0; c.OH = g.OH; c.OW = g.OW;
+    c.y_bs = g.y_bs; c.res_bs = g.res_bs;
+    c.tiles_x = p.tiles_x; c.tiles_y = p.tiles_y;
+    c.nsplit = p.nsplit; c.cps = p.cps; c.part_stride = (long)g.B * g.M * g.OH * g.OW;
+    c.act = g.act; c.act_a = g.act_a; c.act_b = g.act_b;
+    dim3 grid((unsigned)(g.B * p.tiles_x * p.tiles_y), (unsigned)(p.Mpad / p.bm), (unsigned)p.nsplit);
+    if (p.ck == 16) {
+        if (p.bm == 128) launch_patch<128, 16>(c, grid, p.smem, s);
+        else if (p.bm == 64) launch_patch<64, 16>(c, grid, p.smem, s);
+        else launch_patch<32, 16>(c, grid, p.smem, s);
+    } else {
+        if (p.bm == 128) launch_patch<128, 8>(c, grid, p.smem, s);
+        else if (p.bm == 64) launch_patch<64, 8>(c, grid, p.smem, s);
+        else launch_patch<32, 8>(c, grid, p.smem, s);
+    }
+    if (p.nsplit > 1) {
+        const long total = c.part_stride;
+        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)part,
+                           p.nsplit, c.part_stride, g.bias, g.res, g.y, g.M, g.OH * g.OW, g.y_bs, g.res_bs, total, g.act,
+                           g.act_a, g.act_b);
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
-/* y = act(conv2d(x, w, stride, pad) + bias + res).  x: [B,Cin,IH,IW] (batch stride x_bs), w: [Cout,Cin,R,S],
- * y: [B,Cout,OH,OW] (batch stride y_bs; may be a channel slice of a wider tensor). */
-int cc_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, const float* res_or_null, float* y, int B,
-                  int Cin, int IH, int IW, long x_bs, int Cout, int R, int S, int stride, int pad, int OH, int OW,
-                  long y_bs, long res_bs, int act, float act_a, float act_b, void* stream) {
-    if (B <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0) return CC_ERR_ARG;
+static GG make_fwd(const float* x, const float* w, const float* bias, const float* res, float* y, int B, int Cin, int IH,
+                   int IW, long x_bs, int Cout, int R, int S, int stride, int pad, int OH, int OW, long y_bs, long res_bs,
+                   int act, float act_a, float act_b) {
     GG g = {};
-    g.x = x; g.w = w; g.bias = bias_or_null; g.res = res_or_null; g.y = y;
+    g.x = x; g.w = w; g.bias = bias; g.res = res; g.y = y;
     g.B = B; g.Cin = Cin; g.IH = IH; g.IW = IW; g.x_bs = x_bs;
     g.M = Cout; g.w_sm = (long)Cin * R * S; g.w_sc = (long)R * S; g.w0 = 0; g.w_ri = S; g.w_sj = 1;
     g.Rt = R; g.St = S; g.dy0 = -pad; g.dx0 = -pad; g.dstep = 1; g.si = stride;
     g.OHt = OH; g.OWt = OW; g.so = 1; g.oy0 = 0; g.ox0 = 0; g.OH = OH; g.OW = OW; g.y_bs = y_bs; g.res_bs = res_bs;
     g.act = act; g.act_a = act_a; g.act_b = act_b;
-    launch_gg(g, (hipStream_t)stream);
+    return g;
+}
+
+size_t cc_conv2d_fwd_ws_bytes(int B, int Cin, int IH, int IW, int Cout, int R, int S, int stride, int pad, int OH, int OW) {
+    GG g = make_fwd(nullptr, nullptr, nullptr, nullptr, nullptr, B, Cin, IH, IW, 0, Cout, R, S, stride, pad, OH, OW, 0, 0, 0,
+                    1.f, 0.f);
+    return conv_ws_floats(plan_conv(g)) * sizeof(float);
+}
+
+/* y = act(conv2d(x, w, stride, pad) + bias + res).  x: [B,Cin,IH,IW] (batch stride x_bs), w: [Cout,Cin,R,S],
+ * y: [B,Cout,OH,OW] (batch stride y_bs; may be a channel slice of a wider tensor).  ws: cc_conv2d_fwd_ws_bytes(). */
+int cc_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, const float* res_or_null, float* y, float* ws,
+                  int B, int Cin, int IH, int IW, long x_bs, int Cout, int R, int S, int stride, int pad, int OH, int OW,
+                  long y_bs, long res_bs, int act, float act_a, float act_b, void* stream) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0) return CC_ERR_ARG;
+    GG g = make_fwd(x, w, bias_or_null, res_or_null, y, B, Cin, IH, IW, x_bs, Cout, R, S, stride, pad, OH, OW, y_bs, res_bs,
+                    act, act_a, act_b);
+    launch_gg(g, ws, (hipStream_t)stream);
     CC_CHECK_LAUNCH();
     return CC_OK;
 }
@@ -427,31 +738,55 @@ int cc_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, con
  * (b) ConvTranspose2d forward (w: [Cin=K, Cout=C, R, S] -> w_k_stride = C*R*S, w_c_stride = R*S as well),
  * one launch per output parity class so that no structurally-zero tap is multiplied.
  * gy: [B,K,OH,OW]; gx: [B,C,IH,IW]. */
-int cc_conv2d_dgrad(const float* gy, const float* w, const float* bias_or_null, float* gx, int B, int K, int OH, int OW,
-                    long gy_bs, int C, int R, int S, int stride, int pad, int IH, int IW, long gx_bs, long w_k_stride,
-                    long w_c_stride, int act, float act_a, float act_b, void* stream) {
+static bool make_dgrad_class(GG& g, int py, int px, const float* gy, const float* w, const float* bias, float* gx, int B,
+                             int K, int OH, int OW, long gy_bs, int C, int R, int S, int stride, int pad, int IH, int IW,
+                             long gx_bs, long w_k_stride, long w_c_stride, int act, float act_a, float act_b) {
+    // taps r with (py + pad - r) % stride == 0, r ascending: r = r0 + stride*i
+    const int r0 = (py + pad) % stride, s0 = (px + pad) % stride;
+    const int Rt = (r0 < R) ? (R - r0 + stride - 1) / stride : 0;
+    const int St = (s0 < S) ? (S - s0 + stride - 1) / stride : 0;
+    const int OHt = (IH - py + stride - 1) / stride, OWt = (IW - px + stride - 1) / stride;
+    if (OHt <= 0 || OWt <= 0) return false;
+    g = GG();
+    g.x = gy; g.w = w; g.bias = bias; g.res = nullptr; g.y = gx;
+    g.B = B; g.Cin = K; g.IH = OH; g.IW = OW; g.x_bs = gy_bs;
+    g.M = C; g.w_sm = w_c_stride; g.w_sc = w_k_stride;
+    g.w0 = r0 * S + s0; g.w_ri = stride * S; g.w_sj = stride;
+    g.Rt = Rt > 0 ? Rt : 1; g.St = St > 0 ? St : 1;
+    // oy = (iy + pad - r)/stride with iy = py + stride*ty, r = r0 + stride*i  ->  oy = ty + (py + pad - r0)/stride - i
+    g.dy0 = (py + pad - r0) / stride; g.dx0 = (px + pad - s0) / stride; g.dstep = -1; g.si = 1;
+    if (Rt == 0 || St == 0) g.Cin = 0;   // no tap reaches this parity class: output = act(bias)
+    g.OHt = OHt; g.OWt = OWt; g.so = stride; g.oy0 = py; g.ox0 = px; g.OH = IH; g.OW = IW; g.y_bs = gx_bs;
+    g.act = act; g.act_a = act_a; g.act_b = act_b;
+    return true;
+}
+
+size_t cc_conv2d_dgrad_ws_bytes(int B, int K, int OH, int OW, int C, int R, int S, int stride, int pad, int IH, int IW) {
+    size_t best = 64;
+    for (int py = 0; py < stride; py++)
+        for (int px = 0; px < stride; px++) {
+            GG g;
+            if (!make_dgrad_class(g, py, px, nullptr, nullptr, nullptr, nullptr, B, K, OH, OW, 0, C, R, S, stride, pad, IH, IW,
+                                  0, (long)C * R * S, (long)R * S, 0, 1.f, 0.f))
+                continue;
+            const size_t f = conv_ws_floats(plan_conv(g));
+            if (f > best) best = f;
+        }
+    return best * sizeof(float);
+}
+
+int cc_conv2d_dgrad(const float* gy, const float* w, const float* bias_or_null, float* gx, float* ws, int B, int K, int OH,
+                    int OW, long gy_bs, int C, int R, int S, int stride, int pad, int IH, int IW, long gx_bs,
+                    long w_k_stride, long w_c_stride, int act, float act_a, float act_b, void* stream) {
     if (B <= 0 || K <= 0 || C <= 0 || stride <= 0) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     for (int py = 0; py < stride; py++) {
         for (int px = 0; px < stride; px++) {
-            // taps r with (py + pad - r) % stride == 0, r ascending: r = r0 + stride*i
-            int r0 = (py + pad) % stride, s0 = (px + pad) % stride;
-            const int Rt = (r0 < R) ? (R - r0 + stride - 1) / stride : 0;
-            const int St = (s0 < S) ? (S - s0 + stride - 1) / stride : 0;
-            const int OHt = (IH - py + stride - 1) / stride, OWt = (IW - px + stride - 1) / stride;
-            if (OHt <= 0 || OWt <= 0) continue;
-            GG g = {};
-            g.x = gy; g.w = w; g.bias = bias_or_null; g.res = nullptr; g.y = gx;
-            g.B = B; g.Cin = K; g.IH = OH; g.IW = OW; g.x_bs = gy_bs;
-            g.M = C; g.w_sm = w_c_stride; g.w_sc = w_k_stride;
-            g.w0 = r0 * S + s0; g.w_ri = stride * S; g.w_sj = stride;
-            g.Rt = Rt > 0 ? Rt : 1; g.St = St > 0 ? St : 1;
-            // oy = (iy + pad - r)/stride with iy = py + stride*ty, r = r0 + stride*i  ->  oy = ty + (py + pad - r0)/stride - i
-            g.dy0 = (py + pad - r0) / stride; g.dx0 = (px + pad - s0) / stride; g.dstep = -1; g.si = 1;
-            if (Rt == 0 || St == 0) { g.Cin = 0; }   // no tap reaches this parity class: output = act(bias)
-            g.OHt = OHt; g.OWt = OWt; g.so = stride; g.oy0 = py; g.ox0 = px; g.OH = IH; g.OW = IW; g.y_bs = gx_bs;
-            g.act = act; g.act_a = act_a; g.act_b = act_b;
-            launch_gg(g, s);
+            GG g;
+            if (!make_dgrad_class(g, py, px, gy, w, bias_or_null, gx, B, K, OH, OW, gy_bs, C, R, S, stride, pad, IH, IW, gx_bs,
+                                  w_k_stride, w_c_stride, act, act_a, act_b))
+                continue;
+            launch_gg(g, ws, s);
         }
     }
     CC_CHECK_LAUNCH();

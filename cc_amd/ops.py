@@ -34,8 +34,10 @@ class _Conv2dFn(torch.autograd.Function):
         y = torch.empty(B, Cout, OH, OW, device=x.device, dtype=torch.float32)
         bias_c = None if bias is None else _c(bias)
         res_c = None if res is None else _c(res)
-        engine().call("cc_conv2d_fwd", x, w, bias_c, res_c, y, B, Cin, IH, IW, Cin * IH * IW, Cout, R, S, stride, pad,
-                      OH, OW, Cout * OH * OW, Cout * OH * OW, act, act_a, act_b, STREAM)
+        E = engine()
+        ws = _ws(E.call("cc_conv2d_fwd_ws_bytes", B, Cin, IH, IW, Cout, R, S, stride, pad, OH, OW), x)
+        E.call("cc_conv2d_fwd", x, w, bias_c, res_c, y, ws, B, Cin, IH, IW, Cin * IH * IW, Cout, R, S, stride, pad,
+               OH, OW, Cout * OH * OW, Cout * OH * OW, act, act_a, act_b, STREAM)
         ctx.save_for_backward(x, w, y if act != 0 else None)
         ctx.cfg = (stride, pad, act, act_a, act_b, bias is not None, res is not None)
         return y
@@ -60,7 +62,8 @@ class _Conv2dFn(torch.autograd.Function):
         gx = gw = None
         if need[0]:
             gx = torch.empty_like(x)
-            E.call("cc_conv2d_dgrad", gy, w, None, gx, B, Cout, OH, OW, Cout * OH * OW, Cin, R, S, stride, pad, IH, IW,
+            ws = _ws(E.call("cc_conv2d_dgrad_ws_bytes", B, Cout, OH, OW, Cin, R, S, stride, pad, IH, IW), x)
+            E.call("cc_conv2d_dgrad", gy, w, None, gx, ws, B, Cout, OH, OW, Cout * OH * OW, Cin, R, S, stride, pad, IH, IW,
                    Cin * IH * IW, Cin * R * S, R * S, 0, 1.0, 0.0, STREAM)
         if need[1]:
             gw = torch.empty_like(w)
@@ -92,8 +95,10 @@ class _ConvT2dFn(torch.autograd.Function):
         y = torch.empty(B, Cout, OH, OW, device=x.device, dtype=torch.float32)
         bias_c = None if bias is None else _c(bias)
         # ConvTranspose2d forward == the transposed-conv arithmetic of cc_conv2d_dgrad with K = Cin, C = Cout
-        engine().call("cc_conv2d_dgrad", x, w, bias_c, y, B, Cin, IH, IW, Cin * IH * IW, Cout, R, S, stride, pad, OH, OW,
-                      Cout * OH * OW, Cout * R * S, R * S, act, 1.0, 0.0, STREAM)
+        E = engine()
+        ws = _ws(E.call("cc_conv2d_dgrad_ws_bytes", B, Cin, IH, IW, Cout, R, S, stride, pad, OH, OW), x)
+        E.call("cc_conv2d_dgrad", x, w, bias_c, y, ws, B, Cin, IH, IW, Cin * IH * IW, Cout, R, S, stride, pad, OH, OW,
+               Cout * OH * OW, Cout * R * S, R * S, act, 1.0, 0.0, STREAM)
         ctx.save_for_backward(x, w, y if act != 0 else None)
         ctx.cfg = (stride, pad, act, bias is not None)
         return y
@@ -119,7 +124,8 @@ class _ConvT2dFn(torch.autograd.Function):
         if need[0]:
             # d/dx of a transposed conv is a plain strided conv of gy; the [Cin,Cout,R,S] weight IS its [M,C,R,S] weight
             gx = torch.empty_like(x)
-            E.call("cc_conv2d_fwd", gy, w, None, None, gx, B, Cout, OH, OW, Cout * OH * OW, Cin, R, S, stride, pad, IH, IW,
+            ws = _ws(E.call("cc_conv2d_fwd_ws_bytes", B, Cout, OH, OW, Cin, R, S, stride, pad, IH, IW), x)
+            E.call("cc_conv2d_fwd", gy, w, None, None, gx, ws, B, Cout, OH, OW, Cout * OH * OW, Cin, R, S, stride, pad, IH, IW,
                    Cin * IH * IW, 0, 0, 1.0, 0.0, STREAM)
         if need[1]:
             gw = torch.empty_like(w)

@@ -341,6 +341,14 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x4(float a, float b, hipemu_f32x4 c)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu_mfma_32x32x2(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_16x16x4(a, b, c)
 #define __builtin_amdgcn_readfirstlane(x) (x)
+// LDS-DMA: destination = wave-uniform base + lane * size (guide section 5); executes synchronously here
+#define CC_LDS_PTR(p) ((void*)(p))
+#define CC_GLOBAL_PTR(p) ((const void*)(p))
+static inline void hipemu_glds(const void* src, void* dst, unsigned size) {
+    memcpy(static_cast<char*>(dst) + (size_t)hipemu::lane_id() * size, src, size);
+}
+#define __builtin_amdgcn_global_load_lds(src, dst, size, off, aux) hipemu_glds(src, dst, size)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_barrier() hipemu::block_barrier()

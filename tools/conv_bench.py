@@ -62,6 +62,7 @@ def main():
             OH, OW = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
             macs = B * OH * OW * Cin * Cout * k * k
         fl = 2.0 * macs
+        err = float((fwd_hip() - fwd_ref()).abs().max() / fwd_ref().abs().max())
         t_h = timeit(fwd_hip)
         t_r = timeit(fwd_ref)
         xg = x.clone().requires_grad_(True)
@@ -76,7 +77,7 @@ def main():
             torch.autograd.grad(y, [xg, wg], gy)
         t_hb = timeit(lambda: fb(True), 3)
         t_rb = timeit(lambda: fb(False), 3)
-        row = dict(layer=name.strip(), gflop=round(fl / 1e9, 2), hip_fwd_ms=round(t_h, 3), miopen_fwd_ms=round(t_r, 3),
+        row = dict(layer=name.strip(), relerr=round(err, 8), gflop=round(fl / 1e9, 2), hip_fwd_ms=round(t_h, 3), miopen_fwd_ms=round(t_r, 3),
                    hip_fwd_tf=round(fl / t_h / 1e9, 1), miopen_fwd_tf=round(fl / t_r / 1e9, 1),
                    hip_fwdbwd_ms=round(t_hb, 3), miopen_fwdbwd_ms=round(t_rb, 3),
                    hip_fwdbwd_tf=round(3 * fl / t_hb / 1e9, 1), miopen_fwdbwd_tf=round(3 * fl / t_rb / 1e9, 1))
