@@ -326,18 +326,23 @@ __global__ __launch_bounds__(256) void k_conv_patch(CP g) {
                 const int tapoff = (g.dy_base + ti * g.dstep) * g.PWr + (g.dx_base + tj * g.dstep);
                 const float* Pl = Pb + lk * g.PS + (g.si * row0) * g.PWr + g.si * l31 + tapoff;
                 const float* Al = Ab + lk * BM + wm * WM + l31;
+                // all fragments of the stage are fetched up front (2*(TM+TN)*CK/2 VGPRs): one exposed LDS latency per
+                // stage instead of one per k-step; the MFMAs then issue back to back behind counted lgkmcnt waits
+                float af[CK / 2][TM], bf[CK / 2][TN];
 #pragma unroll
                 for (int ks = 0; ks < CK / 2; ks++) {
-                    float af[TM], bf[TN];
 #pragma unroll
-                    for (int a = 0; a < TM; a++) af[a] = Al[(2 * ks) * BM + a * 32];
+                    for (int a = 0; a < TM; a++) af[ks][a] = Al[(2 * ks) * BM + a * 32];
 #pragma unroll
-                    for (int b = 0; b < TN; b++) bf[b] = Pl[(2 * ks) * g.PS + (g.si * b) * g.PWr];
+                    for (int b = 0; b < TN; b++) bf[ks][b] = Pl[(2 * ks) * g.PS + (g.si * b) * g.PWr];
+                }
+#pragma unroll
+                for (int ks = 0; ks < CK / 2; ks++) {
 #pragma unroll
                     for (int a = 0; a < TM; a++)
 #pragma unroll
                         for (int b = 0; b < TN; b++)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks][a], bf[ks][b], acc[a][b], 0, 0, 0);
                 }
                 if (++tj == g.St) { tj = 0; ti++; }
                 CC_WAIT_VMCNT0();
@@ -355,13 +360,15 @@ __global__ __launch_bounds__(256) void k_conv_patch(CP g) {
         if (ty >= g.OHt || tx >= g.OWt) continue;
         const long pix = (long)(g.oy0 + g.so * ty) * g.OW + (g.ox0 + g.so * tx);
         if (g.nsplit > 1) {
-            float* pb = g.part + (long)blockIdx.z * g.part_stride + ((long)n * g.M) * y_cs + pix;
+            // partial slabs are dense over the LATTICE: [split][n][m][ty*OWt + tx]
+            const int HWt = g.OHt * g.OWt;
+            float* pb = g.part + (long)blockIdx.z * g.part_stride + ((long)n * g.M) * HWt + (long)ty * g.OWt + tx;
 #pragma unroll
             for (int a = 0; a < TM; a++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int m = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    if (m < g.M) pb[(long)m * y_cs] = acc[a][b][r];
+                    if (m < g.M) pb[(long)m * HWt] = acc[a][b][r];
                 }
         } else {
             float* yb = g.y + (long)n * g.y_bs + pix;
@@ -382,22 +389,27 @@ __global__ __launch_bounds__(256) void k_conv_patch(CP g) {
     }
 }
 
-// y = act(bias + res + sum_k part[k])   (so == 1 lattices only: the partial slabs are dense [B][M][OH*OW])
+// y[lattice pixel] = act(bias + res + sum_k part[k])  (second, deterministic stage of split-K)
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict__ part, int nsplit, long part_stride,
                                                          const float* __restrict__ bias, const float* __restrict__ res,
-                                                         float* __restrict__ y, int M, int HW, long y_bs, long res_bs,
-                                                         long total, int act, float act_a, float act_b) {
+                                                         float* __restrict__ y, int M, int OHt, int OWt, int so, int oy0,
+                                                         int ox0, int OH, int OW, long y_bs, long res_bs, long total,
+                                                         int act, float act_a, float act_b) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     float v = 0.f;
     for (int k = 0; k < nsplit; k++) v += part[(long)k * part_stride + e];
-    const long per = (long)M * HW;
+    const int HWt = OHt * OWt;
+    const long per = (long)M * HWt;
     const int n = (int)(e / per);
     const long r = e - (long)n * per;
-    const int m = (int)(r / HW);
+    const int m = (int)(r / HWt);
+    const int t = (int)(r - (long)m * HWt);
+    const int ty = t / OWt, tx = t - ty * OWt;
+    const long o = (long)m * OH * OW + (long)(oy0 + so * ty) * OW + (ox0 + so * tx);
     if (bias) v += bias[m];
-    if (res) v += res[(long)n * res_bs + r];
-    y[(long)n * y_bs + r] = apply_act(v, act, act_a, act_b);
+    if (res) v += res[(long)n * res_bs + o];
+    y[(long)n * y_bs + o] = apply_act(v, act, act_a, act_b);
 }
 
 struct ConvPlan {
@@ -430,7 +442,7 @@ inline ConvPlan plan_conv(const GG& g) {
     const int nchunk = p.Cpad / p.ck;
     p.nsplit = 1;
     p.cps = nchunk;
-    if (g.so == 1 && blocks < 256 && nchunk >= 4) {
+    if (blocks < 256 && nchunk >= 4) {
         long want = (512 + blocks - 1) / blocks;
         if (want > nchunk / 2) want = nchunk / 2;
         if (want > 32) want = 32;
@@ -439,7 +451,7 @@ inline ConvPlan plan_conv(const GG& g) {
             p.nsplit = (nchunk + p.cps - 1) / p.cps;
         }
     }
-    p.part_floats = p.nsplit > 1 ? (size_t)p.nsplit * g.B * g.M * g.OH * g.OW : 0;
+    p.part_floats = p.nsplit > 1 ? (size_t)p.nsplit * g.B * g.M * g.OHt * g.OWt : 0;
     return p;
 }
 
@@ -677,7 +689,7 @@ inline void launch_gg(const GG& g, float* ws, hipStream_t s) {
     c.OHt = g.OHt; c.OWt = g.OWt; c.so = g.so; c.oy0 = g.oy0; c.ox0 = g.ox0; c.OH = g.OH; c.OW = g.OW;
     c.y_bs = g.y_bs; c.res_bs = g.res_bs;
     c.tiles_x = p.tiles_x; c.tiles_y = p.tiles_y;
-    c.nsplit = p.nsplit; c.cps = p.cps; c.part_stride = (long)g.B * g.M * g.OH * g.OW;
+    c.nsplit = p.nsplit; c.cps = p.cps; c.part_stride = (long)g.B * g.M * g.OHt * g.OWt;
     c.act = g.act; c.act_a = g.act_a; c.act_b = g.act_b;
     dim3 grid((unsigned)(g.B * p.tiles_x * p.tiles_y), (unsigned)(p.Mpad / p.bm), (unsigned)p.nsplit);
     if (p.ck == 16) {
@@ -692,8 +704,8 @@ inline void launch_gg(const GG& g, float* ws, hipStream_t s) {
     if (p.nsplit > 1) {
         const long total = c.part_stride;
         hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)part,
-                           p.nsplit, c.part_stride, g.bias, g.res, g.y, g.M, g.OH * g.OW, g.y_bs, g.res_bs, total, g.act,
-                           g.act_a, g.act_b);
+                           p.nsplit, c.part_stride, g.bias, g.res, g.y, g.M, g.OHt, g.OWt, g.so, g.oy0, g.ox0, g.OH, g.OW,
+                           g.y_bs, g.res_bs, total, g.act, g.act_a, g.act_b);
     }
 }
 
@@ -798,8 +810,8 @@ size_t cc_conv2d_wgrad_ws_bytes(int B, int M, int AH, int AW, int Cin, int R, in
     const long P = (long)B * AH * AW;
     const int bm = pick_bm(M);
     const long tiles = ((Ntot + BN - 1) / BN) * ((M + bm - 1) / bm);
-    long nsplit = (1024 + tiles - 1) / tiles;
-    const long maxsplit = (P + 255) / 256;
+    long nsplit = (512 + tiles - 1) / tiles;
+    const long maxsplit = (P + 1023) / 1024;
     if (nsplit > maxsplit) nsplit = maxsplit;
     if (nsplit < 1) nsplit = 1;
     return nsplit <= 1 ? 16 : (size_t)nsplit * M * Ntot * sizeof(float);
@@ -816,8 +828,8 @@ int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B,
     const long P = (long)B * AH * AW;
     const int bm = pick_bm(M);
     const long tiles = ((Ntot + BN - 1) / BN) * ((M + bm - 1) / bm);
-    long nsplit = (1024 + tiles - 1) / tiles;
-    const long maxsplit = (P + 255) / 256;
+    long nsplit = (512 + tiles - 1) / tiles;
+    const long maxsplit = (P + 1023) / 1024;
     if (nsplit > maxsplit) nsplit = maxsplit;
     if (nsplit < 1) nsplit = 1;
     long pps = (P + nsplit - 1) / nsplit;

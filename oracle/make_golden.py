@@ -43,10 +43,13 @@ def pyramid_inputs(B, H, W, levels=6, seed=3):
     return out
 
 
-def function_level(ac):
+def function_level(ac, smooth=0):
+    """smooth=0: white-noise frames (worst case for tap-index exactness); smooth>0: low-pass frames, where the
+    losses and their gradients are insensitive to a sampling coordinate landing on the other side of an integer
+    (used for gradient parity on hosts/devices whose P = K.[R|t] differs from the reference's in the last ulp)."""
     ref = ref_import.load(ac)
     iw, lf, ss = ref.inverse_warp, ref.loss_functions, ref.ssim
-    tgt, refs, K, Kinv = syn.sample(FB, FH, FW, seed=1)
+    tgt, refs, K, Kinv = syn.sample(FB, FH, FW, seed=1, smooth=smooth)
     pyr = pyramid_inputs(FB, FH, FW)
     pose = syn.kernel_inputs(FB, 8, 8, seed=2)["pose"] * 3.0
     g = {}
@@ -208,6 +211,10 @@ def main():
     torch.set_num_threads(1)   # run-to-run bit reproducibility of the fixtures
     for tag, ac in (("acF", None), ("acT", True)):
         np.savez_compressed(os.path.join(OUT, "functions_%s.npz" % tag), **function_level(ac))
+        sm = function_level(ac, smooth=3)
+        keep = {k: v for k, v in sm.items() if k.split(".")[0] in (
+            "photometric_reconstruction_loss", "photometric_reconstruction_loss_nomask", "photometric_flow_loss")}
+        np.savez_compressed(os.path.join(OUT, "functions_%s_smooth.npz" % tag), **keep)
         np.savez_compressed(os.path.join(OUT, "step_%s.npz" % tag), **net_and_step_level(ac))
         print("wrote", tag)
     ref_import.set_align_corners(None)

@@ -20,7 +20,7 @@ def test_warps():
 
 
 def test_warps_full_size():
-    parity.check_warps("cuda", B=2, H=256, W=832)
+    parity.check_warps("cuda", B=2, H=256, W=832, smooth=3)
 
 
 def test_ssim():
@@ -29,7 +29,8 @@ def test_ssim():
 
 
 def test_losses():
-    parity.check_losses("cuda")
+    # low-pass frames: the oracle runs on THIS host CPU, whose P = K.[R|t] differs in the last ulp from the device's
+    parity.check_losses("cuda", smooth=3)
 
 
 def test_occluded_flow_loss():
