@@ -602,6 +602,222 @@ __global__ __launch_bounds__(256) void k_wgrad(WG g) {
     }
 }
 
+// ------------------------------------------------------------------ weight gradient, patch-staged (main path)
+// gw[m][c][i][j] = sum_{n,ty,tx} a[n][m][ty][tx] * x[n][c][si*ty + i - pad][si*tx + j - pad] as ONE GEMM PER TAP:
+//   D_t[m][c] += A[m][pixel] * X_t[pixel][c],  X_t = the input patch shifted by tap t (never materialised).
+// Workgroup = (BMW rows of dY) x (32 input channels) x (a group of <= TG taps), looping over 2 x 32 pixel tiles of
+// its split; per tile dY (pixel-minor, row stride 65) and the 32-channel input patch (channel stride odd) are
+// LDS-DMA'd, both MFMA operands are then conflict-free strided ds_reads (lane = m resp. lane = channel, k = pixel).
+// Every MFMA is useful work (no im2col padding); accumulators: one 32x32 tile per (m-tile, tap), spread over the 4 waves.
+constexpr int WTH = 2;          // lattice rows per pixel tile
+constexpr int WPIX = WTH * 32;  // 64 pixels = 32 MFMA k-steps
+constexpr int APS = WPIX + 1;   // dY row stride in LDS (odd -> bank = (m + p) mod 32)
+
+struct WP {
+    const float* a; const float* x; const float* zeros; float* ws;
+    int B, M, AH, AW; long a_bs;
+    int Cin, IH, IW; long x_bs;
+    int R, S, si, pad;
+    int PH, PWr, PSc, npos;
+    int tiles_x, tiles_y, ntiles, tiles_per_split, nsplit;
+    int TG, ngroups, Cp32, nbuf;
+};
+
+template <int BMW, int NT>
+__global__ __launch_bounds__(256) void k_wgrad_patch(WP g) {
+    constexpr int MT = BMW / 32;
+    HIP_DYNAMIC_SHARED(float, smem)
+    const int a_sz = BMW * APS, p_sz = 32 * g.PSc;
+    float* As = smem;                         // [nbuf][BMW][APS]
+    float* Ps = smem + g.nbuf * a_sz;         // [nbuf][32][PSc]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lk = lane >> 5;
+    // blockIdx.x -> (m-tile, c-tile, tap group)
+    int bx = blockIdx.x;
+    const int grp = bx % g.ngroups;
+    bx /= g.ngroups;
+    const int ctile = bx % (g.Cp32 / 32);
+    const int mtile = bx / (g.Cp32 / 32);
+    const int m0 = mtile * BMW, c0 = ctile * 32;
+    const int t_first = grp * g.TG;
+    const int T = g.R * g.S;
+    int ntap = T - t_first;
+    if (ntap > g.TG) ntap = g.TG;
+    const int x_cs = g.IH * g.IW, a_cs = g.AH * g.AW;
+    const int pt_beg = blockIdx.z * g.tiles_per_split;
+    int pt_end = pt_beg + g.tiles_per_split;
+    if (pt_end > g.ntiles) pt_end = g.ntiles;
+    const int RI = (g.npos + 63) >> 6;
+
+    // accumulator tiles of this wave: q = wid + 4*k -> (mt = q % MT, tap = q / MT)
+    int my_mt[NT], my_tap[NT];
+    f32x16 acc[NT];
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        const int q = wid + 4 * k;
+        my_mt[k] = q % MT;
+        my_tap[k] = q / MT;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[k][r] = 0.f;
+    }
+
+    auto load_tile = [&](int pt, int buf) {
+        const int tile_x = pt % g.tiles_x;
+        const int r2 = pt / g.tiles_x;
+        const int tile_y = r2 % g.tiles_y;
+        const int n = r2 / g.tiles_y;
+        const int ty0 = tile_y * WTH, tx0 = tile_x * 32;
+        // dY rows: one LDS-DMA per channel m (64 pixels = 2 lattice rows of 32)
+        {
+            const int ty = ty0 + lk, tx = tx0 + l31;
+            const bool ok = (ty < g.AH) && (tx < g.AW);
+            const float* an = g.a + (long)n * g.a_bs + (long)ty * g.AW + tx;
+            float* dst = As + buf * a_sz;
+            for (int mm = wid; mm < BMW; mm += 4) {
+                const int m = m0 + mm;
+                const float* src = (ok && m < g.M) ? an + (long)m * a_cs : g.zeros + lane;
+                __builtin_amdgcn_global_load_lds(CC_GLOBAL_PTR(src), CC_LDS_PTR(dst + mm * APS), 4, 0, 0);
+            }
+        }
+        // input patch of 32 channels: positions pos = py*PWr + px, py < PH
+        {
+            const int gy0 = g.si * ty0 - g.pad, gx0 = g.si * tx0 - g.pad;
+            const float* xn = g.x + (long)n * g.x_bs;
+            float* dst = Ps + buf * p_sz;
+            for (int r = 0; r < RI; r++) {
+                const int pos = lane + 64 * r;
+                const int py = pos / g.PWr, px = pos - py * g.PWr;
+                const int iy = gy0 + py, ix = gx0 + px;
+                const bool inb = ((unsigned)iy < (unsigned)g.IH) && ((unsigned)ix < (unsigned)g.IW);
+                const long go = (long)iy * g.IW + ix;
+                if (pos < g.npos) {                 // lanes past the patch stay out of the DMA (EXEC-masked)
+                    for (int cc = wid; cc < 32; cc += 4) {
+                        const int c = c0 + cc;
+                        const float* src = (inb && c < g.Cin) ? xn + (long)c * x_cs + go : g.zeros + lane;
+                        __builtin_amdgcn_global_load_lds(CC_GLOBAL_PTR(src), CC_LDS_PTR(dst + cc * g.PSc + 64 * r), 4, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+
+    if (pt_beg < pt_end) {
+        load_tile(pt_beg, 0);
+        CC_WAIT_VMCNT0();
+        __syncthreads();
+        for (int pt = pt_beg; pt < pt_end; pt++) {
+            const int buf = (g.nbuf == 2) ? ((pt - pt_beg) & 1) : 0;
+            if (g.nbuf == 2 && pt + 1 < pt_end) load_tile(pt + 1, buf ^ 1);
+            const float* Ab = As + buf * a_sz + l31 * APS + lk;          // lane = m row, k = pixel
+            const float* Pb = Ps + buf * p_sz + l31 * g.PSc;             // lane = channel
+            int toff[NT];
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                const int t = t_first + my_tap[k];
+                const int i = t / g.S, j = t - i * g.S;
+                toff[k] = i * g.PWr + j;
+            }
+#pragma unroll 4
+            for (int ks = 0; ks < WPIX / 2; ks++) {
+                const int p = 2 * ks + lk;
+                const int pbase = (g.si * (p >> 5)) * g.PWr + g.si * (p & 31);
+                float af[MT];
+#pragma unroll
+                for (int a = 0; a < MT; a++) af[a] = Ab[a * 32 * APS + 2 * ks];
+#pragma unroll
+                for (int k = 0; k < NT; k++) {
+                    if (my_tap[k] < ntap) {          // wave-uniform
+                        const float bv = Pb[pbase + toff[k]];
+                        const float av = (MT == 1) ? af[0] : (my_mt[k] ? af[MT - 1] : af[0]);   // no runtime register indexing
+                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[k], 0, 0, 0);
+                    }
+                }
+            }
+            if (g.nbuf == 1) {
+                __syncthreads();
+                if (pt + 1 < pt_end) load_tile(pt + 1, 0);
+            }
+            CC_WAIT_VMCNT0();
+            __syncthreads();
+        }
+    }
+    // partial slabs: ws[split][t][m][c]  (c contiguous: D col = lane&31 = channel -> coalesced)
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        if (my_tap[k] >= ntap) continue;
+        const int t = t_first + my_tap[k];
+        float* o = g.ws + (((long)blockIdx.z * T + t) * g.M) * g.Cp32 + c0 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = m0 + my_mt[k] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (m < g.M) o[(long)m * g.Cp32] = acc[k][r];
+        }
+    }
+}
+
+// gw[m*o_sm + c*o_sc + t] = sum_z ws[z][t][m][c]
+__global__ __launch_bounds__(256) void k_wgrad_patch_reduce(const float* __restrict__ ws, float* __restrict__ gw, int nsplit,
+                                                            int T, int M, int Cin, int Cp32, long o_sm, long o_sc) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;     // over [t][m][c]
+    const long tot = (long)T * M * Cp32;
+    if (e >= tot) return;
+    const int c = (int)(e % Cp32);
+    if (c >= Cin) return;
+    float s = 0.f;
+    for (int z = 0; z < nsplit; z++) s += ws[(long)z * tot + e];
+    const long r = e / Cp32;
+    const int m = (int)(r % M), t = (int)(r / M);
+    gw[(long)m * o_sm + (long)c * o_sc + t] = s;
+}
+
+struct WPlan {
+    bool ok;
+    int bmw, nt, TG, ngroups, Cp32, PH, PWr, PSc, npos, nbuf, tiles_x, tiles_y, ntiles, nsplit, tps;
+    size_t smem, ws_floats;
+};
+
+template <int BMW, int NT>
+inline void launch_wgrad_patch(const WP& w, dim3 grid, size_t smem, hipStream_t s) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad_patch<BMW, NT>), grid, dim3(256), smem, s, w);
+}
+
+inline WPlan plan_wgrad(int B, int M, int AH, int AW, int Cin, int R, int S, int si) {
+    WPlan p = {};
+    const int T = R * S;
+    p.bmw = (M > 32) ? 64 : 32;
+    const int MT = p.bmw / 32;
+    // NT accumulator tiles per wave: cover min(T, 9) taps per group
+    const int tg_target = T < 9 ? T : 9;
+    p.nt = (MT * tg_target + 3) / 4;
+    if (p.nt > 5) p.nt = 5;
+    p.TG = (4 * p.nt) / MT;
+    if (p.TG > T) p.TG = T;
+    p.ngroups = (T + p.TG - 1) / p.TG;
+    p.Cp32 = ((Cin + 31) / 32) * 32;
+    p.PH = (WTH - 1) * si + R;
+    p.PWr = 31 * si + S;
+    p.npos = p.PH * p.PWr;
+    p.PSc = p.npos | 1;                       // odd channel stride
+    auto smem_of = [&](int nbuf) { return (size_t)nbuf * (p.bmw * APS + 32 * p.PSc) * sizeof(float); };
+    p.nbuf = 2;
+    if (smem_of(2) > 150 * 1024) p.nbuf = 1;
+    p.smem = smem_of(p.nbuf);
+    p.ok = p.smem <= 150 * 1024;
+    p.tiles_x = (AW + 31) / 32;
+    p.tiles_y = (AH + WTH - 1) / WTH;
+    p.ntiles = B * p.tiles_x * p.tiles_y;
+    const long base = (long)((M + p.bmw - 1) / p.bmw) * (p.Cp32 / 32) * p.ngroups;
+    long nsplit = (512 + base - 1) / base;
+    if (nsplit > p.ntiles) nsplit = p.ntiles;
+    if (nsplit < 1) nsplit = 1;
+    p.tps = (int)((p.ntiles + nsplit - 1) / nsplit);
+    p.nsplit = (p.ntiles + p.tps - 1) / p.tps;
+    p.ws_floats = 64 + (size_t)p.nsplit * T * M * p.Cp32;
+    return p;
+}
+
 // second stage: gw[m, (c,i,j)] = sum_split ws[split][m][(c,i,j)]
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ gw, int nsplit,
                                                       int M, int Ntot, int RS, int St, long o_sm, long o_sc, int o_ri,
@@ -805,7 +1021,9 @@ int cc_conv2d_dgrad(const float* gy, const float* w, const float* bias_or_null, 
     return CC_OK;
 }
 
-size_t cc_conv2d_wgrad_ws_bytes(int B, int M, int AH, int AW, int Cin, int R, int S) {
+size_t cc_conv2d_wgrad_ws_bytes(int B, int M, int AH, int AW, int Cin, int R, int S, int si) {
+    const WPlan p = plan_wgrad(B, M, AH, AW, Cin, R, S, si);
+    if (p.ok) return p.ws_floats * sizeof(float);
     const long Ntot = (long)Cin * R * S;
     const long P = (long)B * AH * AW;
     const int bm = pick_bm(M);
@@ -824,6 +1042,33 @@ int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B,
                     int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, void* stream) {
     if (B <= 0 || M <= 0 || Cin <= 0) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    const WPlan p = plan_wgrad(B, M, AH, AW, Cin, R, S, si);
+    if (p.ok) {
+        WP w = {};
+        w.a = a; w.x = x; w.zeros = ws; w.ws = ws + 64;
+        w.B = B; w.M = M; w.AH = AH; w.AW = AW; w.a_bs = a_bs; w.Cin = Cin; w.IH = IH; w.IW = IW; w.x_bs = x_bs;
+        w.R = R; w.S = S; w.si = si; w.pad = pad; w.PH = p.PH; w.PWr = p.PWr; w.PSc = p.PSc; w.npos = p.npos;
+        w.tiles_x = p.tiles_x; w.tiles_y = p.tiles_y; w.ntiles = p.ntiles; w.tiles_per_split = p.tps; w.nsplit = p.nsplit;
+        w.TG = p.TG; w.ngroups = p.ngroups; w.Cp32 = p.Cp32; w.nbuf = p.nbuf;
+        hipMemsetAsync(ws, 0, 64 * sizeof(float), s);
+        dim3 grid((unsigned)(((M + p.bmw - 1) / p.bmw) * (p.Cp32 / 32) * p.ngroups), 1, (unsigned)p.nsplit);
+        if (p.bmw == 64) {
+            if (p.nt == 5) launch_wgrad_patch<64, 5>(w, grid, p.smem, s);
+            else if (p.nt == 4) launch_wgrad_patch<64, 4>(w, grid, p.smem, s);
+            else if (p.nt == 3) launch_wgrad_patch<64, 3>(w, grid, p.smem, s);
+            else if (p.nt == 2) launch_wgrad_patch<64, 2>(w, grid, p.smem, s);
+            else launch_wgrad_patch<64, 1>(w, grid, p.smem, s);
+        } else {
+            if (p.nt >= 3) launch_wgrad_patch<32, 3>(w, grid, p.smem, s);
+            else if (p.nt == 2) launch_wgrad_patch<32, 2>(w, grid, p.smem, s);
+            else launch_wgrad_patch<32, 1>(w, grid, p.smem, s);
+        }
+        const long tot = (long)R * S * M * p.Cp32;
+        hipLaunchKernelGGL(k_wgrad_patch_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const float*)w.ws, gw,
+                           p.nsplit, R * S, M, Cin, p.Cp32, o_sm, o_sc);
+        CC_CHECK_LAUNCH();
+        return CC_OK;
+    }
     const long Ntot = (long)Cin * R * S;
     const long P = (long)B * AH * AW;
     const int bm = pick_bm(M);

@@ -67,7 +67,7 @@ class _Conv2dFn(torch.autograd.Function):
                    Cin * IH * IW, Cin * R * S, R * S, 0, 1.0, 0.0, STREAM)
         if need[1]:
             gw = torch.empty_like(w)
-            ws = _ws(E.call("cc_conv2d_wgrad_ws_bytes", B, Cout, OH, OW, Cin, R, S), x)
+            ws = _ws(E.call("cc_conv2d_wgrad_ws_bytes", B, Cout, OH, OW, Cin, R, S, stride), x)
             E.call("cc_conv2d_wgrad", gy, x, gw, ws, B, Cout, OH, OW, Cout * OH * OW, Cin, IH, IW, Cin * IH * IW, R, S,
                    stride, pad, Cin * R * S, R * S, STREAM)
         gres = gy if (has_res and need[3]) else None
@@ -129,7 +129,7 @@ class _ConvT2dFn(torch.autograd.Function):
                    Cin * IH * IW, 0, 0, 1.0, 0.0, STREAM)
         if need[1]:
             gw = torch.empty_like(w)
-            ws = _ws(E.call("cc_conv2d_wgrad_ws_bytes", B, Cin, IH, IW, Cout, R, S), x)
+            ws = _ws(E.call("cc_conv2d_wgrad_ws_bytes", B, Cin, IH, IW, Cout, R, S, stride), x)
             E.call("cc_conv2d_wgrad", x, gy, gw, ws, B, Cin, IH, IW, Cin * IH * IW, Cout, OH, OW, Cout * OH * OW, R, S,
                    stride, pad, Cout * R * S, R * S, STREAM)
         return gx, gw, gbias, None, None, None, None

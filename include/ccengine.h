@@ -173,7 +173,7 @@ size_t cc_conv2d_dgrad_ws_bytes(int B, int K, int OH, int OW, int C, int R, int 
 int cc_conv2d_dgrad(const float* gy, const float* w, const float* bias_or_null, float* gx, float* ws, int B, int K, int OH,
                     int OW, long gy_bs, int C, int R, int S, int stride, int pad, int IH, int IW, long gx_bs,
                     long w_k_stride, long w_c_stride, int act, float act_a, float act_b, void* stream);
-size_t cc_conv2d_wgrad_ws_bytes(int B, int M, int AH, int AW, int Cin, int R, int S);
+size_t cc_conv2d_wgrad_ws_bytes(int B, int M, int AH, int AW, int Cin, int R, int S, int si);
 /* gw[m*o_sm + c*o_sc + r*S + s] = sum_{n,ty,tx} a[n,m,ty,tx] * x[n,c,si*ty-pad+r,si*tx-pad+s] (split over pixels,
  * deterministic second-stage reduction through ws). */
 int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B, int M, int AH, int AW, long a_bs, int Cin,
