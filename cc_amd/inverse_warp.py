@@ -69,9 +69,39 @@ def pose_vec2mat(vec, rotation_mode='euler'):
     return torch.cat([rot_mat, translation], dim=2)
 
 
-def projection_matrix(pose, intrinsics, rotation_mode='euler'):
-    """inverse_warp.py:214 / :278: P = K.[R|t], returned flat [B,12] (the kernels' input)."""
-    return intrinsics.bmm(pose_vec2mat(pose, rotation_mode)).reshape(-1, 12)
+class _PoseProjFn(torch.autograd.Function):
+    """pose [B,6] (may be a strided slice of [B,R,6]) -> P = (K rows 0,1 / k_div) . [Rx.Ry.Rz | t], flat [B,12]."""
+
+    @staticmethod
+    def forward(ctx, pose, K, k_div):
+        pose = pose.float()
+        if pose.stride(1) != 1:
+            pose = pose.contiguous()
+        Kc = K.detach().contiguous().float()
+        B = pose.shape[0]
+        P = torch.empty(B, 12, device=pose.device, dtype=torch.float32)
+        engine().call("cc_pose_proj_fwd", pose.data_ptr(), pose.stride(0), Kc, P, B, float(k_div), STREAM)
+        ctx.save_for_backward(pose, Kc)
+        ctx.k_div = float(k_div)
+        return P
+
+    @staticmethod
+    def backward(ctx, gP):
+        pose, Kc = ctx.saved_tensors
+        B = pose.shape[0]
+        g = torch.empty(B, 6, device=pose.device, dtype=torch.float32)
+        engine().call("cc_pose_proj_bwd", gP.contiguous().float(), pose.data_ptr(), pose.stride(0), Kc, g, 6, B, ctx.k_div, 0,
+                      STREAM)
+        return g, None, None
+
+
+def projection_matrix(pose, intrinsics, rotation_mode='euler', k_div=1.0):
+    """inverse_warp.py:214 / :278: P = K.[R|t], returned flat [B,12] (the kernels' input).  k_div divides rows 0,1
+    of K (the per-scale intrinsics of loss_functions.py:91)."""
+    if rotation_mode == 'euler':
+        return _PoseProjFn.apply(pose, intrinsics, k_div)
+    K = intrinsics if k_div == 1.0 else torch.cat((intrinsics[:, 0:2] / k_div, intrinsics[:, 2:]), dim=1)
+    return K.bmm(pose_vec2mat(pose, rotation_mode)).reshape(-1, 12)
 
 
 def _ac(align_corners):

@@ -207,6 +207,9 @@ class _PhotoRigidFn(torch.autograd.Function):
             K_d = intrinsics.detach()
             P_full = [projection_matrix(pose_l[:, r], K_d, cfg.rotation_mode) for r in range(R)]
         P_full_c = [_f32c(p.detach()) for p in P_full]
+        direct_pose = cfg.rotation_mode == 'euler'      # HIP pose->P adjoint instead of a torch graph over 17 tiny ops
+        gpose_acc = torch.zeros_like(pose_l.detach(), dtype=torch.float32) if (want_grad and need[4] and direct_pose) else None
+        K_c = _f32c(K_d)
         gdepths, gmasks, gP_all, P_all = [], [], [], []
         for s in range(S):
             d4 = depths[s]
@@ -225,8 +228,12 @@ class _PhotoRigidFn(torch.autograd.Function):
             gm = torch.empty_like(m) if (m is not None and want_grad) else None
             for r in range(R):
                 ref_s = pyramid_cache.get(refs[r], h, w)
-                with torch.enable_grad():
-                    P = projection_matrix(pose_l[:, r], K_s, cfg.rotation_mode)
+                if direct_pose:
+                    with torch.no_grad():
+                        P = projection_matrix(pose_l[:, r], K_d, 'euler', k_div=downscale)
+                else:
+                    with torch.enable_grad():
+                        P = projection_matrix(pose_l[:, r], K_s, cfg.rotation_mode)
                 Pc = _f32c(P.detach())
                 warped = torch.empty_like(ref_s)
                 E.call("cc_inverse_warp_fwd", ref_s, d, Pc, Kinv_s, warped, B, 3, h, w, cfg.border, cfg.ac, STREAM)
@@ -246,12 +253,17 @@ class _PhotoRigidFn(torch.autograd.Function):
                     gd += gd_r
                     if gm is not None:
                         gm[:, r] *= scale
-                    gP_all.append(gP)
-                    P_all.append(P)
+                    if gpose_acc is not None:
+                        pv = pose_l.detach()[:, r]
+                        E.call("cc_pose_proj_bwd", gP, pv.data_ptr(), pv.stride(0), K_c, gpose_acc[:, r].data_ptr(),
+                               gpose_acc.stride(0), B, float(downscale), 1, STREAM)
+                    else:
+                        gP_all.append(gP)
+                        P_all.append(P)
             gdepths.append(None if gd is None else gd.unsqueeze(1))
             gmasks.append(gm)
-        gpose = None
-        if want_grad and need[4]:
+        gpose = gpose_acc
+        if want_grad and need[4] and gpose is None:
             gpose = torch.autograd.grad(P_all, pose_l, gP_all)[0]
         _register_nan_flag(nan_flag)
         ctx.stash = [gpose] + [None] * R + gdepths + gmasks

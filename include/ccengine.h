@@ -64,6 +64,13 @@ int cc_feature_warp_fwd(const float* feat, const float* flow, float* out, int B,
 int cc_feature_warp_bwd(const float* gout, const float* feat, const float* flow, float* gflow_or_null,
                         float* gfeat_or_null, int B, int C, int H, int W, int align_corners, void* stream);
 
+/* inverse_warp.py:82-119,146-162,214,278 (+ loss_functions.py:91): P[n] = K_s[n] . [Rx.Ry.Rz | t] for pose[n] =
+ * (tx,ty,tz,rx,ry,rz) at pose + n*pose_stride, K_s = K with rows 0,1 divided by k_div (the pyramid downscale).
+ * euler rotation mode only (the only mode train.py reaches). */
+int cc_pose_proj_fwd(const float* pose, long pose_stride, const float* K, float* P, int N, float k_div, void* stream);
+int cc_pose_proj_bwd(const float* gP, const float* pose, long pose_stride, const float* K, float* gpose, long gpose_stride,
+                     int N, float k_div, int accumulate, void* stream);
+
 /* ---------------------------------------------------------------- SSIM / photometric (ssim.py, loss_functions.py)
  * gauss13_host is the ONE host pointer of this ABI: the 13 taps of the normalised 1-D Gaussian
  * (ssim.py:9-11, sigma 1.5), copied into the kernel arguments at launch. */
