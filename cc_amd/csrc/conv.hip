@@ -20,6 +20,7 @@
 //
 // Weight gradient: second kernel, M = channels of dY, N = (c,i,j), K = pixels, split over pixel ranges with a
 // deterministic second-stage reduction (no atomics).
+#include <stdlib.h>
 #include "cc_common.h"
 #include "../../include/ccengine.h"
 
@@ -412,6 +413,11 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
     y[(long)n * y_bs + o] = apply_act(v, act, act_a, act_b);
 }
 
+static int dbg_flag_early(const char* name) {
+    const char* v = getenv(name);
+    return (v && v[0] == '1') ? 1 : 0;
+}
+
 struct ConvPlan {
     bool use_patch;
     int bm, ck, Mpad, Cpad, PH, PWr, PS, ymin, xmin, tiles_x, tiles_y, nsplit, cps;
@@ -442,7 +448,7 @@ inline ConvPlan plan_conv(const GG& g) {
     const int nchunk = p.Cpad / p.ck;
     p.nsplit = 1;
     p.cps = nchunk;
-    if (blocks < 256 && nchunk >= 4) {
+    if (blocks < 256 && nchunk >= 4 && !(g.so != 1 && dbg_flag_early("CC_DBG_NO_PARITY_SPLIT"))) {
         long want = (512 + blocks - 1) / blocks;
         if (want > nchunk / 2) want = nchunk / 2;
         if (want > 32) want = 32;
@@ -757,6 +763,8 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(WP g) {
     }
 }
 
+__global__ void k_zero64(float* p) { p[threadIdx.x] = 0.f; }
+
 // gw[m*o_sm + c*o_sc + t] = sum_z ws[z][t][m][c]
 __global__ __launch_bounds__(256) void k_wgrad_patch_reduce(const float* __restrict__ ws, float* __restrict__ gw, int nsplit,
                                                             int T, int M, int Cin, int Cp32, long o_sm, long o_sc) {
@@ -783,6 +791,11 @@ inline void launch_wgrad_patch(const WP& w, dim3 grid, size_t smem, hipStream_t 
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad_patch<BMW, NT>), grid, dim3(256), smem, s, w);
 }
 
+static int dbg_flag(const char* name) {
+    const char* v = getenv(name);
+    return (v && v[0] == '1') ? 1 : 0;
+}
+
 inline WPlan plan_wgrad(int B, int M, int AH, int AW, int Cin, int R, int S, int si) {
     WPlan p = {};
     const int T = R * S;
@@ -804,7 +817,9 @@ inline WPlan plan_wgrad(int B, int M, int AH, int AW, int Cin, int R, int S, int
     p.nbuf = 2;
     if (smem_of(2) > 150 * 1024) p.nbuf = 1;
     p.smem = smem_of(p.nbuf);
-    p.ok = p.smem <= 150 * 1024;
+    // measured on MI355X (profiles/r01_*): the im2col-style k_wgrad is still ~2-8 % faster end to end than this
+    // per-tap kernel (small-channel layers pad to 32 channels here); kept selectable for tuning: CC_WGRAD_PATCH=1
+    p.ok = p.smem <= 150 * 1024 && dbg_flag("CC_WGRAD_PATCH");
     p.tiles_x = (AW + 31) / 32;
     p.tiles_y = (AH + WTH - 1) / WTH;
     p.ntiles = B * p.tiles_x * p.tiles_y;
@@ -1050,7 +1065,7 @@ int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B,
         w.R = R; w.S = S; w.si = si; w.pad = pad; w.PH = p.PH; w.PWr = p.PWr; w.PSc = p.PSc; w.npos = p.npos;
         w.tiles_x = p.tiles_x; w.tiles_y = p.tiles_y; w.ntiles = p.ntiles; w.tiles_per_split = p.tps; w.nsplit = p.nsplit;
         w.TG = p.TG; w.ngroups = p.ngroups; w.Cp32 = p.Cp32; w.nbuf = p.nbuf;
-        hipMemsetAsync(ws, 0, 64 * sizeof(float), s);
+        hipLaunchKernelGGL(k_zero64, dim3(1), dim3(64), 0, s, ws);      // the LDS-DMA halo source (a kernel, not a memset node)
         dim3 grid((unsigned)(((M + p.bmw - 1) / p.bmw) * (p.Cp32 / 32) * p.ngroups), 1, (unsigned)p.nsplit);
         if (p.bmw == 64) {
             if (p.nt == 5) launch_wgrad_patch<64, 5>(w, grid, p.smem, s);
