@@ -521,34 +521,42 @@ __global__ __launch_bounds__(256) void k_wgrad(WG g) {
         }
     }
     float ra[AQ], rb[8];
+    unsigned okA = 0, okB = 0;
+    // branch-free loads: invalid elements read element 0 of their tensor and are zeroed by a select AT STORE TIME
+    // (hipcc otherwise wraps every predicated load in its own s_cbranch_execz block; and a select placed right after
+    // the load would force s_waitcnt vmcnt(0) ahead of the MFMAs of the current chunk)
     auto load_chunk = [&](long pbase) {
+        okA = 0;
+        okB = 0;
         const long p = pbase + pp;
         const bool pv = p < pend;
-        int n = 0, ty = 0, tx = 0;
-        if (pv) {
-            n = (int)(p / HWa);
-            const int t = (int)(p - (long)n * HWa);
-            ty = t / g.AW;
-            tx = t - ty * g.AW;
-        }
+        const long ps = pv ? p : 0;
+        const int n = (int)(ps / HWa);
+        const int t = (int)(ps - (long)n * HWa);
+        const int ty = t / g.AW, tx = t - ty * g.AW;
+        const long abase = (long)n * g.a_bs + ty * g.AW + tx;
 #pragma unroll
         for (int q = 0; q < AQ; q++) {
             const int m = m0 + rgp + 16 * q;
-            ra[q] = (pv && m < g.M) ? g.a[(long)n * g.a_bs + (long)m * HWa + ty * g.AW + tx] : 0.f;
+            const bool ok = pv && (m < g.M);
+            ra[q] = g.a[ok ? abase + (long)m * HWa : 0];
+            okA |= (ok ? 1u : 0u) << q;
         }
         const int iy0 = g.si * ty, ix0 = g.si * tx;
         const long xb = (long)n * g.x_bs + (long)iy0 * g.IW + ix0;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int iy = iy0 + tdy[q], ix = ix0 + tdx[q];
-            rb[q] = (pv && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW) ? g.x[xb + xoff[q]] : 0.f;
+            const bool ok = pv && ((unsigned)iy < (unsigned)g.IH) && ((unsigned)ix < (unsigned)g.IW);
+            rb[q] = g.x[ok ? xb + xoff[q] : 0];
+            okB |= (ok ? 1u : 0u) << q;
         }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < AQ; q++) As[buf][pp * AP + rgp + 16 * q] = ra[q];
+        for (int q = 0; q < AQ; q++) As[buf][pp * AP + rgp + 16 * q] = ((okA >> q) & 1u) ? ra[q] : 0.f;
 #pragma unroll
-        for (int q = 0; q < 8; q++) Bs[buf][pp * BP + rgp + 16 * q] = rb[q];
+        for (int q = 0; q < 8; q++) Bs[buf][pp * BP + rgp + 16 * q] = ((okB >> q) & 1u) ? rb[q] : 0.f;
     };
 
     f32x16 acc[TM][TN];
@@ -569,18 +577,22 @@ __global__ __launch_bounds__(256) void k_wgrad(WG g) {
     for (long ch = 0; ch < nchunks; ch++) {
         const int buf = (int)(ch & 1);
         if (ch + 1 < nchunks) load_chunk(pbeg + (ch + 1) * BK);
+        {
+            float af[BK / 2][TM], bf[BK / 2][TN];
 #pragma unroll
-        for (int ks = 0; ks < BK / 2; ks++) {
-            float af[TM], bf[TN];
+            for (int ks = 0; ks < BK / 2; ks++) {
 #pragma unroll
-            for (int a = 0; a < TM; a++) af[a] = As[buf][(2 * ks + lk) * AP + wm * WM + a * 32 + l31];
+                for (int a = 0; a < TM; a++) af[ks][a] = As[buf][(2 * ks + lk) * AP + wm * WM + a * 32 + l31];
 #pragma unroll
-            for (int b = 0; b < TN; b++) bf[b] = Bs[buf][(2 * ks + lk) * BP + wn * WN + b * 32 + l31];
+                for (int b = 0; b < TN; b++) bf[ks][b] = Bs[buf][(2 * ks + lk) * BP + wn * WN + b * 32 + l31];
+            }
 #pragma unroll
-            for (int a = 0; a < TM; a++)
+            for (int ks = 0; ks < BK / 2; ks++)
 #pragma unroll
-                for (int b = 0; b < TN; b++)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+                for (int a = 0; a < TM; a++)
+#pragma unroll
+                    for (int b = 0; b < TN; b++)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks][a], bf[ks][b], acc[a][b], 0, 0, 0);
         }
         if (ch + 1 < nchunks) store_chunk(buf ^ 1);
         __syncthreads();
