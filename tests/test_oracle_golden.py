@@ -185,3 +185,27 @@ def test_config1_and_config2(golden_dir):
     _close(L.photometric_reconstruction_loss(tgt, refs, K, Kinv, depth, None, pose, wssim=0), g["c1.loss_1"], 0, 2e-6)
     _close(L.smooth_loss(depth), g["c1.loss_3"], 0, 2e-6)
     _close(pose, g["c1.pose"], 1e-9, 1e-6)
+
+
+def test_c_warp_coords(golden_dir):
+    """oracle/warp_coords.c (host-independent exact-rounding restatement) reproduces the
+    reference's sampling grid and rigid flow bit-for-bit."""
+    import ctypes
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-s", "-C", os.path.join(root, "oracle")], check=True)
+    lib = ctypes.CDLL(os.path.join(root, "oracle", "_build", "liboracle_c.so"))
+    g = _load(golden_dir, "functions_acF.npz")
+    pyr = pyramid_inputs(FB, FH, FW)
+    d0 = np.ascontiguousarray(pyr[0]["depth"][:, 0].numpy())
+    _, _, K, Kinv = syn.sample(FB, FH, FW, seed=1)
+    P = np.ascontiguousarray(g["P"].reshape(FB, 12))
+    Ki = np.ascontiguousarray(Kinv.numpy().reshape(FB, 9))
+    grid = np.empty((FB, FH, FW, 2), np.float32)
+    flow = np.empty((FB, 2, FH, FW), np.float32)
+    tap = np.empty((FB, FH, FW, 2), np.int32)
+    vp = ctypes.c_void_p
+    lib.cc_oracle_warp_coords(d0.ctypes.data_as(vp), P.ctypes.data_as(vp), Ki.ctypes.data_as(vp), FB, FH, FW, 0,
+                              grid.ctypes.data_as(vp), flow.ctypes.data_as(vp), tap.ctypes.data_as(vp))
+    assert np.array_equal(grid, g["grid_zeros"])
+    assert np.array_equal(flow, g["pose2flow"])
