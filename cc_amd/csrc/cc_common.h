@@ -17,6 +17,11 @@
 #define CC_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define CC_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #endif
+// keep all four lanes of a float4 LDS read alive so that hipcc emits ONE ds_read_b128 (it otherwise narrows a partially
+// used vector to ds_read_b32 / ds_read2_b32, whose 32-bank rule conflicts on layouts tuned for the b128 64-bank rule)
+#ifndef CC_KEEP4
+#define CC_KEEP4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
+#endif
 // s_waitcnt vmcnt(0) with expcnt/lgkmcnt left at their maxima (gfx9 encoding)
 #define CC_WAIT_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)
 

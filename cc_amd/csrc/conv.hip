@@ -639,10 +639,15 @@ struct WP {
     int PH, PWr, PSc, npos;
     int tiles_x, tiles_y, ntiles, tiles_per_split, nsplit;
     int TG, ngroups, Cp32, nbuf;
+    int dbg;   // ablation switches (CC_WGRAD_DBG): 1 = skip the per-tile LDS-DMA, 2 = skip the MFMAs
 };
 
+// Wave specialisation: waves 0-3 only read LDS and issue MFMAs, waves 4-5 only issue the LDS-DMA of the NEXT pixel
+// tile (their ~20-instruction address chains would otherwise sit in front of the MFMAs of an in-order wave).
+constexpr int WG_THREADS = 384;
+
 template <int BMW, int NT>
-__global__ __launch_bounds__(256) void k_wgrad_patch(WP g) {
+__global__ __launch_bounds__(384) void k_wgrad_patch(WP g) {
     constexpr int MT = BMW / 32;
     HIP_DYNAMIC_SHARED(float, smem)
     const int a_sz = BMW * APS, p_sz = 32 * g.PSc;
@@ -669,12 +674,14 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(WP g) {
     if (pt_end > g.ntiles) pt_end = g.ntiles;
     const int RI = (g.npos + 63) >> 6;
 
+    const bool loader = wid >= 4;
+    const int lw = wid - 4;                    // loader wave index (0/1)
     // accumulator tiles of this wave: q = wid + 4*k -> (mt = q % MT, tap = q / MT)
     int my_mt[NT], my_tap[NT];
     f32x16 acc[NT];
 #pragma unroll
     for (int k = 0; k < NT; k++) {
-        const int q = wid + 4 * k;
+        const int q = (wid & 3) + 4 * k;
         my_mt[k] = q % MT;
         my_tap[k] = q / MT;
 #pragma unroll
@@ -693,7 +700,7 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(WP g) {
             const bool ok = (ty < g.AH) && (tx < g.AW);
             const float* an = g.a + (long)n * g.a_bs + (long)ty * g.AW + tx;
             float* dst = As + buf * a_sz;
-            for (int mm = wid; mm < BMW; mm += 4) {
+            for (int mm = lw; mm < BMW; mm += 2) {
                 const int m = m0 + mm;
                 const float* src = (ok && m < g.M) ? an + (long)m * a_cs : g.zeros + lane;
                 __builtin_amdgcn_global_load_lds(CC_GLOBAL_PTR(src), CC_LDS_PTR(dst + mm * APS), 4, 0, 0);
@@ -711,7 +718,7 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(WP g) {
                 const bool inb = ((unsigned)iy < (unsigned)g.IH) && ((unsigned)ix < (unsigned)g.IW);
                 const long go = (long)iy * g.IW + ix;
                 if (pos < g.npos) {                 // lanes past the patch stay out of the DMA (EXEC-masked)
-                    for (int cc = wid; cc < 32; cc += 4) {
+                    for (int cc = lw; cc < 32; cc += 2) {
                         const int c = c0 + cc;
                         const float* src = (inb && c < g.Cin) ? xn + (long)c * x_cs + go : g.zeros + lane;
                         __builtin_amdgcn_global_load_lds(CC_GLOBAL_PTR(src), CC_LDS_PTR(dst + cc * g.PSc + 64 * r), 4, 0, 0);
@@ -722,45 +729,61 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(WP g) {
     };
 
     if (pt_beg < pt_end) {
-        load_tile(pt_beg, 0);
-        CC_WAIT_VMCNT0();
+        if (loader) {
+            load_tile(pt_beg, 0);
+            CC_WAIT_VMCNT0();
+        }
         __syncthreads();
         for (int pt = pt_beg; pt < pt_end; pt++) {
             const int buf = (g.nbuf == 2) ? ((pt - pt_beg) & 1) : 0;
-            if (g.nbuf == 2 && pt + 1 < pt_end) load_tile(pt + 1, buf ^ 1);
-            const float* Ab = As + buf * a_sz + l31 * APS + lk;          // lane = m row, k = pixel
-            const float* Pb = Ps + buf * p_sz + l31 * g.PSc;             // lane = channel
-            int toff[NT];
-#pragma unroll
-            for (int k = 0; k < NT; k++) {
-                const int t = t_first + my_tap[k];
-                const int i = t / g.S, j = t - i * g.S;
-                toff[k] = i * g.PWr + j;
-            }
-#pragma unroll 4
-            for (int ks = 0; ks < WPIX / 2; ks++) {
-                const int p = 2 * ks + lk;
-                const int pbase = (g.si * (p >> 5)) * g.PWr + g.si * (p & 31);
-                float af[MT];
-#pragma unroll
-                for (int a = 0; a < MT; a++) af[a] = Ab[a * 32 * APS + 2 * ks];
+            if (loader) {
+                if (g.nbuf == 2 && pt + 1 < pt_end && !(g.dbg & 1)) {
+                    load_tile(pt + 1, buf ^ 1);
+                    CC_WAIT_VMCNT0();
+                }
+            } else if (!(g.dbg & 2)) {
+                const float* Ab = As + buf * a_sz + l31 * APS + lk;          // lane = m row, k = pixel
+                const float* Pb = Ps + buf * p_sz + l31 * g.PSc + g.si * lk; // lane = channel
+                // branch-free inner loop: every accumulator slot multiplies (slots past the tap group re-do its last
+                // tap and are dropped in the epilogue), all operands of a k-step are fetched before its MFMAs
+                int toff[NT];
 #pragma unroll
                 for (int k = 0; k < NT; k++) {
-                    if (my_tap[k] < ntap) {          // wave-uniform
-                        const float bv = Pb[pbase + toff[k]];
-                        const float av = (MT == 1) ? af[0] : (my_mt[k] ? af[MT - 1] : af[0]);   // no runtime register indexing
-                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[k], 0, 0, 0);
+                    const int tt = my_tap[k] < ntap ? my_tap[k] : ntap - 1;
+                    const int t = t_first + tt;
+                    const int i = t / g.S, j = t - i * g.S;
+                    toff[k] = i * g.PWr + j;
+                }
+#pragma unroll
+                for (int row = 0; row < WTH; row++) {
+                    const float* Ar = Ab + row * 32;
+                    const float* Pr = Pb + (g.si * row) * g.PWr;
+#pragma unroll 4
+                    for (int ks = 0; ks < 16; ks++) {
+                        float af[MT], bv[NT];
+#pragma unroll
+                        for (int a = 0; a < MT; a++) af[a] = Ar[a * 32 * APS + 2 * ks];
+#pragma unroll
+                        for (int k = 0; k < NT; k++) bv[k] = Pr[(2 * g.si) * ks + toff[k]];
+#pragma unroll
+                        for (int k = 0; k < NT; k++) {
+                            const float av = (MT == 1) ? af[0] : (my_mt[k] ? af[MT - 1] : af[0]);   // no runtime register indexing
+                            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[k], acc[k], 0, 0, 0);
+                        }
                     }
                 }
             }
             if (g.nbuf == 1) {
                 __syncthreads();
-                if (pt + 1 < pt_end) load_tile(pt + 1, 0);
+                if (loader && pt + 1 < pt_end) {
+                    load_tile(pt + 1, 0);
+                    CC_WAIT_VMCNT0();
+                }
             }
-            CC_WAIT_VMCNT0();
             __syncthreads();
         }
     }
+    if (loader) return;
     // partial slabs: ws[split][t][m][c]  (c contiguous: D col = lane&31 = channel -> coalesced)
 #pragma unroll
     for (int k = 0; k < NT; k++) {
@@ -771,6 +794,148 @@ __global__ __launch_bounds__(256) void k_wgrad_patch(WP g) {
         for (int r = 0; r < 16; r++) {
             const int m = m0 + my_mt[k] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
             if (m < g.M) o[(long)m * g.Cp32] = acc[k][r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ weight gradient of 3x3 / stride 1 / pad 1 convs (main path)
+// The layers that carry ~85 % of the step's weight-gradient FLOPs.  Same per-tap GEMM as k_wgrad_patch
+//   D_(i,j)[m][c] += dY[m][pixel] * X[c][pixel + (i-1, j-1)]
+// but every byte moves by 16-byte LDS-DMA (4x fewer DMA instructions -- the dword form is issue-bound, measured) and
+// every MFMA operand comes from a conflict-free ds_read_b128:
+//   * dY tile [BM m][2 x 32 px] as 16-byte chunks, XOR-swizzled by (m & 15) through the SOURCE address of the DMA
+//     (LDS image stays lane-linear); a chunk = 4 pixels = the A operand of two k-steps (lane>>5 picks the pixel);
+//   * input patch [32 c][4 rows][40 cols] (cols tx0-4 .. tx0+35: 16-byte aligned in global memory), channel stride 41
+//     chunks (odd -> 16 consecutive channels hit 16 different bank quads); three chunks of one patch row hold the B
+//     operands of the 3 taps of that row for 4 pixels;
+//   * one wave per (tap row i, 32-row m tile): 3 accumulator tiles, 4 ds_read_b128 per 6 MFMAs.
+constexpr int W3_PC = 41;       // chunks per channel in the patch (40 used + 1 pad)
+
+struct W3 {
+    const float* a; const float* x; const float* zeros; float* ws;
+    int B, M, AH, AW; long a_bs;
+    int Cin; long x_bs;
+    int tiles_x, tiles_y, ntiles, tiles_per_split, nsplit, Cp32, dbg;
+};
+
+template <int MT, int NBUF>
+__global__ __launch_bounds__(192 * MT) void k_wgrad3x3(W3 g) {
+    constexpr int BM = 32 * MT;
+    constexpr int NW = 3 * MT;                     // waves
+    constexpr int A_SLOTS = BM * 16;               // 16-byte slots of the dY tile
+    constexpr int P_SLOTS = ((32 * W3_PC + 63) / 64) * 64;   // rounded up so that every DMA instruction runs all 64 lanes
+    HIP_DYNAMIC_SHARED(float, smem)
+    // single-buffered on purpose: 37.5 KB (MT=2) -> 4 workgroups = 24 waves per CU, evenly spread over the 4 SIMDs, and the
+    // DMA of one workgroup overlaps the MFMAs of the other three (the double-buffered 75 KB version ran ONE 6-wave workgroup
+    // per CU, i.e. 2+2+1+1 waves on the SIMDs: measured 2x slower than the MFMA bound)
+    float4* As = reinterpret_cast<float4*>(smem);                    // [NBUF][A_SLOTS]
+    float4* Ps = reinterpret_cast<float4*>(smem) + NBUF * A_SLOTS;   // [NBUF][P_SLOTS]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lk = lane >> 5;
+    const int ti = wid % 3;                        // tap row of this wave
+    const int mt = wid / 3;                        // its 32-row m tile
+    const int ctiles = g.Cp32 / 32;
+    const int ctile = blockIdx.x % ctiles, mtile = blockIdx.x / ctiles;
+    const int m0 = mtile * BM, c0 = ctile * 32;
+    const int HW = g.AH * g.AW;
+    const int pt_beg = blockIdx.z * g.tiles_per_split;
+    int pt_end = pt_beg + g.tiles_per_split;
+    if (pt_end > g.ntiles) pt_end = g.ntiles;
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+
+    auto load_tile = [&](int pt, int buf) {
+        const int tile_x = pt % g.tiles_x;
+        const int r2 = pt / g.tiles_x;
+        const int tile_y = r2 % g.tiles_y;
+        const int n = r2 / g.tiles_y;
+        const int ty0 = tile_y * 2, tx0 = tile_x * 32;
+        // dY: LDS slot s = m*16 + sc holds pixel chunk pc = sc ^ (m & 15) of row m  (pc = row*8 + col4)
+        for (int s0 = wid * 64; s0 < A_SLOTS; s0 += NW * 64) {
+            const int sl = s0 + lane;
+            const int mm = sl >> 4, sc = sl & 15;
+            const int pc = sc ^ (mm & 15);
+            const int ty = ty0 + (pc >> 3), tx = tx0 + 4 * (pc & 7);
+            const int m = m0 + mm;
+            const bool ok = (m < g.M) && (ty < g.AH) && (tx < g.AW);
+            const float* src = ok ? g.a + (long)n * g.a_bs + (long)m * HW + (long)ty * g.AW + tx : g.zeros;
+            __builtin_amdgcn_global_load_lds(CC_GLOBAL_PTR(src), CC_LDS_PTR(As + buf * A_SLOTS + s0), 16, 0, 0);
+        }
+        // patch: LDS slot s = c*41 + r, r = py*10 + ch (r == 40: pad)
+        for (int s0 = wid * 64; s0 < P_SLOTS; s0 += NW * 64) {
+            const int sl = s0 + lane;
+            const int cc = sl / W3_PC, r = sl - cc * W3_PC;
+            const int py = r / 10, ch = r - py * 10;
+            const int iy = ty0 - 1 + py, ix = tx0 - 4 + 4 * ch;
+            const int c = c0 + cc;
+            const bool ok = (cc < 32) && (r < 40) && (c < g.Cin) && ((unsigned)iy < (unsigned)g.AH) && ((unsigned)ix < (unsigned)g.AW);
+            const float* src = ok ? g.x + (long)n * g.x_bs + (long)c * HW + (long)iy * g.AW + ix : g.zeros;
+            __builtin_amdgcn_global_load_lds(CC_GLOBAL_PTR(src), CC_LDS_PTR(Ps + buf * P_SLOTS + s0), 16, 0, 0);
+        }
+    };
+
+    if (pt_beg < pt_end) {
+        if (NBUF == 2) {
+            load_tile(pt_beg, 0);
+            CC_WAIT_VMCNT0();
+            __syncthreads();
+        }
+        for (int pt = pt_beg; pt < pt_end; pt++) {
+            const int buf = (NBUF == 2) ? ((pt - pt_beg) & 1) : 0;
+            if (NBUF == 2) {
+                if (pt + 1 < pt_end && !(g.dbg & 1)) load_tile(pt + 1, buf ^ 1);
+            } else {
+                if (pt > pt_beg) __syncthreads();                                 // everyone is done reading the previous tile
+                if (!(g.dbg & 1) || pt == pt_beg) load_tile(pt, 0);
+                CC_WAIT_VMCNT0();
+                __syncthreads();
+            }
+            const int mrow = mt * 32 + l31;                                       // this lane's dY row in the tile
+            const float4* Ab = As + buf * A_SLOTS + mrow * 16;
+            const float4* Pb = Ps + buf * P_SLOTS + l31 * W3_PC;                  // this lane's channel
+#pragma unroll
+            for (int row = 0; row < ((g.dbg & 2) ? 0 : 2); row++) {
+                const float4* Pr = Pb + (row + ti) * 10;                          // patch row = pixel row + tap row
+#pragma unroll 2
+                for (int pq = 0; pq < 8; pq++) {
+                    float4 av = Ab[((row * 8 + pq) ^ (mrow & 15))];
+                    float4 w0 = Pr[pq], w1 = Pr[pq + 1], w2 = Pr[pq + 2];
+                    CC_KEEP4(av); CC_KEEP4(w0); CC_KEEP4(w1); CC_KEEP4(w2);
+                    const float w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+                    const float a_lo = lk ? av.y : av.x, a_hi = lk ? av.w : av.z;
+                    float b_lo[3], b_hi[3];
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        b_lo[j] = lk ? w[4 + j] : w[3 + j];
+                        b_hi[j] = lk ? w[6 + j] : w[5 + j];
+                    }
+                    // the two MFMAs of one accumulator are issued three MFMAs apart (no back-to-back RAW on the accumulator)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo, b_lo[j], acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 3; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi, b_hi[j], acc[j], 0, 0, 0);
+                }
+            }
+            if (NBUF == 2) {
+                CC_WAIT_VMCNT0();
+                __syncthreads();
+            }
+        }
+    }
+    // partial slabs ws[split][t][m][c], t = ti*3 + j   (same layout as k_wgrad_patch -> same reduce kernel)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        float* o = g.ws + (((long)blockIdx.z * 9 + (ti * 3 + j)) * g.M) * g.Cp32 + c0 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (m < g.M) o[(long)m * g.Cp32] = acc[j][r];
         }
     }
 }
@@ -800,7 +965,7 @@ struct WPlan {
 
 template <int BMW, int NT>
 inline void launch_wgrad_patch(const WP& w, dim3 grid, size_t smem, hipStream_t s) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad_patch<BMW, NT>), grid, dim3(256), smem, s, w);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad_patch<BMW, NT>), grid, dim3(WG_THREADS), smem, s, w);
 }
 
 static int dbg_flag(const char* name) {
@@ -1048,7 +1213,41 @@ int cc_conv2d_dgrad(const float* gy, const float* w, const float* bias_or_null, 
     return CC_OK;
 }
 
+struct W3Plan { bool ok; int mt, nbuf, tiles_x, tiles_y, ntiles, nsplit, tps, Cp32; size_t smem, ws_floats; };
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+inline W3Plan plan_w3(int B, int M, int AH, int AW, int Cin, int R, int S, int si, int pad, int IH, int IW) {
+    W3Plan p = {};
+    p.ok = (R == 3 && S == 3 && si == 1 && pad == 1 && IH == AH && IW == AW && (AW % 4) == 0 && AW >= 16 && Cin >= 16 && M >= 16 &&
+            !dbg_flag("CC_NO_WGRAD3X3"));
+    if (!p.ok) return p;
+    p.mt = (M > 32) ? 2 : 1;
+    const int BM = 32 * p.mt;
+    p.Cp32 = ((Cin + 31) / 32) * 32;
+    p.tiles_x = (AW + 31) / 32;
+    p.tiles_y = (AH + 1) / 2;
+    p.ntiles = B * p.tiles_x * p.tiles_y;
+    const long base = (long)((M + BM - 1) / BM) * (p.Cp32 / 32);
+    long nsplit = (env_int("CC_W3_SPLIT", 512) + base - 1) / base;
+    if (nsplit > p.ntiles) nsplit = p.ntiles;
+    if (nsplit < 1) nsplit = 1;
+    p.tps = (int)((p.ntiles + nsplit - 1) / nsplit);
+    p.nsplit = (p.ntiles + p.tps - 1) / p.tps;
+    p.nbuf = env_int("CC_W3_NBUF", 1);
+    p.smem = (size_t)p.nbuf * (BM * 16 + ((32 * W3_PC + 63) / 64) * 64) * 16;
+    p.ws_floats = 64 + (size_t)p.nsplit * 9 * M * p.Cp32;
+    return p;
+}
+
 size_t cc_conv2d_wgrad_ws_bytes(int B, int M, int AH, int AW, int Cin, int R, int S, int si) {
+    {   // the 3x3/s1/p1 path (pad and input size are implied by "same" convolutions: checked again at launch)
+        const W3Plan q = plan_w3(B, M, AH, AW, Cin, R, S, si, 1, AH, AW);
+        if (q.ok) return q.ws_floats * sizeof(float);
+    }
     const WPlan p = plan_wgrad(B, M, AH, AW, Cin, R, S, si);
     if (p.ok) return p.ws_floats * sizeof(float);
     const long Ntot = (long)Cin * R * S;
@@ -1069,6 +1268,27 @@ int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B,
                     int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, void* stream) {
     if (B <= 0 || M <= 0 || Cin <= 0) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    const W3Plan q = plan_w3(B, M, AH, AW, Cin, R, S, si, pad, IH, IW);
+    if (q.ok) {
+        W3 w = {};
+        w.a = a; w.x = x; w.zeros = ws; w.ws = ws + 64;
+        w.B = B; w.M = M; w.AH = AH; w.AW = AW; w.a_bs = a_bs; w.Cin = Cin; w.x_bs = x_bs;
+        w.tiles_x = q.tiles_x; w.tiles_y = q.tiles_y; w.ntiles = q.ntiles; w.tiles_per_split = q.tps; w.nsplit = q.nsplit;
+        w.Cp32 = q.Cp32;
+        hipLaunchKernelGGL(k_zero64, dim3(1), dim3(64), 0, s, ws);
+        const int BM = 32 * q.mt;
+        dim3 grid((unsigned)(((M + BM - 1) / BM) * (q.Cp32 / 32)), 1, (unsigned)q.nsplit);
+        w.dbg = env_int("CC_W3_DBG", 0);
+        if (q.mt == 2 && q.nbuf == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<2, 2>), grid, dim3(384), q.smem, s, w);
+        else if (q.mt == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<2, 1>), grid, dim3(384), q.smem, s, w);
+        else if (q.nbuf == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<1, 2>), grid, dim3(192), q.smem, s, w);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<1, 1>), grid, dim3(192), q.smem, s, w);
+        const long tot = (long)9 * M * q.Cp32;
+        hipLaunchKernelGGL(k_wgrad_patch_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const float*)w.ws, gw,
+                           q.nsplit, 9, M, Cin, q.Cp32, o_sm, o_sc);
+        CC_CHECK_LAUNCH();
+        return CC_OK;
+    }
     const WPlan p = plan_wgrad(B, M, AH, AW, Cin, R, S, si);
     if (p.ok) {
         WP w = {};
@@ -1077,6 +1297,7 @@ int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B,
         w.R = R; w.S = S; w.si = si; w.pad = pad; w.PH = p.PH; w.PWr = p.PWr; w.PSc = p.PSc; w.npos = p.npos;
         w.tiles_x = p.tiles_x; w.tiles_y = p.tiles_y; w.ntiles = p.ntiles; w.tiles_per_split = p.tps; w.nsplit = p.nsplit;
         w.TG = p.TG; w.ngroups = p.ngroups; w.Cp32 = p.Cp32; w.nbuf = p.nbuf;
+        { const char* v = getenv("CC_WGRAD_DBG"); w.dbg = v ? atoi(v) : 0; }
         hipLaunchKernelGGL(k_zero64, dim3(1), dim3(64), 0, s, ws);      // the LDS-DMA halo source (a kernel, not a memset node)
         dim3 grid((unsigned)(((M + p.bmw - 1) / p.bmw) * (p.Cp32 / 32) * p.ngroups), 1, (unsigned)p.nsplit);
         if (p.bmw == 64) {

@@ -343,6 +343,7 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x4(float a, float b, hipemu_f32x4 c)
 #define __builtin_amdgcn_readfirstlane(x) (x)
 // LDS-DMA: destination = wave-uniform base + lane * size (guide section 5); executes synchronously here
 #define CC_LDS_PTR(p) ((void*)(p))
+#define CC_KEEP4(v) ((void)0)
 #define CC_GLOBAL_PTR(p) ((const void*)(p))
 static inline void hipemu_glds(const void* src, void* dst, unsigned size) {
     memcpy(static_cast<char*>(dst) + (size_t)hipemu::lane_id() * size, src, size);
