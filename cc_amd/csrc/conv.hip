@@ -815,49 +815,56 @@ struct W3 {
     const float* a; const float* x; const float* zeros; float* ws;
     int B, M, AH, AW; long a_bs;
     int Cin; long x_bs;
-    int tiles_x, tiles_y, ntiles, tiles_per_split, nsplit, Cp32, dbg;
+    int tiles_x, tiles_y, ntiles, tiles_per_split, nsplit, Cpad, dbg;
 };
 
-template <int MT, int NBUF>
-__global__ __launch_bounds__(192 * MT) void k_wgrad3x3(W3 g) {
-    constexpr int BM = 32 * MT;
-    constexpr int NW = 3 * MT;                     // waves
-    constexpr int A_SLOTS = BM * 16;               // 16-byte slots of the dY tile
-    constexpr int P_SLOTS = ((32 * W3_PC + 63) / 64) * 64;   // rounded up so that every DMA instruction runs all 64 lanes
+// Workgroup = 4 waves (a 3- or 6-wave workgroup lands 2+2+1+1 on the SIMDs and caps at 75 % of the MFMA rate:
+// tools/mfma_probe.hip measures 116 vs 155 TFLOP/s).  It covers MT m-tiles x CT channel-tiles (MT*CT = 4) x 3 tap rows
+// = 12 (tap row, tile) groups, three per wave = 9 accumulators; every k-step pair costs 4 ds_read_b128 per 12 MFMAs.
+template <int MT, int CT>
+__global__ __launch_bounds__(256, 2) void k_wgrad3x3(W3 g) {
+    constexpr int BM = 32 * MT, BC = 32 * CT;
+    constexpr int A_SLOTS = BM * 16;                           // 16-byte slots of the dY tile
+    constexpr int P_SLOTS = ((BC * W3_PC + 63) / 64) * 64;     // rounded up so that every DMA instruction runs all 64 lanes
     HIP_DYNAMIC_SHARED(float, smem)
-    // single-buffered on purpose: 37.5 KB (MT=2) -> 4 workgroups = 24 waves per CU, evenly spread over the 4 SIMDs, and the
-    // DMA of one workgroup overlaps the MFMAs of the other three (the double-buffered 75 KB version ran ONE 6-wave workgroup
-    // per CU, i.e. 2+2+1+1 waves on the SIMDs: measured 2x slower than the MFMA bound)
-    float4* As = reinterpret_cast<float4*>(smem);                    // [NBUF][A_SLOTS]
-    float4* Ps = reinterpret_cast<float4*>(smem) + NBUF * A_SLOTS;   // [NBUF][P_SLOTS]
+    float4* As = reinterpret_cast<float4*>(smem);              // [A_SLOTS]
+    float4* Ps = reinterpret_cast<float4*>(smem) + A_SLOTS;    // [P_SLOTS]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lk = lane >> 5;
-    const int ti = wid % 3;                        // tap row of this wave
-    const int mt = wid / 3;                        // its 32-row m tile
-    const int ctiles = g.Cp32 / 32;
+    const int ctiles = g.Cpad / BC;
     const int ctile = blockIdx.x % ctiles, mtile = blockIdx.x / ctiles;
-    const int m0 = mtile * BM, c0 = ctile * 32;
+    const int m0 = mtile * BM, c0 = ctile * BC;
     const int HW = g.AH * g.AW;
     const int pt_beg = blockIdx.z * g.tiles_per_split;
     int pt_end = pt_beg + g.tiles_per_split;
     if (pt_end > g.ntiles) pt_end = g.ntiles;
 
-    f32x16 acc[3];
+    // this wave's three groups: gidx = wid + 4k -> tap row gidx % 3, tile gidx / 3 -> (mt, ct)
+    int g_row[3], g_mt[3], g_ct[3];
+    f32x16 acc[3][3];
 #pragma unroll
-    for (int j = 0; j < 3; j++)
+    for (int k = 0; k < 3; k++) {
+        const int gi = wid + 4 * k;
+        g_row[k] = gi % 3;
+        const int tl = gi / 3;
+        g_mt[k] = tl % MT;
+        g_ct[k] = tl / MT;
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[k][j][r] = 0.f;
+    }
 
-    auto load_tile = [&](int pt, int buf) {
+    auto load_tile = [&](int pt) {
         const int tile_x = pt % g.tiles_x;
         const int r2 = pt / g.tiles_x;
         const int tile_y = r2 % g.tiles_y;
         const int n = r2 / g.tiles_y;
         const int ty0 = tile_y * 2, tx0 = tile_x * 32;
         // dY: LDS slot s = m*16 + sc holds pixel chunk pc = sc ^ (m & 15) of row m  (pc = row*8 + col4)
-        for (int s0 = wid * 64; s0 < A_SLOTS; s0 += NW * 64) {
+        for (int s0 = wid * 64; s0 < A_SLOTS; s0 += 256) {
             const int sl = s0 + lane;
             const int mm = sl >> 4, sc = sl & 15;
             const int pc = sc ^ (mm & 15);
@@ -865,77 +872,62 @@ __global__ __launch_bounds__(192 * MT) void k_wgrad3x3(W3 g) {
             const int m = m0 + mm;
             const bool ok = (m < g.M) && (ty < g.AH) && (tx < g.AW);
             const float* src = ok ? g.a + (long)n * g.a_bs + (long)m * HW + (long)ty * g.AW + tx : g.zeros;
-            __builtin_amdgcn_global_load_lds(CC_GLOBAL_PTR(src), CC_LDS_PTR(As + buf * A_SLOTS + s0), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(CC_GLOBAL_PTR(src), CC_LDS_PTR(As + s0), 16, 0, 0);
         }
         // patch: LDS slot s = c*41 + r, r = py*10 + ch (r == 40: pad)
-        for (int s0 = wid * 64; s0 < P_SLOTS; s0 += NW * 64) {
+        for (int s0 = wid * 64; s0 < P_SLOTS; s0 += 256) {
             const int sl = s0 + lane;
             const int cc = sl / W3_PC, r = sl - cc * W3_PC;
             const int py = r / 10, ch = r - py * 10;
             const int iy = ty0 - 1 + py, ix = tx0 - 4 + 4 * ch;
             const int c = c0 + cc;
-            const bool ok = (cc < 32) && (r < 40) && (c < g.Cin) && ((unsigned)iy < (unsigned)g.AH) && ((unsigned)ix < (unsigned)g.AW);
+            const bool ok = (cc < BC) && (r < 40) && (c < g.Cin) && ((unsigned)iy < (unsigned)g.AH) && ((unsigned)ix < (unsigned)g.AW);
             const float* src = ok ? g.x + (long)n * g.x_bs + (long)c * HW + (long)iy * g.AW + ix : g.zeros;
-            __builtin_amdgcn_global_load_lds(CC_GLOBAL_PTR(src), CC_LDS_PTR(Ps + buf * P_SLOTS + s0), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(CC_GLOBAL_PTR(src), CC_LDS_PTR(Ps + s0), 16, 0, 0);
         }
     };
 
-    if (pt_beg < pt_end) {
-        if (NBUF == 2) {
-            load_tile(pt_beg, 0);
-            CC_WAIT_VMCNT0();
-            __syncthreads();
-        }
-        for (int pt = pt_beg; pt < pt_end; pt++) {
-            const int buf = (NBUF == 2) ? ((pt - pt_beg) & 1) : 0;
-            if (NBUF == 2) {
-                if (pt + 1 < pt_end && !(g.dbg & 1)) load_tile(pt + 1, buf ^ 1);
-            } else {
-                if (pt > pt_beg) __syncthreads();                                 // everyone is done reading the previous tile
-                if (!(g.dbg & 1) || pt == pt_beg) load_tile(pt, 0);
-                CC_WAIT_VMCNT0();
-                __syncthreads();
-            }
-            const int mrow = mt * 32 + l31;                                       // this lane's dY row in the tile
-            const float4* Ab = As + buf * A_SLOTS + mrow * 16;
-            const float4* Pb = Ps + buf * P_SLOTS + l31 * W3_PC;                  // this lane's channel
+    for (int pt = pt_beg; pt < pt_end; pt++) {
+        if (pt > pt_beg) __syncthreads();                                 // everyone is done reading the previous tile
+        if (!(g.dbg & 1) || pt == pt_beg) load_tile(pt);
+        CC_WAIT_VMCNT0();
+        __syncthreads();
+        // MFMA k index (lane>>5) <-> the two HALVES of a 32-pixel row: lanes 0-31 take pixel chunk pq, lanes 32-63 chunk
+        // pq+4, each through its own ds_read_b128 address -> element e of every chunk feeds MFMA e directly
+        if (g.dbg & 2) continue;
 #pragma unroll
-            for (int row = 0; row < ((g.dbg & 2) ? 0 : 2); row++) {
-                const float4* Pr = Pb + (row + ti) * 10;                          // patch row = pixel row + tap row
+        for (int row = 0; row < 2; row++) {
 #pragma unroll 2
-                for (int pq = 0; pq < 8; pq++) {
-                    float4 av = Ab[((row * 8 + pq) ^ (mrow & 15))];
-                    float4 w0 = Pr[pq], w1 = Pr[pq + 1], w2 = Pr[pq + 2];
+            for (int pq = 0; pq < 4; pq++) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const int mrow = g_mt[k] * 32 + l31;
+                    float4 av = As[mrow * 16 + ((row * 8 + pq + 4 * lk) ^ (mrow & 15))];
+                    const float4* Pr = Ps + (g_ct[k] * 32 + l31) * W3_PC + (row + g_row[k]) * 10 + 4 * lk + pq;
+                    float4 w0 = Pr[0], w1 = Pr[1], w2 = Pr[2];
                     CC_KEEP4(av); CC_KEEP4(w0); CC_KEEP4(w1); CC_KEEP4(w2);
+                    const float a[4] = {av.x, av.y, av.z, av.w};
                     const float w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
-                    const float a_lo = lk ? av.y : av.x, a_hi = lk ? av.w : av.z;
-                    float b_lo[3], b_hi[3];
 #pragma unroll
-                    for (int j = 0; j < 3; j++) {
-                        b_lo[j] = lk ? w[4 + j] : w[3 + j];
-                        b_hi[j] = lk ? w[6 + j] : w[5 + j];
-                    }
-                    // the two MFMAs of one accumulator are issued three MFMAs apart (no back-to-back RAW on the accumulator)
+                    for (int e = 0; e < 4; e++)
 #pragma unroll
-                    for (int j = 0; j < 3; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo, b_lo[j], acc[j], 0, 0, 0);
-#pragma unroll
-                    for (int j = 0; j < 3; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi, b_hi[j], acc[j], 0, 0, 0);
+                        for (int j = 0; j < 3; j++)
+                            acc[k][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], w[3 + j + e], acc[k][j], 0, 0, 0);
                 }
-            }
-            if (NBUF == 2) {
-                CC_WAIT_VMCNT0();
-                __syncthreads();
             }
         }
     }
-    // partial slabs ws[split][t][m][c], t = ti*3 + j   (same layout as k_wgrad_patch -> same reduce kernel)
+    // partial slabs ws[split][t][m][c], t = tap_row*3 + j   (same layout as k_wgrad_patch -> same reduce kernel)
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-        float* o = g.ws + (((long)blockIdx.z * 9 + (ti * 3 + j)) * g.M) * g.Cp32 + c0 + l31;
+    for (int k = 0; k < 3; k++) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (m < g.M) o[(long)m * g.Cp32] = acc[j][r];
+        for (int j = 0; j < 3; j++) {
+            float* o = g.ws + (((long)blockIdx.z * 9 + (g_row[k] * 3 + j)) * g.M) * g.Cpad + c0 + g_ct[k] * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + g_mt[k] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m < g.M) o[(long)m * g.Cpad] = acc[k][j][r];
+            }
         }
     }
 }
@@ -1222,23 +1214,23 @@ static int env_int(const char* name, int dflt) {
 
 inline W3Plan plan_w3(int B, int M, int AH, int AW, int Cin, int R, int S, int si, int pad, int IH, int IW) {
     W3Plan p = {};
-    p.ok = (R == 3 && S == 3 && si == 1 && pad == 1 && IH == AH && IW == AW && (AW % 4) == 0 && AW >= 16 && Cin >= 16 && M >= 16 &&
-            !dbg_flag("CC_NO_WGRAD3X3"));
+    p.ok = (R == 3 && S == 3 && si == 1 && pad == 1 && IH == AH && IW == AW && (AW % 4) == 0 && AW >= 16 && Cin >= 32 && M > 64 &&
+            !dbg_flag("CC_NO_WGRAD3X3"));   // measured (tools/wgrad_ablate.py): wins for M > 64 (1.2-1.45x), loses below
     if (!p.ok) return p;
-    p.mt = (M > 32) ? 2 : 1;
-    const int BM = 32 * p.mt;
-    p.Cp32 = ((Cin + 31) / 32) * 32;
+    p.mt = (M > 64) ? 4 : ((M > 32 && Cin > 32) ? 2 : ((Cin > 64) ? 1 : 2));
+    p.nbuf = 1;
+    const int BM = 32 * p.mt, BC = 32 * (4 / p.mt);
+    p.Cp32 = ((Cin + BC - 1) / BC) * BC;
     p.tiles_x = (AW + 31) / 32;
     p.tiles_y = (AH + 1) / 2;
     p.ntiles = B * p.tiles_x * p.tiles_y;
-    const long base = (long)((M + BM - 1) / BM) * (p.Cp32 / 32);
+    const long base = (long)((M + BM - 1) / BM) * (p.Cp32 / BC);
     long nsplit = (env_int("CC_W3_SPLIT", 512) + base - 1) / base;
     if (nsplit > p.ntiles) nsplit = p.ntiles;
     if (nsplit < 1) nsplit = 1;
     p.tps = (int)((p.ntiles + nsplit - 1) / nsplit);
     p.nsplit = (p.ntiles + p.tps - 1) / p.tps;
-    p.nbuf = env_int("CC_W3_NBUF", 1);
-    p.smem = (size_t)p.nbuf * (BM * 16 + ((32 * W3_PC + 63) / 64) * 64) * 16;
+    p.smem = (size_t)(BM * 16 + ((BC * W3_PC + 63) / 64) * 64) * 16;
     p.ws_floats = 64 + (size_t)p.nsplit * 9 * M * p.Cp32;
     return p;
 }
@@ -1274,15 +1266,14 @@ int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B,
         w.a = a; w.x = x; w.zeros = ws; w.ws = ws + 64;
         w.B = B; w.M = M; w.AH = AH; w.AW = AW; w.a_bs = a_bs; w.Cin = Cin; w.x_bs = x_bs;
         w.tiles_x = q.tiles_x; w.tiles_y = q.tiles_y; w.ntiles = q.ntiles; w.tiles_per_split = q.tps; w.nsplit = q.nsplit;
-        w.Cp32 = q.Cp32;
+        w.Cpad = q.Cp32;
         hipLaunchKernelGGL(k_zero64, dim3(1), dim3(64), 0, s, ws);
-        const int BM = 32 * q.mt;
-        dim3 grid((unsigned)(((M + BM - 1) / BM) * (q.Cp32 / 32)), 1, (unsigned)q.nsplit);
+        const int BM = 32 * q.mt, BC = 32 * (4 / q.mt);
+        dim3 grid((unsigned)(((M + BM - 1) / BM) * (q.Cp32 / BC)), 1, (unsigned)q.nsplit);
         w.dbg = env_int("CC_W3_DBG", 0);
-        if (q.mt == 2 && q.nbuf == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<2, 2>), grid, dim3(384), q.smem, s, w);
-        else if (q.mt == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<2, 1>), grid, dim3(384), q.smem, s, w);
-        else if (q.nbuf == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<1, 2>), grid, dim3(192), q.smem, s, w);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<1, 1>), grid, dim3(192), q.smem, s, w);
+        if (q.mt == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<4, 1>), grid, dim3(256), q.smem, s, w);
+        else if (q.mt == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<2, 2>), grid, dim3(256), q.smem, s, w);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<1, 4>), grid, dim3(256), q.smem, s, w);
         const long tot = (long)9 * M * q.Cp32;
         hipLaunchKernelGGL(k_wgrad_patch_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const float*)w.ws, gw,
                            q.nsplit, 9, M, Cin, q.Cp32, o_sm, o_sc);

@@ -32,8 +32,6 @@ if len(sys.argv) > 1:
         err = float((gw - wr.grad).abs().max() / wr.grad.abs().max())
     print("%-8s nbuf=%s split=%s dbg=%s  %.3f ms  %.1f TF  relerr %.2e" % (sys.argv[1], os.environ.get("CC_W3_NBUF", "-"), os.environ.get("CC_W3_SPLIT", "-"), os.environ.get("CC_W3_DBG", "0"), ms, fl / ms / 1e9, err))
 else:
-    for shape in ("b2f128", "conv3"):
-        for env in ({"CC_W3_NBUF": "1", "CC_W3_SPLIT": "512"}, {"CC_W3_NBUF": "1", "CC_W3_SPLIT": "1024"}, {"CC_W3_NBUF": "1", "CC_W3_SPLIT": "2048"},
-                    {"CC_W3_NBUF": "2", "CC_W3_SPLIT": "512"}, {"CC_W3_NBUF": "2", "CC_W3_SPLIT": "1024"},
-                    {"CC_W3_NBUF": "1", "CC_W3_DBG": "1"}, {"CC_W3_NBUF": "1", "CC_W3_DBG": "2"}, {"CC_W3_NBUF": "2", "CC_W3_DBG": "1"}):
+    for shape in ("b2f128", "dec0", "dec6", "conv2", "conv3", "iconv2"):
+        for env in ({"CC_NO_WGRAD3X3": "1"}, {"CC_W3_DBG": "0"}, {"CC_W3_DBG": "1"}, {"CC_W3_SPLIT": "1024"}):
             subprocess.run([sys.executable, __file__, shape], env=dict(os.environ, **env))
