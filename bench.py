@@ -94,7 +94,7 @@ class CallTimer:
                 r = self._orig(name, *args)
                 e.record()
                 d = dict(zip(self.eng.sigs[name][2], args))
-                self.records.append((name, WORK[name][1](d), s, e))
+                self.records.append((name, WORK[name][1](d), s, e, {k: v for k, v in d.items() if isinstance(v, int) and k not in ("x_bs", "y_bs", "res_bs", "a_bs", "gy_bs", "gx_bs")}))
                 return r
             return self._orig(name, *args)
         self.eng.call = call
@@ -106,7 +106,18 @@ class CallTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for name, work, s, e in self.records:
+        detail = {}
+        for name, work, s, e, shp in self.records:
+            key = name + " " + " ".join("%s=%s" % kv for kv in sorted(shp.items()))
+            dd = detail.setdefault(key, [0, 0.0, 0.0])
+            dd[0] += 1
+            dd[1] += work
+            dd[2] += s.elapsed_time(e)
+        if os.environ.get("CC_BENCH_DETAIL"):
+            with open(os.environ["CC_BENCH_DETAIL"], "w") as f:
+                for key, (n, work, ms) in sorted(detail.items(), key=lambda kv: -kv[1][2]):
+                    f.write("%8.3f ms  n=%3d  %7.2f G  %6.1f rate  %s\n" % (ms, n, work / 1e9, work / ms / 1e9 if ms > 0 else 0, key))
+        for name, work, s, e, shp in self.records:
             a = agg.setdefault(name, [0, 0.0, 0.0])
             a[0] += 1
             a[1] += work

@@ -1226,6 +1226,8 @@ inline W3Plan plan_w3(int B, int M, int AH, int AW, int Cin, int R, int S, int s
     p.ntiles = B * p.tiles_x * p.tiles_y;
     const long base = (long)((M + BM - 1) / BM) * (p.Cp32 / BC);
     long nsplit = (env_int("CC_W3_SPLIT", 512) + base - 1) / base;
+    const long cap = (p.ntiles + 5) / 6;          // >= 6 pixel tiles per split: every split writes a 9*M*Cpad partial slab
+    if (nsplit > cap) nsplit = cap;
     if (nsplit > p.ntiles) nsplit = p.ntiles;
     if (nsplit < 1) nsplit = 1;
     p.tps = (int)((p.ntiles + nsplit - 1) / nsplit);
@@ -1247,7 +1249,7 @@ size_t cc_conv2d_wgrad_ws_bytes(int B, int M, int AH, int AW, int Cin, int R, in
     const int bm = pick_bm(M);
     const long tiles = ((Ntot + BN - 1) / BN) * ((M + bm - 1) / bm);
     long nsplit = (512 + tiles - 1) / tiles;
-    const long maxsplit = (P + 1023) / 1024;
+    const long maxsplit = (P + 63) / 64;      // small maps still need >= 256 workgroups: split down to 64-pixel ranges
     if (nsplit > maxsplit) nsplit = maxsplit;
     if (nsplit < 1) nsplit = 1;
     return nsplit <= 1 ? 16 : (size_t)nsplit * M * Ntot * sizeof(float);
@@ -1313,7 +1315,7 @@ int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B,
     const int bm = pick_bm(M);
     const long tiles = ((Ntot + BN - 1) / BN) * ((M + bm - 1) / bm);
     long nsplit = (512 + tiles - 1) / tiles;
-    const long maxsplit = (P + 1023) / 1024;
+    const long maxsplit = (P + 63) / 64;      // small maps still need >= 256 workgroups: split down to 64-pixel ranges
     if (nsplit > maxsplit) nsplit = maxsplit;
     if (nsplit < 1) nsplit = 1;
     long pps = (P + nsplit - 1) / nsplit;
