@@ -60,6 +60,7 @@ def _px(args, names, *keys):
 
 
 WORK = {   # entry point -> (kind, fn(args dict) -> algorithmic flops or bytes)
+    "cc_repack_table": ("byte", lambda d: 0.0),
     "cc_conv2d_fwd": ("flop", lambda d: 2.0 * d["B"] * d["OH"] * d["OW"] * d["Cout"] * d["Cin"] * d["R"] * d["S"]),
     "cc_conv2d_dgrad": ("flop", lambda d: 2.0 * d["B"] * d["OH"] * d["OW"] * d["K"] * d["C"] * d["R"] * d["S"]),
     "cc_conv2d_wgrad": ("flop", lambda d: 2.0 * d["B"] * d["AH"] * d["AW"] * d["M"] * d["Cin"] * d["R"] * d["S"]),

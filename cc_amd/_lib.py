@@ -65,7 +65,7 @@ class Engine:
         if self.require_device and not t.is_cuda:
             raise RuntimeError("%s arg %d: tensor is on %s; the ccengine kernels need a HIP device (no CPU path)"
                                % (name, i, t.device))
-        if t.dtype != torch.float32 and t.dtype != torch.int32 and t.dtype != torch.uint8:
+        if t.dtype not in (torch.float32, torch.int32, torch.uint8, torch.int64):
             raise TypeError("%s arg %d: unsupported dtype %s" % (name, i, t.dtype))
         if not t.is_contiguous():
             raise ValueError("%s arg %d: tensor must be contiguous" % (name, i))

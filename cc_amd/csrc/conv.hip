@@ -236,6 +236,29 @@ __global__ __launch_bounds__(256) void k_repack_w(const float* __restrict__ w, f
     wp[e] = (m < M && c < Cin) ? w[(long)w0 + (long)m * w_sm + (long)c * w_sc + i * w_ri + j * w_sj] : 0.f;
 }
 
+// All weight repacks of a training step in ONE launch: desc[d] = 16 longs
+//   {src, dst, M, Cin, Mpad, Cpad, T, St, w_sm, w_sc, w0, w_ri, w_sj, nfloats, first_block, 0}
+// (the per-call k_repack_w launches were ~540 tiny kernels = 3 ms of launch latency per step).
+__global__ __launch_bounds__(256) void k_repack_table(const long* __restrict__ desc, int ndesc) {
+    // binary search the descriptor whose block range contains blockIdx.x
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[16 * mid + 14] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long* d = desc + 16 * lo;
+    const float* w = reinterpret_cast<const float*>(d[0]);
+    float* wp = reinterpret_cast<float*>(d[1]);
+    const int M = (int)d[2], Cin = (int)d[3], Mpad = (int)d[4], Cpad = (int)d[5], St = (int)d[7];
+    const long e = ((long)blockIdx.x - d[14]) * 256 + threadIdx.x;
+    if (e >= d[13]) return;
+    const int m = (int)(e % Mpad);
+    const long r = e / Mpad;
+    const int c = (int)(r % Cpad), t = (int)(r / Cpad);
+    const int i = t / St, j = t - i * St;
+    wp[e] = (m < M && c < Cin) ? w[d[10] + (long)m * d[8] + (long)c * d[9] + i * d[11] + j * d[12]] : 0.f;
+}
+
 template <int BM, int CK>
 __global__ __launch_bounds__(256) void k_conv_patch(CP g) {
     constexpr int WM = (BM >= 64) ? BM / 2 : 32;
@@ -1070,15 +1093,21 @@ inline void launch_patch(const CP& c, dim3 grid, size_t smem, hipStream_t s) {
 }
 
 // ws: [64 zeros][repacked weights][split-K partial slabs]; sized by conv_ws_floats(plan_conv(g))
-inline void launch_gg(const GG& g, float* ws, hipStream_t s) {
+// prepacked (optional): {64 zeros, wp} produced earlier by k_repack_table -> no repack launch here
+inline void launch_gg(const GG& g, float* ws, hipStream_t s, const float* prepacked = nullptr, const float* pre_zeros = nullptr) {
     const ConvPlan p = plan_conv(g);
     if (!p.use_patch || ws == nullptr) { launch_gg_flat(g, s); return; }
-    float* zeros = ws;
-    float* wp = ws + 64;
-    float* part = wp + p.wp_floats;
+    const float* zeros = ws;
+    const float* wp = ws + 64;
+    float* part = ws + 64 + (prepacked ? 0 : p.wp_floats);
     const int T = g.Rt * g.St;
-    hipLaunchKernelGGL(k_repack_w, dim3((unsigned)((p.wp_floats + 255) / 256)), dim3(256), 0, s, g.w, wp, zeros, g.M, g.Cin,
-                       p.Mpad, p.Cpad, T, g.St, g.w_sm, g.w_sc, g.w0, g.w_ri, g.w_sj);
+    if (prepacked) {
+        zeros = pre_zeros;
+        wp = prepacked;
+    } else {
+        hipLaunchKernelGGL(k_repack_w, dim3((unsigned)((p.wp_floats + 255) / 256)), dim3(256), 0, s, g.w, ws + 64, ws, g.M, g.Cin,
+                           p.Mpad, p.Cpad, T, g.St, g.w_sm, g.w_sc, g.w0, g.w_ri, g.w_sj);
+    }
     CP c = {};
     c.x = g.x; c.wp = wp; c.zeros = zeros; c.bias = g.bias; c.res = g.res; c.y = g.y; c.part = part;
     c.B = g.B; c.Cin = g.Cin; c.IH = g.IH; c.IW = g.IW; c.x_bs = g.x_bs;
@@ -1126,6 +1155,33 @@ static GG make_fwd(const float* x, const float* w, const float* bias, const floa
     return g;
 }
 
+static void fill_desc(const GG& g, const ConvPlan& p, long src, long dst, long* d) {
+    d[0] = src; d[1] = dst; d[2] = g.M; d[3] = g.Cin; d[4] = p.Mpad; d[5] = p.Cpad; d[6] = (long)g.Rt * g.St; d[7] = g.St;
+    d[8] = g.w_sm; d[9] = g.w_sc; d[10] = g.w0; d[11] = g.w_ri; d[12] = g.w_sj; d[13] = (long)p.wp_floats; d[14] = 0; d[15] = 0;
+}
+
+/* Per-step weight prepack (optional fast path).  *_pack_desc fill 16-long descriptors ({src, dst, ...}; dst = where the
+ * [tap][c][m] image of this layer goes: pack_base + 64 floats (+ the images of earlier parity classes for dgrad)) and
+ * return the number of descriptors (0: this geometry does not use the patch kernel); cc_repack_table runs all of them in
+ * one launch after the caller has filled d[14] = first block of each descriptor (cumulative ceil(nfloats/256)).
+ * Buffers passed as `prepacked` to the conv entry points must start with 64 zero floats. */
+size_t cc_conv2d_fwd_pack_floats(int B, int Cin, int IH, int IW, int Cout, int R, int S, int stride, int pad, int OH, int OW) {
+    GG g = make_fwd(nullptr, nullptr, nullptr, nullptr, nullptr, B, Cin, IH, IW, 0, Cout, R, S, stride, pad, OH, OW, 0, 0, 0,
+                    1.f, 0.f);
+    const ConvPlan p = plan_conv(g);
+    return p.use_patch ? 64 + p.wp_floats : 0;
+}
+
+int cc_conv2d_fwd_pack_desc(int B, int Cin, int IH, int IW, int Cout, int R, int S, int stride, int pad, int OH, int OW,
+                            long src_ptr, long pack_base_ptr, long* desc_out_host) {
+    GG g = make_fwd(nullptr, nullptr, nullptr, nullptr, nullptr, B, Cin, IH, IW, 0, Cout, R, S, stride, pad, OH, OW, 0, 0, 0,
+                    1.f, 0.f);
+    const ConvPlan p = plan_conv(g);
+    if (!p.use_patch) return 0;
+    fill_desc(g, p, src_ptr, pack_base_ptr + 64 * (long)sizeof(float), desc_out_host);
+    return 1;
+}
+
 size_t cc_conv2d_fwd_ws_bytes(int B, int Cin, int IH, int IW, int Cout, int R, int S, int stride, int pad, int OH, int OW) {
     GG g = make_fwd(nullptr, nullptr, nullptr, nullptr, nullptr, B, Cin, IH, IW, 0, Cout, R, S, stride, pad, OH, OW, 0, 0, 0,
                     1.f, 0.f);
@@ -1135,12 +1191,12 @@ size_t cc_conv2d_fwd_ws_bytes(int B, int Cin, int IH, int IW, int Cout, int R, i
 /* y = act(conv2d(x, w, stride, pad) + bias + res).  x: [B,Cin,IH,IW] (batch stride x_bs), w: [Cout,Cin,R,S],
  * y: [B,Cout,OH,OW] (batch stride y_bs; may be a channel slice of a wider tensor).  ws: cc_conv2d_fwd_ws_bytes(). */
 int cc_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, const float* res_or_null, float* y, float* ws,
-                  int B, int Cin, int IH, int IW, long x_bs, int Cout, int R, int S, int stride, int pad, int OH, int OW,
-                  long y_bs, long res_bs, int act, float act_a, float act_b, void* stream) {
+                  const float* prepacked_or_null, int B, int Cin, int IH, int IW, long x_bs, int Cout, int R, int S, int stride,
+                  int pad, int OH, int OW, long y_bs, long res_bs, int act, float act_a, float act_b, void* stream) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0) return CC_ERR_ARG;
     GG g = make_fwd(x, w, bias_or_null, res_or_null, y, B, Cin, IH, IW, x_bs, Cout, R, S, stride, pad, OH, OW, y_bs, res_bs,
                     act, act_a, act_b);
-    launch_gg(g, ws, (hipStream_t)stream);
+    launch_gg(g, ws, (hipStream_t)stream, prepacked_or_null ? prepacked_or_null + 64 : nullptr, prepacked_or_null);
     CC_CHECK_LAUNCH();
     return CC_OK;
 }
@@ -1187,18 +1243,68 @@ size_t cc_conv2d_dgrad_ws_bytes(int B, int K, int OH, int OW, int C, int R, int 
     return best * sizeof(float);
 }
 
-int cc_conv2d_dgrad(const float* gy, const float* w, const float* bias_or_null, float* gx, float* ws, int B, int K, int OH,
-                    int OW, long gy_bs, int C, int R, int S, int stride, int pad, int IH, int IW, long gx_bs,
-                    long w_k_stride, long w_c_stride, int act, float act_a, float act_b, void* stream) {
+size_t cc_conv2d_dgrad_pack_floats(int B, int K, int OH, int OW, int C, int R, int S, int stride, int pad, int IH, int IW,
+                                   long w_k_stride, long w_c_stride) {
+    size_t tot = 64;
+    for (int py = 0; py < stride; py++)
+        for (int px = 0; px < stride; px++) {
+            GG g;
+            if (!make_dgrad_class(g, py, px, nullptr, nullptr, nullptr, nullptr, B, K, OH, OW, 0, C, R, S, stride, pad, IH, IW, 0,
+                                  w_k_stride, w_c_stride, 0, 1.f, 0.f))
+                continue;
+            const ConvPlan p = plan_conv(g);
+            if (!p.use_patch) return 0;
+            tot += p.wp_floats;
+        }
+    return tot;
+}
+
+int cc_conv2d_dgrad_pack_desc(int B, int K, int OH, int OW, int C, int R, int S, int stride, int pad, int IH, int IW,
+                              long w_k_stride, long w_c_stride, long src_ptr, long pack_base_ptr, long* desc_out_host) {
+    int n = 0;
+    long off = 64;
+    for (int py = 0; py < stride; py++)
+        for (int px = 0; px < stride; px++) {
+            GG g;
+            if (!make_dgrad_class(g, py, px, nullptr, nullptr, nullptr, nullptr, B, K, OH, OW, 0, C, R, S, stride, pad, IH, IW, 0,
+                                  w_k_stride, w_c_stride, 0, 1.f, 0.f))
+                continue;
+            const ConvPlan p = plan_conv(g);
+            if (!p.use_patch) return 0;
+            fill_desc(g, p, src_ptr, pack_base_ptr + off * (long)sizeof(float), desc_out_host + 16 * n);
+            off += (long)p.wp_floats;
+            n++;
+        }
+    return n;
+}
+
+int cc_repack_table(const long* table_dev, int ndesc, long total_blocks, void* stream) {
+    if (ndesc <= 0 || total_blocks <= 0) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_repack_table, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, table_dev, ndesc);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_conv2d_dgrad(const float* gy, const float* w, const float* bias_or_null, float* gx, float* ws,
+                    const float* prepacked_or_null, int B, int K, int OH, int OW, long gy_bs, int C, int R, int S, int stride,
+                    int pad, int IH, int IW, long gx_bs, long w_k_stride, long w_c_stride, int act, float act_a, float act_b,
+                    void* stream) {
     if (B <= 0 || K <= 0 || C <= 0 || stride <= 0) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    long off = 64;
     for (int py = 0; py < stride; py++) {
         for (int px = 0; px < stride; px++) {
             GG g;
             if (!make_dgrad_class(g, py, px, gy, w, bias_or_null, gx, B, K, OH, OW, gy_bs, C, R, S, stride, pad, IH, IW, gx_bs,
                                   w_k_stride, w_c_stride, act, act_a, act_b))
                 continue;
-            launch_gg(g, ws, s);
+            if (prepacked_or_null) {
+                const ConvPlan p = plan_conv(g);
+                launch_gg(g, ws, s, prepacked_or_null + off, prepacked_or_null);
+                off += (long)p.wp_floats;
+            } else {
+                launch_gg(g, ws, s);
+            }
         }
     }
     CC_CHECK_LAUNCH();

@@ -22,6 +22,75 @@ def _ws(nbytes, ref):
     return torch.empty(max(int(nbytes) // 4, 4), device=ref.device, dtype=torch.float32)
 
 
+# ----------------------------------------------------------------------------- per-step weight prepack
+class PackRegistry:
+    """The [tap][c][m] weight images of every conv layer (forward + data-gradient layouts), refreshed by ONE
+    cc_repack_table launch per training step (trainer calls prepack_all() at the start of forward) instead of one
+    tiny repack launch inside each of the ~540 conv calls.  Outside a trainer step `valid` is False and every conv
+    call repacks for itself."""
+
+    def __init__(self):
+        self.entries = {}
+        self.valid = False
+        self.epoch = 0
+        self.dirty = False
+        self.table = None
+        self.total_blocks = 0
+
+    def get(self, kind, w, geom):
+        """-> prepacked buffer (tensor) or None.  Unknown layers are registered for the next prepack_all()."""
+        key = (kind, w.data_ptr(), geom)
+        ent = self.entries.get(key)
+        if ent is None:
+            self._register(key, kind, w, geom)
+            return None
+        if ent is False or not self.valid or ent["epoch"] != self.epoch:
+            return None
+        return ent["buf"]
+
+    def _register(self, key, kind, w, geom):
+        import ctypes
+        E = engine()
+        fn = "cc_conv2d_fwd_pack" if kind == "fwd" else "cc_conv2d_dgrad_pack"
+        n = E.call(fn + "_floats", *geom)
+        if n == 0:
+            self.entries[key] = False
+            return
+        buf = torch.zeros(int(n), device=w.device, dtype=torch.float32)
+        host = (ctypes.c_long * 64)()
+        nd = E.fn[fn + "_desc"](*geom, w.data_ptr(), buf.data_ptr(), ctypes.addressof(host))
+        descs = [[int(host[16 * i + k]) for k in range(16)] for i in range(nd)]
+        self.entries[key] = {"buf": buf, "descs": descs, "epoch": -1, "w": w}
+        self.dirty = True
+
+    def prepack_all(self):
+        live = [e for e in self.entries.values() if e]
+        if not live:
+            return
+        if self.dirty or self.table is None:
+            rows, blk = [], 0
+            for e in live:
+                for d in e["descs"]:
+                    d = list(d)
+                    d[14] = blk
+                    blk += (d[13] + 255) // 256
+                    rows.append(d)
+            self.table = torch.tensor(rows, dtype=torch.int64, device=live[0]["buf"].device).contiguous()
+            self.total_blocks = blk
+            self.dirty = False
+        engine().call("cc_repack_table", self.table, self.table.shape[0], self.total_blocks, STREAM)
+        self.epoch += 1
+        for e in live:
+            e["epoch"] = self.epoch
+        self.valid = True
+
+    def invalidate(self):
+        self.valid = False
+
+
+packs = PackRegistry()
+
+
 # ----------------------------------------------------------------------------- convolution
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
@@ -36,7 +105,8 @@ class _Conv2dFn(torch.autograd.Function):
         res_c = None if res is None else _c(res)
         E = engine()
         ws = _ws(E.call("cc_conv2d_fwd_ws_bytes", B, Cin, IH, IW, Cout, R, S, stride, pad, OH, OW), x)
-        E.call("cc_conv2d_fwd", x, w, bias_c, res_c, y, ws, B, Cin, IH, IW, Cin * IH * IW, Cout, R, S, stride, pad,
+        pk = packs.get("fwd", w, (B, Cin, IH, IW, Cout, R, S, stride, pad, OH, OW))
+        E.call("cc_conv2d_fwd", x, w, bias_c, res_c, y, ws, pk, B, Cin, IH, IW, Cin * IH * IW, Cout, R, S, stride, pad,
                OH, OW, Cout * OH * OW, Cout * OH * OW, act, act_a, act_b, STREAM)
         ctx.save_for_backward(x, w, y if act != 0 else None)
         ctx.cfg = (stride, pad, act, act_a, act_b, bias is not None, res is not None)
@@ -63,7 +133,8 @@ class _Conv2dFn(torch.autograd.Function):
         if need[0]:
             gx = torch.empty_like(x)
             ws = _ws(E.call("cc_conv2d_dgrad_ws_bytes", B, Cout, OH, OW, Cin, R, S, stride, pad, IH, IW), x)
-            E.call("cc_conv2d_dgrad", gy, w, None, gx, ws, B, Cout, OH, OW, Cout * OH * OW, Cin, R, S, stride, pad, IH, IW,
+            pk = packs.get("dgrad", w, (B, Cout, OH, OW, Cin, R, S, stride, pad, IH, IW, Cin * R * S, R * S))
+            E.call("cc_conv2d_dgrad", gy, w, None, gx, ws, pk, B, Cout, OH, OW, Cout * OH * OW, Cin, R, S, stride, pad, IH, IW,
                    Cin * IH * IW, Cin * R * S, R * S, 0, 1.0, 0.0, STREAM)
         if need[1]:
             gw = torch.empty_like(w)
@@ -97,7 +168,8 @@ class _ConvT2dFn(torch.autograd.Function):
         # ConvTranspose2d forward == the transposed-conv arithmetic of cc_conv2d_dgrad with K = Cin, C = Cout
         E = engine()
         ws = _ws(E.call("cc_conv2d_dgrad_ws_bytes", B, Cin, IH, IW, Cout, R, S, stride, pad, OH, OW), x)
-        E.call("cc_conv2d_dgrad", x, w, bias_c, y, ws, B, Cin, IH, IW, Cin * IH * IW, Cout, R, S, stride, pad, OH, OW,
+        pk = packs.get("dgrad", w, (B, Cin, IH, IW, Cout, R, S, stride, pad, OH, OW, Cout * R * S, R * S))
+        E.call("cc_conv2d_dgrad", x, w, bias_c, y, ws, pk, B, Cin, IH, IW, Cin * IH * IW, Cout, R, S, stride, pad, OH, OW,
                Cout * OH * OW, Cout * R * S, R * S, act, 1.0, 0.0, STREAM)
         ctx.save_for_backward(x, w, y if act != 0 else None)
         ctx.cfg = (stride, pad, act, bias is not None)
@@ -125,7 +197,8 @@ class _ConvT2dFn(torch.autograd.Function):
             # d/dx of a transposed conv is a plain strided conv of gy; the [Cin,Cout,R,S] weight IS its [M,C,R,S] weight
             gx = torch.empty_like(x)
             ws = _ws(E.call("cc_conv2d_fwd_ws_bytes", B, Cout, OH, OW, Cin, R, S, stride, pad, IH, IW), x)
-            E.call("cc_conv2d_fwd", gy, w, None, None, gx, ws, B, Cout, OH, OW, Cout * OH * OW, Cin, R, S, stride, pad, IH, IW,
+            pk = packs.get("fwd", w, (B, Cout, OH, OW, Cin, R, S, stride, pad, IH, IW))
+            E.call("cc_conv2d_fwd", gy, w, None, None, gx, ws, pk, B, Cout, OH, OW, Cout * OH * OW, Cin, R, S, stride, pad, IH, IW,
                    Cin * IH * IW, 0, 0, 1.0, 0.0, STREAM)
         if need[1]:
             gw = torch.empty_like(w)

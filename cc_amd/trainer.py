@@ -13,7 +13,7 @@ MI355X-first structure around that body:
 import torch
 import torch.distributed as dist
 
-from . import config, models
+from . import config, models, ops
 from . import loss_functions as LF
 from ._lib import engine, STREAM
 from .inverse_warp import pose2flow
@@ -152,9 +152,11 @@ class CCTrainer:
 
     def _fwd_bwd(self, batch):
         LF.pyramid_cache.clear()
+        ops.packs.prepack_all()            # every conv layer's [tap][c][m] weight images, one launch (weights changed in Adam)
         self.opt.zero_grad()                                                # :566
         out = cc_forward(self.nets, batch, self.cfg)
         out["loss"].backward()                                              # :567
+        ops.packs.invalidate()
         return {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
 
     def _copy_in(self, batch):

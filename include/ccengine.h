@@ -169,17 +169,31 @@ int cc_corr9x9_bwd(const float* gout, const float* f1, const float* f2, float* g
  * Batch strides (elements) let inputs/outputs be channel slices of wider NCHW tensors (no torch.cat copies). */
 size_t cc_conv2d_fwd_ws_bytes(int B, int Cin, int IH, int IW, int Cout, int R, int S, int stride, int pad, int OH, int OW);
 int cc_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, const float* res_or_null, float* y, float* ws,
-                  int B, int Cin, int IH, int IW, long x_bs, int Cout, int R, int S, int stride, int pad, int OH, int OW,
-                  long y_bs, long res_bs, int act, float act_a, float act_b, void* stream);
+                  const float* prepacked_or_null, int B, int Cin, int IH, int IW, long x_bs, int Cout, int R, int S, int stride,
+                  int pad, int OH, int OW, long y_bs, long res_bs, int act, float act_a, float act_b, void* stream);
 /* gx[n,c,iy,ix] = act(bias[c] + sum_{k,r,s} w(k,c,r,s) * gy[n,k,oy,ox]), iy = oy*stride - pad + r: the data-gradient of
  * conv2d (act 0, bias null) and the forward of ConvTranspose2d (weight [Cin=K, Cout=C, R, S]); one launch per
  * output parity class.  w(k,c,r,s) = w[k*w_k_stride + c*w_c_stride + r*S + s].
  * ws (both calls): scratch for the per-call weight repack [tap][c][m], a zero line for the LDS-DMA halo and the
  * split-K partial slabs of deep layers on small maps. */
 size_t cc_conv2d_dgrad_ws_bytes(int B, int K, int OH, int OW, int C, int R, int S, int stride, int pad, int IH, int IW);
-int cc_conv2d_dgrad(const float* gy, const float* w, const float* bias_or_null, float* gx, float* ws, int B, int K, int OH,
-                    int OW, long gy_bs, int C, int R, int S, int stride, int pad, int IH, int IW, long gx_bs,
-                    long w_k_stride, long w_c_stride, int act, float act_a, float act_b, void* stream);
+int cc_conv2d_dgrad(const float* gy, const float* w, const float* bias_or_null, float* gx, float* ws,
+                    const float* prepacked_or_null, int B, int K, int OH, int OW, long gy_bs, int C, int R, int S, int stride,
+                    int pad, int IH, int IW, long gx_bs, long w_k_stride, long w_c_stride, int act, float act_a, float act_b,
+                    void* stream);
+/* Optional per-step weight prepack: the [tap][c][m] weight images every conv call otherwise builds itself (one tiny
+ * launch each, ~540 per step) are produced for ALL layers by one cc_repack_table launch.  *_pack_floats = size of a
+ * layer's image buffer (0: geometry not eligible), which must start with 64 zero floats; *_pack_desc write 16-long
+ * descriptors into a HOST array (src_ptr / pack_base_ptr are device addresses) and return their count; the caller sets
+ * desc[14] = first block (cumulative ceil(desc[13]/256)) and uploads the table. */
+size_t cc_conv2d_fwd_pack_floats(int B, int Cin, int IH, int IW, int Cout, int R, int S, int stride, int pad, int OH, int OW);
+int cc_conv2d_fwd_pack_desc(int B, int Cin, int IH, int IW, int Cout, int R, int S, int stride, int pad, int OH, int OW,
+                            long src_ptr, long pack_base_ptr, long* desc_out_host);
+size_t cc_conv2d_dgrad_pack_floats(int B, int K, int OH, int OW, int C, int R, int S, int stride, int pad, int IH, int IW,
+                                   long w_k_stride, long w_c_stride);
+int cc_conv2d_dgrad_pack_desc(int B, int K, int OH, int OW, int C, int R, int S, int stride, int pad, int IH, int IW,
+                              long w_k_stride, long w_c_stride, long src_ptr, long pack_base_ptr, long* desc_out_host);
+int cc_repack_table(const long* table_dev, int ndesc, long total_blocks, void* stream);
 size_t cc_conv2d_wgrad_ws_bytes(int B, int M, int AH, int AW, int Cin, int R, int S, int si);
 /* gw[m*o_sm + c*o_sc + r*S + s] = sum_{n,ty,tx} a[n,m,ty,tx] * x[n,c,si*ty-pad+r,si*tx-pad+s] (split over pixels,
  * deterministic second-stage reduction through ws). */
