@@ -30,7 +30,7 @@ def leaf(t, dev):
     return t.detach().clone().to(dev).requires_grad_(True)
 
 
-def check_warps(dev, B=2, H=24, W=40, smooth=0):
+def check_warps(dev, B=2, H=24, W=40, smooth=0, atol=1e-5):
     """a8/a9/a10 + Back2Future.warp vs the oracle run on THIS host's CPU: forward 1e-5 abs, gradients 2e-5 rel
     (bit-exactness is checked against the reference's own outputs in check_warps_bit_exact_vs_golden)."""
     tgt, refs, K, Kinv = syn.sample(B, H, W, seed=1, smooth=smooth)
@@ -47,8 +47,8 @@ def check_warps(dev, B=2, H=24, W=40, smooth=0):
             go = torch.randn(r.shape, generator=torch.Generator().manual_seed(5))
             o.backward(go.to(dev))
             r.backward(go)
-            assert frac_bad(o, r) < 2e-3
-            assert frac_bad(d.grad, d0.grad, 1e-6 * float(d0.grad.abs().max())) < 2e-3
+            assert frac_bad(o, r, atol) < 2e-3, (frac_bad(o, r, atol), float((o.detach().cpu() - r.detach()).abs().max()))
+            assert frac_bad(d.grad, d0.grad, max(1e-6, atol * 0.1) * float(d0.grad.abs().max())) < 2e-3
             assert frac_bad(im.grad, im0.grad, 1e-5) < 2e-3 and rel(p.grad, p0.grad) < 1e-2
         d, p = leaf(ki["depth"][:, 0], dev), leaf(pose[:, 1], dev)
         d0, p0 = leaf(ki["depth"][:, 0], "cpu"), leaf(pose[:, 1], "cpu")
@@ -61,7 +61,7 @@ def check_warps(dev, B=2, H=24, W=40, smooth=0):
         fl, im = leaf(ki["flow_fwd"], dev), leaf(refs[1], dev)
         fl0, im0 = leaf(ki["flow_fwd"], "cpu"), leaf(refs[1], "cpu")
         o, r = IW.flow_warp(im, fl, align_corners=ac), G.flow_warp(im0, fl0, align_corners=ac)
-        assert frac_bad(o, r) < 2e-3
+        assert frac_bad(o, r, atol) < 2e-3
         go = torch.randn(r.shape, generator=torch.Generator().manual_seed(7))
         g1 = torch.autograd.grad(o, [im, fl], go.to(dev))
         g0 = torch.autograd.grad(r, [im0, fl0], go)
@@ -69,7 +69,7 @@ def check_warps(dev, B=2, H=24, W=40, smooth=0):
         ft = torch.randn(B, 8, H, W, generator=torch.Generator().manual_seed(8))
         fe, fe0 = leaf(ft, dev), leaf(ft, "cpu")
         o, r = IW.feature_warp(fe, fl, align_corners=ac), G.feature_warp(fe0, fl0, align_corners=ac)
-        assert frac_bad(o, r) < 2e-3
+        assert frac_bad(o, r, atol) < 2e-3
         go = torch.randn(r.shape, generator=torch.Generator().manual_seed(9))
         g1 = torch.autograd.grad(o, [fe, fl], go.to(dev))
         g0 = torch.autograd.grad(r, [fe0, fl0], go)

@@ -20,7 +20,8 @@ def test_warps():
 
 
 def test_warps_full_size():
-    parity.check_warps("cuda", B=2, H=256, W=832, smooth=3)
+    # sampling coordinates reach ~800 px here: a last-ulp difference in P (device sin/cos vs host) is ~1e-4 px
+    parity.check_warps("cuda", B=2, H=256, W=832, smooth=3, atol=3e-4)
 
 
 def test_ssim():
