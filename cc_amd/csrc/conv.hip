@@ -215,6 +215,7 @@ struct CP {
     int M, Mpad, Cpad;
     int Rt, St, si, dstep, dy_base, dx_base, ymin, xmin;
     int PH, PWr, PS;
+    int aligned, shift;    // aligned: patch rows start on a 16-byte boundary of x (PWr = padded row length) -> dwordx4 LDS-DMA
     int OHt, OWt, so, oy0, ox0, OH, OW; long y_bs, res_bs;
     int tiles_x, tiles_y;
     int nsplit, cps; long part_stride;
@@ -293,6 +294,27 @@ __global__ __launch_bounds__(256) void k_conv_patch(CP g) {
 
     auto load_patch = [&](int chunk, int buf) {
         float* dst = Ps + buf * CK * g.PS;
+        if (g.aligned) {
+            // 16-byte LDS-DMA: lane = one 4-float chunk of a patch row (rows are 16-byte aligned in x, see plan_conv);
+            // a chunk is entirely inside or outside the image because IW % 4 == 0
+            const int cpr = g.PWr >> 2;                       // chunks per patch row
+            const int nq = g.PS >> 2;                         // chunks per channel (multiple of 16)
+            for (int q0 = 0; q0 < nq; q0 += 64) {
+                const int q = q0 + lane;
+                const int py = q / cpr, qx = q - py * cpr;
+                const int iy = gy0 + py, ix = gx0 - g.shift + 4 * qx;
+                const bool ok = (q < nq) && (py < g.PH) && ((unsigned)iy < (unsigned)g.IH) && ((unsigned)ix < (unsigned)g.IW);
+                const long go = (long)iy * g.IW + ix;
+#pragma unroll
+                for (int k = 0; k < CK / 4; k++) {
+                    const int cl = wid + 4 * k;
+                    const int c = chunk * CK + cl;
+                    const float* src = (ok && c < g.Cin) ? xn + (long)c * x_cs + go : g.zeros;
+                    __builtin_amdgcn_global_load_lds(CC_GLOBAL_PTR(src), CC_LDS_PTR(dst + cl * g.PS + 4 * q0), 16, 0, 0);
+                }
+            }
+            return;
+        }
         for (int r = 0; r < R; r++) {
             const int pos = lane + 64 * r;
             const int py = pos / g.PWr, px = pos - py * g.PWr;
@@ -347,7 +369,7 @@ __global__ __launch_bounds__(256) void k_conv_patch(CP g) {
                 else if (chunk + 1 < c_end) load_A(chunk + 1, 0, (s + 1) & 1);
                 if (tap == 0 && chunk + 1 < c_end) load_patch(chunk + 1, (chunk + 1) & 1);
                 const float* Ab = As + (s & 1) * CK * BM;
-                const int tapoff = (g.dy_base + ti * g.dstep) * g.PWr + (g.dx_base + tj * g.dstep);
+                const int tapoff = (g.dy_base + ti * g.dstep) * g.PWr + (g.dx_base + tj * g.dstep) + g.shift;
                 const float* Pl = Pb + lk * g.PS + (g.si * row0) * g.PWr + g.si * l31 + tapoff;
                 const float* Al = Ab + lk * BM + wm * WM + l31;
                 // all fragments of the stage are fetched up front (2*(TM+TN)*CK/2 VGPRs): one exposed LDS latency per
@@ -443,7 +465,7 @@ static int dbg_flag_early(const char* name) {
 
 struct ConvPlan {
     bool use_patch;
-    int bm, ck, Mpad, Cpad, PH, PWr, PS, ymin, xmin, tiles_x, tiles_y, nsplit, cps;
+    int bm, ck, Mpad, Cpad, PH, PWr, PS, ymin, xmin, tiles_x, tiles_y, nsplit, cps, aligned, shift;
     size_t smem, wp_floats, part_floats;
 };
 
@@ -456,7 +478,15 @@ inline ConvPlan plan_conv(const GG& g) {
     const int ymax = g.dy0 < ylast ? ylast : g.dy0, xmax = g.dx0 < xlast ? xlast : g.dx0;
     p.PH = (TH - 1) * g.si + (ymax - p.ymin) + 1;
     p.PWr = (TW - 1) * g.si + (xmax - p.xmin) + 1;
+    // 16-byte aligned variant: start every patch row at the 4-float boundary at or below its first column
+    p.aligned = (g.IW % 4 == 0) && !dbg_flag_early("CC_NO_ALIGNED_PATCH");
+    p.shift = 0;
+    if (p.aligned) {
+        p.shift = ((p.xmin % 4) + 4) % 4;                  // si * tx0 is a multiple of 4
+        p.PWr = ((p.shift + p.PWr + 3) / 4) * 4;
+    }
     p.PS = ((p.PH * p.PWr + 63) / 64) * 64;
+    if (p.aligned) p.PS = ((p.PH * p.PWr + 255) / 256) * 256;     // whole 64-lane x 16-byte DMA instructions per channel
     p.ck = 16;
     auto smem_of = [&](int ck) { return (size_t)(2 * ck * p.bm + 2 * ck * p.PS) * sizeof(float); };
     if (smem_of(16) > 64 * 1024) p.ck = 8;
@@ -1114,7 +1144,7 @@ inline void launch_gg(const GG& g, float* ws, hipStream_t s, const float* prepac
     c.M = g.M; c.Mpad = p.Mpad; c.Cpad = p.Cpad;
     c.Rt = g.Rt; c.St = g.St; c.si = g.si; c.dstep = g.dstep;
     c.dy_base = g.dy0 - p.ymin; c.dx_base = g.dx0 - p.xmin; c.ymin = p.ymin; c.xmin = p.xmin;
-    c.PH = p.PH; c.PWr = p.PWr; c.PS = p.PS;
+    c.PH = p.PH; c.PWr = p.PWr; c.PS = p.PS; c.aligned = p.aligned; c.shift = p.shift;
     c.OHt = g.OHt; c.OWt = g.OWt; c.so = g.so; c.oy0 = g.oy0; c.ox0 = g.ox0; c.OH = g.OH; c.OW = g.OW;
     c.y_bs = g.y_bs; c.res_bs = g.res_bs;
     c.tiles_x = p.tiles_x; c.tiles_y = p.tiles_y;
