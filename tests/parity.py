@@ -49,7 +49,10 @@ def check_warps(dev, B=2, H=24, W=40, smooth=0, atol=1e-5):
             r.backward(go)
             assert frac_bad(o, r, atol) < 2e-3, (frac_bad(o, r, atol), float((o.detach().cpu() - r.detach()).abs().max()))
             assert frac_bad(d.grad, d0.grad, max(1e-6, atol * 0.1) * float(d0.grad.abs().max())) < 2e-3
-            assert frac_bad(im.grad, im0.grad, 1e-5) < 2e-3 and rel(p.grad, p0.grad) < 1e-2
+            # d(out)/d(img) is the bilinear weight itself: a coordinate difference of atol px shows up as ~4*atol*|go|
+            tol_im = 1e-5 if atol <= 1e-5 else 8 * atol
+            assert frac_bad(im.grad, im0.grad, tol_im) < 2e-3, frac_bad(im.grad, im0.grad, tol_im)
+            assert rel(p.grad, p0.grad) < 1e-2, rel(p.grad, p0.grad)
         d, p = leaf(ki["depth"][:, 0], dev), leaf(pose[:, 1], dev)
         d0, p0 = leaf(ki["depth"][:, 0], "cpu"), leaf(pose[:, 1], "cpu")
         f, f0 = IW.pose2flow(d, p, Kd, Kinvd), G.pose2flow(d0, p0, K, Kinv)
@@ -65,7 +68,7 @@ def check_warps(dev, B=2, H=24, W=40, smooth=0, atol=1e-5):
         go = torch.randn(r.shape, generator=torch.Generator().manual_seed(7))
         g1 = torch.autograd.grad(o, [im, fl], go.to(dev))
         g0 = torch.autograd.grad(r, [im0, fl0], go)
-        assert frac_bad(g1[0], g0[0], 1e-5) < 2e-3 and frac_bad(g1[1], g0[1], 1e-4) < 2e-3
+        assert frac_bad(g1[0], g0[0], (1e-5 if atol <= 1e-5 else 8 * atol)) < 2e-3 and frac_bad(g1[1], g0[1], (1e-4 if atol <= 1e-5 else 8 * atol)) < 2e-3
         ft = torch.randn(B, 8, H, W, generator=torch.Generator().manual_seed(8))
         fe, fe0 = leaf(ft, dev), leaf(ft, "cpu")
         o, r = IW.feature_warp(fe, fl, align_corners=ac), G.feature_warp(fe0, fl0, align_corners=ac)
@@ -73,7 +76,7 @@ def check_warps(dev, B=2, H=24, W=40, smooth=0, atol=1e-5):
         go = torch.randn(r.shape, generator=torch.Generator().manual_seed(9))
         g1 = torch.autograd.grad(o, [fe, fl], go.to(dev))
         g0 = torch.autograd.grad(r, [fe0, fl0], go)
-        assert frac_bad(g1[0], g0[0], 1e-5) < 2e-3 and frac_bad(g1[1], g0[1], 1e-4) < 2e-3
+        assert frac_bad(g1[0], g0[0], (1e-5 if atol <= 1e-5 else 8 * atol)) < 2e-3 and frac_bad(g1[1], g0[1], (1e-4 if atol <= 1e-5 else 8 * atol)) < 2e-3
 
 
 def check_ssim(dev, cases=((2, 40, 70, 0), (1, 64, 96, 3), (2, 8, 26, 0), (1, 33, 31, 1))):
