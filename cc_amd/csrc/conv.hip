@@ -22,6 +22,7 @@
 // deterministic second-stage reduction (no atomics).
 #include <stdlib.h>
 #include "cc_common.h"
+#include "conv_internal.h"
 #include "../../include/ccengine.h"
 
 namespace {
@@ -1373,7 +1374,16 @@ inline W3Plan plan_w3(int B, int M, int AH, int AW, int Cin, int R, int S, int s
     return p;
 }
 
+static size_t wgrad_ws_bytes_base(int B, int M, int AH, int AW, int Cin, int R, int S, int si);
+
 size_t cc_conv2d_wgrad_ws_bytes(int B, int M, int AH, int AW, int Cin, int R, int S, int si) {
+    // the thin path is confirmed at launch (pad, input width): size for it AND for the path it would fall back to
+    const size_t thin = ccint::wgrad_thin_ws_floats(B, M, AH, AW, Cin, R, S, si) * sizeof(float);
+    const size_t base = wgrad_ws_bytes_base(B, M, AH, AW, Cin, R, S, si);
+    return thin > base ? thin : base;
+}
+
+static size_t wgrad_ws_bytes_base(int B, int M, int AH, int AW, int Cin, int R, int S, int si) {
     {   // the 3x3/s1/p1 path (pad and input size are implied by "same" convolutions: checked again at launch)
         const W3Plan q = plan_w3(B, M, AH, AW, Cin, R, S, si, 1, AH, AW);
         if (q.ok) return q.ws_floats * sizeof(float);
@@ -1398,6 +1408,10 @@ int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B,
                     int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, void* stream) {
     if (B <= 0 || M <= 0 || Cin <= 0) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (ccint::wgrad_thin_launch(a, x, gw, ws, B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, s)) {
+        CC_CHECK_LAUNCH();
+        return CC_OK;
+    }
     const W3Plan q = plan_w3(B, M, AH, AW, Cin, R, S, si, pad, IH, IW);
     if (q.ok) {
         W3 w = {};

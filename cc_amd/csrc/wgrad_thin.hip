@@ -1,0 +1,292 @@
+// Weight gradient of the "thin" layers: <= 32 channels on either side but 50 k - 850 k pixels per call (the full- and
+// half-resolution layers of DispResNet6 / MaskNet6 / Back2Future: first convs, last iconvs, prediction heads).
+//
+//      gw[m, c, r, s] = sum_{n, y, x}  a[n, m, y, x] * X[n, c, SI*y + r - PAD, SI*x + s - PAD]
+//
+// These calls are HBM-shaped (16-32 channel planes of up to 213 k pixels read once, 2-5 k outputs), and an
+// im2col-style GEMM spends its time gathering: every X element is fetched R*S times with per-element address
+// arithmetic.  Here the reduction (pixel) axis is the MFMA K axis and NOTHING is staged:
+//   * v_mfma_f32_16x16x4_f32:  D[m][c] += sum_{k<4} A[m][k] * B[k][c]  with k = 4 consecutive output pixels;
+//     lane (i = lane & 15, k = lane >> 4) supplies a[m = i][pixel k] and X[c = i][pixel k shifted by the tap];
+//   * one "unit" = 16 consecutive output pixels of one row: lane k owns pixels x0 + 4k .. x0 + 4k + 3, so its A operand
+//     for the 4 MFMA steps is ONE aligned float4 of the dY row and its B operands for all S taps of a tap row are a
+//     window of NQ aligned float4 of the X row (global_load_dwordx4 straight into the MFMA source registers);
+//   * every tap (r, s) has its own 16x16 accumulator (4 VGPRs): 9 taps = 36 VGPRs, the window index of (step j, tap s)
+//     is a compile-time constant, so the inner loop is loads + v_cndmask (zero padding) + MFMAs only;
+//   * the loads of unit u+4 are issued before the MFMAs of unit u (register double buffer), addresses are clamped
+//     instead of predicated so that no branch sits between loads and MFMAs.
+// Work split: blockIdx.x = a contiguous range of units (4 waves interleave over it), blockIdx.y = (16-channel group of
+// a) x (16-channel group of X) x (group of TR tap rows).  Each workgroup reduces its 4 waves in LDS (fixed order) and
+// writes one partial slab; k_wgrad_thin_reduce sums the slabs in a fixed order (deterministic, no atomics).
+#include <stdio.h>
+#include <stdlib.h>
+#include "cc_common.h"
+#include "conv_internal.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WT {
+    const float* a; const float* x; float* ws;
+    int B, M, AH, AW; long a_bs;
+    int Cin, IH, IW; long x_bs;
+    int R, nxc, units, upb, npb, ngc, ngt;
+};
+
+template <int S, int SI, int PAD, int TR>
+struct ThinCfg {
+    static constexpr int PQ = (PAD + 3) / 4;                         // float4s to the left of the unit's first pixel
+    static constexpr int IMAX = SI * 3 + S - 1 - PAD + 4 * PQ;       // largest window index used
+    static constexpr int NQ = IMAX / 4 + 1;                          // float4s per tap row window
+    static constexpr int TS = TR * S;
+};
+
+template <int S, int SI, int PAD, int TR>
+__global__ __launch_bounds__(256) void k_wgrad_thin(WT g) {
+    typedef ThinCfg<S, SI, PAD, TR> C;
+    constexpr int PQ = C::PQ, NQ = C::NQ, TS = C::TS;
+    __shared__ float red[TS * 256];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = lane & 15, k = lane >> 4;
+    int combo = blockIdx.y;
+    const int tg = combo % g.ngt;
+    combo /= g.ngt;
+    const int cg = combo % g.ngc, mg = combo / g.ngc;
+    const int r0 = tg * TR;
+    const int m = mg * 16 + i, c = cg * 16 + i;
+    const bool mok = m < g.M, cok = c < g.Cin;
+    const float* __restrict__ abase = g.a + (long)(mok ? m : 0) * g.AH * g.AW;
+    const float* __restrict__ xbase = g.x + (long)(cok ? c : 0) * g.IH * g.IW;
+
+    f32x4 acc[TR][S];
+#pragma unroll
+    for (int tr = 0; tr < TR; tr++)
+#pragma unroll
+        for (int s = 0; s < S; s++) acc[tr][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int u0 = blockIdx.x * g.upb;
+    const int u1 = (u0 + g.upb < g.units) ? (u0 + g.upb) : g.units;
+
+    float4 An;
+    float4 Wn[TR][NQ];
+    // issue the loads of unit u (clamped addresses: always in bounds, the padding mask is applied at use)
+    auto issue = [&](int u, float4& A, float4 (&W)[TR][NQ]) {
+        const int row = u / g.nxc, xc = u - row * g.nxc;
+        const int b = row / g.AH, y = row - b * g.AH;
+        const int x0 = xc * 16 + 4 * k;
+        const int xa = (x0 < g.AW) ? x0 : 0;
+        A = *(const float4*)(abase + (long)b * g.a_bs + (long)y * g.AW + xa);
+        const float* xb = xbase + (long)b * g.x_bs;
+#pragma unroll
+        for (int tr = 0; tr < TR; tr++) {
+            int iy = y * SI + r0 + tr - PAD;
+            iy = iy < 0 ? 0 : (iy >= g.IH ? g.IH - 1 : iy);
+            const float* xr = xb + (long)iy * g.IW;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                int col = SI * x0 - 4 * PQ + 4 * q;
+                col = (col < 0 || col >= g.IW) ? 0 : col;
+                W[tr][q] = *(const float4*)(xr + col);
+            }
+        }
+    };
+
+    int u = u0 + wave;
+    if (u < u1) {
+        issue(u, An, Wn);
+        for (; u < u1; u += 4) {
+            const float4 Ac = An;
+            float4 Wc[TR][NQ];
+#pragma unroll
+            for (int tr = 0; tr < TR; tr++)
+#pragma unroll
+                for (int q = 0; q < NQ; q++) Wc[tr][q] = Wn[tr][q];
+            const int un = (u + 4 < u1) ? (u + 4) : u;          // the last iteration re-loads its own unit (no branch)
+            issue(un, An, Wn);
+
+            const int row = u / g.nxc, xc = u - row * g.nxc;
+            const int y = row % g.AH;
+            const int x0 = xc * 16 + 4 * k;
+            const bool aok = mok && (x0 < g.AW);
+            float a4[4];
+            a4[0] = aok ? Ac.x : 0.f;
+            a4[1] = aok ? Ac.y : 0.f;
+            a4[2] = aok ? Ac.z : 0.f;
+            a4[3] = aok ? Ac.w : 0.f;
+#pragma unroll
+            for (int tr = 0; tr < TR; tr++) {
+                // a short last tap-row group (r0 + tr >= R) multiplies zeros: no branch between the MFMAs
+                const int iy = y * SI + r0 + tr - PAD;
+                const bool rok = cok && (r0 + tr < g.R) && iy >= 0 && iy < g.IH;
+                float w[NQ * 4];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const int col = SI * x0 - 4 * PQ + 4 * q;
+                    const bool ok = rok && col >= 0 && col < g.IW;
+                    w[4 * q + 0] = ok ? Wc[tr][q].x : 0.f;
+                    w[4 * q + 1] = ok ? Wc[tr][q].y : 0.f;
+                    w[4 * q + 2] = ok ? Wc[tr][q].z : 0.f;
+                    w[4 * q + 3] = ok ? Wc[tr][q].w : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int s = 0; s < S; s++)
+                        acc[tr][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], w[SI * j + s - PAD + 4 * PQ], acc[tr][s], 0, 0, 0);
+            }
+        }
+    }
+
+    // workgroup reduction, waves in a fixed order: red[(t*4 + reg)*64 + lane]
+#pragma unroll 1
+    for (int wv = 0; wv < 4; wv++) {
+        if (wave == wv) {
+#pragma unroll
+            for (int tr = 0; tr < TR; tr++)
+#pragma unroll
+                for (int s = 0; s < S; s++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int idx = ((tr * S + s) * 4 + r) * 64 + lane;
+                        const float v = acc[tr][s][r];
+                        red[idx] = (wv == 0) ? v : (red[idx] + v);
+                    }
+        }
+        __syncthreads();
+    }
+    // slab [t][m16][c16]; D element (reg, lane) is m = 4*(lane>>4) + reg, c = lane & 15
+    float* __restrict__ slab = g.ws + ((long)blockIdx.y * g.npb + blockIdx.x) * (TS * 256);
+    for (int e = threadIdx.x; e < TS * 256; e += 256) {
+        const int t = e >> 8, mc = e & 255, mm = mc >> 4, cc_ = mc & 15;
+        slab[e] = red[(t * 4 + (mm & 3)) * 64 + (mm >> 2) * 16 + cc_];
+    }
+}
+
+// gw[m*o_sm + c*o_sc + r*S + s] = sum_pb slab[combo][pb][t][m16][c16]   (fixed summation order)
+__global__ __launch_bounds__(1024) void k_wgrad_thin_reduce(const float* __restrict__ ws, float* __restrict__ gw, int npb, int TS,
+                                                            int S, int TR, int ngc, int ngt, int M, int Cin, int R, long o_sm,
+                                                            long o_sc) {
+    __shared__ float4 part[16][64];
+    const int combo = blockIdx.x / TS, t = blockIdx.x - combo * TS;
+    const int sub = threadIdx.x >> 6, q = threadIdx.x & 63;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int pb = sub; pb < npb; pb += 16) {
+        const float4 v = *(const float4*)(ws + (((long)combo * npb + pb) * TS + t) * 256 + 4 * q);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    part[sub][q] = s;
+    __syncthreads();
+    if (sub == 0) {
+        for (int z = 1; z < 16; z++) {
+            const float4 v = part[z][q];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        int cb = combo;
+        const int tg = cb % ngt;
+        cb /= ngt;
+        const int cg = cb % ngc, mg = cb / ngc;
+        const int r = tg * TR + t / S, sc = t % S;
+        const int m = mg * 16 + (q >> 2), c0 = cg * 16 + (q & 3) * 4;
+        if (m < M && r < R) {
+            float* o = gw + (long)m * o_sm + (long)r * S + sc;
+            if (c0 + 0 < Cin) o[(long)(c0 + 0) * o_sc] = s.x;
+            if (c0 + 1 < Cin) o[(long)(c0 + 1) * o_sc] = s.y;
+            if (c0 + 2 < Cin) o[(long)(c0 + 2) * o_sc] = s.z;
+            if (c0 + 3 < Cin) o[(long)(c0 + 3) * o_sc] = s.w;
+        }
+    }
+}
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+struct ThinPlan {
+    bool ok;
+    int kind, TR, ngm, ngc, ngt, nxc, units, upb, npb, TS;
+    size_t ws_floats;
+};
+
+// kinds: (S, SI, PAD, TR) instantiations
+enum { K_3_1 = 0, K_3_2, K_7_2, K_7_1, K_1_1, K_5_2, K_4_2, K_NONE };
+
+ThinPlan plan_thin(int B, int M, int AH, int AW, int Cin, int R, int S, int si) {
+    ThinPlan p = {};
+    p.kind = K_NONE;
+    if (R != S || env_int("CC_NO_WGRAD_THIN", 0)) return p;
+    if (S == 3 && si == 1) { p.kind = K_3_1; p.TR = 3; }
+    else if (S == 3 && si == 2) { p.kind = K_3_2; p.TR = 3; }
+    else if (S == 7 && si == 2) { p.kind = K_7_2; p.TR = 2; }
+    else if (S == 7 && si == 1) { p.kind = K_7_1; p.TR = 2; }
+    else if (S == 1 && si == 1) { p.kind = K_1_1; p.TR = 1; }
+    else if (S == 5 && si == 2) { p.kind = K_5_2; p.TR = 3; }
+    else if (S == 4 && si == 2) { p.kind = K_4_2; p.TR = 4; }
+    else return p;
+    p.ngm = (M + 15) / 16;
+    p.ngc = (Cin + 15) / 16;
+    const long P = (long)B * AH * AW;
+    if ((AW & 3) || p.ngm * p.ngc > env_int("CC_WGRAD_THIN_MAXCOMBO", 4) || P < env_int("CC_WGRAD_THIN_MINPIX", 32768)) return p;
+    p.ngt = (R + p.TR - 1) / p.TR;
+    p.TS = p.TR * S;
+    p.nxc = (AW + 15) / 16;
+    const long units = (long)B * AH * p.nxc;
+    if (units > (1l << 30)) return p;
+    p.units = (int)units;
+    long npb = units / env_int("CC_WGRAD_THIN_UPB", 32);
+    const long cap = env_int("CC_WGRAD_THIN_NPB", 512);
+    npb = npb < 1 ? 1 : (npb > cap ? cap : npb);
+    p.upb = (int)((units + npb - 1) / npb);
+    p.upb = ((p.upb + 3) / 4) * 4;
+    p.npb = (p.units + p.upb - 1) / p.upb;
+    p.ws_floats = (size_t)p.ngm * p.ngc * p.ngt * p.npb * p.TS * 256;
+    p.ok = true;
+    return p;
+}
+
+template <int S, int SI, int PAD, int TR>
+void launch_thin(const WT& g, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad_thin<S, SI, PAD, TR>), grid, dim3(256), 0, s, g);
+}
+
+}  // namespace
+
+namespace ccint {
+
+size_t wgrad_thin_ws_floats(int B, int M, int AH, int AW, int Cin, int R, int S, int si) {
+    const ThinPlan p = plan_thin(B, M, AH, AW, Cin, R, S, si);
+    return p.ok ? p.ws_floats : 0;
+}
+
+bool wgrad_thin_launch(const float* a, const float* x, float* gw, float* ws, int B, int M, int AH, int AW, long a_bs, int Cin,
+                       int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, hipStream_t s) {
+    const ThinPlan p = plan_thin(B, M, AH, AW, Cin, R, S, si);
+    if (!p.ok || (IW & 3) || (a_bs & 3) || (x_bs & 3)) return false;
+    static const int want_pad[] = {1, 1, 3, 3, 0, 2, 1};
+    if (pad != want_pad[p.kind]) return false;
+    WT g = {};
+    g.a = a; g.x = x; g.ws = ws;
+    g.B = B; g.M = M; g.AH = AH; g.AW = AW; g.a_bs = a_bs; g.Cin = Cin; g.IH = IH; g.IW = IW; g.x_bs = x_bs;
+    g.R = R; g.nxc = p.nxc; g.units = p.units; g.upb = p.upb; g.npb = p.npb; g.ngc = p.ngc; g.ngt = p.ngt;
+    const int ncombo = p.ngm * p.ngc * p.ngt;
+    if (env_int("CC_WGRAD_THIN_TRACE", 0))
+        fprintf(stderr, "[wgrad_thin] kind %d M %d Cin %d A %dx%d X %dx%d npb %d upb %d combos %d\n", p.kind, M, Cin, AH, AW, IH, IW,
+                p.npb, p.upb, ncombo);
+    dim3 grid((unsigned)p.npb, (unsigned)ncombo);
+    switch (p.kind) {
+        case K_3_1: launch_thin<3, 1, 1, 3>(g, grid, s); break;
+        case K_3_2: launch_thin<3, 2, 1, 3>(g, grid, s); break;
+        case K_7_2: launch_thin<7, 2, 3, 2>(g, grid, s); break;
+        case K_7_1: launch_thin<7, 1, 3, 2>(g, grid, s); break;
+        case K_1_1: launch_thin<1, 1, 0, 1>(g, grid, s); break;
+        case K_5_2: launch_thin<5, 2, 2, 3>(g, grid, s); break;
+        default: launch_thin<4, 2, 1, 4>(g, grid, s); break;
+    }
+    hipLaunchKernelGGL(k_wgrad_thin_reduce, dim3((unsigned)(ncombo * p.TS)), dim3(1024), 0, s, (const float*)ws, gw, p.npb, p.TS, S,
+                       p.TR, p.ngc, p.ngt, M, Cin, R, o_sm, o_sc);
+    return true;
+}
+
+}  // namespace ccint

@@ -331,3 +331,82 @@ def check_losses_vs_golden(dev, golden_dir):
             l5 = LF.consensus_depth_flow_mask(a["mask"], rb, rf, tgt_ref, tgt_ref, THRESH=0.5, wbce=0.5)
             assert abs(float(l5) - float(g["consensus_depth_flow_mask"])) <= 1e-3 * abs(float(g["consensus_depth_flow_mask"]))
     return res
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# convolutions (the networks' hot kernels): engine vs torch fp32 on the CPU (the reference's nn.Conv2d / ConvTranspose2d)
+CONV_CASES = [  # B, Cin, H, W, Cout, k, stride, pad, act, bias, residual
+    (2, 3, 16, 20, 32, 7, 2, 3, "relu", True, False),
+    (2, 16, 9, 13, 40, 3, 1, 1, "lrelu", True, False),
+    (1, 20, 8, 10, 2, 3, 1, 1, None, True, False),
+    (2, 33, 7, 9, 70, 3, 2, 1, "relu", False, False),
+    (2, 24, 6, 7, 24, 3, 1, 1, "relu", False, True),
+    (1, 130, 5, 6, 150, 1, 1, 0, None, True, False),
+    (2, 8, 10, 12, 1, 3, 1, 1, "sigmoid", True, False),
+    (2, 5, 12, 9, 16, 5, 2, 2, "relu", True, False),
+    (2, 12, 6, 8, 12, 1, 2, 0, None, False, False),
+    (2, 10, 11, 70, 20, 3, 1, 1, "relu", True, False),
+    (1, 6, 21, 75, 8, 3, 2, 1, "relu", True, False),
+    (2, 64, 5, 40, 64, 3, 1, 1, "relu", False, True),
+    (1, 40, 6, 32, 96, 3, 1, 1, "lrelu", True, False),
+]
+# few channels x many pixels (wgrad_thin.hip; the pixel threshold is lowered for the small test maps)
+CONV_CASES_THIN = [
+    (2, 16, 9, 16, 16, 3, 1, 1, "relu", True, False),
+    (2, 17, 6, 20, 16, 3, 1, 1, "lrelu", True, False),
+    (1, 16, 7, 36, 4, 3, 1, 1, "sigmoid", True, False),
+    (2, 3, 12, 24, 16, 3, 2, 1, "relu", True, False),
+    (2, 15, 16, 40, 16, 7, 2, 3, "relu", True, False),
+    (1, 32, 6, 16, 32, 7, 1, 3, "relu", True, False),
+    (2, 17, 5, 12, 16, 1, 1, 0, None, False, False),
+    (2, 16, 10, 24, 32, 5, 2, 2, "relu", True, False),
+    (2, 16, 5, 8, 1, 3, 1, 1, "sigmoid", True, False),
+    (2, 20, 6, 44, 30, 3, 2, 1, None, True, False),
+]
+CONVT_CASES = [  # B, Cin, H, W, Cout, k, stride, pad, output_padding, act
+    (2, 16, 5, 7, 24, 3, 2, 1, 1, "relu"),
+    (2, 20, 4, 6, 12, 4, 2, 1, 0, "relu"),
+    (1, 40, 3, 5, 40, 3, 2, 1, 1, None),
+    (2, 48, 6, 8, 16, 4, 2, 1, 0, "relu"),
+    (2, 32, 5, 8, 16, 3, 2, 1, 1, None),
+]
+
+
+def check_convs(dev, cases=CONV_CASES, tcases=CONVT_CASES, tol=2e-5, seed=0):
+    """conv2d / conv_transpose2d forward (+ fused bias / residual / activation epilogue) and all gradients, max-abs
+    error relative to the largest reference magnitude <= tol (fp32 MFMA accumulation order differs from the CPU's)."""
+    import torch.nn.functional as F
+    from cc_amd import ops
+    g = torch.Generator().manual_seed(seed)
+
+    def rn(*s):
+        return torch.randn(*s, generator=g)
+    for (B, Cin, H, W, Cout, k, st, pad, act, hb, hr) in cases:
+        x0, w0 = rn(B, Cin, H, W), rn(Cout, Cin, k, k) * 0.2
+        b0 = rn(Cout) if hb else None
+        OH, OW = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
+        r0 = rn(B, Cout, OH, OW) if hr else None
+        aa, ab = (10.0, 0.01) if act == "sigmoid" else (1.0, 0.0)
+        ins_d = [leaf(t, dev) if t is not None else None for t in (x0, w0, b0, r0)]
+        ins_c = [leaf(t, "cpu") if t is not None else None for t in (x0, w0, b0, r0)]
+        y = ops.conv2d(ins_d[0], ins_d[1], ins_d[2], st, pad, act, ins_d[3], aa, ab)
+        r = F.conv2d(ins_c[0], ins_c[1], ins_c[2], st, pad)
+        if hr:
+            r = r + ins_c[3]
+        r = ops._torch_act(r, act, aa, ab)
+        go = rn(*r.shape)
+        g1 = torch.autograd.grad(y, [t for t in ins_d if t is not None], go.to(dev))
+        g0 = torch.autograd.grad(r, [t for t in ins_c if t is not None], go)
+        errs = [rel(y, r)] + [rel(a, b) for a, b in zip(g1, g0)]
+        assert max(errs) < tol, ((B, Cin, H, W, Cout, k, st, pad, act), errs)
+    for (B, Cin, H, W, Cout, k, st, pad, op, act) in tcases:
+        x0, w0, b0 = rn(B, Cin, H, W), rn(Cin, Cout, k, k) * 0.2, rn(Cout)
+        ins_d = [leaf(t, dev) for t in (x0, w0, b0)]
+        ins_c = [leaf(t, "cpu") for t in (x0, w0, b0)]
+        y = ops.conv_transpose2d(ins_d[0], ins_d[1], ins_d[2], st, pad, op, act)
+        r = ops._torch_act(F.conv_transpose2d(ins_c[0], ins_c[1], ins_c[2], st, pad, op), act, 1.0, 0.0)
+        go = rn(*r.shape)
+        g1 = torch.autograd.grad(y, ins_d, go.to(dev))
+        g0 = torch.autograd.grad(r, ins_c, go)
+        errs = [rel(y, r)] + [rel(a, b) for a, b in zip(g1, g0)]
+        assert max(errs) < tol, ((B, Cin, H, W, Cout, k, st, pad, op, act), errs)

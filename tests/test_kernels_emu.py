@@ -43,3 +43,13 @@ def test_warps_bit_exact_vs_reference_golden(golden_dir):
 
 def test_losses_vs_reference_golden(golden_dir):
     print(parity.check_losses_vs_golden("cpu", golden_dir))
+
+
+def test_convs():
+    parity.check_convs("cpu")
+
+
+def test_convs_thin_wgrad(monkeypatch):
+    monkeypatch.setenv("CC_WGRAD_THIN_MINPIX", "0")      # route the small test maps through wgrad_thin.hip
+    monkeypatch.setenv("CC_WGRAD_THIN_UPB", "8")
+    parity.check_convs("cpu", cases=parity.CONV_CASES_THIN)

@@ -52,3 +52,21 @@ def test_warps_bit_exact_vs_reference_golden(golden_dir):
 
 def test_losses_vs_reference_golden(golden_dir):
     print(parity.check_losses_vs_golden("cuda", golden_dir))
+
+
+def test_convs():
+    parity.check_convs("cuda")
+
+
+def test_convs_thin_wgrad(monkeypatch):
+    monkeypatch.setenv("CC_WGRAD_THIN_MINPIX", "0")
+    monkeypatch.setenv("CC_WGRAD_THIN_UPB", "8")
+    parity.check_convs("cuda", cases=parity.CONV_CASES_THIN)
+
+
+def test_convs_full_size_thin_layers():
+    # the real thin layers of the 256x832 step (default thresholds): DispResNet6 iconv1 / head, MaskNet6 conv1, B2F feat1
+    cases = [(2, 17, 256, 832, 16, 3, 1, 1, "relu", True, False), (2, 16, 256, 832, 1, 3, 1, 1, "sigmoid", True, False),
+             (2, 15, 256, 832, 16, 7, 2, 3, "relu", True, False), (2, 3, 256, 832, 16, 3, 2, 1, "lrelu", True, False),
+             (2, 32, 128, 416, 32, 7, 1, 3, "relu", True, False)]
+    parity.check_convs("cuda", cases=cases, tcases=[(2, 48, 64, 208, 16, 4, 2, 1, 0, "relu")], tol=5e-5)
