@@ -526,7 +526,7 @@ struct WG {
     int Cin, IH, IW; long x_bs;
     int Rt, St, dy0, dx0, dstep, si;
     long o_sm, o_sc; int o_ri, o_sj;     // gradient strides (used when direct == 1)
-    int direct;
+    int direct, accum;
     int pix_per_split;
 };
 
@@ -669,7 +669,10 @@ __global__ __launch_bounds__(256) void k_wgrad(WG g) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int m = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (m < g.M) g.out[obase + (g.direct ? (long)m * g.o_sm : (long)m * Ntot)] = acc[a][b][r];
+                if (m < g.M) {
+                    float* o = g.out + obase + (g.direct ? (long)m * g.o_sm : (long)m * Ntot);
+                    *o = (g.direct && g.accum) ? (*o + acc[a][b][r]) : acc[a][b][r];
+                }
             }
     }
 }
@@ -990,7 +993,7 @@ __global__ void k_zero64(float* p) { p[threadIdx.x] = 0.f; }
 
 // gw[m*o_sm + c*o_sc + t] = sum_z ws[z][t][m][c]
 __global__ __launch_bounds__(256) void k_wgrad_patch_reduce(const float* __restrict__ ws, float* __restrict__ gw, int nsplit,
-                                                            int T, int M, int Cin, int Cp32, long o_sm, long o_sc) {
+                                                            int T, int M, int Cin, int Cp32, long o_sm, long o_sc, int accum) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;     // over [t][m][c]
     const long tot = (long)T * M * Cp32;
     if (e >= tot) return;
@@ -1000,7 +1003,8 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_reduce(const float* __restr
     for (int z = 0; z < nsplit; z++) s += ws[(long)z * tot + e];
     const long r = e / Cp32;
     const int m = (int)(r % M), t = (int)(r / M);
-    gw[(long)m * o_sm + (long)c * o_sc + t] = s;
+    float* o = gw + (long)m * o_sm + (long)c * o_sc + t;
+    *o = accum ? (*o + s) : s;
 }
 
 struct WPlan {
@@ -1059,7 +1063,7 @@ inline WPlan plan_wgrad(int B, int M, int AH, int AW, int Cin, int R, int S, int
 // second stage: gw[m, (c,i,j)] = sum_split ws[split][m][(c,i,j)]
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ gw, int nsplit,
                                                       int M, int Ntot, int RS, int St, long o_sm, long o_sc, int o_ri,
-                                                      int o_sj) {
+                                                      int o_sj, int accum) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     const long tot = (long)M * Ntot;
     if (e >= tot) return;
@@ -1068,7 +1072,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     const int m = (int)(e / Ntot), jn = (int)(e - (long)m * Ntot);
     const int c = jn / RS, rem = jn - c * RS;
     const int i = rem / St, j = rem - i * St;
-    gw[(long)m * o_sm + (long)c * o_sc + i * o_ri + j * o_sj] = s;
+    float* o = gw + (long)m * o_sm + (long)c * o_sc + i * o_ri + j * o_sj;
+    *o = accum ? (*o + s) : s;
 }
 
 // ------------------------------------------------------------------ activation backward + bias gradient
@@ -1099,12 +1104,12 @@ __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ gy, c
     if (threadIdx.x == 0 && partial) partial[(long)m * nchunk + blockIdx.x] = s[0];
 }
 
-__global__ __launch_bounds__(64) void k_bias_reduce(const float* __restrict__ partial, float* __restrict__ gbias, int nchunk) {
+__global__ __launch_bounds__(64) void k_bias_reduce(const float* __restrict__ partial, float* __restrict__ gbias, int nchunk, int accum) {
     const int m = blockIdx.x;
     float s = 0.f;
     for (int k = threadIdx.x; k < nchunk; k += 64) s += partial[(long)m * nchunk + k];
     s = cc::wave_sum(s);
-    if (threadIdx.x == 0) gbias[m] = s;
+    if (threadIdx.x == 0) gbias[m] = accum ? (gbias[m] + s) : s;
 }
 
 inline int pick_bm(int M) { return M > 64 ? 128 : (M > 32 ? 64 : 32); }
@@ -1405,10 +1410,10 @@ static size_t wgrad_ws_bytes_base(int B, int M, int AH, int AW, int Cin, int R, 
  * conv2d weight-gradient: a = dY [B,Cout,OH,OW], x = input, si = stride, o strides of [Cout,Cin,R,S];
  * ConvTranspose2d weight-gradient: a = input [B,Cin,IH,IW], x = dY, si = stride, o strides of [Cin,Cout,R,S]. */
 int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B, int M, int AH, int AW, long a_bs, int Cin,
-                    int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, void* stream) {
+                    int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, int accumulate, void* stream) {
     if (B <= 0 || M <= 0 || Cin <= 0) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (ccint::wgrad_thin_launch(a, x, gw, ws, B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, s)) {
+    if (ccint::wgrad_thin_launch(a, x, gw, ws, B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, accumulate, s)) {
         CC_CHECK_LAUNCH();
         return CC_OK;
     }
@@ -1428,7 +1433,7 @@ int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B,
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<1, 4>), grid, dim3(256), q.smem, s, w);
         const long tot = (long)9 * M * q.Cp32;
         hipLaunchKernelGGL(k_wgrad_patch_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const float*)w.ws, gw,
-                           q.nsplit, 9, M, Cin, q.Cp32, o_sm, o_sc);
+                           q.nsplit, 9, M, Cin, q.Cp32, o_sm, o_sc, accumulate);
         CC_CHECK_LAUNCH();
         return CC_OK;
     }
@@ -1456,7 +1461,7 @@ int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B,
         }
         const long tot = (long)R * S * M * p.Cp32;
         hipLaunchKernelGGL(k_wgrad_patch_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const float*)w.ws, gw,
-                           p.nsplit, R * S, M, Cin, p.Cp32, o_sm, o_sc);
+                           p.nsplit, R * S, M, Cin, p.Cp32, o_sm, o_sc, accumulate);
         CC_CHECK_LAUNCH();
         return CC_OK;
     }
@@ -1477,6 +1482,7 @@ int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B,
     g.Rt = R; g.St = S; g.dy0 = -pad; g.dx0 = -pad; g.dstep = 1; g.si = si;
     g.o_sm = o_sm; g.o_sc = o_sc; g.o_ri = S; g.o_sj = 1;
     g.direct = (nsplit == 1);
+    g.accum = accumulate;
     g.out = g.direct ? gw : ws;
     g.pix_per_split = (int)pps;
     dim3 grid((unsigned)((Ntot + BN - 1) / BN), (unsigned)((M + bm - 1) / bm), (unsigned)nsplit);
@@ -1486,7 +1492,7 @@ int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B,
     if (!g.direct) {
         const long tot = (long)M * Ntot;
         hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const float*)ws, gw,
-                           (int)nsplit, M, (int)Ntot, R * S, S, o_sm, o_sc, S, 1);
+                           (int)nsplit, M, (int)Ntot, R * S, S, o_sm, o_sc, S, 1, accumulate);
     }
     CC_CHECK_LAUNCH();
     return CC_OK;
@@ -1497,7 +1503,7 @@ size_t cc_act_bwd_ws_bytes(int C) { return (size_t)C * 64 * sizeof(float); }
 /* geff = gy * act'(y) (geff may alias gy or be null), gbias[c] = sum_{n,p} geff (gbias may be null) */
 int cc_act_bwd_bias(const float* gy, const float* y_or_null, float* geff_or_null, float* gbias_or_null, float* ws, int B,
                     int C, int H, int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b,
-                    void* stream) {
+                    int accumulate_bias, void* stream) {
     if (B <= 0 || C <= 0) return CC_ERR_ARG;
     if (act != ACT_NONE && !y_or_null) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -1506,7 +1512,7 @@ int cc_act_bwd_bias(const float* gy, const float* y_or_null, float* geff_or_null
     int nchunk = (int)(want < 1 ? 1 : (want > 64 ? 64 : want));
     hipLaunchKernelGGL(k_act_bwd, dim3(nchunk, C), dim3(256), 0, s, gy, y_or_null, geff_or_null,
                        gbias_or_null ? ws : (float*)nullptr, C, HW, gy_bs, y_bs, geff_bs, act, act_a, act_b, B);
-    if (gbias_or_null) hipLaunchKernelGGL(k_bias_reduce, dim3(C), dim3(64), 0, s, (const float*)ws, gbias_or_null, nchunk);
+    if (gbias_or_null) hipLaunchKernelGGL(k_bias_reduce, dim3(C), dim3(64), 0, s, (const float*)ws, gbias_or_null, nchunk, accumulate_bias);
     CC_CHECK_LAUNCH();
     return CC_OK;
 }

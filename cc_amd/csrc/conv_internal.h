@@ -10,6 +10,6 @@ namespace ccint {
 size_t wgrad_thin_ws_floats(int B, int M, int AH, int AW, int Cin, int R, int S, int si);
 // -> true when it launched (same argument meaning as cc_conv2d_wgrad), false when not eligible (nothing launched).
 bool wgrad_thin_launch(const float* a, const float* x, float* gw, float* ws, int B, int M, int AH, int AW, long a_bs, int Cin,
-                       int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, hipStream_t s);
+                       int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, int accumulate, hipStream_t s);
 
 }  // namespace ccint

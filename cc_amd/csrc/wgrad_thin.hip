@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(WT g) {
 // gw[m*o_sm + c*o_sc + r*S + s] = sum_pb slab[combo][pb][t][m16][c16]   (fixed summation order)
 __global__ __launch_bounds__(1024) void k_wgrad_thin_reduce(const float* __restrict__ ws, float* __restrict__ gw, int npb, int TS,
                                                             int S, int TR, int ngc, int ngt, int M, int Cin, int R, long o_sm,
-                                                            long o_sc) {
+                                                            long o_sc, int accum) {
     __shared__ float4 part[16][64];
     const int combo = blockIdx.x / TS, t = blockIdx.x - combo * TS;
     const int sub = threadIdx.x >> 6, q = threadIdx.x & 63;
@@ -191,10 +191,13 @@ __global__ __launch_bounds__(1024) void k_wgrad_thin_reduce(const float* __restr
         const int m = mg * 16 + (q >> 2), c0 = cg * 16 + (q & 3) * 4;
         if (m < M && r < R) {
             float* o = gw + (long)m * o_sm + (long)r * S + sc;
-            if (c0 + 0 < Cin) o[(long)(c0 + 0) * o_sc] = s.x;
-            if (c0 + 1 < Cin) o[(long)(c0 + 1) * o_sc] = s.y;
-            if (c0 + 2 < Cin) o[(long)(c0 + 2) * o_sc] = s.z;
-            if (c0 + 3 < Cin) o[(long)(c0 + 3) * o_sc] = s.w;
+            const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (c0 + e < Cin) {
+                    float* oe = o + (long)(c0 + e) * o_sc;
+                    *oe = accum ? (*oe + v[e]) : v[e];
+                }
         }
     }
 }
@@ -228,7 +231,8 @@ ThinPlan plan_thin(int B, int M, int AH, int AW, int Cin, int R, int S, int si) 
     p.ngm = (M + 15) / 16;
     p.ngc = (Cin + 15) / 16;
     const long P = (long)B * AH * AW;
-    if ((AW & 3) || p.ngm * p.ngc > env_int("CC_WGRAD_THIN_MAXCOMBO", 4) || P < env_int("CC_WGRAD_THIN_MINPIX", 32768)) return p;
+    if ((AW & 3) || p.ngm * p.ngc > env_int("CC_WGRAD_THIN_MAXCOMBO", 16) || P < env_int("CC_WGRAD_THIN_MINPIX", 8192) ||
+        (S == 7 && Cin < 8)) return p;
     p.ngt = (R + p.TR - 1) / p.TR;
     p.TS = p.TR * S;
     p.nxc = (AW + 15) / 16;
@@ -261,7 +265,7 @@ size_t wgrad_thin_ws_floats(int B, int M, int AH, int AW, int Cin, int R, int S,
 }
 
 bool wgrad_thin_launch(const float* a, const float* x, float* gw, float* ws, int B, int M, int AH, int AW, long a_bs, int Cin,
-                       int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, hipStream_t s) {
+                       int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, int accumulate, hipStream_t s) {
     const ThinPlan p = plan_thin(B, M, AH, AW, Cin, R, S, si);
     if (!p.ok || (IW & 3) || (a_bs & 3) || (x_bs & 3)) return false;
     static const int want_pad[] = {1, 1, 3, 3, 0, 2, 1};
@@ -285,7 +289,7 @@ bool wgrad_thin_launch(const float* a, const float* x, float* gw, float* ws, int
         default: launch_thin<4, 2, 1, 4>(g, grid, s); break;
     }
     hipLaunchKernelGGL(k_wgrad_thin_reduce, dim3((unsigned)(ncombo * p.TS)), dim3(1024), 0, s, (const float*)ws, gw, p.npb, p.TS, S,
-                       p.TR, p.ngc, p.ngt, M, Cin, R, o_sm, o_sc);
+                       p.TR, p.ngc, p.ngt, M, Cin, R, o_sm, o_sc, accumulate);
     return true;
 }
 

@@ -90,6 +90,15 @@ class PackRegistry:
 
 packs = PackRegistry()
 
+# parameter data_ptr -> gradient buffer (a view of the optimizer's flat gradient bucket).  When a conv weight / bias is
+# registered here (trainer.FlatAdam does it), its gradient is ACCUMULATED into that buffer by the wgrad / bias kernels
+# themselves and autograd receives None: no per-parameter `grad += new` launch (~330 per step), same arithmetic.
+grad_sinks = {}
+
+
+def _sink(p):
+    return grad_sinks.get(p.data_ptr()) if grad_sinks else None
+
 
 # ----------------------------------------------------------------------------- convolution
 class _Conv2dFn(torch.autograd.Function):
@@ -110,6 +119,7 @@ class _Conv2dFn(torch.autograd.Function):
                OH, OW, Cout * OH * OW, Cout * OH * OW, act, act_a, act_b, STREAM)
         ctx.save_for_backward(x, w, y if act != 0 else None)
         ctx.cfg = (stride, pad, act, act_a, act_b, bias is not None, res is not None)
+        ctx.bias_ptr = bias_c.data_ptr() if bias_c is not None else 0
         return y
 
     @staticmethod
@@ -122,13 +132,18 @@ class _Conv2dFn(torch.autograd.Function):
         Cout, _, R, S = w.shape
         OH, OW = gy.shape[2], gy.shape[3]
         need = ctx.needs_input_grad
-        gbias = torch.empty(Cout, device=x.device, dtype=torch.float32) if (has_bias and need[2]) else None
+        gbias, bsink = None, None
+        if has_bias and need[2]:
+            bsink = grad_sinks.get(ctx.bias_ptr) if grad_sinks else None
+            gbias = bsink if bsink is not None else torch.empty(Cout, device=x.device, dtype=torch.float32)
         if act != 0 or gbias is not None:
             geff = torch.empty_like(gy) if act != 0 else None
             E.call("cc_act_bwd_bias", gy, y, geff, gbias, _ws(E.call("cc_act_bwd_ws_bytes", Cout), x), B, Cout, OH, OW,
-                   Cout * OH * OW, Cout * OH * OW, Cout * OH * OW, act, act_a, act_b, STREAM)
+                   Cout * OH * OW, Cout * OH * OW, Cout * OH * OW, act, act_a, act_b, int(bsink is not None), STREAM)
             if geff is not None:
                 gy = geff
+        if bsink is not None:
+            gbias = None
         gx = gw = None
         if need[0]:
             gx = torch.empty_like(x)
@@ -137,10 +152,13 @@ class _Conv2dFn(torch.autograd.Function):
             E.call("cc_conv2d_dgrad", gy, w, None, gx, ws, pk, B, Cout, OH, OW, Cout * OH * OW, Cin, R, S, stride, pad, IH, IW,
                    Cin * IH * IW, Cin * R * S, R * S, 0, 1.0, 0.0, STREAM)
         if need[1]:
-            gw = torch.empty_like(w)
+            wsink = _sink(w)
+            gw = wsink if wsink is not None else torch.empty_like(w)
             ws = _ws(E.call("cc_conv2d_wgrad_ws_bytes", B, Cout, OH, OW, Cin, R, S, stride), x)
             E.call("cc_conv2d_wgrad", gy, x, gw, ws, B, Cout, OH, OW, Cout * OH * OW, Cin, IH, IW, Cin * IH * IW, R, S,
-                   stride, pad, Cin * R * S, R * S, STREAM)
+                   stride, pad, Cin * R * S, R * S, int(wsink is not None), STREAM)
+            if wsink is not None:
+                gw = None
         gres = gy if (has_res and need[3]) else None
         return gx, gw, gbias, gres, None, None, None, None, None
 
@@ -173,6 +191,7 @@ class _ConvT2dFn(torch.autograd.Function):
                Cout * OH * OW, Cout * R * S, R * S, act, 1.0, 0.0, STREAM)
         ctx.save_for_backward(x, w, y if act != 0 else None)
         ctx.cfg = (stride, pad, act, bias is not None)
+        ctx.bias_ptr = bias_c.data_ptr() if bias_c is not None else 0
         return y
 
     @staticmethod
@@ -185,13 +204,18 @@ class _ConvT2dFn(torch.autograd.Function):
         _, Cout, R, S = w.shape
         OH, OW = gy.shape[2], gy.shape[3]
         need = ctx.needs_input_grad
-        gbias = torch.empty(Cout, device=x.device, dtype=torch.float32) if (has_bias and need[2]) else None
+        gbias, bsink = None, None
+        if has_bias and need[2]:
+            bsink = grad_sinks.get(ctx.bias_ptr) if grad_sinks else None
+            gbias = bsink if bsink is not None else torch.empty(Cout, device=x.device, dtype=torch.float32)
         if act != 0 or gbias is not None:
             geff = torch.empty_like(gy) if act != 0 else None
             E.call("cc_act_bwd_bias", gy, y, geff, gbias, _ws(E.call("cc_act_bwd_ws_bytes", Cout), x), B, Cout, OH, OW,
-                   Cout * OH * OW, Cout * OH * OW, Cout * OH * OW, act, 1.0, 0.0, STREAM)
+                   Cout * OH * OW, Cout * OH * OW, Cout * OH * OW, act, 1.0, 0.0, int(bsink is not None), STREAM)
             if geff is not None:
                 gy = geff
+        if bsink is not None:
+            gbias = None
         gx = gw = None
         if need[0]:
             # d/dx of a transposed conv is a plain strided conv of gy; the [Cin,Cout,R,S] weight IS its [M,C,R,S] weight
@@ -201,10 +225,13 @@ class _ConvT2dFn(torch.autograd.Function):
             E.call("cc_conv2d_fwd", gy, w, None, None, gx, ws, pk, B, Cout, OH, OW, Cout * OH * OW, Cin, R, S, stride, pad, IH, IW,
                    Cin * IH * IW, 0, 0, 1.0, 0.0, STREAM)
         if need[1]:
-            gw = torch.empty_like(w)
+            wsink = _sink(w)
+            gw = wsink if wsink is not None else torch.empty_like(w)
             ws = _ws(E.call("cc_conv2d_wgrad_ws_bytes", B, Cin, IH, IW, Cout, R, S, stride), x)
             E.call("cc_conv2d_wgrad", x, gy, gw, ws, B, Cin, IH, IW, Cin * IH * IW, Cout, OH, OW, Cout * OH * OW, R, S,
-                   stride, pad, Cout * R * S, R * S, STREAM)
+                   stride, pad, Cout * R * S, R * S, int(wsink is not None), STREAM)
+            if wsink is not None:
+                gw = None
         return gx, gw, gbias, None, None, None, None
 
 

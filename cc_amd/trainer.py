@@ -116,6 +116,9 @@ class FlatAdam:
             p.grad = self.flat_g[off:off + k].view_as(p.data)
             off += k
         self.lr, self.betas = cfg.lr, cfg.betas
+        # conv weights / biases: the wgrad and bias-gradient kernels accumulate straight into the flat bucket
+        # (the trainer switches ops.grad_sinks to this table for the duration of its own forward+backward only)
+        self.sinks = {p.data_ptr(): p.grad for p in params}
 
     def zero_grad(self):
         engine().call("cc_fill", self.flat_g, self.flat_g.numel(), 0.0, STREAM)
@@ -154,9 +157,13 @@ class CCTrainer:
         LF.pyramid_cache.clear()
         ops.packs.prepack_all()            # every conv layer's [tap][c][m] weight images, one launch (weights changed in Adam)
         self.opt.zero_grad()                                                # :566
-        out = cc_forward(self.nets, batch, self.cfg)
-        out["loss"].backward()                                              # :567
-        ops.packs.invalidate()
+        ops.grad_sinks = self.opt.sinks
+        try:
+            out = cc_forward(self.nets, batch, self.cfg)
+            out["loss"].backward()                                          # :567
+        finally:
+            ops.grad_sinks = {}
+            ops.packs.invalidate()
         return {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
 
     def _copy_in(self, batch):

@@ -196,14 +196,16 @@ int cc_conv2d_dgrad_pack_desc(int B, int K, int OH, int OW, int C, int R, int S,
 int cc_repack_table(const long* table_dev, int ndesc, long total_blocks, void* stream);
 size_t cc_conv2d_wgrad_ws_bytes(int B, int M, int AH, int AW, int Cin, int R, int S, int si);
 /* gw[m*o_sm + c*o_sc + r*S + s] = sum_{n,ty,tx} a[n,m,ty,tx] * x[n,c,si*ty-pad+r,si*tx-pad+s] (split over pixels,
- * deterministic second-stage reduction through ws). */
+ * deterministic second-stage reduction through ws).  accumulate != 0: gw += (gradient accumulation of a weight that is
+ * used more than once per step / written straight into the optimizer's flat gradient bucket, train.py:566-567). */
 int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B, int M, int AH, int AW, long a_bs, int Cin,
-                    int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, void* stream);
+                    int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, int accumulate,
+                    void* stream);
 size_t cc_act_bwd_ws_bytes(int C);
-/* geff = gy * act'(y);  gbias[c] = sum geff  (either output may be null; geff may alias gy) */
+/* geff = gy * act'(y);  gbias[c] (+)= sum geff  (either output may be null; geff may alias gy) */
 int cc_act_bwd_bias(const float* gy, const float* y_or_null, float* geff_or_null, float* gbias_or_null, float* ws, int B,
                     int C, int H, int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b,
-                    void* stream);
+                    int accumulate_bias, void* stream);
 
 /* ---------------------------------------------------------------- optimizer (train.py:307-310,568)
  * torch.optim.Adam(betas, eps, weight_decay=0) on the flat fp32 bucket; grads are multiplied by grad_scale first

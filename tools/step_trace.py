@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""Post-process a rocprofv3 kernel trace of bench.py: isolate ONE hipGraph-replayed training step (the dispatches
+between the last two k_adam launches) and print, per kernel name, launches / total / average duration, plus the
+idle time between consecutive kernels (launch gaps)."""
+import csv, sys, collections, re
+
+rows = []
+with open(sys.argv[1]) as f:
+    for r in csv.DictReader(f):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+rows.sort()
+adam = [i for i, r in enumerate(rows) if "k_adam" in r[2]]
+adam = [i for j, i in enumerate(adam) if j + 1 == len(adam) or adam[j + 1] != i + 1]     # the optimizer is 2 back-to-back launches
+assert len(adam) >= 2, "need two optimizer launches"
+step = rows[adam[-2] + 1: adam[-1] + 1]
+t0, t1 = step[0][0], step[-1][1]
+busy = sum(e - s for s, e, _ in step)
+gaps = sum(max(0, step[i + 1][0] - step[i][1]) for i in range(len(step) - 1))
+agg = collections.defaultdict(lambda: [0, 0])
+for s, e, n in step:
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"^void ", "", n)
+    n = n.split("(")[0][:70]
+    agg[n][0] += 1
+    agg[n][1] += e - s
+print("one replayed step: %d kernels, wall %.3f ms, kernel-busy %.3f ms, gaps %.3f ms" % (len(step), (t1 - t0) / 1e6, busy / 1e6, gaps / 1e6))
+print("%-72s %6s %10s %9s %6s" % ("kernel", "calls", "total_us", "avg_us", "%"))
+for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print("%-72s %6d %10.1f %9.2f %6.2f" % (n, c, t / 1e3, t / 1e3 / c, 100.0 * t / (t1 - t0)))

@@ -16,7 +16,7 @@ if len(sys.argv) > 1:
     gw = torch.empty(M, Cin, R, R, device="cuda")
     ws = torch.empty(E.call("cc_conv2d_wgrad_ws_bytes", B, M, AH, AW, Cin, R, R, si) // 4 + 64, device="cuda")
     def run():
-        E.call("cc_conv2d_wgrad", a, x, gw, ws, B, M, AH, AW, M * AH * AW, Cin, IH, IW, Cin * IH * IW, R, R, si, pad, Cin * R * R, R * R, STREAM)
+        E.call("cc_conv2d_wgrad", a, x, gw, ws, B, M, AH, AW, M * AH * AW, Cin, IH, IW, Cin * IH * IW, R, R, si, pad, Cin * R * R, R * R, 0, STREAM)
     run(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
