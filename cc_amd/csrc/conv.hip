@@ -239,9 +239,19 @@ __global__ __launch_bounds__(256) void k_repack_w(const float* __restrict__ w, f
 }
 
 // All weight repacks of a training step in ONE launch: desc[d] = 16 longs
-//   {src, dst, M, Cin, Mpad, Cpad, T, St, w_sm, w_sc, w0, w_ri, w_sj, nfloats, first_block, 0}
+//   {src, dst, M, Cin, Mpad, Cpad, T, St, w_sm, w_sc, w0, w_ri, w_sj, nfloats, first_block, nblocks}
 // (the per-call k_repack_w launches were ~540 tiny kernels = 3 ms of launch latency per step).
+// It is a transpose ([m][c][tap] or [c][m][tap] in memory -> [tap][c][m]) of ~600 MB per step, so it goes through an
+// LDS tile: one workgroup = 64 m x CT c x all T taps, read in SOURCE memory order (tap fastest, then whichever of c / m
+// has the smaller stride), written in destination order (m fastest): both sides coalesced.
+__host__ __device__ inline int repack_ct(int T) { const int ct = 72 / T; return ct < 1 ? 1 : (ct > 64 ? 64 : ct); }
+inline long repack_blocks(int Mpad, int Cpad, int T) {
+    const int ct = repack_ct(T);
+    return (long)((Mpad + 63) / 64) * ((Cpad + ct - 1) / ct);
+}
+
 __global__ __launch_bounds__(256) void k_repack_table(const long* __restrict__ desc, int ndesc) {
+    __shared__ float tile[72 * 65 + 64 * 65];
     // binary search the descriptor whose block range contains blockIdx.x
     int lo = 0, hi = ndesc - 1;
     while (lo < hi) {
@@ -249,16 +259,35 @@ __global__ __launch_bounds__(256) void k_repack_table(const long* __restrict__ d
         if (desc[16 * mid + 14] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const long* d = desc + 16 * lo;
-    const float* w = reinterpret_cast<const float*>(d[0]);
-    float* wp = reinterpret_cast<float*>(d[1]);
-    const int M = (int)d[2], Cin = (int)d[3], Mpad = (int)d[4], Cpad = (int)d[5], St = (int)d[7];
-    const long e = ((long)blockIdx.x - d[14]) * 256 + threadIdx.x;
-    if (e >= d[13]) return;
-    const int m = (int)(e % Mpad);
-    const long r = e / Mpad;
-    const int c = (int)(r % Cpad), t = (int)(r / Cpad);
-    const int i = t / St, j = t - i * St;
-    wp[e] = (m < M && c < Cin) ? w[d[10] + (long)m * d[8] + (long)c * d[9] + i * d[11] + j * d[12]] : 0.f;
+    const float* __restrict__ w = reinterpret_cast<const float*>(d[0]);
+    float* __restrict__ wp = reinterpret_cast<float*>(d[1]);
+    const int M = (int)d[2], Cin = (int)d[3], Mpad = (int)d[4], Cpad = (int)d[5], T = (int)d[6], St = (int)d[7];
+    const long w_sm = d[8], w_sc = d[9], w0 = d[10], w_ri = d[11], w_sj = d[12];
+    const int CT = repack_ct(T);
+    const int nmt = (Mpad + 63) / 64;
+    const int bid = (int)((long)blockIdx.x - d[14]);
+    if (bid >= (int)d[15]) return;
+    const int m0 = (bid % nmt) * 64, c0 = (bid / nmt) * CT;
+    const int CTT = CT * T, n = 64 * CTT;
+    const bool m_slow = w_sm > w_sc;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        int m_, c_, t;
+        if (m_slow) { m_ = e / CTT; const int r = e - m_ * CTT; c_ = r / T; t = r - c_ * T; }
+        else { c_ = e / (64 * T); const int r = e - c_ * 64 * T; m_ = r / T; t = r - m_ * T; }
+        const int m = m0 + m_, c = c0 + c_;
+        float v = 0.f;
+        if (m < M && c < Cin) {
+            const int i = t / St, j = t - i * St;
+            v = w[w0 + (long)m * w_sm + (long)c * w_sc + i * w_ri + j * w_sj];
+        }
+        tile[(t * CT + c_) * 65 + m_] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int m_ = e & 63, r = e >> 6;
+        const int t = r / CT, c_ = r - t * CT;
+        if (m0 + m_ < Mpad && c0 + c_ < Cpad) wp[((long)t * Cpad + c0 + c_) * Mpad + m0 + m_] = tile[r * 65 + m_];
+    }
 }
 
 template <int BM, int CK>
@@ -1077,31 +1106,59 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------ activation backward + bias gradient
-// geff = gy * act'(y) (in place allowed);  partial[m][chunk] = sum over the chunk of geff
+// geff = gy * act'(y) (in place allowed);  partial[m][n*cpp + chunk] = sum over the chunk of geff.
+// grid (cpp, C, B): one (image, channel) plane chunk per workgroup -> no per-element index arithmetic, float4 accesses
+// when the plane size allows (HBM-bound: 2 reads + 1 write per element).
+__device__ __forceinline__ float act_grad(float g, float v, int act, float act_a, float act_b) {
+    if (act == ACT_RELU) return v > 0.f ? g : 0.f;
+    if (act == ACT_LRELU) return v > 0.f ? g : 0.2f * g;
+    const float sg = (v - act_b) / act_a;
+    return g * act_a * sg * (1.f - sg);
+}
+
+template <bool VEC4>
 __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ gy, const float* __restrict__ y,
-                                                 float* __restrict__ geff, float* __restrict__ partial, int C, int HW,
+                                                 float* __restrict__ geff, float* __restrict__ partial, int HW,
                                                  long gy_bs, long y_bs, long ge_bs, int act, float act_a, float act_b,
-                                                 int B) {
+                                                 int nb, float* __restrict__ gbias_direct, int accum) {
     __shared__ float red[4];
-    const int m = blockIdx.y;
-    const int nchunk = gridDim.x;
+    const int m = blockIdx.y, cpp = gridDim.x;
     float s[1] = {0.f};
-    const long tot = (long)B * HW;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)nchunk * 256) {
-        const int n = (int)(e / HW);
-        const int p = (int)(e - (long)n * HW);
-        float g = gy[(long)n * gy_bs + (long)m * HW + p];
-        if (act != ACT_NONE) {
-            const float v = y[(long)n * y_bs + (long)m * HW + p];
-            if (act == ACT_RELU) g = v > 0.f ? g : 0.f;
-            else if (act == ACT_LRELU) g = v > 0.f ? g : 0.2f * g;
-            else { const float sg = (v - act_b) / act_a; g = g * act_a * sg * (1.f - sg); }
+    // nb == 1: this workgroup owns image blockIdx.z; nb == B (small maps, grid.z == 1): it walks all images itself and
+    // writes the channel's bias gradient directly (no second-stage launch)
+    for (int nn = 0; nn < nb; nn++) {
+        const int n = blockIdx.z + nn;
+        const float* __restrict__ gp = gy + (long)n * gy_bs + (long)m * HW;
+        const float* __restrict__ yp = (act != ACT_NONE) ? y + (long)n * y_bs + (long)m * HW : nullptr;
+        float* __restrict__ ep = geff ? geff + (long)n * ge_bs + (long)m * HW : nullptr;
+        if (VEC4) {
+            const int nq = HW >> 2;
+            for (int q = blockIdx.x * 256 + threadIdx.x; q < nq; q += cpp * 256) {
+                float4 g = ((const float4*)gp)[q];
+                if (act != ACT_NONE) {
+                    const float4 v = ((const float4*)yp)[q];
+                    g.x = act_grad(g.x, v.x, act, act_a, act_b);
+                    g.y = act_grad(g.y, v.y, act, act_a, act_b);
+                    g.z = act_grad(g.z, v.z, act, act_a, act_b);
+                    g.w = act_grad(g.w, v.w, act, act_a, act_b);
+                }
+                if (ep) ((float4*)ep)[q] = g;
+                s[0] += (g.x + g.y) + (g.z + g.w);
+            }
+        } else {
+            for (int e = blockIdx.x * 256 + threadIdx.x; e < HW; e += cpp * 256) {
+                float g = gp[e];
+                if (act != ACT_NONE) g = act_grad(g, yp[e], act, act_a, act_b);
+                if (ep) ep[e] = g;
+                s[0] += g;
+            }
         }
-        if (geff) geff[(long)n * ge_bs + (long)m * HW + p] = g;
-        s[0] += g;
     }
     cc::block_sum_256<1>(s, red);
-    if (threadIdx.x == 0 && partial) partial[(long)m * nchunk + blockIdx.x] = s[0];
+    if (threadIdx.x == 0) {
+        if (gbias_direct) gbias_direct[m] = accum ? (gbias_direct[m] + s[0]) : s[0];
+        else if (partial) partial[(long)m * (cpp * gridDim.z) + blockIdx.z * cpp + blockIdx.x] = s[0];
+    }
 }
 
 __global__ __launch_bounds__(64) void k_bias_reduce(const float* __restrict__ partial, float* __restrict__ gbias, int nchunk, int accum) {
@@ -1193,19 +1250,20 @@ static GG make_fwd(const float* x, const float* w, const float* bias, const floa
 
 static void fill_desc(const GG& g, const ConvPlan& p, long src, long dst, long* d) {
     d[0] = src; d[1] = dst; d[2] = g.M; d[3] = g.Cin; d[4] = p.Mpad; d[5] = p.Cpad; d[6] = (long)g.Rt * g.St; d[7] = g.St;
-    d[8] = g.w_sm; d[9] = g.w_sc; d[10] = g.w0; d[11] = g.w_ri; d[12] = g.w_sj; d[13] = (long)p.wp_floats; d[14] = 0; d[15] = 0;
+    d[8] = g.w_sm; d[9] = g.w_sc; d[10] = g.w0; d[11] = g.w_ri; d[12] = g.w_sj; d[13] = (long)p.wp_floats; d[14] = 0;
+    d[15] = repack_blocks(p.Mpad, p.Cpad, g.Rt * g.St);
 }
 
 /* Per-step weight prepack (optional fast path).  *_pack_desc fill 16-long descriptors ({src, dst, ...}; dst = where the
  * [tap][c][m] image of this layer goes: pack_base + 64 floats (+ the images of earlier parity classes for dgrad)) and
  * return the number of descriptors (0: this geometry does not use the patch kernel); cc_repack_table runs all of them in
- * one launch after the caller has filled d[14] = first block of each descriptor (cumulative ceil(nfloats/256)).
+ * one launch after the caller has filled d[14] = first block of each descriptor (cumulative sum of d[15] = its block count).
  * Buffers passed as `prepacked` to the conv entry points must start with 64 zero floats. */
 size_t cc_conv2d_fwd_pack_floats(int B, int Cin, int IH, int IW, int Cout, int R, int S, int stride, int pad, int OH, int OW) {
     GG g = make_fwd(nullptr, nullptr, nullptr, nullptr, nullptr, B, Cin, IH, IW, 0, Cout, R, S, stride, pad, OH, OW, 0, 0, 0,
                     1.f, 0.f);
     const ConvPlan p = plan_conv(g);
-    return p.use_patch ? 64 + p.wp_floats : 0;
+    return (p.use_patch && R * S <= 136) ? 64 + p.wp_floats : 0;      // 136 = tile rows of k_repack_table
 }
 
 int cc_conv2d_fwd_pack_desc(int B, int Cin, int IH, int IW, int Cout, int R, int S, int stride, int pad, int OH, int OW,
@@ -1282,6 +1340,7 @@ size_t cc_conv2d_dgrad_ws_bytes(int B, int K, int OH, int OW, int C, int R, int 
 size_t cc_conv2d_dgrad_pack_floats(int B, int K, int OH, int OW, int C, int R, int S, int stride, int pad, int IH, int IW,
                                    long w_k_stride, long w_c_stride) {
     size_t tot = 64;
+    if (R * S > 136) return 0;
     for (int py = 0; py < stride; py++)
         for (int px = 0; px < stride; px++) {
             GG g;
@@ -1508,11 +1567,28 @@ int cc_act_bwd_bias(const float* gy, const float* y_or_null, float* geff_or_null
     if (act != ACT_NONE && !y_or_null) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int HW = H * W;
-    long want = ((long)B * HW + 4095) / 4096;
-    int nchunk = (int)(want < 1 ? 1 : (want > 64 ? 64 : want));
-    hipLaunchKernelGGL(k_act_bwd, dim3(nchunk, C), dim3(256), 0, s, gy, y_or_null, geff_or_null,
-                       gbias_or_null ? ws : (float*)nullptr, C, HW, gy_bs, y_bs, geff_bs, act, act_a, act_b, B);
-    if (gbias_or_null) hipLaunchKernelGGL(k_bias_reduce, dim3(C), dim3(64), 0, s, (const float*)ws, gbias_or_null, nchunk, accumulate_bias);
+    int cpp = (HW + 8191) / 8192;                       // chunks per (image, channel) plane; B * cpp <= 64 partials per channel
+    const int cap = 64 / B > 0 ? 64 / B : 1;
+    cpp = cpp < 1 ? 1 : (cpp > cap ? cap : cpp);
+    if (B > 64) return CC_ERR_ARG;
+    const bool vec4 = (HW % 4 == 0) && (gy_bs % 4 == 0) && (y_bs % 4 == 0) && (geff_bs % 4 == 0) &&
+                      (((uintptr_t)gy | (uintptr_t)y_or_null | (uintptr_t)geff_or_null) % 16 == 0);
+    // small maps with enough channels to occupy the chip: one workgroup per channel, bias gradient written in place
+    const bool single = ((long)B * HW <= 32768) && ((long)C * B * HW <= (1l << 22) || C >= 128);
+    int nb = 1;
+    dim3 grid(cpp, C, B);
+    float* direct = nullptr;
+    if (single) { nb = B; grid = dim3(1, C, 1); direct = gbias_or_null; }
+    const int nchunk = single ? 1 : cpp * B;
+    float* part = (gbias_or_null && !single) ? ws : (float*)nullptr;
+    if (vec4)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_act_bwd<true>), grid, dim3(256), 0, s, gy, y_or_null, geff_or_null, part, HW,
+                           gy_bs, y_bs, geff_bs, act, act_a, act_b, nb, direct, accumulate_bias);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_act_bwd<false>), grid, dim3(256), 0, s, gy, y_or_null, geff_or_null, part, HW,
+                           gy_bs, y_bs, geff_bs, act, act_a, act_b, nb, direct, accumulate_bias);
+    if (gbias_or_null && !single)
+        hipLaunchKernelGGL(k_bias_reduce, dim3(C), dim3(64), 0, s, (const float*)ws, gbias_or_null, nchunk, accumulate_bias);
     CC_CHECK_LAUNCH();
     return CC_OK;
 }

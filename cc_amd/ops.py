@@ -73,7 +73,7 @@ class PackRegistry:
                 for d in e["descs"]:
                     d = list(d)
                     d[14] = blk
-                    blk += (d[13] + 255) // 256
+                    blk += d[15]
                     rows.append(d)
             self.table = torch.tensor(rows, dtype=torch.int64, device=live[0]["buf"].device).contiguous()
             self.total_blocks = blk

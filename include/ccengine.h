@@ -185,7 +185,7 @@ int cc_conv2d_dgrad(const float* gy, const float* w, const float* bias_or_null, 
  * launch each, ~540 per step) are produced for ALL layers by one cc_repack_table launch.  *_pack_floats = size of a
  * layer's image buffer (0: geometry not eligible), which must start with 64 zero floats; *_pack_desc write 16-long
  * descriptors into a HOST array (src_ptr / pack_base_ptr are device addresses) and return their count; the caller sets
- * desc[14] = first block (cumulative ceil(desc[13]/256)) and uploads the table. */
+ * desc[14] = first block (cumulative sum of desc[15], the descriptor's workgroup count) and uploads the table. */
 size_t cc_conv2d_fwd_pack_floats(int B, int Cin, int IH, int IW, int Cout, int R, int S, int stride, int pad, int OH, int OW);
 int cc_conv2d_fwd_pack_desc(int B, int Cin, int IH, int IW, int Cout, int R, int S, int stride, int pad, int OH, int OW,
                             long src_ptr, long pack_base_ptr, long* desc_out_host);
