@@ -290,14 +290,17 @@ __global__ __launch_bounds__(256) void k_repack_table(const long* __restrict__ d
     }
 }
 
-template <int BM, int CK>
+// TPS = taps per pipeline stage: one barrier (+ DMA wait) per TPS*CK/2*TM*TN MFMAs per wave.  With TPS = 1 a stage is only
+// 32 MFMAs (2 k cycles) and the LDS-read latency + barrier skew at every stage boundary costs ~10-15 %; TPS = 3 (a whole
+// tap row of a 3x3) amortises it 3x for 32 KB more LDS (still two workgroups per CU).
+template <int BM, int CK, int TPS>
 __global__ __launch_bounds__(256) void k_conv_patch(CP g) {
     constexpr int WM = (BM >= 64) ? BM / 2 : 32;
     constexpr int TM = WM / 32;
     constexpr int TN = (BM >= 64) ? 2 : 1;           // lattice rows of the tile per wave
     HIP_DYNAMIC_SHARED(float, smem)
-    float* As = smem;                    // [2][CK][BM]
-    float* Ps = smem + 2 * CK * BM;      // [2][CK][PS]
+    float* As = smem;                          // [2][TPS][CK][BM]
+    float* Ps = smem + 2 * TPS * CK * BM;      // [2][CK][PS]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -360,18 +363,23 @@ __global__ __launch_bounds__(256) void k_conv_patch(CP g) {
             }
         }
     };
-    auto load_A = [&](int chunk, int tap, int buf) {
-        // CK rows of BM contiguous floats: wp[((tap*Cpad + chunk*CK + kk) * Mpad) + m0 + mm]
-        const float* base = g.wp + ((long)tap * g.Cpad + (long)chunk * CK) * g.Mpad + m0;
-        float* dst = As + buf * CK * BM;
-        constexpr int N4 = CK * BM / 4;                        // float4 count
+    auto load_A = [&](int chunk, int tap0, int buf) {
+        // per tap: CK rows of BM contiguous floats: wp[((tap*Cpad + chunk*CK + kk) * Mpad) + m0 + mm]
+        constexpr int N4 = CK * BM / 4;                        // float4 count of one tap
 #pragma unroll
-        for (int q = 0; q < (N4 + 255) / 256; q++) {
-            const int w4 = q * 256 + wid * 64;                 // first float4 of this wave (uniform)
-            if (w4 < N4) {
-                const int f = 4 * (w4 + lane);
-                const int kk = f / BM, mm = f - kk * BM;
-                __builtin_amdgcn_global_load_lds(CC_GLOBAL_PTR(base + (long)kk * g.Mpad + mm), CC_LDS_PTR(dst + 4 * w4), 16, 0, 0);
+        for (int tt = 0; tt < TPS; tt++) {
+            if (tap0 + tt < T) {
+                const float* base = g.wp + ((long)(tap0 + tt) * g.Cpad + (long)chunk * CK) * g.Mpad + m0;
+                float* dst = As + (buf * TPS + tt) * CK * BM;
+#pragma unroll
+                for (int q = 0; q < (N4 + 255) / 256; q++) {
+                    const int w4 = q * 256 + wid * 64;         // first float4 of this wave (uniform)
+                    if (w4 < N4) {
+                        const int f = 4 * (w4 + lane);
+                        const int kk = f / BM, mm = f - kk * BM;
+                        __builtin_amdgcn_global_load_lds(CC_GLOBAL_PTR(base + (long)kk * g.Mpad + mm), CC_LDS_PTR(dst + 4 * w4), 16, 0, 0);
+                    }
+                }
             }
         }
     };
@@ -393,34 +401,39 @@ __global__ __launch_bounds__(256) void k_conv_patch(CP g) {
         for (int chunk = c_beg; chunk < c_end; chunk++) {
             const float* Pb = Ps + (chunk & 1) * CK * g.PS;
             int ti = 0, tj = 0;
-            for (int tap = 0; tap < T; tap++, s++) {
+            for (int tap0 = 0; tap0 < T; tap0 += TPS, s++) {
                 // prefetch the next stage's operands (other buffers; their last readers passed the previous barrier)
-                if (tap + 1 < T) load_A(chunk, tap + 1, (s + 1) & 1);
+                if (tap0 + TPS < T) load_A(chunk, tap0 + TPS, (s + 1) & 1);
                 else if (chunk + 1 < c_end) load_A(chunk + 1, 0, (s + 1) & 1);
-                if (tap == 0 && chunk + 1 < c_end) load_patch(chunk + 1, (chunk + 1) & 1);
-                const float* Ab = As + (s & 1) * CK * BM;
-                const int tapoff = (g.dy_base + ti * g.dstep) * g.PWr + (g.dx_base + tj * g.dstep) + g.shift;
-                const float* Pl = Pb + lk * g.PS + (g.si * row0) * g.PWr + g.si * l31 + tapoff;
-                const float* Al = Ab + lk * BM + wm * WM + l31;
-                // all fragments of the stage are fetched up front (2*(TM+TN)*CK/2 VGPRs): one exposed LDS latency per
-                // stage instead of one per k-step; the MFMAs then issue back to back behind counted lgkmcnt waits
-                float af[CK / 2][TM], bf[CK / 2][TN];
+                if (tap0 == 0 && chunk + 1 < c_end) load_patch(chunk + 1, (chunk + 1) & 1);
 #pragma unroll
-                for (int ks = 0; ks < CK / 2; ks++) {
+                for (int tt = 0; tt < TPS; tt++) {
+                    if (tap0 + tt < T) {
+                        const float* Ab = As + ((s & 1) * TPS + tt) * CK * BM;
+                        const int tapoff = (g.dy_base + ti * g.dstep) * g.PWr + (g.dx_base + tj * g.dstep) + g.shift;
+                        const float* Pl = Pb + lk * g.PS + (g.si * row0) * g.PWr + g.si * l31 + tapoff;
+                        const float* Al = Ab + lk * BM + wm * WM + l31;
+                        // all fragments of a tap are fetched up front (2*(TM+TN)*CK/2 VGPRs): one exposed LDS latency per
+                        // tap instead of one per k-step; the MFMAs then issue back to back behind counted lgkmcnt waits
+                        float af[CK / 2][TM], bf[CK / 2][TN];
 #pragma unroll
-                    for (int a = 0; a < TM; a++) af[ks][a] = Al[(2 * ks) * BM + a * 32];
+                        for (int ks = 0; ks < CK / 2; ks++) {
 #pragma unroll
-                    for (int b = 0; b < TN; b++) bf[ks][b] = Pl[(2 * ks) * g.PS + (g.si * b) * g.PWr];
+                            for (int a = 0; a < TM; a++) af[ks][a] = Al[(2 * ks) * BM + a * 32];
+#pragma unroll
+                            for (int b = 0; b < TN; b++) bf[ks][b] = Pl[(2 * ks) * g.PS + (g.si * b) * g.PWr];
+                        }
+#pragma unroll
+                        for (int ks = 0; ks < CK / 2; ks++) {
+#pragma unroll
+                            for (int a = 0; a < TM; a++)
+#pragma unroll
+                                for (int b = 0; b < TN; b++)
+                                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks][a], bf[ks][b], acc[a][b], 0, 0, 0);
+                        }
+                        if (++tj == g.St) { tj = 0; ti++; }
+                    }
                 }
-#pragma unroll
-                for (int ks = 0; ks < CK / 2; ks++) {
-#pragma unroll
-                    for (int a = 0; a < TM; a++)
-#pragma unroll
-                        for (int b = 0; b < TN; b++)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks][a], bf[ks][b], acc[a][b], 0, 0, 0);
-                }
-                if (++tj == g.St) { tj = 0; ti++; }
                 CC_WAIT_VMCNT0();
                 __syncthreads();
             }
@@ -495,7 +508,7 @@ static int dbg_flag_early(const char* name) {
 
 struct ConvPlan {
     bool use_patch;
-    int bm, ck, Mpad, Cpad, PH, PWr, PS, ymin, xmin, tiles_x, tiles_y, nsplit, cps, aligned, shift;
+    int bm, ck, tps, Mpad, Cpad, PH, PWr, PS, ymin, xmin, tiles_x, tiles_y, nsplit, cps, aligned, shift;
     size_t smem, wp_floats, part_floats;
 };
 
@@ -518,9 +531,11 @@ inline ConvPlan plan_conv(const GG& g) {
     p.PS = ((p.PH * p.PWr + 63) / 64) * 64;
     if (p.aligned) p.PS = ((p.PH * p.PWr + 255) / 256) * 256;     // whole 64-lane x 16-byte DMA instructions per channel
     p.ck = 16;
-    auto smem_of = [&](int ck) { return (size_t)(2 * ck * p.bm + 2 * ck * p.PS) * sizeof(float); };
-    if (smem_of(16) > 64 * 1024) p.ck = 8;
-    p.smem = smem_of(p.ck);
+    auto smem_of = [&](int ck, int tps) { return (size_t)(2 * tps * ck * p.bm + 2 * ck * p.PS) * sizeof(float); };
+    if (smem_of(16, 1) > 64 * 1024) p.ck = 8;
+    // three taps per pipeline stage when the extra weight buffers still leave two workgroups per CU (2 x 80 KB)
+    p.tps = (g.Rt * g.St >= 3 && smem_of(p.ck, 3) <= 80 * 1024 && !dbg_flag_early("CC_CONV_TPS1")) ? 3 : 1;
+    p.smem = smem_of(p.ck, p.tps);
     p.use_patch = (p.smem <= 150 * 1024) && g.Cin > 0;
     p.Mpad = ((g.M + p.bm - 1) / p.bm) * p.bm;
     p.Cpad = ((g.Cin + p.ck - 1) / p.ck) * p.ck;
@@ -1180,9 +1195,15 @@ inline void launch_gg_flat(const GG& g, hipStream_t s) {
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_gemm<32>), grid, dim3(256), 0, s, g);
 }
 
-template <int BM, int CK>
+template <int BM, int CK, int TPS>
 inline void launch_patch(const CP& c, dim3 grid, size_t smem, hipStream_t s) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_patch<BM, CK>), grid, dim3(256), smem, s, c);
+    static bool big_lds_enabled = false;       // > 64 KB of dynamic LDS has to be requested once per kernel
+    if (smem > 64 * 1024 && !big_lds_enabled) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_patch<BM, CK, TPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+        big_lds_enabled = true;
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_patch<BM, CK, TPS>), grid, dim3(256), smem, s, c);
 }
 
 // ws: [64 zeros][repacked weights][split-K partial slabs]; sized by conv_ws_floats(plan_conv(g))
@@ -1214,14 +1235,24 @@ inline void launch_gg(const GG& g, float* ws, hipStream_t s, const float* prepac
     c.nsplit = p.nsplit; c.cps = p.cps; c.part_stride = (long)g.B * g.M * g.OHt * g.OWt;
     c.act = g.act; c.act_a = g.act_a; c.act_b = g.act_b;
     dim3 grid((unsigned)(g.B * p.tiles_x * p.tiles_y), (unsigned)(p.Mpad / p.bm), (unsigned)p.nsplit);
-    if (p.ck == 16) {
-        if (p.bm == 128) launch_patch<128, 16>(c, grid, p.smem, s);
-        else if (p.bm == 64) launch_patch<64, 16>(c, grid, p.smem, s);
-        else launch_patch<32, 16>(c, grid, p.smem, s);
+    if (p.tps == 3) {
+        if (p.ck == 16) {
+            if (p.bm == 128) launch_patch<128, 16, 3>(c, grid, p.smem, s);
+            else if (p.bm == 64) launch_patch<64, 16, 3>(c, grid, p.smem, s);
+            else launch_patch<32, 16, 3>(c, grid, p.smem, s);
+        } else {
+            if (p.bm == 128) launch_patch<128, 8, 3>(c, grid, p.smem, s);
+            else if (p.bm == 64) launch_patch<64, 8, 3>(c, grid, p.smem, s);
+            else launch_patch<32, 8, 3>(c, grid, p.smem, s);
+        }
+    } else if (p.ck == 16) {
+        if (p.bm == 128) launch_patch<128, 16, 1>(c, grid, p.smem, s);
+        else if (p.bm == 64) launch_patch<64, 16, 1>(c, grid, p.smem, s);
+        else launch_patch<32, 16, 1>(c, grid, p.smem, s);
     } else {
-        if (p.bm == 128) launch_patch<128, 8>(c, grid, p.smem, s);
-        else if (p.bm == 64) launch_patch<64, 8>(c, grid, p.smem, s);
-        else launch_patch<32, 8>(c, grid, p.smem, s);
+        if (p.bm == 128) launch_patch<128, 8, 1>(c, grid, p.smem, s);
+        else if (p.bm == 64) launch_patch<64, 8, 1>(c, grid, p.smem, s);
+        else launch_patch<32, 8, 1>(c, grid, p.smem, s);
     }
     if (p.nsplit > 1) {
         const long total = c.part_stride;
