@@ -20,6 +20,7 @@
 //
 // Weight gradient: second kernel, M = channels of dY, N = (c,i,j), K = pixels, split over pixel ranges with a
 // deterministic second-stage reduction (no atomics).
+#include <stdio.h>
 #include <stdlib.h>
 #include "cc_common.h"
 #include "conv_internal.h"
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256) void k_repack_table(const long* __restrict__ d
 // 32 MFMAs (2 k cycles) and the LDS-read latency + barrier skew at every stage boundary costs ~10-15 %; TPS = 3 (a whole
 // tap row of a 3x3) amortises it 3x for 32 KB more LDS (still two workgroups per CU).
 template <int BM, int CK, int TPS>
-__global__ __launch_bounds__(256) void k_conv_patch(CP g) {
+__device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
     constexpr int WM = (BM >= 64) ? BM / 2 : 32;
     constexpr int TM = WM / 32;
     constexpr int TN = (BM >= 64) ? 2 : 1;           // lattice rows of the tile per wave
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void k_conv_patch(CP g) {
     const int row0 = (BM >= 64) ? 2 * (wid & 1) : wid;       // first lattice row (0..3) of this wave
     const int l31 = lane & 31, lk = lane >> 5;
 
-    int bx = blockIdx.x;
+    int bx = bx_in;
     const int tile_x = bx % g.tiles_x;
     bx /= g.tiles_x;
     const int tile_y = bx % g.tiles_y;
@@ -478,6 +479,31 @@ __global__ __launch_bounds__(256) void k_conv_patch(CP g) {
     }
 }
 
+template <int BM, int CK, int TPS>
+__global__ __launch_bounds__(256) void k_conv_patch(CP g) {
+    conv_patch_body<BM, CK, TPS>(g, (int)blockIdx.x);
+}
+
+// The (up to) four output-parity classes of a stride-2 data-gradient / transposed convolution in ONE launch:
+// blockIdx.x ranges over the classes' tiles back to back (each class has its own geometry, weight image and partial
+// slabs; the small-map layers are launch-bound, and four quarter-size grids in a row under-fill the chip).
+struct CPM {
+    CP c[4];
+    int n;
+    int bx_end[4];
+};
+
+template <int BM, int CK, int TPS>
+__global__ __launch_bounds__(256) void k_conv_patch_multi(CPM a) {
+    int k = 0, first = 0;
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+        if (q + 1 < a.n && (int)blockIdx.x >= a.bx_end[q]) { k = q + 1; first = a.bx_end[q]; }
+    const CP& g = a.c[k];
+    if ((int)blockIdx.z >= g.nsplit) return;
+    conv_patch_body<BM, CK, TPS>(g, (int)blockIdx.x - first);
+}
+
 // y[lattice pixel] = act(bias + res + sum_k part[k])  (second, deterministic stage of split-K)
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict__ part, int nsplit, long part_stride,
                                                          const float* __restrict__ bias, const float* __restrict__ res,
@@ -499,6 +525,38 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
     if (bias) v += bias[m];
     if (res) v += res[(long)n * res_bs + o];
     y[(long)n * y_bs + o] = apply_act(v, act, act_a, act_b);
+}
+
+struct EPC { const float* part; int nsplit; long part_stride; int OHt, OWt, oy0, ox0; long total; };
+struct EPM {
+    EPC c[4];
+    int n;
+    int bx_end[4];
+    const float* bias; float* y;
+    int M, so, OH, OW; long y_bs;
+    int act; float act_a, act_b;
+};
+
+__global__ __launch_bounds__(256) void k_splitk_epilogue_multi(EPM a) {
+    int k = 0, first = 0;
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+        if (q + 1 < a.n && (int)blockIdx.x >= a.bx_end[q]) { k = q + 1; first = a.bx_end[q]; }
+    const EPC& c = a.c[k];
+    const long e = (long)((int)blockIdx.x - first) * 256 + threadIdx.x;
+    if (e >= c.total) return;
+    float v = 0.f;
+    for (int z = 0; z < c.nsplit; z++) v += c.part[(long)z * c.part_stride + e];
+    const int HWt = c.OHt * c.OWt;
+    const long per = (long)a.M * HWt;
+    const int n = (int)(e / per);
+    const long r = e - (long)n * per;
+    const int m = (int)(r / HWt);
+    const int t = (int)(r - (long)m * HWt);
+    const int ty = t / c.OWt, tx = t - ty * c.OWt;
+    const long o = (long)m * a.OH * a.OW + (long)(c.oy0 + a.so * ty) * a.OW + (c.ox0 + a.so * tx);
+    if (a.bias) v += a.bias[m];
+    a.y[(long)n * a.y_bs + o] = apply_act(v, a.act, a.act_a, a.act_b);
 }
 
 static int dbg_flag_early(const char* name) {
@@ -1200,10 +1258,60 @@ inline void launch_patch(const CP& c, dim3 grid, size_t smem, hipStream_t s) {
     static bool big_lds_enabled = false;       // > 64 KB of dynamic LDS has to be requested once per kernel
     if (smem > 64 * 1024 && !big_lds_enabled) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_patch<BM, CK, TPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
+                                  160 * 1024);
         big_lds_enabled = true;
     }
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_patch<BM, CK, TPS>), grid, dim3(256), smem, s, c);
+}
+
+template <int BM, int CK, int TPS>
+inline void launch_patch(const CPM& c, dim3 grid, size_t smem, hipStream_t s) {
+    static bool big_lds_enabled = false;
+    if (smem > 64 * 1024 && !big_lds_enabled) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_patch_multi<BM, CK, TPS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        big_lds_enabled = true;
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_patch_multi<BM, CK, TPS>), grid, dim3(256), smem, s, c);
+}
+
+template <class ARGS>
+inline void dispatch_patch(int bm, int ck, int tps, const ARGS& c, dim3 grid, size_t smem, hipStream_t s) {
+    if (tps == 3) {
+        if (ck == 16) {
+            if (bm == 128) launch_patch<128, 16, 3>(c, grid, smem, s);
+            else if (bm == 64) launch_patch<64, 16, 3>(c, grid, smem, s);
+            else launch_patch<32, 16, 3>(c, grid, smem, s);
+        } else {
+            if (bm == 128) launch_patch<128, 8, 3>(c, grid, smem, s);
+            else if (bm == 64) launch_patch<64, 8, 3>(c, grid, smem, s);
+            else launch_patch<32, 8, 3>(c, grid, smem, s);
+        }
+    } else if (ck == 16) {
+        if (bm == 128) launch_patch<128, 16, 1>(c, grid, smem, s);
+        else if (bm == 64) launch_patch<64, 16, 1>(c, grid, smem, s);
+        else launch_patch<32, 16, 1>(c, grid, smem, s);
+    } else {
+        if (bm == 128) launch_patch<128, 8, 1>(c, grid, smem, s);
+        else if (bm == 64) launch_patch<64, 8, 1>(c, grid, smem, s);
+        else launch_patch<32, 8, 1>(c, grid, smem, s);
+    }
+}
+
+inline CP make_cp(const GG& g, const ConvPlan& p, const float* zeros, const float* wp, float* part) {
+    CP c = {};
+    c.x = g.x; c.wp = wp; c.zeros = zeros; c.bias = g.bias; c.res = g.res; c.y = g.y; c.part = part;
+    c.B = g.B; c.Cin = g.Cin; c.IH = g.IH; c.IW = g.IW; c.x_bs = g.x_bs;
+    c.M = g.M; c.Mpad = p.Mpad; c.Cpad = p.Cpad;
+    c.Rt = g.Rt; c.St = g.St; c.si = g.si; c.dstep = g.dstep;
+    c.dy_base = g.dy0 - p.ymin; c.dx_base = g.dx0 - p.xmin; c.ymin = p.ymin; c.xmin = p.xmin;
+    c.PH = p.PH; c.PWr = p.PWr; c.PS = p.PS; c.aligned = p.aligned; c.shift = p.shift;
+    c.OHt = g.OHt; c.OWt = g.OWt; c.so = g.so; c.oy0 = g.oy0; c.ox0 = g.ox0; c.OH = g.OH; c.OW = g.OW;
+    c.y_bs = g.y_bs; c.res_bs = g.res_bs;
+    c.tiles_x = p.tiles_x; c.tiles_y = p.tiles_y;
+    c.nsplit = p.nsplit; c.cps = p.cps; c.part_stride = (long)g.B * g.M * g.OHt * g.OWt;
+    c.act = g.act; c.act_a = g.act_a; c.act_b = g.act_b;
+    return c;
 }
 
 // ws: [64 zeros][repacked weights][split-K partial slabs]; sized by conv_ws_floats(plan_conv(g))
@@ -1222,44 +1330,66 @@ inline void launch_gg(const GG& g, float* ws, hipStream_t s, const float* prepac
         hipLaunchKernelGGL(k_repack_w, dim3((unsigned)((p.wp_floats + 255) / 256)), dim3(256), 0, s, g.w, ws + 64, ws, g.M, g.Cin,
                            p.Mpad, p.Cpad, T, g.St, g.w_sm, g.w_sc, g.w0, g.w_ri, g.w_sj);
     }
-    CP c = {};
-    c.x = g.x; c.wp = wp; c.zeros = zeros; c.bias = g.bias; c.res = g.res; c.y = g.y; c.part = part;
-    c.B = g.B; c.Cin = g.Cin; c.IH = g.IH; c.IW = g.IW; c.x_bs = g.x_bs;
-    c.M = g.M; c.Mpad = p.Mpad; c.Cpad = p.Cpad;
-    c.Rt = g.Rt; c.St = g.St; c.si = g.si; c.dstep = g.dstep;
-    c.dy_base = g.dy0 - p.ymin; c.dx_base = g.dx0 - p.xmin; c.ymin = p.ymin; c.xmin = p.xmin;
-    c.PH = p.PH; c.PWr = p.PWr; c.PS = p.PS; c.aligned = p.aligned; c.shift = p.shift;
-    c.OHt = g.OHt; c.OWt = g.OWt; c.so = g.so; c.oy0 = g.oy0; c.ox0 = g.ox0; c.OH = g.OH; c.OW = g.OW;
-    c.y_bs = g.y_bs; c.res_bs = g.res_bs;
-    c.tiles_x = p.tiles_x; c.tiles_y = p.tiles_y;
-    c.nsplit = p.nsplit; c.cps = p.cps; c.part_stride = (long)g.B * g.M * g.OHt * g.OWt;
-    c.act = g.act; c.act_a = g.act_a; c.act_b = g.act_b;
+    const CP c = make_cp(g, p, zeros, wp, part);
     dim3 grid((unsigned)(g.B * p.tiles_x * p.tiles_y), (unsigned)(p.Mpad / p.bm), (unsigned)p.nsplit);
-    if (p.tps == 3) {
-        if (p.ck == 16) {
-            if (p.bm == 128) launch_patch<128, 16, 3>(c, grid, p.smem, s);
-            else if (p.bm == 64) launch_patch<64, 16, 3>(c, grid, p.smem, s);
-            else launch_patch<32, 16, 3>(c, grid, p.smem, s);
-        } else {
-            if (p.bm == 128) launch_patch<128, 8, 3>(c, grid, p.smem, s);
-            else if (p.bm == 64) launch_patch<64, 8, 3>(c, grid, p.smem, s);
-            else launch_patch<32, 8, 3>(c, grid, p.smem, s);
-        }
-    } else if (p.ck == 16) {
-        if (p.bm == 128) launch_patch<128, 16, 1>(c, grid, p.smem, s);
-        else if (p.bm == 64) launch_patch<64, 16, 1>(c, grid, p.smem, s);
-        else launch_patch<32, 16, 1>(c, grid, p.smem, s);
-    } else {
-        if (p.bm == 128) launch_patch<128, 8, 1>(c, grid, p.smem, s);
-        else if (p.bm == 64) launch_patch<64, 8, 1>(c, grid, p.smem, s);
-        else launch_patch<32, 8, 1>(c, grid, p.smem, s);
-    }
+    dispatch_patch(p.bm, p.ck, p.tps, c, grid, p.smem, s);
     if (p.nsplit > 1) {
         const long total = c.part_stride;
         hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)part,
                            p.nsplit, c.part_stride, g.bias, g.res, g.y, g.M, g.OHt, g.OWt, g.so, g.oy0, g.ox0, g.OH, g.OW,
                            g.y_bs, g.res_bs, total, g.act, g.act_a, g.act_b);
     }
+}
+
+// All parity classes of one stride-s data-gradient in ONE conv launch (+ ONE split-K epilogue launch).  Needs the
+// prepacked weight images (class k's image follows class k-1's) and every class on the patch kernel with the same tile
+// configuration; partial slabs of the classes are laid out back to back in ws.  -> false: caller launches them one by one.
+inline bool launch_gg_classes(const GG* gs, int n, float* ws, hipStream_t s, const float* prepacked) {
+    if (n < 2 || n > 4 || !prepacked || !ws || dbg_flag_early("CC_NO_CLASS_MERGE")) return false;
+    ConvPlan ps[4];
+    size_t smem = 0;
+    int tps = 3, maxsplit = 1;
+    for (int k = 0; k < n; k++) {
+        ps[k] = plan_conv(gs[k]);
+        if (!ps[k].use_patch || ps[k].bm != ps[0].bm || ps[k].ck != ps[0].ck || gs[k].res != nullptr) return false;
+        if (ps[k].tps != 3) tps = 1;
+        if (ps[k].nsplit > maxsplit) maxsplit = ps[k].nsplit;
+    }
+    CPM a = {};
+    EPM e = {};
+    a.n = n; e.n = n;
+    long off = 64, poff = 64;
+    int bx = 0, ebx = 0, nsplit_any = 0;
+    for (int k = 0; k < n; k++) {
+        const GG& g = gs[k];
+        const ConvPlan& p = ps[k];
+        // LDS: A buffers follow the launch-wide TPS, the patch buffers this class's PS
+        const size_t sm = (size_t)(2 * tps * p.ck * p.bm + 2 * p.ck * p.PS) * sizeof(float);
+        if (sm > smem) smem = sm;
+        a.c[k] = make_cp(g, p, prepacked, prepacked + off, ws + poff);
+        off += (long)p.wp_floats;
+        bx += g.B * p.tiles_x * p.tiles_y;
+        a.bx_end[k] = bx;
+        EPC& c = e.c[k];
+        c.part = ws + poff; c.nsplit = p.nsplit; c.part_stride = a.c[k].part_stride;
+        c.OHt = g.OHt; c.OWt = g.OWt; c.oy0 = g.oy0; c.ox0 = g.ox0;
+        c.total = (p.nsplit > 1) ? a.c[k].part_stride : 0;
+        ebx += (int)((c.total + 255) / 256);
+        e.bx_end[k] = ebx;
+        if (p.nsplit > 1) { nsplit_any = 1; poff += (long)p.part_floats; }
+    }
+    if (smem > 80 * 1024) return false;
+    if (dbg_flag_early("CC_CLASS_MERGE_TRACE"))
+        fprintf(stderr, "[conv] %d parity classes in one launch: %d tiles, bm %d ck %d tps %d split %d\n", n, bx, ps[0].bm, ps[0].ck, tps, maxsplit);
+    dim3 grid((unsigned)bx, (unsigned)(ps[0].Mpad / ps[0].bm), (unsigned)maxsplit);
+    dispatch_patch(ps[0].bm, ps[0].ck, tps, a, grid, smem, s);
+    if (nsplit_any) {
+        const GG& g = gs[0];
+        e.bias = g.bias; e.y = g.y; e.M = g.M; e.so = g.so; e.OH = g.OH; e.OW = g.OW; e.y_bs = g.y_bs;
+        e.act = g.act; e.act_a = g.act_a; e.act_b = g.act_b;
+        hipLaunchKernelGGL(k_splitk_epilogue_multi, dim3((unsigned)ebx), dim3(256), 0, s, e);
+    }
+    return true;
 }
 
 }  // namespace
@@ -1355,17 +1485,18 @@ static bool make_dgrad_class(GG& g, int py, int px, const float* gy, const float
 }
 
 size_t cc_conv2d_dgrad_ws_bytes(int B, int K, int OH, int OW, int C, int R, int S, int stride, int pad, int IH, int IW) {
-    size_t best = 64;
+    size_t wmax = 0, psum = 0;        // the merged launch keeps every class's partial slabs alive at once
     for (int py = 0; py < stride; py++)
         for (int px = 0; px < stride; px++) {
             GG g;
             if (!make_dgrad_class(g, py, px, nullptr, nullptr, nullptr, nullptr, B, K, OH, OW, 0, C, R, S, stride, pad, IH, IW,
                                   0, (long)C * R * S, (long)R * S, 0, 1.f, 0.f))
                 continue;
-            const size_t f = conv_ws_floats(plan_conv(g));
-            if (f > best) best = f;
+            const ConvPlan p = plan_conv(g);
+            if (p.wp_floats > wmax) wmax = p.wp_floats;
+            psum += p.part_floats;
         }
-    return best * sizeof(float);
+    return (64 + wmax + psum) * sizeof(float);
 }
 
 size_t cc_conv2d_dgrad_pack_floats(int B, int K, int OH, int OW, int C, int R, int S, int stride, int pad, int IH, int IW,
@@ -1418,6 +1549,21 @@ int cc_conv2d_dgrad(const float* gy, const float* w, const float* bias_or_null, 
     if (B <= 0 || K <= 0 || C <= 0 || stride <= 0) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     long off = 64;
+    if (stride == 2 && prepacked_or_null) {
+        GG gs[4];
+        int n = 0;
+        bool all = true;
+        for (int py = 0; py < stride && all; py++)
+            for (int px = 0; px < stride; px++) {
+                if (!make_dgrad_class(gs[n], py, px, gy, w, bias_or_null, gx, B, K, OH, OW, gy_bs, C, R, S, stride, pad, IH, IW,
+                                      gx_bs, w_k_stride, w_c_stride, act, act_a, act_b)) { all = false; break; }
+                n++;
+            }
+        if (all && launch_gg_classes(gs, n, ws, s, prepacked_or_null)) {
+            CC_CHECK_LAUNCH();
+            return CC_OK;
+        }
+    }
     for (int py = 0; py < stride; py++) {
         for (int px = 0; px < stride; px++) {
             GG g;

@@ -87,6 +87,11 @@ class PackRegistry:
     def invalidate(self):
         self.valid = False
 
+    def reset(self):
+        """Forget every registered layer (tests; a new set of networks)."""
+        self.entries.clear()
+        self.valid, self.dirty, self.table, self.total_blocks = False, False, None, 0
+
 
 packs = PackRegistry()
 

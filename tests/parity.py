@@ -372,12 +372,16 @@ CONVT_CASES = [  # B, Cin, H, W, Cout, k, stride, pad, output_padding, act
 ]
 
 
-def check_convs(dev, cases=CONV_CASES, tcases=CONVT_CASES, tol=2e-5, seed=0):
+def check_convs(dev, cases=CONV_CASES, tcases=CONVT_CASES, tol=2e-5, seed=0, prepack=False):
     """conv2d / conv_transpose2d forward (+ fused bias / residual / activation epilogue) and all gradients, max-abs
-    error relative to the largest reference magnitude <= tol (fp32 MFMA accumulation order differs from the CPU's)."""
+    error relative to the largest reference magnitude <= tol (fp32 MFMA accumulation order differs from the CPU's).
+    prepack=True runs every case a second time through the trainer's per-step weight images (cc_repack_table) -- the
+    path on which the parity classes of stride-2 data-gradients / transposed convs share one launch."""
     import torch.nn.functional as F
     from cc_amd import ops
     g = torch.Generator().manual_seed(seed)
+    passes = 2 if prepack else 1
+    ops.packs.reset()
 
     def rn(*s):
         return torch.randn(*s, generator=g)
@@ -389,24 +393,33 @@ def check_convs(dev, cases=CONV_CASES, tcases=CONVT_CASES, tol=2e-5, seed=0):
         aa, ab = (10.0, 0.01) if act == "sigmoid" else (1.0, 0.0)
         ins_d = [leaf(t, dev) if t is not None else None for t in (x0, w0, b0, r0)]
         ins_c = [leaf(t, "cpu") if t is not None else None for t in (x0, w0, b0, r0)]
-        y = ops.conv2d(ins_d[0], ins_d[1], ins_d[2], st, pad, act, ins_d[3], aa, ab)
         r = F.conv2d(ins_c[0], ins_c[1], ins_c[2], st, pad)
         if hr:
             r = r + ins_c[3]
         r = ops._torch_act(r, act, aa, ab)
         go = rn(*r.shape)
-        g1 = torch.autograd.grad(y, [t for t in ins_d if t is not None], go.to(dev))
         g0 = torch.autograd.grad(r, [t for t in ins_c if t is not None], go)
-        errs = [rel(y, r)] + [rel(a, b) for a, b in zip(g1, g0)]
-        assert max(errs) < tol, ((B, Cin, H, W, Cout, k, st, pad, act), errs)
+        for ps in range(passes):
+            if ps == 1:
+                ops.packs.prepack_all()
+            y = ops.conv2d(ins_d[0], ins_d[1], ins_d[2], st, pad, act, ins_d[3], aa, ab)
+            g1 = torch.autograd.grad(y, [t for t in ins_d if t is not None], go.to(dev))
+            errs = [rel(y, r)] + [rel(a, b) for a, b in zip(g1, g0)]
+            assert max(errs) < tol, ((B, Cin, H, W, Cout, k, st, pad, act), ps, errs)
+            ops.packs.invalidate()
     for (B, Cin, H, W, Cout, k, st, pad, op, act) in tcases:
         x0, w0, b0 = rn(B, Cin, H, W), rn(Cin, Cout, k, k) * 0.2, rn(Cout)
         ins_d = [leaf(t, dev) for t in (x0, w0, b0)]
         ins_c = [leaf(t, "cpu") for t in (x0, w0, b0)]
-        y = ops.conv_transpose2d(ins_d[0], ins_d[1], ins_d[2], st, pad, op, act)
         r = ops._torch_act(F.conv_transpose2d(ins_c[0], ins_c[1], ins_c[2], st, pad, op), act, 1.0, 0.0)
         go = rn(*r.shape)
-        g1 = torch.autograd.grad(y, ins_d, go.to(dev))
         g0 = torch.autograd.grad(r, ins_c, go)
-        errs = [rel(y, r)] + [rel(a, b) for a, b in zip(g1, g0)]
-        assert max(errs) < tol, ((B, Cin, H, W, Cout, k, st, pad, op, act), errs)
+        for ps in range(passes):
+            if ps == 1:
+                ops.packs.prepack_all()
+            y = ops.conv_transpose2d(ins_d[0], ins_d[1], ins_d[2], st, pad, op, act)
+            g1 = torch.autograd.grad(y, ins_d, go.to(dev))
+            errs = [rel(y, r)] + [rel(a, b) for a, b in zip(g1, g0)]
+            assert max(errs) < tol, ((B, Cin, H, W, Cout, k, st, pad, op, act), ps, errs)
+            ops.packs.invalidate()
+    ops.packs.reset()

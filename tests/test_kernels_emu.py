@@ -49,6 +49,10 @@ def test_convs():
     parity.check_convs("cpu")
 
 
+def test_convs_prepacked_weight_images():
+    parity.check_convs("cpu", prepack=True)
+
+
 def test_convs_thin_wgrad(monkeypatch):
     monkeypatch.setenv("CC_WGRAD_THIN_MINPIX", "0")      # route the small test maps through wgrad_thin.hip
     monkeypatch.setenv("CC_WGRAD_THIN_UPB", "8")

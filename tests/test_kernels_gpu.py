@@ -58,6 +58,10 @@ def test_convs():
     parity.check_convs("cuda")
 
 
+def test_convs_prepacked_weight_images():
+    parity.check_convs("cuda", prepack=True)
+
+
 def test_convs_thin_wgrad(monkeypatch):
     monkeypatch.setenv("CC_WGRAD_THIN_MINPIX", "0")
     monkeypatch.setenv("CC_WGRAD_THIN_UPB", "8")
