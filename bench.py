@@ -79,12 +79,43 @@ WORK = {   # entry point -> (kind, fn(args dict) -> algorithmic flops or bytes)
 }
 
 
+def kernel_of(eng, name, d):
+    """Device kernel a conv entry point dispatches to for this geometry (C-ABI introspection, host only)."""
+    import ctypes
+    buf = ctypes.create_string_buffer(96)
+    a = ctypes.addressof(buf)
+    if name == "cc_conv2d_fwd":
+        eng.fn["cc_conv2d_fwd_kernel"](d["B"], d["Cin"], d["IH"], d["IW"], d["Cout"], d["R"], d["S"], d["stride"], d["pad"],
+                                       d["OH"], d["OW"], a, 96)
+    elif name == "cc_conv2d_dgrad":
+        eng.fn["cc_conv2d_dgrad_kernel"](d["B"], d["K"], d["OH"], d["OW"], d["C"], d["R"], d["S"], d["stride"], d["pad"],
+                                         d["IH"], d["IW"], int(d["prepacked_or_null"] is not None), a, 96)
+    elif name == "cc_conv2d_wgrad":
+        eng.fn["cc_conv2d_wgrad_kernel"](d["B"], d["M"], d["AH"], d["AW"], d["Cin"], d["IH"], d["IW"], d["R"], d["S"], d["si"],
+                                         d["pad"], a, 96)
+    else:
+        return None
+    return buf.value.decode()
+
+
+def algorithmic_bytes(name, d):
+    """fp32 bytes of each distinct tensor argument once (input, weights, output) for one conv call."""
+    if name == "cc_conv2d_fwd":
+        return 4.0 * (d["B"] * d["Cin"] * d["IH"] * d["IW"] + d["Cout"] * d["Cin"] * d["R"] * d["S"] + d["B"] * d["Cout"] * d["OH"] * d["OW"])
+    if name == "cc_conv2d_dgrad":
+        return 4.0 * (d["B"] * d["K"] * d["OH"] * d["OW"] + d["K"] * d["C"] * d["R"] * d["S"] + d["B"] * d["C"] * d["IH"] * d["IW"])
+    if name == "cc_conv2d_wgrad":
+        return 4.0 * (d["B"] * d["M"] * d["AH"] * d["AW"] + d["B"] * d["Cin"] * d["IH"] * d["IW"] + d["M"] * d["Cin"] * d["R"] * d["S"])
+    return 0.0
+
+
 class CallTimer:
     """Brackets selected C-ABI calls with HIP events on the launch stream (torch's current stream)."""
 
     def __init__(self, eng):
         self.eng = eng
         self.records = []
+        self.by_kernel = []
         self._orig = eng.call
 
     def __enter__(self):
@@ -95,6 +126,9 @@ class CallTimer:
                 r = self._orig(name, *args)
                 e.record()
                 d = dict(zip(self.eng.sigs[name][2], args))
+                kn = kernel_of(self.eng, name, d)
+                if kn is not None:
+                    self.by_kernel.append((kn, WORK[name][1](d), algorithmic_bytes(name, d), s, e))
                 self.records.append((name, WORK[name][1](d), s, e, {k: v for k, v in d.items() if isinstance(v, int) and k not in ("x_bs", "y_bs", "res_bs", "a_bs", "gy_bs", "gx_bs")}))
                 return r
             return self._orig(name, *args)
@@ -103,6 +137,19 @@ class CallTimer:
 
     def __exit__(self, *a):
         self.eng.call = self._orig
+
+    def kernel_groups(self):
+        """-> {device kernel: {launches, ms, gflop, bytes}} over the conv calls (one call = one launch of that kernel,
+        plus its split-K epilogue where the name says so)."""
+        torch.cuda.synchronize()
+        g = {}
+        for kn, fl, by, s, e in self.by_kernel:
+            a = g.setdefault(kn, {"launches": 0, "ms": 0.0, "gflop": 0.0, "bytes": 0.0})
+            a["launches"] += 1
+            a["ms"] += s.elapsed_time(e)
+            a["gflop"] += fl / 1e9
+            a["bytes"] += by
+        return g
 
     def summary(self):
         torch.cuda.synchronize()
@@ -135,6 +182,22 @@ class CallTimer:
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/pmc_traffic.json, written by tools/pmc_traffic.py: (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch, the
+    gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md).  bench.py cannot run the profiler on itself."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        ent = t["kernels"].get(kernel.split("+")[0])
+        if ent:
+            return round(ent["hbm_bytes_per_launch"]), "profiles/pmc_traffic.json (%s)" % t.get("command", "")
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
 
 
 def cpu_baseline(batch_cpu, args):
@@ -223,15 +286,27 @@ def main():
         with CallTimer(eng) as ct:
             tr_e.step(batch)
         kernels = ct.summary()
+        groups = ct.kernel_groups()
         convs = {k: v for k, v in kernels.items() if "tflops" in v}
-        if convs:
+        if groups:
+            # the dominant kernel = the conv kernel with the largest share of the step
+            kn, a = max(groups.items(), key=lambda kv: kv[1]["ms"])
+            ach = a["gflop"] / a["ms"] if a["ms"] > 0 else 0.0                       # GFLOP / ms = TFLOP/s
             tot_ms = sum(v["ms"] for v in convs.values())
-            tot_fl = sum(v["tflops"] * v["ms"] for v in convs.values())           # TFLOP/s * ms = GFLOP
-            ach = tot_fl / tot_ms if tot_ms > 0 else 0.0
-            roof = {"bound": "mfma", "kernel": "k_gather_gemm/k_wgrad (cc_conv2d_fwd+dgrad+wgrad)",
-                    "achieved": round(ach, 2), "peak": PEAK_MFMA_F32, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_MFMA_F32, 4), "traffic": None,
-                    "launches": sum(v["calls"] for v in convs.values()), "ms_per_step": round(tot_ms, 3)}
+            tot_fl = sum(v["tflops"] * v["ms"] for v in convs.values())
+            fam = tot_fl / tot_ms if tot_ms > 0 else 0.0
+            traffic, src = pmc_traffic(kn)
+            roof = {"bound": "mfma", "kernel": kn, "achieved": round(ach, 2), "peak": PEAK_MFMA_F32, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_MFMA_F32, 4), "traffic": traffic, "traffic_source": src,
+                    "launches": a["launches"], "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2),
+                    "algorithmic_gflop_per_launch": round(a["gflop"] / a["launches"], 3),
+                    "algorithmic_bytes_per_launch": round(a["bytes"] / a["launches"]),
+                    "ms_per_step": round(a["ms"], 3),
+                    "conv_family": {"achieved": round(fam, 2), "frac": round(fam / PEAK_MFMA_F32, 4),
+                                    "launches": sum(v["calls"] for v in convs.values()), "ms_per_step": round(tot_ms, 3)},
+                    "by_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                      "tflops": round(v["gflop"] / v["ms"], 2) if v["ms"] > 0 else 0.0}
+                                  for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:8]}}
 
     if rank == 0:
         imgs = B * world * args.steps

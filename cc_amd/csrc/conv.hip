@@ -1734,6 +1734,63 @@ int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B,
     return CC_OK;
 }
 
+/* ---- introspection (bench.py groups its per-call timings by the kernel a call dispatches to) */
+static void patch_name(const ConvPlan& p, bool multi, char* out, int cap) {
+    if (!p.use_patch) { snprintf(out, cap, "k_gather_gemm<%d>", pick_bm(p.Mpad ? p.Mpad : 32)); return; }
+    snprintf(out, cap, "%s<%d, %d, %d>%s", multi ? "k_conv_patch_multi" : "k_conv_patch", p.bm, p.ck, p.tps,
+             p.nsplit > 1 ? "+splitk" : "");
+}
+
+int cc_conv2d_fwd_kernel(int B, int Cin, int IH, int IW, int Cout, int R, int S, int stride, int pad, int OH, int OW,
+                         void* name_out_host, int cap) {
+    GG g = make_fwd(nullptr, nullptr, nullptr, nullptr, nullptr, B, Cin, IH, IW, 0, Cout, R, S, stride, pad, OH, OW, 0, 0, 0,
+                    1.f, 0.f);
+    patch_name(plan_conv(g), false, (char*)name_out_host, cap);
+    return CC_OK;
+}
+
+int cc_conv2d_dgrad_kernel(int B, int K, int OH, int OW, int C, int R, int S, int stride, int pad, int IH, int IW,
+                           int prepacked, void* name_out_host, int cap) {
+    GG gs[4];
+    int n = 0;
+    bool all = true;
+    for (int py = 0; py < stride && all; py++)
+        for (int px = 0; px < stride; px++) {
+            if (n >= 4 || !make_dgrad_class(gs[n], py, px, nullptr, nullptr, nullptr, nullptr, B, K, OH, OW, 0, C, R, S, stride, pad,
+                                            IH, IW, 0, (long)C * R * S, (long)R * S, 0, 1.f, 0.f)) { all = false; break; }
+            n++;
+        }
+    if (n == 0) { ((char*)name_out_host)[0] = 0; return CC_OK; }
+    ConvPlan p = plan_conv(gs[0]);
+    bool multi = false;
+    if (stride == 2 && prepacked && all && n >= 2 && !dbg_flag_early("CC_NO_CLASS_MERGE")) {
+        multi = true;
+        int tps = 3, maxsplit = 1;
+        for (int k = 0; k < n; k++) {
+            const ConvPlan q = plan_conv(gs[k]);
+            if (!q.use_patch || q.bm != p.bm || q.ck != p.ck) multi = false;
+            if (q.tps != 3) tps = 1;
+            if (q.nsplit > maxsplit) maxsplit = q.nsplit;
+        }
+        if (multi) { p.tps = tps; p.nsplit = maxsplit; }
+    }
+    patch_name(p, multi, (char*)name_out_host, cap);
+    return CC_OK;
+}
+
+int cc_conv2d_wgrad_kernel(int B, int M, int AH, int AW, int Cin, int IH, int IW, int R, int S, int si, int pad,
+                           void* name_out_host, int cap) {
+    char* out = (char*)name_out_host;
+    ccint::wgrad_thin_name(B, M, AH, AW, Cin, IH, IW, R, S, si, pad, out, cap);
+    if (out[0]) return CC_OK;
+    const W3Plan q = plan_w3(B, M, AH, AW, Cin, R, S, si, pad, IH, IW);
+    if (q.ok) { snprintf(out, cap, "k_wgrad3x3<%d, %d>", q.mt, 4 / q.mt); return CC_OK; }
+    const WPlan p = plan_wgrad(B, M, AH, AW, Cin, R, S, si);
+    if (p.ok) { snprintf(out, cap, "k_wgrad_patch<%d, %d>", p.bmw, p.nt); return CC_OK; }
+    snprintf(out, cap, "k_wgrad<%d>", pick_bm(M));
+    return CC_OK;
+}
+
 size_t cc_act_bwd_ws_bytes(int C) { return (size_t)C * 64 * sizeof(float); }
 
 /* geff = gy * act'(y) (geff may alias gy or be null), gbias[c] = sum_{n,p} geff (gbias may be null) */

@@ -28,6 +28,36 @@ __global__ __launch_bounds__(256) void k_adaptive_pool(const float* __restrict__
     out[(size_t)pl * n + i] = s / (float)((y1 - y0) * (x1 - x0));
 }
 
+// all pyramid levels of one 32x32 level-0 tile (see cc_pyramid_build)
+__global__ __launch_bounds__(256) void k_pyramid_tile(const float* __restrict__ in, float* __restrict__ out, int nlevels,
+                                                      int planes, int H, int W) {
+    __shared__ float tile[32 * 33];
+    const int tw = W / 32;
+    const int ty = blockIdx.x / tw, tx = blockIdx.x - ty * tw;
+    const int pl = blockIdx.y;
+    const float* src = in + (size_t)pl * H * W + (size_t)(ty * 32) * W + tx * 32;
+    {
+        const int r = threadIdx.x >> 3, q = threadIdx.x & 7;        // row 0..31, float4 0..7
+        const float4 v = *(const float4*)(src + (size_t)r * W + 4 * q);
+        float* t = tile + r * 33 + 4 * q;
+        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    }
+    __syncthreads();
+    size_t off = 0;
+    for (int l = 1; l < nlevels; l++) {
+        const int k = 1 << l, n = 32 >> l;              // window size, outputs per tile side
+        const int h = H >> l, w = W >> l;
+        if ((int)threadIdx.x < n * n) {
+            const int oy = threadIdx.x / n, ox = threadIdx.x - oy * n;
+            float s = 0.f;
+            for (int y = 0; y < k; y++)
+                for (int x = 0; x < k; x++) s += tile[(oy * k + y) * 33 + ox * k + x];
+            out[off + (size_t)pl * h * w + (size_t)(ty * n + oy) * w + tx * n + ox] = s / (float)(k * k);
+        }
+        off += (size_t)planes * h * w;
+    }
+}
+
 // ------------------------------------------------------------------ occlusion masks
 // loss_functions.py:343-352 occlusion_masks: occ = sum_c(f_fw + f_bw) > 0.08*(|f_fw|^2 + |f_bw|^2) + 1
 // (signed sum; occ_fw == occ_bw).  Output is (1 - occ), the factor the losses multiply by.
@@ -250,8 +280,17 @@ int cc_adaptive_avg_pool(const float* in, float* out, int planes, int H, int W, 
 
 // levels 1..nlevels-1 of the 2^l box-mean pyramid of `planes` H x W images, each computed from level 0
 // (as the reference does); out_packed holds the levels back to back: [planes, H>>1, W>>1], [planes, H>>2, W>>2] ...
+// H, W multiples of 32 and <= 6 levels: ONE launch, every 32x32 tile of level 0 is read once into LDS and all its
+// descendants are produced from it, each window summed in the reference's row-major order (bit-identical to the
+// per-level kernel); otherwise one k_adaptive_pool launch per level.
 int cc_pyramid_build(const float* level0, float* out_packed, int nlevels, int planes, int H, int W, void* stream) {
     if (nlevels < 1 || planes <= 0) return CC_ERR_ARG;
+    if (nlevels >= 2 && nlevels <= 6 && H % 32 == 0 && W % 32 == 0 && ((uintptr_t)level0 % 16) == 0) {
+        hipLaunchKernelGGL(k_pyramid_tile, dim3((unsigned)((H / 32) * (W / 32)), (unsigned)planes), dim3(256), 0,
+                           (hipStream_t)stream, level0, out_packed, nlevels, planes, H, W);
+        CC_CHECK_LAUNCH();
+        return CC_OK;
+    }
     size_t off = 0;
     for (int l = 1; l < nlevels; l++) {
         const int h = H >> l, w = W >> l;

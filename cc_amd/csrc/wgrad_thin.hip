@@ -293,4 +293,13 @@ bool wgrad_thin_launch(const float* a, const float* x, float* gw, float* ws, int
     return true;
 }
 
+void wgrad_thin_name(int B, int M, int AH, int AW, int Cin, int IH, int IW, int R, int S, int si, int pad, char* out, int cap) {
+    out[0] = 0;
+    const ThinPlan p = plan_thin(B, M, AH, AW, Cin, R, S, si);
+    static const int want_pad[] = {1, 1, 3, 3, 0, 2, 1};
+    static const int tr[] = {3, 3, 2, 2, 1, 3, 4};
+    if (!p.ok || (IW & 3) || pad != want_pad[p.kind]) return;
+    snprintf(out, cap, "k_wgrad_thin<%d, %d, %d, %d>", S, si, pad, tr[p.kind]);
+}
+
 }  // namespace ccint

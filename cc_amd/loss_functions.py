@@ -84,6 +84,17 @@ class _PyramidCache:
         if lv is None:
             src = _f32c(img.detach())
             B, C = src.shape[0], src.shape[1]
+            lvl = next((k for k in range(1, 6) if (H >> k, W >> k) == (h, w)), None)
+            if lvl is not None and H % 32 == 0 and W % 32 == 0:
+                # the whole 2^l pyramid (levels 1..5) of this image in ONE launch: every loss scale will ask for it
+                sizes = [(H >> k, W >> k) for k in range(1, 6)]
+                packed = torch.empty(sum(B * C * a * b for a, b in sizes), device=src.device, dtype=torch.float32)
+                engine().call("cc_pyramid_build", src, packed, 6, B * C, H, W, STREAM)
+                off = 0
+                for a, b in sizes:
+                    ent[2][(a, b)] = packed[off:off + B * C * a * b].view(B, C, a, b)
+                    off += B * C * a * b
+                return ent[2][(h, w)]
             lv = torch.empty(B, C, h, w, device=src.device, dtype=torch.float32)
             engine().call("cc_adaptive_avg_pool", src, lv, B * C, H, W, h, w, STREAM)
             ent[2][(h, w)] = lv

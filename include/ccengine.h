@@ -201,6 +201,14 @@ size_t cc_conv2d_wgrad_ws_bytes(int B, int M, int AH, int AW, int Cin, int R, in
 int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B, int M, int AH, int AW, long a_bs, int Cin,
                     int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, int accumulate,
                     void* stream);
+/* introspection: the name of the device kernel the corresponding entry point dispatches to for this geometry (as it
+ * appears in a rocprofv3 kernel trace; "+splitk" = followed by the split-K epilogue).  name_out_host: HOST char buffer. */
+int cc_conv2d_fwd_kernel(int B, int Cin, int IH, int IW, int Cout, int R, int S, int stride, int pad, int OH, int OW,
+                         void* name_out_host, int cap);
+int cc_conv2d_dgrad_kernel(int B, int K, int OH, int OW, int C, int R, int S, int stride, int pad, int IH, int IW,
+                           int prepacked, void* name_out_host, int cap);
+int cc_conv2d_wgrad_kernel(int B, int M, int AH, int AW, int Cin, int IH, int IW, int R, int S, int si, int pad,
+                           void* name_out_host, int cap);
 size_t cc_act_bwd_ws_bytes(int C);
 /* geff = gy * act'(y);  gbias[c] (+)= sum geff  (either output may be null; geff may alias gy) */
 int cc_act_bwd_bias(const float* gy, const float* y_or_null, float* geff_or_null, float* gbias_or_null, float* ws, int B,

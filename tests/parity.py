@@ -205,10 +205,10 @@ def check_pyramid(dev):
         out = torch.empty(2, 3, h, w, device=dev)
         engine().call("cc_adaptive_avg_pool", xd, out, 6, 64, 96, h, w, STREAM)
         assert float((out.cpu() - ref).abs().max()) < 1e-6
-    packed = torch.empty(6 * (32 * 48 + 16 * 24 + 8 * 12), device=dev)
-    engine().call("cc_pyramid_build", xd, packed, 4, 6, 64, 96, STREAM)
+    packed = torch.empty(6 * (32 * 48 + 16 * 24 + 8 * 12 + 4 * 6 + 2 * 3), device=dev)
+    engine().call("cc_pyramid_build", xd, packed, 6, 6, 64, 96, STREAM)      # one launch: all levels of each 32x32 tile
     off = 0
-    for l in (1, 2, 3):
+    for l in (1, 2, 3, 4, 5):
         h, w = 64 >> l, 96 >> l
         lv = packed[off:off + 6 * h * w].view(2, 3, h, w).cpu()
         assert float((lv - torch.nn.functional.adaptive_avg_pool2d(x, (h, w))).abs().max()) < 1e-6
