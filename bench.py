@@ -299,6 +299,8 @@ def main():
             roof = {"bound": "mfma", "kernel": kn, "achieved": round(ach, 2), "peak": PEAK_MFMA_F32, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_MFMA_F32, 4), "traffic": traffic, "traffic_source": src,
                     "launches": a["launches"], "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2),
+                    # "+splitk": the bracketed C-ABI call is this kernel followed by one k_splitk_epilogue launch
+                    "kernels_per_call": 2 if kn.endswith("+splitk") else 1,
                     "algorithmic_gflop_per_launch": round(a["gflop"] / a["launches"], 3),
                     "algorithmic_bytes_per_launch": round(a["bytes"] / a["launches"]),
                     "ms_per_step": round(a["ms"], 3),

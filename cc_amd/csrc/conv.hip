@@ -294,7 +294,8 @@ __global__ __launch_bounds__(256) void k_repack_table(const long* __restrict__ d
 // TPS = taps per pipeline stage: one barrier (+ DMA wait) per TPS*CK/2*TM*TN MFMAs per wave.  With TPS = 1 a stage is only
 // 32 MFMAs (2 k cycles) and the LDS-read latency + barrier skew at every stage boundary costs ~10-15 %; TPS = 3 (a whole
 // tap row of a 3x3) amortises it 3x for 32 KB more LDS (still two workgroups per CU).
-template <int BM, int CK, int TPS>
+// SPLIT: 0 = whole reduction in this workgroup (fused epilogue), 1 = split-K partial slabs, 2 = decided per class at run time
+template <int BM, int CK, int TPS, int SPLIT>
 __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
     constexpr int WM = (BM >= 64) ? BM / 2 : 32;
     constexpr int TM = WM / 32;
@@ -449,7 +450,7 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
         const int ty = ty0 + row0 + b;
         if (ty >= g.OHt || tx >= g.OWt) continue;
         const long pix = (long)(g.oy0 + g.so * ty) * g.OW + (g.ox0 + g.so * tx);
-        if (g.nsplit > 1) {
+        if (SPLIT == 1 || (SPLIT == 2 && g.nsplit > 1)) {
             // partial slabs are dense over the LATTICE: [split][n][m][ty*OWt + tx]
             const int HWt = g.OHt * g.OWt;
             float* pb = g.part + (long)blockIdx.z * g.part_stride + ((long)n * g.M) * HWt + (long)ty * g.OWt + tx;
@@ -479,9 +480,9 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
     }
 }
 
-template <int BM, int CK, int TPS>
+template <int BM, int CK, int TPS, int SPLIT>
 __global__ __launch_bounds__(256) void k_conv_patch(CP g) {
-    conv_patch_body<BM, CK, TPS>(g, (int)blockIdx.x);
+    conv_patch_body<BM, CK, TPS, SPLIT>(g, (int)blockIdx.x);
 }
 
 // The (up to) four output-parity classes of a stride-2 data-gradient / transposed convolution in ONE launch:
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(256) void k_conv_patch_multi(CPM a) {
         if (q + 1 < a.n && (int)blockIdx.x >= a.bx_end[q]) { k = q + 1; first = a.bx_end[q]; }
     const CP& g = a.c[k];
     if ((int)blockIdx.z >= g.nsplit) return;
-    conv_patch_body<BM, CK, TPS>(g, (int)blockIdx.x - first);
+    conv_patch_body<BM, CK, TPS, 2>(g, (int)blockIdx.x - first);
 }
 
 // y[lattice pixel] = act(bias + res + sum_k part[k])  (second, deterministic stage of split-K)
@@ -570,9 +571,19 @@ struct ConvPlan {
     size_t smem, wp_floats, part_floats;
 };
 
+static int env_int_early(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 inline ConvPlan plan_conv(const GG& g) {
     ConvPlan p = {};
     p.bm = pick_bm_fwd(g.M);
+    {   // few pixel tiles: halve the channel tile before resorting to split-K (no partial slabs, no epilogue launch)
+        const long tiles = (long)g.B * ((g.OWt + TW - 1) / TW) * ((g.OHt + TH - 1) / TH);
+        const int thr = env_int_early("CC_CONV_BM64_BELOW", 0);
+        if (p.bm == 128 && tiles * ((g.M + 127) / 128) < thr) p.bm = 64;
+    }
     const int ylast = g.dy0 + (g.Rt - 1) * g.dstep, xlast = g.dx0 + (g.St - 1) * g.dstep;
     p.ymin = g.dy0 < ylast ? g.dy0 : ylast;
     p.xmin = g.dx0 < xlast ? g.dx0 : xlast;
@@ -605,7 +616,7 @@ inline ConvPlan plan_conv(const GG& g) {
     p.nsplit = 1;
     p.cps = nchunk;
     if (blocks < 256 && nchunk >= 4 && !(g.so != 1 && dbg_flag_early("CC_DBG_NO_PARITY_SPLIT"))) {
-        long want = (512 + blocks - 1) / blocks;
+        long want = (env_int_early("CC_CONV_SPLIT_TARGET", 512) + blocks - 1) / blocks;
         if (want > nchunk / 2) want = nchunk / 2;
         if (want > 32) want = 32;
         if (want >= 2) {
@@ -1253,15 +1264,21 @@ inline void launch_gg_flat(const GG& g, hipStream_t s) {
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_gemm<32>), grid, dim3(256), 0, s, g);
 }
 
-template <int BM, int CK, int TPS>
-inline void launch_patch(const CP& c, dim3 grid, size_t smem, hipStream_t s) {
+template <int BM, int CK, int TPS, int SPLIT>
+inline void launch_patch1(const CP& c, dim3 grid, size_t smem, hipStream_t s) {
     static bool big_lds_enabled = false;       // > 64 KB of dynamic LDS has to be requested once per kernel
     if (smem > 64 * 1024 && !big_lds_enabled) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_patch<BM, CK, TPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_patch<BM, CK, TPS, SPLIT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         big_lds_enabled = true;
     }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_patch<BM, CK, TPS>), grid, dim3(256), smem, s, c);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_patch<BM, CK, TPS, SPLIT>), grid, dim3(256), smem, s, c);
+}
+
+template <int BM, int CK, int TPS>
+inline void launch_patch(const CP& c, dim3 grid, size_t smem, hipStream_t s) {
+    if (c.nsplit > 1) launch_patch1<BM, CK, TPS, 1>(c, grid, smem, s);
+    else launch_patch1<BM, CK, TPS, 0>(c, grid, smem, s);
 }
 
 template <int BM, int CK, int TPS>
@@ -1737,8 +1754,8 @@ int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B,
 /* ---- introspection (bench.py groups its per-call timings by the kernel a call dispatches to) */
 static void patch_name(const ConvPlan& p, bool multi, char* out, int cap) {
     if (!p.use_patch) { snprintf(out, cap, "k_gather_gemm<%d>", pick_bm(p.Mpad ? p.Mpad : 32)); return; }
-    snprintf(out, cap, "%s<%d, %d, %d>%s", multi ? "k_conv_patch_multi" : "k_conv_patch", p.bm, p.ck, p.tps,
-             p.nsplit > 1 ? "+splitk" : "");
+    if (multi) snprintf(out, cap, "k_conv_patch_multi<%d, %d, %d>%s", p.bm, p.ck, p.tps, p.nsplit > 1 ? "+splitk" : "");
+    else snprintf(out, cap, "k_conv_patch<%d, %d, %d, %d>%s", p.bm, p.ck, p.tps, p.nsplit > 1 ? 1 : 0, p.nsplit > 1 ? "+splitk" : "");
 }
 
 int cc_conv2d_fwd_kernel(int B, int Cin, int IH, int IW, int Cout, int R, int S, int stride, int pad, int OH, int OW,
