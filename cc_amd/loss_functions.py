@@ -111,16 +111,30 @@ def _scaled_intrinsics(intrinsics, intrinsics_inv, downscale):
     return K_s, Kinv_s
 
 
-def _scale_grads(stash, gout):
-    out = []
-    for g in stash:
-        if g is None:
-            out.append(None)
-        else:
-            r = torch.empty_like(g)
-            engine().call("cc_scale_by_scalar", g, _f32c(gout).reshape(1), r, g.numel(), STREAM)
-            out.append(r)
-    return out
+class _GradArena:
+    """The gradients a fused loss stashes in forward live in ONE flat buffer (one view per differentiable input, same
+    shape), so that backward is ONE `* grad_output` launch for the whole loss instead of one per tensor."""
+
+    def __init__(self, inputs, need):
+        ref = next(t for t in inputs if torch.is_tensor(t))
+        sizes = [t.numel() if (torch.is_tensor(t) and nd) else 0 for t, nd in zip(inputs, need)]
+        self.flat = torch.empty(max(sum(sizes), 1), device=ref.device, dtype=torch.float32)
+        self.spans, off = [], 0
+        for t, n in zip(inputs, sizes):
+            self.spans.append((off, n, tuple(t.shape)) if n else None)
+            off += n
+
+    def view(self, i, flat=None):
+        sp = self.spans[i]
+        if sp is None:
+            return None
+        return (self.flat if flat is None else flat)[sp[0]:sp[0] + sp[1]].view(sp[2])
+
+    def scaled(self, gout):
+        """-> [grad_i * gout or None] (fresh storage: the arena itself stays valid for a second backward)."""
+        out = torch.empty_like(self.flat)
+        engine().call("cc_scale_by_scalar", self.flat, _f32c(gout).reshape(1), out, self.flat.numel(), STREAM)
+        return [self.view(i, out) for i in range(len(self.spans))]
 
 
 # ----------------------------------------------------------------------------- small public helpers
@@ -182,12 +196,13 @@ class _PhotoCfg:
         self.__dict__.update(kw)
 
 
-def _photo_term(E, tgt_s, warped, mask_a, a_bs, mask_b, b_bs, gmask, gm_bs, want_grad, cfg, loss_acc, nan_flag):
+def _photo_term(E, tgt_s, warped, mask_a, a_bs, mask_b, b_bs, gmask, gm_bs, want_grad, cfg, loss_acc, nan_flag, scale=None):
     """One (scale, reference) term: fused forward (+ adjoint maps).  Returns the scratch needed by the adjoint."""
     B, _, h, w = tgt_s.shape
     nblk = E.call("cc_ssim_num_blocks", B, h, w)
     partials = _empty(nblk * 4, tgt_s)
-    scale = _empty(1, tgt_s)
+    if scale is None:
+        scale = _empty(1, tgt_s)
     if want_grad:
         adj = [torch.empty_like(warped) for _ in range(4)]
     else:
@@ -219,9 +234,13 @@ class _PhotoRigidFn(torch.autograd.Function):
             P_full = [projection_matrix(pose_l[:, r], K_d, cfg.rotation_mode) for r in range(R)]
         P_full_c = [_f32c(p.detach()) for p in P_full]
         direct_pose = cfg.rotation_mode == 'euler'      # HIP pose->P adjoint instead of a torch graph over 17 tiny ops
-        gpose_acc = torch.zeros_like(pose_l.detach(), dtype=torch.float32) if (want_grad and need[4] and direct_pose) else None
+        # stash layout = the differentiable inputs: pose, refs (no gradient), depths, masks
+        arena = _GradArena([pose] + list(rest), [need[4]] + [False] * R + list(need[5 + R:]))
+        gpose_acc = None
+        if want_grad and need[4] and direct_pose:
+            gpose_acc = arena.view(0).zero_()
         K_c = _f32c(K_d)
-        gdepths, gmasks, gP_all, P_all = [], [], [], []
+        gP_all, P_all = [], []
         for s in range(S):
             d4 = depths[s]
             assert masks[s] is None or d4.size()[2:] == masks[s].size()[2:]
@@ -235,8 +254,9 @@ class _PhotoRigidFn(torch.autograd.Function):
             K_s, Kinv_s = _scaled_intrinsics(K_d, intrinsics_inv.detach(), downscale)
             Kinv_s = _f32c(Kinv_s)
             m = None if masks[s] is None else _f32c(masks[s].detach())
-            gd = torch.zeros_like(d) if want_grad else None
-            gm = torch.empty_like(m) if (m is not None and want_grad) else None
+            gd_all = torch.empty((R,) + tuple(d.shape), device=dev, dtype=torch.float32) if (want_grad and need[5 + R + s]) else None
+            gm = arena.view(1 + R + S + s) if (m is not None and want_grad) else None
+            scales = _empty(R, tgt_s)
             for r in range(R):
                 ref_s = pyramid_cache.get(refs[r], h, w)
                 if direct_pose:
@@ -251,19 +271,17 @@ class _PhotoRigidFn(torch.autograd.Function):
                 adj, scale = _photo_term(
                     E, tgt_s, warped, no.view(-1)[r * HW:], 4 * HW,
                     None if m is None else m.view(-1)[r * HW:], 4 * HW,
-                    None if gm is None else gm.view(-1)[r * HW:], 4 * HW, want_grad, cfg, loss_acc, nan_flag)
+                    None if gm is None else gm.view(-1)[r * HW:], 4 * HW, want_grad, cfg, loss_acc, nan_flag,
+                    scale=scales[r:r + 1])
                 if want_grad:
                     gw = torch.empty_like(warped)
                     E.call("cc_ssim_photo_bwd", adj[0], adj[1], adj[2], adj[3], tgt_s, warped, scale, gw, 0, gauss13_ptr(),
                            B, h, w, STREAM)
-                    gd_r = torch.empty_like(d)
+                    gd_r = gd_all[r] if gd_all is not None else torch.empty_like(d)
                     gP = torch.empty_like(Pc)
                     ws = _empty(E.call("cc_warp_partials_bytes", B, h, w) // 4, d)
                     E.call("cc_inverse_warp_bwd", gw, ref_s, d, Pc, Kinv_s, gd_r, gP, None, ws, B, 3, h, w, cfg.border,
                            cfg.ac, STREAM)
-                    gd += gd_r
-                    if gm is not None:
-                        gm[:, r] *= scale
                     if gpose_acc is not None:
                         pv = pose_l.detach()[:, r]
                         E.call("cc_pose_proj_bwd", gP, pv.data_ptr(), pv.stride(0), K_c, gpose_acc[:, r].data_ptr(),
@@ -271,19 +289,20 @@ class _PhotoRigidFn(torch.autograd.Function):
                     else:
                         gP_all.append(gP)
                         P_all.append(P)
-            gdepths.append(None if gd is None else gd.unsqueeze(1))
-            gmasks.append(gm)
-        gpose = gpose_acc
-        if want_grad and need[4] and gpose is None:
-            gpose = torch.autograd.grad(P_all, pose_l, gP_all)[0]
+            if gd_all is not None:       # sum over the reference frames in the reference's order (r = 0..3), one launch
+                torch.sum(gd_all, dim=0, out=arena.view(1 + R + s).view(d.shape))
+            if gm is not None:           # the per-reference normaliser (known only after the reduction), one launch
+                gm *= scales.view(1, R, 1, 1)
+        if want_grad and need[4] and gpose_acc is None:
+            arena.view(0).copy_(torch.autograd.grad(P_all, pose_l, gP_all)[0])
         _register_nan_flag(nan_flag)
-        ctx.stash = [gpose] + [None] * R + gdepths + gmasks
+        ctx.arena = arena
         ctx.need = need
         return loss_acc.reshape(())
 
     @staticmethod
     def backward(ctx, gout):
-        grads = _scale_grads(ctx.stash, gout)
+        grads = ctx.arena.scaled(gout)
         need = ctx.need
         out = [None, None, None, None] + grads
         return tuple(g if (g is not None and need[i]) else None for i, g in enumerate(out))
@@ -320,8 +339,7 @@ class _PhotoFlowFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         want_grad = any(need)
         loss_acc, nan_flag = _zeros1(tgt_img), _zeros1(tgt_img)
-        gflows = [[None] * S for _ in range(R)]
-        gmasks = []
+        arena = _GradArena(list(rest), [False] * R + list(need[2 + R:]))      # refs (no gradient), flows, masks
         for s in range(S):
             fl = [_f32c(flows[i][s].detach()) for i in range(R)]
             B, _, h, w = fl[0].shape
@@ -332,7 +350,10 @@ class _PhotoFlowFn(torch.autograd.Function):
             E.call("cc_flow_noocc", fl[0], fl[1], no, B, h, w, STREAM)        # occlusion_masks(flow[0], flow[1]), :70
             m = None if masks[s] is None else _f32c(masks[s].detach())
             MC = 0 if m is None else m.shape[1]
-            gm = torch.empty_like(m) if (m is not None and want_grad) else None
+            gm = arena.view(R + R * S + s) if (m is not None and want_grad) else None
+            if gm is None and m is not None and want_grad:
+                gm = torch.empty_like(m)                      # the mask itself needs no gradient: scratch for the kernel
+            scales = torch.ones(max(MC, R), device=tgt_s.device, dtype=torch.float32) if MC > R else _empty(R, tgt_s)
             for i in range(R):
                 ref_s = pyramid_cache.get(refs[i], h, w)
                 warped = torch.empty_like(ref_s)
@@ -340,27 +361,28 @@ class _PhotoFlowFn(torch.autograd.Function):
                 adj, scale = _photo_term(
                     E, tgt_s, warped, no, HW,
                     None if m is None else m.view(-1)[i * HW:], MC * HW,
-                    None if gm is None else gm.view(-1)[i * HW:], MC * HW, want_grad, cfg, loss_acc, nan_flag)
+                    None if gm is None else gm.view(-1)[i * HW:], MC * HW, want_grad, cfg, loss_acc, nan_flag,
+                    scale=scales[i:i + 1])
                 if want_grad:
                     gw = torch.empty_like(warped)
                     E.call("cc_ssim_photo_bwd", adj[0], adj[1], adj[2], adj[3], tgt_s, warped, scale, gw, 0, gauss13_ptr(),
                            B, h, w, STREAM)
-                    gf = torch.empty_like(fl[i])
+                    gf = arena.view(R + i * S + s)
+                    if gf is None:
+                        gf = torch.empty_like(fl[i])
                     E.call("cc_flow_warp_bwd", gw, ref_s, fl[i], gf, None, B, 3, h, w, 0, cfg.ac, STREAM)
-                    gflows[i][s] = gf
-                    if gm is not None:
-                        gm[:, i] *= scale
-            if gm is not None and MC > R:
-                gm[:, R:] = 0
-            gmasks.append(gm)
+            if gm is not None:
+                if MC > R:
+                    gm[:, R:] = 0
+                gm *= scales[:MC].view(1, MC, 1, 1)           # per-reference normalisers, one launch
         _register_nan_flag(nan_flag)
-        ctx.stash = [None] * R + [g for i in range(R) for g in gflows[i]] + gmasks
+        ctx.arena = arena
         ctx.need = need
         return loss_acc.reshape(())
 
     @staticmethod
     def backward(ctx, gout):
-        grads = _scale_grads(ctx.stash, gout)
+        grads = ctx.arena.scaled(gout)
         need = ctx.need
         out = [None, None] + grads
         return tuple(g if (g is not None and need[i]) else None for i, g in enumerate(out))
@@ -402,18 +424,15 @@ class _PerScaleFn(torch.autograd.Function):
     def forward(ctx, launch, *preds):
         need = ctx.needs_input_grad
         loss_acc = _zeros1(preds[0])
-        stash = []
+        arena = _GradArena(list(preds), list(need[1:]))
         for s, p in enumerate(preds):
-            pc = _f32c(p.detach())
-            g = torch.empty_like(pc) if need[1 + s] else None
-            launch(s, pc, g, loss_acc)
-            stash.append(g)
-        ctx.stash = stash
+            launch(s, _f32c(p.detach()), arena.view(s), loss_acc)
+        ctx.arena = arena
         return loss_acc.reshape(())
 
     @staticmethod
     def backward(ctx, gout):
-        return (None,) + tuple(_scale_grads(ctx.stash, gout))
+        return (None,) + tuple(ctx.arena.scaled(gout))
 
 
 def explainability_loss(mask):
@@ -506,24 +525,23 @@ class _ConsensusBCEFn(torch.autograd.Function):
         E = engine()
         need = ctx.needs_input_grad
         loss_acc = _zeros1(masks[0])
-        stash = []
+        arena = _GradArena(list(masks), list(need[1:1 + S]))
         for s in range(S):
             e = _f32c(masks[s].detach())
             B, C, h, w = e.shape
             assert C == 4
-            g = torch.empty_like(e) if need[1 + s] else None
+            g = arena.view(s)
             nb = E.call("cc_elem_num_blocks", h * w) * B
             E.call("cc_consensus_bce_fwd_bwd", e, _f32c(cb[s].detach()), _f32c(cf[s].detach()), _f32c(tb[s].detach()),
                    _f32c(tf[s].detach()), g, _empty(nb, e), loss_acc, float(cfg.THRESH), float(cfg.wbce), 1.0, B, h, w,
                    STREAM)
-            stash.append(g)
-        ctx.stash = stash
+        ctx.arena = arena
         ctx.n_rest = len(rest)
         return loss_acc.reshape(())
 
     @staticmethod
     def backward(ctx, gout):
-        g = _scale_grads(ctx.stash, gout)
+        g = ctx.arena.scaled(gout)
         return (None,) + tuple(g) + (None,) * (ctx.n_rest - len(g))
 
 
