@@ -105,6 +105,157 @@ __global__ __launch_bounds__(256) void k_corr_bwd_f2(const float* __restrict__ g
     g2[((size_t)b * C + c) * HW + p] = acc / (float)C;
 }
 
+// ---- W % 4 == 0 variants: every work-item owns 4 consecutive pixels (and 4 channels in the backward kernels), so the
+// f2 / f1 / gout window of a row is read as three aligned float4 and reused from registers for all 9 dx (the scalar
+// kernels above issue one load per FMA).  Same summation order per output element -> bit-identical results.
+__device__ __forceinline__ void load12(const float* __restrict__ row, int x, int W, float (&v)[12]) {
+    // row[x-4 .. x+7], zero outside [0, W); x % 4 == 0 and W % 4 == 0 -> each quad is entirely inside or outside
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int xx = x - 4 + 4 * q;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (xx >= 0 && xx < W) t = *(const float4*)(row + xx);
+        v[4 * q + 0] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_corr_fwd4(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                   float* __restrict__ out, const int* __restrict__ chan_of_disp, int C,
+                                                   int H, int W, int out_cstride_total, int out_coffset) {
+    const int HW = H * W, W4 = W >> 2;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int dy = blockIdx.y, b = blockIdx.z;
+    if (t >= H * W4) return;
+    const int y = t / W4, x = (t - y * W4) * 4;
+    const int p = y * W + x;
+    const int yy = y + dy - R;
+    float acc[PATCH][4];
+#pragma unroll
+    for (int j = 0; j < PATCH; j++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[j][k] = 0.f;
+    if (yy >= 0 && yy < H) {
+        const float* a = f1 + (size_t)b * C * HW + p;
+        const float* bb = f2 + (size_t)b * C * HW + yy * W;
+        for (int c = 0; c < C; c++) {
+            const float4 av = *(const float4*)(a + (size_t)c * HW);
+            const float a4[4] = {av.x, av.y, av.z, av.w};
+            float v[12];
+            load12(bb + (size_t)c * HW, x, W, v);
+#pragma unroll
+            for (int j = 0; j < PATCH; j++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc[j][k] = fmaf(a4[k], v[k + j], acc[j][k]);      // x+k + j-4 -> v[k+j]
+        }
+    }
+    const float inv = 1.f / (float)C;
+#pragma unroll
+    for (int j = 0; j < PATCH; j++) {
+        const int d = dy * PATCH + j;
+        const int ch = (chan_of_disp ? chan_of_disp[d] : d) + out_coffset;
+        *(float4*)(out + ((size_t)b * out_cstride_total + ch) * HW + p) =
+            make_float4(acc[j][0] * inv, acc[j][1] * inv, acc[j][2] * inv, acc[j][3] * inv);
+    }
+}
+
+// 4 pixels x 4 channels per work-item
+__global__ __launch_bounds__(256) void k_corr_bwd_f1_4(const float* __restrict__ gout, const float* __restrict__ f2,
+                                                       float* __restrict__ g1, const int* __restrict__ chan_of_disp, int C,
+                                                       int H, int W, int g_cstride_total, int g_coffset, int accumulate) {
+    const int HW = H * W, W4 = W >> 2;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int c0 = blockIdx.y * 4, b = blockIdx.z;
+    if (t >= H * W4) return;
+    const int y = t / W4, x = (t - y * W4) * 4;
+    const int p = y * W + x;
+    const float* g = gout + ((size_t)b * g_cstride_total + g_coffset) * HW + p;
+    float acc[4][4];
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[cc][k] = 0.f;
+    for (int dy = 0; dy < PATCH; dy++) {
+        const int yy = y + dy - R;
+        if (yy < 0 || yy >= H) continue;
+        float v[4][12];
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) {
+            const int c = (c0 + cc < C) ? c0 + cc : C - 1;
+            load12(f2 + ((size_t)b * C + c) * HW + yy * W, x, W, v[cc]);
+        }
+#pragma unroll
+        for (int dx = 0; dx < PATCH; dx++) {
+            const int d = dy * PATCH + dx;
+            const int ch = chan_of_disp ? chan_of_disp[d] : d;
+            const float4 gv = *(const float4*)(g + (size_t)ch * HW);
+            const float g4[4] = {gv.x, gv.y, gv.z, gv.w};
+            // the scalar kernel skips taps outside the row (xx < 0 || xx >= W): load12 returns 0 there, and
+            // fmaf(g, 0, acc) == acc exactly, so the chain is the same
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc[cc][k] = fmaf(g4[k], v[cc][k + dx], acc[cc][k]);
+        }
+    }
+    const float invC = (float)C;
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++) {
+        if (c0 + cc >= C) break;
+        float* o = g1 + ((size_t)b * C + c0 + cc) * HW + p;
+        float4 r = make_float4(acc[cc][0] / invC, acc[cc][1] / invC, acc[cc][2] / invC, acc[cc][3] / invC);
+        if (accumulate) {
+            const float4 old = *(const float4*)o;
+            r.x = old.x + r.x; r.y = old.y + r.y; r.z = old.z + r.z; r.w = old.w + r.w;
+        }
+        *(float4*)o = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_corr_bwd_f2_4(const float* __restrict__ gout, const float* __restrict__ f1,
+                                                       float* __restrict__ g2, const int* __restrict__ chan_of_disp, int C,
+                                                       int H, int W, int g_cstride_total, int g_coffset) {
+    const int HW = H * W, W4 = W >> 2;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int c0 = blockIdx.y * 4, b = blockIdx.z;
+    if (t >= H * W4) return;
+    const int y = t / W4, x = (t - y * W4) * 4;
+    const int p = y * W + x;
+    const float* g = gout + ((size_t)b * g_cstride_total + g_coffset) * HW;
+    float acc[4][4];
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[cc][k] = 0.f;
+    for (int dy = 0; dy < PATCH; dy++) {
+        const int ys = y - dy + R;
+        if (ys < 0 || ys >= H) continue;
+        float v[4][12];                         // f1[c][ys][x-4 .. x+7]
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) {
+            const int c = (c0 + cc < C) ? c0 + cc : C - 1;
+            load12(f1 + ((size_t)b * C + c) * HW + ys * W, x, W, v[cc]);
+        }
+#pragma unroll
+        for (int dx = 0; dx < PATCH; dx++) {
+            const int d = dy * PATCH + dx;
+            const int ch = chan_of_disp ? chan_of_disp[d] : d;
+            float gv[12];                       // gout[ch][ys][x-4 .. x+7]; source pixel xs = x + k - dx + 4 -> index k + 8 - dx
+            load12(g + (size_t)ch * HW + ys * W, x, W, gv);
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc[cc][k] = fmaf(gv[k + 8 - dx], v[cc][k + 8 - dx], acc[cc][k]);
+        }
+    }
+    const float invC = (float)C;
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++) {
+        if (c0 + cc >= C) break;
+        *(float4*)(g2 + ((size_t)b * C + c0 + cc) * HW + p) =
+            make_float4(acc[cc][0] / invC, acc[cc][1] / invC, acc[cc][2] / invC, acc[cc][3] / invC);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -112,8 +263,13 @@ extern "C" {
 int cc_corr9x9_fwd(const float* f1, const float* f2, float* out, const int* chan_of_disp_or_null, int B, int C, int H,
                    int W, int out_channels_total, int out_channel_offset, void* stream) {
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || out_channel_offset + ND > out_channels_total) return CC_ERR_ARG;
-    hipLaunchKernelGGL(k_corr_fwd, dim3((H * W + 255) / 256, PATCH, B), dim3(256), 0, (hipStream_t)stream, f1, f2, out,
-                       chan_of_disp_or_null, C, H, W, out_channels_total, out_channel_offset);
+    const bool v4 = (W % 4 == 0) && (((uintptr_t)f1 | (uintptr_t)f2 | (uintptr_t)out) % 16 == 0);
+    if (v4)
+        hipLaunchKernelGGL(k_corr_fwd4, dim3((H * (W / 4) + 255) / 256, PATCH, B), dim3(256), 0, (hipStream_t)stream, f1, f2, out,
+                           chan_of_disp_or_null, C, H, W, out_channels_total, out_channel_offset);
+    else
+        hipLaunchKernelGGL(k_corr_fwd, dim3((H * W + 255) / 256, PATCH, B), dim3(256), 0, (hipStream_t)stream, f1, f2, out,
+                           chan_of_disp_or_null, C, H, W, out_channels_total, out_channel_offset);
     CC_CHECK_LAUNCH();
     return CC_OK;
 }
@@ -123,6 +279,18 @@ int cc_corr9x9_bwd(const float* gout, const float* f1, const float* f2, float* g
                    int g_channel_offset, int accumulate_g1, void* stream) {
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || g_channel_offset + ND > g_channels_total) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    const bool v4 = (W % 4 == 0) &&
+                    (((uintptr_t)gout | (uintptr_t)f1 | (uintptr_t)f2 | (uintptr_t)g1 | (uintptr_t)g2_or_null) % 16 == 0);
+    if (v4) {
+        dim3 g4((H * (W / 4) + 255) / 256, (C + 3) / 4, B);
+        hipLaunchKernelGGL(k_corr_bwd_f1_4, g4, dim3(256), 0, s, gout, f2, g1, chan_of_disp_or_null, C, H, W, g_channels_total,
+                           g_channel_offset, accumulate_g1);
+        if (g2_or_null)
+            hipLaunchKernelGGL(k_corr_bwd_f2_4, g4, dim3(256), 0, s, gout, f1, g2_or_null, chan_of_disp_or_null, C, H, W,
+                               g_channels_total, g_channel_offset);
+        CC_CHECK_LAUNCH();
+        return CC_OK;
+    }
     dim3 g((H * W + 255) / 256, C, B);
     hipLaunchKernelGGL(k_corr_bwd_f1, g, dim3(256), 0, s, gout, f2, g1, chan_of_disp_or_null, C, H, W, g_channels_total,
                        g_channel_offset, accumulate_g1);

@@ -423,3 +423,33 @@ def check_convs(dev, cases=CONV_CASES, tcases=CONVT_CASES, tol=2e-5, seed=0, pre
             assert max(errs) < tol, ((B, Cin, H, W, Cout, k, st, pad, op, act), ps, errs)
             ops.packs.invalidate()
     ops.packs.reset()
+
+
+def check_corr(dev, cases=((2, 8, 6, 12), (1, 5, 7, 13), (2, 12, 5, 8), (1, 33, 9, 20))):
+    """9x9 cost volume (Back2Future): plain `correlate` and the fused pair with the idx_fwd / idx_bwd channel
+    permutations, forward and all gradients, vs the oracle; W % 4 == 0 runs the register-blocked kernels, other widths
+    the scalar ones."""
+    from cc_amd import ops
+    from oracle.corr import correlate9
+    idx = [k for n in range(80, 71, -1) for k in range(n, -1, -9)]          # models/back2future.py:56-57
+    idx_b = list(reversed(idx))
+    g = torch.Generator().manual_seed(3)
+    for (B, C, H, W) in cases:
+        a0, b0, c0 = (torch.randn(B, C, H, W, generator=g) for _ in range(3))
+        ad, bd, cd = leaf(a0, dev), leaf(b0, dev), leaf(c0, dev)
+        ac, bc, cc_ = leaf(a0, "cpu"), leaf(b0, "cpu"), leaf(c0, "cpu")
+        o = ops.correlate(ad, bd)
+        r = correlate9(ac, bc)
+        assert rel(o, r) < 2e-6, ("correlate", (B, C, H, W), rel(o, r))
+        go = torch.randn(r.shape, generator=g)
+        g1 = torch.autograd.grad(o, [ad, bd], go.to(dev))
+        g0 = torch.autograd.grad(r, [ac, bc], go)
+        assert max(rel(x, y) for x, y in zip(g1, g0)) < 5e-6, ("correlate grads", (B, C, H, W))
+        o = ops.correlation_pair(ad, bd, cd, idx, idx_b)
+        r = torch.cat((correlate9(ac, bc).index_select(1, torch.tensor(idx)),
+                       correlate9(ac, cc_).index_select(1, torch.tensor(idx_b))), 1)
+        assert rel(o, r) < 2e-6, ("pair", (B, C, H, W), rel(o, r))
+        go = torch.randn(r.shape, generator=g)
+        g1 = torch.autograd.grad(o, [ad, bd, cd], go.to(dev))
+        g0 = torch.autograd.grad(r, [ac, bc, cc_], go)
+        assert max(rel(x, y) for x, y in zip(g1, g0)) < 5e-6, ("pair grads", (B, C, H, W), [rel(x, y) for x, y in zip(g1, g0)])

@@ -57,3 +57,7 @@ def test_convs_thin_wgrad(monkeypatch):
     monkeypatch.setenv("CC_WGRAD_THIN_MINPIX", "0")      # route the small test maps through wgrad_thin.hip
     monkeypatch.setenv("CC_WGRAD_THIN_UPB", "8")
     parity.check_convs("cpu", cases=parity.CONV_CASES_THIN)
+
+
+def test_cost_volume():
+    parity.check_corr("cpu")

@@ -74,3 +74,8 @@ def test_convs_full_size_thin_layers():
              (2, 15, 256, 832, 16, 7, 2, 3, "relu", True, False), (2, 3, 256, 832, 16, 3, 2, 1, "lrelu", True, False),
              (2, 32, 128, 416, 32, 7, 1, 3, "relu", True, False)]
     parity.check_convs("cuda", cases=cases, tcases=[(2, 48, 64, 208, 16, 4, 2, 1, 0, "relu")], tol=5e-5)
+
+
+def test_cost_volume():
+    parity.check_corr("cuda")
+    parity.check_corr("cuda", cases=((2, 32, 64, 208), (2, 196, 8, 26)))
