@@ -27,11 +27,16 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// waves per workgroup.  Measured on the 16->16 3x3 256x832 layer (tools/gpu_thin_ablate.sh): full kernel 73 us, no-MFMA build
+// 69 us, no-load build 45 us -> bound by its load path (253 MB L1->L2 requests for 109 MB of unique data: every X row is
+// requested once per tap row); 8 waves per workgroup, more/smaller workgroups and the XCD swizzle below all left it unchanged.
+constexpr int THIN_NW = 4;
+
 struct WT {
     const float* a; const float* x; float* ws;
     int B, M, AH, AW; long a_bs;
     int Cin, IH, IW; long x_bs;
-    int R, nxc, units, upb, npb, ngc, ngt;
+    int R, nxc, units, upb, npb, ngc, ngt, swz;
 };
 
 template <int S, int SI, int PAD, int TR>
@@ -42,8 +47,10 @@ struct ThinCfg {
     static constexpr int TS = TR * S;
 };
 
-template <int S, int SI, int PAD, int TR>
-__global__ __launch_bounds__(256) void k_wgrad_thin(WT g) {
+// DBG (ablation builds of the 3x3/s1 kernel only, CC_WGRAD_THIN_DBG): 1 = no MFMAs (loads + masks), 2 = no loads after the
+// first unit (MFMAs + masks on stale registers); results are wrong by construction.
+template <int S, int SI, int PAD, int TR, int DBG = 0>
+__global__ __launch_bounds__(64 * THIN_NW) void k_wgrad_thin(WT g) {
     typedef ThinCfg<S, SI, PAD, TR> C;
     constexpr int PQ = C::PQ, NQ = C::NQ, TS = C::TS;
     __shared__ float red[TS * 256];
@@ -66,48 +73,66 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(WT g) {
 #pragma unroll
         for (int s = 0; s < S; s++) acc[tr][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int u0 = blockIdx.x * g.upb;
+    // XCD-aware range assignment: workgroups are dealt round-robin to the 8 XCDs (private L2 each); give XCD k the k-th
+    // CONTIGUOUS eighth of the unit ranges so that the halo rows two neighbouring ranges share are fetched by ONE L2
+    // (npb is a multiple of 8; blockIdx.x % 8 is the XCD for every blockIdx.y)
+    const int pb = (g.swz ? ((int)(blockIdx.x & 7) * (g.npb >> 3) + (int)(blockIdx.x >> 3)) : (int)blockIdx.x);
+    const int u0 = pb * g.upb;
     const int u1 = (u0 + g.upb < g.units) ? (u0 + g.upb) : g.units;
 
     float4 An;
     float4 Wn[TR][NQ];
-    // issue the loads of unit u (clamped addresses: always in bounds, the padding mask is applied at use)
-    auto issue = [&](int u, float4& A, float4 (&W)[TR][NQ]) {
-        const int row = u / g.nxc, xc = u - row * g.nxc;
-        const int b = row / g.AH, y = row - b * g.AH;
+    // unit position (image b, row y, 16-pixel chunk xc): decoded once, then advanced incrementally on the scalar unit
+    // (per-unit integer divisions cost ~190 dependent SALU instructions = more issue time than the 36 MFMAs)
+    int nb, ny, nxcpos;
+    {
+        const int u = u0 + wave;
+        const int row = u / g.nxc;
+        nxcpos = u - row * g.nxc;
+        nb = row / g.AH;
+        ny = row - nb * g.AH;
+    }
+    // issue the loads of unit (b, y, xc) (clamped addresses: always in bounds, the padding mask is applied at use)
+    auto issue = [&](int b, int y, int xc, float4& A, float4 (&W)[TR][NQ]) {
         const int x0 = xc * 16 + 4 * k;
         const int xa = (x0 < g.AW) ? x0 : 0;
-        A = *(const float4*)(abase + (long)b * g.a_bs + (long)y * g.AW + xa);
-        const float* xb = xbase + (long)b * g.x_bs;
+        // 32-bit element offsets (the host side only takes this path for tensors below 2^31 elements)
+        A = *(const float4*)(abase + (unsigned)(b * (int)g.a_bs + y * g.AW + xa));
+        const unsigned xb = (unsigned)(b * (int)g.x_bs);
 #pragma unroll
         for (int tr = 0; tr < TR; tr++) {
             int iy = y * SI + r0 + tr - PAD;
             iy = iy < 0 ? 0 : (iy >= g.IH ? g.IH - 1 : iy);
-            const float* xr = xb + (long)iy * g.IW;
+            const unsigned xr = xb + (unsigned)(iy * g.IW);
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
                 int col = SI * x0 - 4 * PQ + 4 * q;
                 col = (col < 0 || col >= g.IW) ? 0 : col;
-                W[tr][q] = *(const float4*)(xr + col);
+                W[tr][q] = *(const float4*)(xbase + (xr + (unsigned)col));
             }
         }
     };
 
     int u = u0 + wave;
     if (u < u1) {
-        issue(u, An, Wn);
-        for (; u < u1; u += 4) {
+        issue(nb, ny, nxcpos, An, Wn);
+        for (; u < u1; u += THIN_NW) {
             const float4 Ac = An;
             float4 Wc[TR][NQ];
 #pragma unroll
             for (int tr = 0; tr < TR; tr++)
 #pragma unroll
                 for (int q = 0; q < NQ; q++) Wc[tr][q] = Wn[tr][q];
-            const int un = (u + 4 < u1) ? (u + 4) : u;          // the last iteration re-loads its own unit (no branch)
-            issue(un, An, Wn);
+            const int y = ny, xc = nxcpos;
+            if (u + THIN_NW < u1) {                             // the last iteration re-loads its own unit
+                nxcpos += THIN_NW;
+                while (nxcpos >= g.nxc) {
+                    nxcpos -= g.nxc;
+                    if (++ny == g.AH) { ny = 0; nb++; }
+                }
+            }
+            if (DBG != 2) issue(nb, ny, nxcpos, An, Wn);
 
-            const int row = u / g.nxc, xc = u - row * g.nxc;
-            const int y = row % g.AH;
             const int x0 = xc * 16 + 4 * k;
             const bool aok = mok && (x0 < g.AW);
             float a4[4];
@@ -130,6 +155,13 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(WT g) {
                     w[4 * q + 2] = ok ? Wc[tr][q].z : 0.f;
                     w[4 * q + 3] = ok ? Wc[tr][q].w : 0.f;
                 }
+                if (DBG == 1) {
+#pragma unroll
+                    for (int s = 0; s < S; s++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) acc[tr][s][j] += a4[j] * w[SI * j + s - PAD + 4 * PQ];
+                    continue;
+                }
 #pragma unroll
                 for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -141,7 +173,7 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(WT g) {
 
     // workgroup reduction, waves in a fixed order: red[(t*4 + reg)*64 + lane]
 #pragma unroll 1
-    for (int wv = 0; wv < 4; wv++) {
+    for (int wv = 0; wv < THIN_NW; wv++) {
         if (wave == wv) {
 #pragma unroll
             for (int tr = 0; tr < TR; tr++)
@@ -157,8 +189,8 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(WT g) {
         __syncthreads();
     }
     // slab [t][m16][c16]; D element (reg, lane) is m = 4*(lane>>4) + reg, c = lane & 15
-    float* __restrict__ slab = g.ws + ((long)blockIdx.y * g.npb + blockIdx.x) * (TS * 256);
-    for (int e = threadIdx.x; e < TS * 256; e += 256) {
+    float* __restrict__ slab = g.ws + ((long)blockIdx.y * g.npb + pb) * (TS * 256);
+    for (int e = threadIdx.x; e < TS * 256; e += 64 * THIN_NW) {
         const int t = e >> 8, mc = e & 255, mm = mc >> 4, cc_ = mc & 15;
         slab[e] = red[(t * 4 + (mm & 3)) * 64 + (mm >> 2) * 16 + cc_];
     }
@@ -243,8 +275,9 @@ ThinPlan plan_thin(int B, int M, int AH, int AW, int Cin, int R, int S, int si) 
     const long cap = env_int("CC_WGRAD_THIN_NPB", 512);
     npb = npb < 1 ? 1 : (npb > cap ? cap : npb);
     p.upb = (int)((units + npb - 1) / npb);
-    p.upb = ((p.upb + 3) / 4) * 4;
+    p.upb = ((p.upb + THIN_NW - 1) / THIN_NW) * THIN_NW;
     p.npb = (p.units + p.upb - 1) / p.upb;
+    if (p.npb >= 64) p.npb = ((p.npb + 7) / 8) * 8;       // XCD swizzle needs a multiple of 8 (surplus ranges are empty)
     p.ws_floats = (size_t)p.ngm * p.ngc * p.ngt * p.npb * p.TS * 256;
     p.ok = true;
     return p;
@@ -252,7 +285,7 @@ ThinPlan plan_thin(int B, int M, int AH, int AW, int Cin, int R, int S, int si) 
 
 template <int S, int SI, int PAD, int TR>
 void launch_thin(const WT& g, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad_thin<S, SI, PAD, TR>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad_thin<S, SI, PAD, TR>), grid, dim3(64 * THIN_NW), 0, s, g);
 }
 
 }  // namespace
@@ -267,20 +300,28 @@ size_t wgrad_thin_ws_floats(int B, int M, int AH, int AW, int Cin, int R, int S,
 bool wgrad_thin_launch(const float* a, const float* x, float* gw, float* ws, int B, int M, int AH, int AW, long a_bs, int Cin,
                        int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, int accumulate, hipStream_t s) {
     const ThinPlan p = plan_thin(B, M, AH, AW, Cin, R, S, si);
-    if (!p.ok || (IW & 3) || (a_bs & 3) || (x_bs & 3)) return false;
+    if (!p.ok || (IW & 3) || (a_bs & 3) || (x_bs & 3) || (((uintptr_t)a | (uintptr_t)x) & 15)) return false;
+    if ((long)B * a_bs >= (1l << 31) || (long)B * x_bs >= (1l << 31)) return false;      // 32-bit offsets in the kernel
     static const int want_pad[] = {1, 1, 3, 3, 0, 2, 1};
     if (pad != want_pad[p.kind]) return false;
     WT g = {};
     g.a = a; g.x = x; g.ws = ws;
     g.B = B; g.M = M; g.AH = AH; g.AW = AW; g.a_bs = a_bs; g.Cin = Cin; g.IH = IH; g.IW = IW; g.x_bs = x_bs;
     g.R = R; g.nxc = p.nxc; g.units = p.units; g.upb = p.upb; g.npb = p.npb; g.ngc = p.ngc; g.ngt = p.ngt;
+    g.swz = (p.npb % 8 == 0 && p.npb >= 64 && !env_int("CC_WGRAD_THIN_NOSWZ", 0)) ? 1 : 0;
     const int ncombo = p.ngm * p.ngc * p.ngt;
     if (env_int("CC_WGRAD_THIN_TRACE", 0))
         fprintf(stderr, "[wgrad_thin] kind %d M %d Cin %d A %dx%d X %dx%d npb %d upb %d combos %d\n", p.kind, M, Cin, AH, AW, IH, IW,
                 p.npb, p.upb, ncombo);
     dim3 grid((unsigned)p.npb, (unsigned)ncombo);
     switch (p.kind) {
-        case K_3_1: launch_thin<3, 1, 1, 3>(g, grid, s); break;
+        case K_3_1: {
+            const int dbg = env_int("CC_WGRAD_THIN_DBG", 0);
+            if (dbg == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad_thin<3, 1, 1, 3, 1>), grid, dim3(64 * THIN_NW), 0, s, g);
+            else if (dbg == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad_thin<3, 1, 1, 3, 2>), grid, dim3(64 * THIN_NW), 0, s, g);
+            else launch_thin<3, 1, 1, 3>(g, grid, s);
+            break;
+        }
         case K_3_2: launch_thin<3, 2, 1, 3>(g, grid, s); break;
         case K_7_2: launch_thin<7, 2, 3, 2>(g, grid, s); break;
         case K_7_1: launch_thin<7, 1, 3, 2>(g, grid, s); break;

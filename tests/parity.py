@@ -362,6 +362,7 @@ CONV_CASES_THIN = [
     (2, 16, 10, 24, 32, 5, 2, 2, "relu", True, False),
     (2, 16, 5, 8, 1, 3, 1, 1, "sigmoid", True, False),
     (2, 20, 6, 44, 30, 3, 2, 1, None, True, False),
+    (2, 16, 32, 128, 16, 3, 1, 1, "relu", True, False),          # 64 unit ranges: the XCD-swizzled assignment
 ]
 CONVT_CASES = [  # B, Cin, H, W, Cout, k, stride, pad, output_padding, act
     (2, 16, 5, 7, 24, 3, 2, 1, 1, "relu"),

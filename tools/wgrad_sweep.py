@@ -7,11 +7,9 @@ import torch
 from cc_amd._lib import engine, STREAM
 
 CONFIGS = [("base", {"CC_NO_WGRAD_THIN": "1"}),
-           ("thin4", {}),
-           ("thin8", {"CC_WGRAD_THIN_MAXCOMBO": "8", "CC_WGRAD_THIN_MINPIX": "8192"}),
-           ("thin16", {"CC_WGRAD_THIN_MAXCOMBO": "16", "CC_WGRAD_THIN_MINPIX": "8192"}),
-           ("t16upb16", {"CC_WGRAD_THIN_MAXCOMBO": "16", "CC_WGRAD_THIN_MINPIX": "8192", "CC_WGRAD_THIN_UPB": "16"}),
-           ("t16upb64", {"CC_WGRAD_THIN_MAXCOMBO": "16", "CC_WGRAD_THIN_MINPIX": "8192", "CC_WGRAD_THIN_UPB": "64", "CC_WGRAD_THIN_NPB": "1024"})]
+           ("thin", {}),
+           ("upb64", {"CC_WGRAD_THIN_UPB": "64"}),
+           ("upb16n1k", {"CC_WGRAD_THIN_UPB": "16", "CC_WGRAD_THIN_NPB": "1024"})]
 KEYS = ["CC_NO_WGRAD_THIN", "CC_WGRAD_THIN_MAXCOMBO", "CC_WGRAD_THIN_MINPIX", "CC_WGRAD_THIN_UPB", "CC_WGRAD_THIN_NPB"]
 
 shapes = []
