@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--config", default="c3", choices=["c2", "c3"],
                     help="c3 = full CC (BASELINE configs[2], the metric's config); c2 = DispResNet6+PoseNetB6 only")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--elide-occ", action="store_true",
+                    help="NOT the default metric: skip Back2Future's occlusion decoders, whose output train.py:463 discards "
+                         "(SURVEY.md 8a D1); reported separately in DESIGN.md")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--conv-backend", default="hip", choices=["hip", "miopen"])
@@ -246,6 +249,8 @@ def main():
     torch.manual_seed(0)                                             # train.py:152
     nets = T.build_nets(dev, flow=(args.config == "c3"), mask=(args.config == "c3"))
     cfg = T.StepConfig()
+    if args.elide_occ and nets[3] is not None:
+        nets[3].elide_occ = True
     B, H, W = args.batch, args.height, args.width
     batch_cpu = syn.sample(B, H, W, seed=1 + rank, smooth=3)
     batch = (batch_cpu[0].to(dev), [r.to(dev) for r in batch_cpu[1]], batch_cpu[2].to(dev), batch_cpu[3].to(dev))
@@ -321,7 +326,8 @@ def main():
                                     if args.config == "c3" else "DispResNet6+PoseNetB6, photometric+smoothness"),
                        "per_gpu_batch": B, "global_batch": B * world, "height": H, "width": W, "scales": 6,
                        "frames": 5, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph,
-                       "conv_backend": args.conv_backend, "loss": round(loss_val, 6)},
+                       "conv_backend": args.conv_backend, "loss": round(loss_val, 6),
+                       "dead_occlusion_decoders_elided": bool(args.elide_occ)},
             "roofline": roof, "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -40,6 +40,10 @@ class Model(nn.Module):
     def __init__(self, nlevels):
         super().__init__()
         self.nlevels = nlevels
+        # SURVEY.md 8a "dead work" D1: train.py:463 discards the occlusion output and no gradient reaches decoder_occ*.
+        # Default False = identical API (occlusion maps are computed and returned as in the reference); a trainer that
+        # does not consume them may set it (bench.py --elide-occ) and gets None in their place.
+        self.elide_occ = False
         idx = [k for n in range(80, 71, -1) for k in range(n, -1, -9)]          # back2future.py:56-57
         self.idx_fwd = idx
         self.idx_bwd = list(reversed(idx))
@@ -98,18 +102,20 @@ class Model(nn.Module):
             up_f[lvl] = up(flow_f[lvl])
             flow_b[lvl] = getattr(self, "decoder_bwd%d" % lvl)(in_b)
             up_b[lvl] = up(flow_b[lvl])
-            occ[lvl] = torch.softmax(getattr(self, "decoder_occ%d" % lvl)(in_o), dim=1)
+            if not self.elide_occ:
+                occ[lvl] = torch.softmax(getattr(self, "decoder_occ%d" % lvl)(in_o), dim=1)
             if lvl > 2:
                 s = self.WARP_SCALE[lvl]
                 bw = self.warp(feats[(lvl - 1, "b")], s * up_f[lvl])
                 cw = self.warp(feats[(lvl - 1, "c")], -s * up_f[lvl])      # the FORWARD flow for both (Q9)
         ff = [self.FULL_SCALE[l] * up(up_f[l]) for l in range(2, 7)]
         fb = [-self.FULL_SCALE[l] * up(up_b[l]) for l in range(2, 7)]
-        oc = [F.interpolate(occ[l], scale_factor=4) for l in range(2, 7)]
+        oc = None if self.elide_occ else [F.interpolate(occ[l], scale_factor=4) for l in range(2, 7)]
         if self.training:
             if self.nlevels == 6:
                 ff.append(0.625 * up_f[6])
                 fb.append(-0.625 * up_b[6])
-                oc.append(F.interpolate(occ[6], scale_factor=2))
+                if oc is not None:
+                    oc.append(F.interpolate(occ[6], scale_factor=2))
             return ff, fb, oc
-        return ff[0], fb[0], oc[0]
+        return ff[0], fb[0], (None if oc is None else oc[0])
