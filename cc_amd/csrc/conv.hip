@@ -1652,7 +1652,7 @@ static size_t wgrad_ws_bytes_base(int B, int M, int AH, int AW, int Cin, int R, 
     const long P = (long)B * AH * AW;
     const int bm = pick_bm(M);
     const long tiles = ((Ntot + BN - 1) / BN) * ((M + bm - 1) / bm);
-    long nsplit = (512 + tiles - 1) / tiles;
+    long nsplit = (env_int_early("CC_WGRAD_SPLIT_TARGET", 512) + tiles - 1) / tiles;
     const long maxsplit = (P + 63) / 64;      // small maps still need >= 256 workgroups: split down to 64-pixel ranges
     if (nsplit > maxsplit) nsplit = maxsplit;
     if (nsplit < 1) nsplit = 1;
@@ -1722,7 +1722,7 @@ int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B,
     const long P = (long)B * AH * AW;
     const int bm = pick_bm(M);
     const long tiles = ((Ntot + BN - 1) / BN) * ((M + bm - 1) / bm);
-    long nsplit = (512 + tiles - 1) / tiles;
+    long nsplit = (env_int_early("CC_WGRAD_SPLIT_TARGET", 512) + tiles - 1) / tiles;
     const long maxsplit = (P + 63) / 64;      // small maps still need >= 256 workgroups: split down to 64-pixel ranges
     if (nsplit > maxsplit) nsplit = maxsplit;
     if (nsplit < 1) nsplit = 1;

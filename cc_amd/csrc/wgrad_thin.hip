@@ -246,7 +246,7 @@ struct ThinPlan {
 };
 
 // kinds: (S, SI, PAD, TR) instantiations
-enum { K_3_1 = 0, K_3_2, K_7_2, K_7_1, K_1_1, K_5_2, K_4_2, K_NONE };
+enum { K_3_1 = 0, K_3_2, K_7_2, K_7_1, K_1_1, K_5_2, K_4_2, K_1_2, K_NONE };
 
 ThinPlan plan_thin(int B, int M, int AH, int AW, int Cin, int R, int S, int si) {
     ThinPlan p = {};
@@ -259,6 +259,7 @@ ThinPlan plan_thin(int B, int M, int AH, int AW, int Cin, int R, int S, int si) 
     else if (S == 1 && si == 1) { p.kind = K_1_1; p.TR = 1; }
     else if (S == 5 && si == 2) { p.kind = K_5_2; p.TR = 3; }
     else if (S == 4 && si == 2) { p.kind = K_4_2; p.TR = 4; }
+    else if (S == 1 && si == 2) { p.kind = K_1_2; p.TR = 1; }
     else return p;
     p.ngm = (M + 15) / 16;
     p.ngc = (Cin + 15) / 16;
@@ -302,7 +303,7 @@ bool wgrad_thin_launch(const float* a, const float* x, float* gw, float* ws, int
     const ThinPlan p = plan_thin(B, M, AH, AW, Cin, R, S, si);
     if (!p.ok || (IW & 3) || (a_bs & 3) || (x_bs & 3) || (((uintptr_t)a | (uintptr_t)x) & 15)) return false;
     if ((long)B * a_bs >= (1l << 31) || (long)B * x_bs >= (1l << 31)) return false;      // 32-bit offsets in the kernel
-    static const int want_pad[] = {1, 1, 3, 3, 0, 2, 1};
+    static const int want_pad[] = {1, 1, 3, 3, 0, 2, 1, 0};
     if (pad != want_pad[p.kind]) return false;
     WT g = {};
     g.a = a; g.x = x; g.ws = ws;
@@ -327,6 +328,7 @@ bool wgrad_thin_launch(const float* a, const float* x, float* gw, float* ws, int
         case K_7_1: launch_thin<7, 1, 3, 2>(g, grid, s); break;
         case K_1_1: launch_thin<1, 1, 0, 1>(g, grid, s); break;
         case K_5_2: launch_thin<5, 2, 2, 3>(g, grid, s); break;
+        case K_1_2: launch_thin<1, 2, 0, 1>(g, grid, s); break;
         default: launch_thin<4, 2, 1, 4>(g, grid, s); break;
     }
     hipLaunchKernelGGL(k_wgrad_thin_reduce, dim3((unsigned)(ncombo * p.TS)), dim3(1024), 0, s, (const float*)ws, gw, p.npb, p.TS, S,
@@ -337,8 +339,8 @@ bool wgrad_thin_launch(const float* a, const float* x, float* gw, float* ws, int
 void wgrad_thin_name(int B, int M, int AH, int AW, int Cin, int IH, int IW, int R, int S, int si, int pad, char* out, int cap) {
     out[0] = 0;
     const ThinPlan p = plan_thin(B, M, AH, AW, Cin, R, S, si);
-    static const int want_pad[] = {1, 1, 3, 3, 0, 2, 1};
-    static const int tr[] = {3, 3, 2, 2, 1, 3, 4};
+    static const int want_pad[] = {1, 1, 3, 3, 0, 2, 1, 0};
+    static const int tr[] = {3, 3, 2, 2, 1, 3, 4, 1};
     if (!p.ok || (IW & 3) || pad != want_pad[p.kind]) return;
     snprintf(out, cap, "k_wgrad_thin<%d, %d, %d, %d>", S, si, pad, tr[p.kind]);
 }

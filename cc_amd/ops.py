@@ -257,9 +257,57 @@ def _torch_act(y, act, a, b):
 
 
 # ----------------------------------------------------------------------------- small ATen-backed pieces
+class _BNTrainFn(torch.autograd.Function):
+    """nn.BatchNorm2d in training mode on the HIP kernels (csrc/bnorm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        x = _c(x)
+        B, C, H, W = x.shape
+        E = engine()
+        y = torch.empty_like(x)
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        invstd = torch.empty_like(mean)
+        E.call("cc_bn_train_fwd", x, weight, bias, running_mean, running_var, y, mean, invstd,
+               _ws(E.call("cc_bn_ws_bytes", C), x), B, C, H, W, float(momentum), float(eps), STREAM)
+        ctx.save_for_backward(x, weight, mean, invstd)
+        ctx.ptrs = (weight.data_ptr() if weight is not None else 0, bias.data_ptr() if bias is not None else 0,
+                    bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, mean, invstd = ctx.saved_tensors
+        wptr, bptr, has_bias = ctx.ptrs
+        gy = _c(gy)
+        B, C, H, W = x.shape
+        E = engine()
+        need = ctx.needs_input_grad
+        gx = torch.empty_like(x)
+        wsink = grad_sinks.get(wptr) if (grad_sinks and weight is not None and need[1]) else None
+        bsink = grad_sinks.get(bptr) if (grad_sinks and has_bias and need[2]) else None
+        sink = wsink is not None and (bsink is not None or not (has_bias and need[2]))
+        if sink:
+            gw, gb = wsink, bsink
+        else:
+            gw = torch.empty(C, device=x.device, dtype=torch.float32) if (weight is not None and need[1]) else None
+            gb = torch.empty(C, device=x.device, dtype=torch.float32) if (has_bias and need[2]) else None
+        E.call("cc_bn_train_bwd", gy, x, weight, mean, invstd, gx, gw, gb, _ws(E.call("cc_bn_ws_bytes", C), x), B, C, H, W,
+               int(sink), STREAM)
+        if sink:
+            gw = gb = None
+        return gx, gw, gb, None, None, None, None
+
+
+BN_HIP_MIN_PER_CHANNEL = 16384      # below this the vendor's one-launch kernel is as fast (3 launches here)
+
+
 def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps):
     if training and num_batches_tracked is not None:
         num_batches_tracked.add_(1)
+    if (training and config.conv_backend == "hip" and x.dim() == 4 and x.dtype == torch.float32 and momentum is not None
+            and x.shape[0] * x.shape[2] * x.shape[3] >= BN_HIP_MIN_PER_CHANNEL and x.shape[0] <= 64):
+        return _BNTrainFn.apply(x, weight, bias, running_mean, running_var, momentum, eps)
     return F.batch_norm(x, running_mean, running_var, weight, bias, training, momentum, eps)
 
 

@@ -215,6 +215,19 @@ int cc_act_bwd_bias(const float* gy, const float* y_or_null, float* geff_or_null
                     int C, int H, int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b,
                     int accumulate_bias, void* stream);
 
+/* ---------------------------------------------------------------- BatchNorm2d, training mode
+ * (models/DispResNet6.py:53-56: the Conv1x1 + BatchNorm2d shortcut of every ResNet stage; 13 per forward)
+ * y = (x - mean_c) / sqrt(var_c + eps) * w_c + b_c with batch statistics over (B,H,W); running stats updated with
+ * `momentum` (unbiased variance); save_mean / save_invstd [C] feed the backward.  ws: cc_bn_ws_bytes(C) bytes. */
+size_t cc_bn_ws_bytes(int C);
+int cc_bn_train_fwd(const float* x, const float* weight_or_null, const float* bias_or_null, float* running_mean_or_null,
+                    float* running_var_or_null, float* y, float* save_mean, float* save_invstd, float* ws, int B, int C,
+                    int H, int W, float momentum, float eps, void* stream);
+/* gx; gweight[c] (+)= sum gy * xhat, gbias[c] (+)= sum gy (either may be null; accumulate_wb: add into them) */
+int cc_bn_train_bwd(const float* gy, const float* x, const float* weight_or_null, const float* save_mean,
+                    const float* save_invstd, float* gx, float* gweight_or_null, float* gbias_or_null, float* ws, int B, int C,
+                    int H, int W, int accumulate_wb, void* stream);
+
 /* ---------------------------------------------------------------- optimizer (train.py:307-310,568)
  * torch.optim.Adam(betas, eps, weight_decay=0) on the flat fp32 bucket; grads are multiplied by grad_scale first
  * (1/world_size after the RCCL all-reduce).  step_dev: device float, incremented by the call. */

@@ -363,6 +363,7 @@ CONV_CASES_THIN = [
     (2, 16, 5, 8, 1, 3, 1, 1, "sigmoid", True, False),
     (2, 20, 6, 44, 30, 3, 2, 1, None, True, False),
     (2, 16, 32, 128, 16, 3, 1, 1, "relu", True, False),          # 64 unit ranges: the XCD-swizzled assignment
+    (2, 24, 10, 24, 40, 1, 2, 0, None, False, False),            # 1x1 stride-2 shortcut convs of the ResNet blocks
 ]
 CONVT_CASES = [  # B, Cin, H, W, Cout, k, stride, pad, output_padding, act
     (2, 16, 5, 7, 24, 3, 2, 1, 1, "relu"),
@@ -454,3 +455,26 @@ def check_corr(dev, cases=((2, 8, 6, 12), (1, 5, 7, 13), (2, 12, 5, 8), (1, 33, 
         g1 = torch.autograd.grad(o, [ad, bd, cd], go.to(dev))
         g0 = torch.autograd.grad(r, [ac, bc, cc_], go)
         assert max(rel(x, y) for x, y in zip(g1, g0)) < 5e-6, ("pair grads", (B, C, H, W), [rel(x, y) for x, y in zip(g1, g0)])
+
+
+def check_batch_norm(dev, cases=((2, 5, 7, 12), (3, 16, 9, 13), (2, 8, 32, 64))):
+    """Training-mode BatchNorm2d (csrc/bnorm.hip) vs ATen on the CPU: output, running statistics and all gradients."""
+    import torch.nn.functional as F
+    from cc_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for (B, C, H, W) in cases:
+        x0 = torch.randn(B, C, H, W, generator=g) * 2.0 + 0.7
+        w0, b0 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+        rm0, rv0 = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+        xd, wd, bd = leaf(x0, dev), leaf(w0, dev), leaf(b0, dev)
+        xc, wc, bc = leaf(x0, "cpu"), leaf(w0, "cpu"), leaf(b0, "cpu")
+        rmd, rvd, rmc, rvc = rm0.clone().to(dev), rv0.clone().to(dev), rm0.clone(), rv0.clone()
+        y = ops._BNTrainFn.apply(xd, wd, bd, rmd, rvd, 0.1, 1e-5)
+        r = F.batch_norm(xc, rmc, rvc, wc, bc, True, 0.1, 1e-5)
+        assert rel(y, r) < 2e-6, ("bn out", (B, C, H, W), rel(y, r))
+        assert rel(rmd, rmc) < 2e-6 and rel(rvd, rvc) < 2e-6, ("bn running stats", rel(rmd, rmc), rel(rvd, rvc))
+        go = torch.randn(r.shape, generator=g)
+        g1 = torch.autograd.grad(y, [xd, wd, bd], go.to(dev))
+        g0 = torch.autograd.grad(r, [xc, wc, bc], go)
+        errs = [rel(a, b) for a, b in zip(g1, g0)]
+        assert max(errs) < 1e-5, ("bn grads", (B, C, H, W), errs)

@@ -61,3 +61,7 @@ def test_convs_thin_wgrad(monkeypatch):
 
 def test_cost_volume():
     parity.check_corr("cpu")
+
+
+def test_batch_norm():
+    parity.check_batch_norm("cpu")

@@ -79,3 +79,8 @@ def test_convs_full_size_thin_layers():
 def test_cost_volume():
     parity.check_corr("cuda")
     parity.check_corr("cuda", cases=((2, 32, 64, 208), (2, 196, 8, 26)))
+
+
+def test_batch_norm():
+    parity.check_batch_norm("cuda")
+    parity.check_batch_norm("cuda", cases=((4, 16, 256, 832), (4, 64, 64, 208)))

@@ -6,11 +6,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cc_amd._lib import engine, STREAM
 
-CONFIGS = [("base", {"CC_NO_WGRAD_THIN": "1"}),
-           ("thin", {}),
-           ("upb64", {"CC_WGRAD_THIN_UPB": "64"}),
-           ("upb16n1k", {"CC_WGRAD_THIN_UPB": "16", "CC_WGRAD_THIN_NPB": "1024"})]
-KEYS = ["CC_NO_WGRAD_THIN", "CC_WGRAD_THIN_MAXCOMBO", "CC_WGRAD_THIN_MINPIX", "CC_WGRAD_THIN_UPB", "CC_WGRAD_THIN_NPB"]
+CONFIGS = [("t512", {}),
+           ("t256", {"CC_WGRAD_SPLIT_TARGET": "256"}),
+           ("t128", {"CC_WGRAD_SPLIT_TARGET": "128"}),
+           ("t1024", {"CC_WGRAD_SPLIT_TARGET": "1024"}),
+           ("w3s256", {"CC_W3_SPLIT": "256"}),
+           ("w3s1024", {"CC_W3_SPLIT": "1024"})]
+KEYS = ["CC_WGRAD_SPLIT_TARGET", "CC_W3_SPLIT", "CC_NO_WGRAD_THIN", "CC_WGRAD_THIN_MAXCOMBO", "CC_WGRAD_THIN_MINPIX", "CC_WGRAD_THIN_UPB", "CC_WGRAD_THIN_NPB"]
 
 shapes = []
 for l in open(os.path.join(os.path.dirname(__file__), "..", "profiles", "r01_conv_calls_v3.txt")):
