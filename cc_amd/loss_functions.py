@@ -564,3 +564,116 @@ def weighted_binary_cross_entropy(output, target, weights=None):
     else:
         loss = target * torch.log(output + epsilon) + (1 - target) * torch.log(1 - output + epsilon)
     return torch.neg(torch.mean(loss))
+
+
+# ----------------------------------------------------------------------------- validation metrics
+# loss_functions.py:355-467, consumed by train.py's validate_* loops (train.py:588-777).  Device-side torch arithmetic
+# on whatever device the inputs live on (they run once per validation batch, far off the training hot path), same
+# values as the reference.  The reference returns Python floats through .item() (a host sync per metric); sync=False
+# returns 0-dim device tensors instead so that a validation loop can stay asynchronous.
+def _upsample_to(pred, size):
+    """nn.functional.upsample(pred, size=size, mode='bilinear') (loss_functions.py:359,373,394,414-415): align_corners
+    has defaulted to False for upsample since torch 0.4, i.e. for the authors' torch 1.0 as well as today's -- it does
+    NOT follow config.align_corners (that knob mirrors grid_sample's later change of default)."""
+    return nn.functional.interpolate(pred, size=size, mode='bilinear', align_corners=False)
+
+
+def _scaled_uv(gt, pred):
+    _, _, h_pred, w_pred = pred.size()
+    _, _, h_gt, w_gt = gt.size()
+    pred = _upsample_to(pred, (h_gt, w_gt))
+    return gt[:, 0], gt[:, 1], pred[:, 0] * (w_gt / w_pred), pred[:, 1] * (h_gt / h_pred)
+
+
+def flow_diff(gt, pred):
+    """loss_functions.py:355-365 -> per-pixel end-point error [B,H,W] at the ground truth's resolution."""
+    u_gt, v_gt, u_pred, v_pred = _scaled_uv(gt, pred)
+    return torch.sqrt(torch.pow((u_gt - u_pred), 2) + torch.pow((v_gt - v_pred), 2))
+
+
+def compute_epe(gt, pred, sync=True):
+    """loss_functions.py:368-388: mean EPE; a third ground-truth channel is a validity mask."""
+    bs, nc, h_gt, w_gt = gt.size()
+    u_gt, v_gt, u_pred, v_pred = _scaled_uv(gt, pred)
+    epe = torch.sqrt(torch.pow((u_gt - u_pred), 2) + torch.pow((v_gt - v_pred), 2))
+    if nc == 3:
+        valid = gt[:, 2]
+        epe = epe * valid
+        avg_epe = epe.sum() / (valid.sum() + epsilon)
+    else:
+        avg_epe = epe.sum() / (bs * h_gt * w_gt)
+    avg_epe = avg_epe.detach()
+    return avg_epe.item() if sync else avg_epe
+
+
+def outlier_err(gt, pred, tau=[3, 0.05], sync=True):
+    """loss_functions.py:390-409: KITTI Fl outlier ratio (EPE > 3 px AND > 5 % of the flow magnitude)."""
+    u_gt, v_gt, u_pred, v_pred = _scaled_uv(gt, pred)
+    valid_gt = gt[:, 2]
+    epe = torch.sqrt(torch.pow((u_gt - u_pred), 2) + torch.pow((v_gt - v_pred), 2))
+    epe = epe * valid_gt
+    F_mag = torch.sqrt(torch.pow(u_gt, 2) + torch.pow(v_gt, 2))
+    E_0 = (epe > tau[0]).type_as(epe)
+    E_1 = ((epe / (F_mag + epsilon)) > tau[1]).type_as(epe)
+    n_err = E_0 * E_1 * valid_gt
+    f_err = (n_err.sum() / (valid_gt.sum() + epsilon)).detach()
+    return f_err.item() if sync else f_err
+
+
+def compute_all_epes(gt, rigid_pred, non_rigid_pred, rigidity_mask, THRESH=0.5, sync=True):
+    """loss_functions.py:411-429 -> [all_epe, rigid_epe, non_rigid_epe, outliers]."""
+    _, _, h_pred, w_pred = rigid_pred.size()
+    _, _, h_gt, w_gt = gt.size()
+    rigidity_pred_mask = _upsample_to(rigidity_mask, (h_pred, w_pred))
+    rigidity_gt_mask = _upsample_to(rigidity_mask, (h_gt, w_gt))
+    non_rigid_pred = (rigidity_pred_mask <= THRESH).type_as(non_rigid_pred).expand_as(non_rigid_pred) * non_rigid_pred
+    rigid_pred = (rigidity_pred_mask > THRESH).type_as(rigid_pred).expand_as(rigid_pred) * rigid_pred
+    total_pred = non_rigid_pred + rigid_pred
+    gt_non_rigid = (rigidity_gt_mask <= THRESH).type_as(gt).expand_as(gt) * gt
+    gt_rigid = (rigidity_gt_mask > THRESH).type_as(gt).expand_as(gt) * gt
+    all_epe = compute_epe(gt, total_pred, sync)
+    rigid_epe = compute_epe(gt_rigid, rigid_pred, sync)
+    non_rigid_epe = compute_epe(gt_non_rigid, non_rigid_pred, sync)
+    outliers = outlier_err(gt, total_pred, sync=sync)
+    return [all_epe, rigid_epe, non_rigid_epe, outliers]
+
+
+def compute_errors(gt, pred, crop=True):
+    """loss_functions.py:432-467: [abs_diff, abs_rel, sq_rel, a1, a2, a3] of median-scaled depth (Garg/Eigen crop).
+    gt, pred: [B,H,W]; returns 0-dim tensors like the reference (no host sync inside)."""
+    abs_diff, abs_rel, sq_rel, a1, a2, a3 = 0, 0, 0, 0, 0, 0
+    batch_size = gt.size(0)
+    if crop:
+        crop_mask = torch.zeros_like(gt[0], dtype=torch.bool)               # gt[0] != gt[0], :441
+        y1, y2 = int(0.40810811 * gt.size(1)), int(0.99189189 * gt.size(1))
+        x1, x2 = int(0.03594771 * gt.size(2)), int(0.96405229 * gt.size(2))
+        crop_mask[y1:y2, x1:x2] = True
+    for current_gt, current_pred in zip(gt, pred):
+        valid = (current_gt > 0) & (current_gt < 80)
+        if crop:
+            valid = valid & crop_mask
+        valid_gt = current_gt[valid]
+        valid_pred = current_pred[valid].clamp(1e-3, 80)
+        valid_pred = valid_pred * torch.median(valid_gt) / torch.median(valid_pred)
+        thresh = torch.max((valid_gt / valid_pred), (valid_pred / valid_gt))
+        a1 += (thresh < 1.25).float().mean()
+        a2 += (thresh < 1.25 ** 2).float().mean()
+        a3 += (thresh < 1.25 ** 3).float().mean()
+        abs_diff += torch.mean(torch.abs(valid_gt - valid_pred))
+        abs_rel += torch.mean(torch.abs(valid_gt - valid_pred) / valid_gt)
+        sq_rel += torch.mean(((valid_gt - valid_pred) ** 2) / valid_gt)
+    return [metric / batch_size for metric in [abs_diff, abs_rel, sq_rel, a1, a2, a3]]
+
+
+def edge_aware_smoothness_per_pixel(img, pred):
+    """loss_functions.py:263-284 (the reference drops into ipdb before returning, :283; the value is what it returns)."""
+    def gradient_x(t):
+        return t[:, :, :-1, :] - t[:, :, 1:, :]
+
+    def gradient_y(t):
+        return t[:, :, :, :-1] - t[:, :, :, 1:]
+    weights_x = torch.exp(-torch.mean(torch.abs(gradient_x(img)), 1, keepdim=True))
+    weights_y = torch.exp(-torch.mean(torch.abs(gradient_y(img)), 1, keepdim=True))
+    smoothness_x = torch.abs(gradient_x(pred)) * weights_x
+    smoothness_y = torch.abs(gradient_y(pred)) * weights_y
+    return smoothness_x + smoothness_y                                     # broadcasting error for H != W, as upstream

@@ -12,6 +12,7 @@ torch-1.0 semantics (grid_sample patched to align_corners=True).
 """
 import os
 import sys
+import warnings
 
 import numpy as np
 import torch
@@ -206,9 +207,45 @@ def net_and_step_level(ac):
     return g
 
 
+def metric_inputs(seed=21, B=2, H=48, W=64, h=24, w=32):
+    """Seeded inputs of the validation metrics: KITTI-like flow ground truth (u, v, valid), two predictions at half
+    resolution, a soft rigidity mask, and depth ground truth / prediction with invalid (0 / > 80 m) pixels."""
+    r = np.random.RandomState(seed)
+    gt = np.concatenate([r.randn(B, 2, H, W).astype(np.float32) * 6.0, (r.rand(B, 1, H, W) > 0.3).astype(np.float32)], 1)
+    rigid = r.randn(B, 2, h, w).astype(np.float32) * 3.0
+    nonrigid = r.randn(B, 2, h, w).astype(np.float32) * 3.0
+    mask = r.rand(B, 1, h, w).astype(np.float32)
+    dgt = (r.rand(B, H, W).astype(np.float32) * 100.0 - 10.0)          # some <= 0 and some >= 80
+    dpred = (r.rand(B, H, W).astype(np.float32) * 60.0 + 0.5)
+    t = torch.from_numpy
+    return dict(gt=t(gt), rigid=t(rigid), nonrigid=t(nonrigid), mask=t(mask), dgt=t(dgt), dpred=t(dpred))
+
+
+def metrics_level():
+    """Validation metrics (loss_functions.py:355-467) from the unmodified reference (no grid_sample inside: one flavour)."""
+    ref = ref_import.load(None)
+    lf = ref.loss_functions
+    m = metric_inputs()
+    g = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        g["flow_diff"] = npy(lf.flow_diff(m["gt"], m["rigid"]))
+        g["epe3"] = np.float32(lf.compute_epe(m["gt"], m["rigid"]))
+        g["epe2"] = np.float32(lf.compute_epe(m["gt"][:, :2].contiguous(), m["nonrigid"]))
+        g["outlier"] = np.float32(lf.outlier_err(m["gt"], m["rigid"]))
+        g["all_epes"] = np.asarray(lf.compute_all_epes(m["gt"], m["rigid"], m["nonrigid"], m["mask"]), dtype=np.float32)
+        g["errors_crop"] = np.asarray([float(v) for v in lf.compute_errors(m["dgt"], m["dpred"])], dtype=np.float32)
+        g["errors_nocrop"] = np.asarray([float(v) for v in lf.compute_errors(m["dgt"], m["dpred"], crop=False)], dtype=np.float32)
+    return g
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)   # run-to-run bit reproducibility of the fixtures
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), **metrics_level())
+    print("wrote metrics")
+    if len(sys.argv) > 1 and sys.argv[1] == "metrics":
+        return
     for tag, ac in (("acF", None), ("acT", True)):
         np.savez_compressed(os.path.join(OUT, "functions_%s.npz" % tag), **function_level(ac))
         sm = function_level(ac, smooth=3)
