@@ -320,6 +320,80 @@ __global__ __launch_bounds__(256) void k_flow_warp_bwd(const float* __restrict__
     }
 }
 
+// Feature-warp backward (Back2Future.warp on 32-128 channel maps): one work-item per pixel walking all C channels leaves
+// the chip with < 1 workgroup per CU on the 64x208 level (146 us avg).  Here a workgroup is 64 pixels x 4 channel groups
+// (wave w = channels [w*C/4, (w+1)*C/4) of 64 consecutive pixels: coalesced), the four partial flow gradients are summed
+// in LDS in a fixed order; the feature gradient is the same float-atomic scatter as the reference's grid_sample backward.
+template <bool AC>
+__global__ __launch_bounds__(256) void k_feature_warp_bwd4(const float* __restrict__ gout, const float* __restrict__ img,
+                                                           const float* __restrict__ flow, float* __restrict__ gflow,
+                                                           float* __restrict__ gimg, int C, int H, int W) {
+    __shared__ float part[4][64][2];
+    const int b = blockIdx.y, HW = H * W;
+    const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lane;
+    const int cper = (C + 3) >> 2;
+    const int c0 = cg * cper, c1 = (c0 + cper < C) ? c0 + cper : C;
+    float gix = 0.f, giy = 0.f, gmx = 0.f, gmy = 0.f, dxn = 0.f, dyn = 0.f;
+    if (p < HW) {
+        const int y = p / W, x = p - y * W;
+        float xn, yn;
+        flow_coords<true>((float)x, (float)y, flow[((size_t)b * 2) * HW + p], flow[((size_t)b * 2 + 1) * HW + p], W, H, xn, yn,
+                          dxn, dyn);
+        Bilinear t;
+        bilinear_setup<AC, true>(xn, yn, W, H, t);
+        gmx = t.gmx;
+        gmy = t.gmy;
+        if (c0 < c1)
+            sample_grad(img + ((size_t)b * C + c0) * HW, gout + ((size_t)b * C + c0) * HW + p, c1 - c0, HW, W, t,
+                        gimg ? gimg + ((size_t)b * C + c0) * HW : nullptr, gix, giy);
+    }
+    part[cg][lane][0] = gix;
+    part[cg][lane][1] = giy;
+    __syncthreads();
+    if (cg == 0 && p < HW && gflow) {
+        const float sx = ((part[0][lane][0] + part[1][lane][0]) + part[2][lane][0]) + part[3][lane][0];
+        const float sy = ((part[0][lane][1] + part[1][lane][1]) + part[2][lane][1]) + part[3][lane][1];
+        gflow[((size_t)b * 2) * HW + p] = sx * gmx * dxn;
+        gflow[((size_t)b * 2 + 1) * HW + p] = sy * gmy * dyn;
+    }
+}
+
+// loss_functions.py:132-137 depth_occlusion_masks in ONE pass: the four rigid flows (pose2flow with the full-resolution K,
+// inverse_warp.py:195-220, no OOB rewrite) stay in registers, then occlusion_masks (:343-352) on the pairs (1,2) and (0,3)
+// -> (1 - occ) for refs 0..3, [B,4,H,W].  Replaces 4 cc_pose2flow_fwd launches + cc_rigid_noocc and the [4,B,2,H,W] buffer.
+__device__ __forceinline__ float noocc_pair(float bu, float bv, float fu, float fv) {
+    const float mag = (fu * fu + fv * fv) + (bu * bu + bv * bv);
+    const float thr = 0.08f * mag + 1.0f;
+    const float s = (fu + bu) + (fv + bv);
+    return (s > thr) ? 0.f : 1.f;
+}
+
+__global__ __launch_bounds__(256) void k_rigid_noocc_fused(const float* __restrict__ depth, const float* __restrict__ P4,
+                                                           const float* __restrict__ Kinv, float* __restrict__ out, int B, int H,
+                                                           int W) {
+    const int b = blockIdx.y, HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    const float d = depth[(size_t)b * HW + p];
+    float u[4], v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        Rigid rg;
+        rigid_project(P4 + ((size_t)r * B + b) * 12, Kinv + 9 * b, (float)x, (float)y, d, W, H, false, rg);
+        u[r] = (float)(W - 1) * (rg.xn / 2.0f + 0.5f) - (float)x;
+        v[r] = (float)(H - 1) * (rg.yn / 2.0f + 0.5f) - (float)y;
+    }
+    const float m12 = noocc_pair(u[1], v[1], u[2], v[2]);
+    const float m03 = noocc_pair(u[0], v[0], u[3], v[3]);
+    float* o = out + (size_t)b * 4 * HW + p;
+    o[0] = m03;
+    o[HW] = m12;
+    o[2 * HW] = m12;
+    o[3 * HW] = m03;
+}
+
 inline dim3 pix_grid(int B, int H, int W) { return dim3((unsigned)((H * W + 255) / 256), (unsigned)B); }
 
 }  // namespace
@@ -367,6 +441,13 @@ int cc_pose2flow_fwd(const float* depth, const float* P, const float* Kinv, floa
     if (B <= 0 || H < 2 || W < 2) return CC_ERR_ARG;
     hipLaunchKernelGGL(k_pose2flow_fwd, pix_grid(B, H, W), dim3(256), 0, (hipStream_t)stream, depth, P, Kinv, flow, H, W,
                        rewrite_oob);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_rigid_noocc_fused(const float* depth, const float* P4, const float* Kinv, float* out, int B, int H, int W, void* stream) {
+    if (B <= 0 || H < 2 || W < 2) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_rigid_noocc_fused, pix_grid(B, H, W), dim3(256), 0, (hipStream_t)stream, depth, P4, Kinv, out, B, H, W);
     CC_CHECK_LAUNCH();
     return CC_OK;
 }
@@ -432,6 +513,13 @@ int cc_feature_warp_bwd(const float* gout, const float* feat, const float* flow,
     if (B <= 0 || C <= 0 || H < 1 || W < 1) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     dim3 g = pix_grid(B, H, W);
+    if (C >= 16) {
+        dim3 g4((unsigned)((H * W + 63) / 64), (unsigned)B);
+        if (align_corners) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feature_warp_bwd4<true>), g4, dim3(256), 0, s, gout, feat, flow, gflow_or_null, gfeat_or_null, C, H, W);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feature_warp_bwd4<false>), g4, dim3(256), 0, s, gout, feat, flow, gflow_or_null, gfeat_or_null, C, H, W);
+        CC_CHECK_LAUNCH();
+        return CC_OK;
+    }
     if (align_corners) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<true, true, true>), g, dim3(256), 0, s, gout, feat, flow, gflow_or_null, gfeat_or_null, C, H, W);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<false, true, true>), g, dim3(256), 0, s, gout, feat, flow, gflow_or_null, gfeat_or_null, C, H, W);
     CC_CHECK_LAUNCH();

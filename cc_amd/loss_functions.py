@@ -32,8 +32,36 @@ def _f32c(t):
     return t.contiguous().float()
 
 
+class _ScalarPool:
+    """Zero-initialised device scalars (loss accumulators, NaN flags) handed out from ONE zero-filled buffer per training
+    step instead of one fill launch each (~25 per step).  Opt-in: only a trainer that brackets its forward+backward with
+    begin()/end() gets pooled scalars (under hipGraph capture the fill is then part of the graph); everybody else gets a
+    fresh torch.zeros(1)."""
+    SIZE = 128
+
+    def __init__(self):
+        self.buf, self.used = None, 0
+
+    def begin(self, device):
+        self.buf = torch.zeros(self.SIZE, device=device, dtype=torch.float32)
+        self.used = 0
+
+    def end(self):
+        self.buf = None
+
+    def take(self, ref):
+        if self.buf is None or self.used >= self.SIZE or self.buf.device != ref.device:
+            return torch.zeros(1, device=ref.device, dtype=torch.float32)
+        v = self.buf[self.used:self.used + 1]
+        self.used += 1
+        return v
+
+
+scalar_pool = _ScalarPool()
+
+
 def _zeros1(ref):
-    return torch.zeros(1, device=ref.device, dtype=torch.float32)
+    return scalar_pool.take(ref)
 
 
 def _empty(n, ref):
@@ -170,14 +198,11 @@ def occlusion_masks(flow_bw, flow_fw):
 
 
 def _rigid_noocc(depth_bhw, P_full, Kinv):
-    """(1 - depth_occlusion_masks) laid out [4,B,h,w] (reference-frame major)."""
+    """(1 - depth_occlusion_masks) [B,4,h,w].  P_full: the four [B,3,4] projection matrices, or already stacked [4,B,3,4]."""
     B, h, w = depth_bhw.shape
-    E = engine()
-    flows4 = torch.empty(4, B, 2, h, w, device=depth_bhw.device, dtype=torch.float32)
-    for r in range(4):
-        E.call("cc_pose2flow_fwd", depth_bhw, P_full[r], Kinv, flows4[r], B, h, w, 0, STREAM)
+    P4 = P_full if torch.is_tensor(P_full) else torch.stack(list(P_full)).contiguous()
     no = torch.empty(B, 4, h, w, device=depth_bhw.device, dtype=torch.float32)
-    E.call("cc_rigid_noocc", flows4, no, B, h, w, STREAM)
+    engine().call("cc_rigid_noocc_fused", depth_bhw, P4, Kinv, no, B, h, w, STREAM)
     return no
 
 
@@ -232,7 +257,7 @@ class _PhotoRigidFn(torch.autograd.Function):
             pose_l = pose.detach().requires_grad_(bool(need[4]))
             K_d = intrinsics.detach()
             P_full = [projection_matrix(pose_l[:, r], K_d, cfg.rotation_mode) for r in range(R)]
-        P_full_c = [_f32c(p.detach()) for p in P_full]
+        P_full_c = torch.stack([_f32c(p.detach()) for p in P_full]).contiguous()      # [4,B,3,4], shared by all scales
         direct_pose = cfg.rotation_mode == 'euler'      # HIP pose->P adjoint instead of a torch graph over 17 tiny ops
         # stash layout = the differentiable inputs: pose, refs (no gradient), depths, masks
         arena = _GradArena([pose] + list(rest), [need[4]] + [False] * R + list(need[5 + R:]))

@@ -158,10 +158,12 @@ class CCTrainer:
         ops.packs.prepack_all()            # every conv layer's [tap][c][m] weight images, one launch (weights changed in Adam)
         self.opt.zero_grad()                                                # :566
         ops.grad_sinks = self.opt.sinks
+        LF.scalar_pool.begin(batch[0].device)
         try:
             out = cc_forward(self.nets, batch, self.cfg)
             out["loss"].backward()                                          # :567
         finally:
+            LF.scalar_pool.end()
             ops.grad_sinks = {}
             ops.packs.invalidate()
         return {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}

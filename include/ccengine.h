@@ -132,6 +132,9 @@ int cc_flow_noocc(const float* flow_bw, const float* flow_fw, float* out, int B,
 /* loss_functions.py:132-137 depth_occlusion_masks -> (1 - occ) [B,4,H,W]; flows4 = the four rigid flows
  * [4][B,2,H,W] (pose2flow with the full-resolution K) */
 int cc_rigid_noocc(const float* flows4, float* out, int B, int H, int W, void* stream);
+/* the same from depth [B,H,W], the four projection matrices P4 = [4][B,3,4] (K.[R|t] with the FULL-resolution K) and
+ * Kinv [B,3,3]: the four pose2flow results never leave the registers */
+int cc_rigid_noocc_fused(const float* depth, const float* P4, const float* Kinv, float* out, int B, int H, int W, void* stream);
 
 /* accum[0] += coef * sum(partials[0..n)) -- deterministic second reduction stage */
 int cc_reduce_add(const float* partials, int n, float coef, float* accum, void* stream);

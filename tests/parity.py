@@ -69,14 +69,15 @@ def check_warps(dev, B=2, H=24, W=40, smooth=0, atol=1e-5):
         g1 = torch.autograd.grad(o, [im, fl], go.to(dev))
         g0 = torch.autograd.grad(r, [im0, fl0], go)
         assert frac_bad(g1[0], g0[0], (1e-5 if atol <= 1e-5 else 8 * atol)) < 2e-3 and frac_bad(g1[1], g0[1], (1e-4 if atol <= 1e-5 else 8 * atol)) < 2e-3
-        ft = torch.randn(B, 8, H, W, generator=torch.Generator().manual_seed(8))
-        fe, fe0 = leaf(ft, dev), leaf(ft, "cpu")
-        o, r = IW.feature_warp(fe, fl, align_corners=ac), G.feature_warp(fe0, fl0, align_corners=ac)
-        assert frac_bad(o, r, atol) < 2e-3
-        go = torch.randn(r.shape, generator=torch.Generator().manual_seed(9))
-        g1 = torch.autograd.grad(o, [fe, fl], go.to(dev))
-        g0 = torch.autograd.grad(r, [fe0, fl0], go)
-        assert frac_bad(g1[0], g0[0], (1e-5 if atol <= 1e-5 else 8 * atol)) < 2e-3 and frac_bad(g1[1], g0[1], (1e-4 if atol <= 1e-5 else 8 * atol)) < 2e-3
+        for FC in (8, 18):          # 18 >= 16 channels: the channel-group parallel backward (4 groups of 5,5,5,3)
+            ft = torch.randn(B, FC, H, W, generator=torch.Generator().manual_seed(8))
+            fe, fe0 = leaf(ft, dev), leaf(ft, "cpu")
+            o, r = IW.feature_warp(fe, fl, align_corners=ac), G.feature_warp(fe0, fl0, align_corners=ac)
+            assert frac_bad(o, r, atol) < 2e-3
+            go = torch.randn(r.shape, generator=torch.Generator().manual_seed(9))
+            g1 = torch.autograd.grad(o, [fe, fl], go.to(dev))
+            g0 = torch.autograd.grad(r, [fe0, fl0], go)
+            assert frac_bad(g1[0], g0[0], (1e-5 if atol <= 1e-5 else 8 * atol)) < 2e-3 and frac_bad(g1[1], g0[1], (1e-4 if atol <= 1e-5 else 8 * atol)) < 2e-3
 
 
 def check_ssim(dev, cases=((2, 40, 70, 0), (1, 64, 96, 3), (2, 8, 26, 0), (1, 33, 31, 1))):
