@@ -1620,7 +1620,7 @@ inline W3Plan plan_w3(int B, int M, int AH, int AW, int Cin, int R, int S, int s
     p.tiles_y = (AH + 1) / 2;
     p.ntiles = B * p.tiles_x * p.tiles_y;
     const long base = (long)((M + BM - 1) / BM) * (p.Cp32 / BC);
-    long nsplit = (env_int("CC_W3_SPLIT", 512) + base - 1) / base;
+    long nsplit = (env_int("CC_W3_SPLIT", 256) + base - 1) / base;
     const long cap = (p.ntiles + 5) / 6;          // >= 6 pixel tiles per split: every split writes a 9*M*Cpad partial slab
     if (nsplit > cap) nsplit = cap;
     if (nsplit > p.ntiles) nsplit = p.ntiles;

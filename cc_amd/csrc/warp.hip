@@ -291,7 +291,10 @@ __global__ __launch_bounds__(256) void k_flow_warp_fwd(const float* __restrict__
     bilinear_setup<AC, BORDER>(xn, yn, W, H, t);
     const float* src = img + (size_t)b * C * HW;
     float* dst = out + (size_t)b * C * HW + p;
-    for (int c = 0; c < C; c++) {
+    // gridDim.z > 1: channel groups (many-channel feature maps on small pyramid levels need more than HW work-items)
+    const int cper = (C + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int c0 = (int)blockIdx.z * cper, c1 = (c0 + cper < C) ? c0 + cper : C;
+    for (int c = c0; c < c1; c++) {
         float nw, ne, sw, se;
         gather4(src + (size_t)c * HW, W, t, nw, ne, sw, se);
         dst[(size_t)c * HW] = blend(t, nw, ne, sw, se);
@@ -501,6 +504,7 @@ int cc_feature_warp_fwd(const float* feat, const float* flow, float* out, int B,
     if (B <= 0 || C <= 0 || H < 1 || W < 1) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     dim3 g = pix_grid(B, H, W);
+    if (C >= 16) g.z = 4;
     if (align_corners) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_fwd<true, true, true>), g, dim3(256), 0, s, feat, flow, out, C, H, W);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_fwd<false, true, true>), g, dim3(256), 0, s, feat, flow, out, C, H, W);
     CC_CHECK_LAUNCH();
