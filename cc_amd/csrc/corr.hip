@@ -105,6 +105,29 @@ __global__ __launch_bounds__(256) void k_corr_bwd_f2(const float* __restrict__ g
     g2[((size_t)b * C + c) * HW + p] = acc / (float)C;
 }
 
+// ---- small maps (W = 13, 26: the two coarsest pyramid levels, 128-192 channels): one work-item per (pixel, displacement)
+// instead of per (pixel, dy) -- 9x more work-items for maps of 52-208 pixels; same channel order -> same bits.
+__global__ __launch_bounds__(256) void k_corr_fwd_small(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                        float* __restrict__ out, const int* __restrict__ chan_of_disp, int C,
+                                                        int H, int W, int out_cstride_total, int out_coffset) {
+    const int HW = H * W;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (t >= HW * ND) return;
+    const int d = t / HW, p = t - d * HW;
+    const int dy = d / PATCH, dx = d - dy * PATCH;
+    const int y = p / W, x = p - y * W;
+    const int yy = y + dy - R, xx = x + dx - R;
+    float acc = 0.f;
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const float* a = f1 + (size_t)b * C * HW + p;
+        const float* bb = f2 + (size_t)b * C * HW + yy * W + xx;
+        for (int c = 0; c < C; c++) acc = fmaf(a[(size_t)c * HW], bb[(size_t)c * HW], acc);
+    }
+    const int ch = (chan_of_disp ? chan_of_disp[d] : d) + out_coffset;
+    out[((size_t)b * out_cstride_total + ch) * HW + p] = acc * (1.f / (float)C);
+}
+
 // ---- W % 4 == 0 variants: every work-item owns 4 consecutive pixels (and 4 channels in the backward kernels), so the
 // f2 / f1 / gout window of a row is read as three aligned float4 and reused from registers for all 9 dx (the scalar
 // kernels above issue one load per FMA).  Same summation order per output element -> bit-identical results.
@@ -266,6 +289,9 @@ int cc_corr9x9_fwd(const float* f1, const float* f2, float* out, const int* chan
     const bool v4 = (W % 4 == 0) && (((uintptr_t)f1 | (uintptr_t)f2 | (uintptr_t)out) % 16 == 0);
     if (v4)
         hipLaunchKernelGGL(k_corr_fwd4, dim3((H * (W / 4) + 255) / 256, PATCH, B), dim3(256), 0, (hipStream_t)stream, f1, f2, out,
+                           chan_of_disp_or_null, C, H, W, out_channels_total, out_channel_offset);
+    else if (H * W <= 4096)
+        hipLaunchKernelGGL(k_corr_fwd_small, dim3((H * W * ND + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, f1, f2, out,
                            chan_of_disp_or_null, C, H, W, out_channels_total, out_channel_offset);
     else
         hipLaunchKernelGGL(k_corr_fwd, dim3((H * W + 255) / 256, PATCH, B), dim3(256), 0, (hipStream_t)stream, f1, f2, out,

@@ -31,16 +31,15 @@ __global__ __launch_bounds__(256) void k_adaptive_pool(const float* __restrict__
 // all pyramid levels of one 32x32 level-0 tile (see cc_pyramid_build)
 __global__ __launch_bounds__(256) void k_pyramid_tile(const float* __restrict__ in, float* __restrict__ out, int nlevels,
                                                       int planes, int H, int W) {
-    __shared__ float tile[32 * 33];
+    constexpr int TS = 36;                    // row stride: float4-aligned rows
+    __shared__ __attribute__((aligned(16))) float tile[32 * TS];
     const int tw = W / 32;
     const int ty = blockIdx.x / tw, tx = blockIdx.x - ty * tw;
     const int pl = blockIdx.y;
     const float* src = in + (size_t)pl * H * W + (size_t)(ty * 32) * W + tx * 32;
     {
         const int r = threadIdx.x >> 3, q = threadIdx.x & 7;        // row 0..31, float4 0..7
-        const float4 v = *(const float4*)(src + (size_t)r * W + 4 * q);
-        float* t = tile + r * 33 + 4 * q;
-        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+        *(float4*)(tile + r * TS + 4 * q) = *(const float4*)(src + (size_t)r * W + 4 * q);
     }
     __syncthreads();
     size_t off = 0;
@@ -50,8 +49,24 @@ __global__ __launch_bounds__(256) void k_pyramid_tile(const float* __restrict__ 
         if ((int)threadIdx.x < n * n) {
             const int oy = threadIdx.x / n, ox = threadIdx.x - oy * n;
             float s = 0.f;
-            for (int y = 0; y < k; y++)
-                for (int x = 0; x < k; x++) s += tile[(oy * k + y) * 33 + ox * k + x];
+            // the reference's row-major summation order; the loads of a window row are issued together (float4 / float2)
+            // so that the chain waits for LDS once per row instead of once per element
+            if (k >= 4) {
+                for (int y = 0; y < k; y++) {
+                    const float4* row = (const float4*)(tile + (oy * k + y) * TS + ox * k);
+                    for (int x4 = 0; x4 < k / 4; x4 += 2) {
+                        const float4 a = row[x4];
+                        const float4 b = (x4 + 1 < k / 4) ? row[x4 + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        s += a.x; s += a.y; s += a.z; s += a.w;
+                        if (x4 + 1 < k / 4) { s += b.x; s += b.y; s += b.z; s += b.w; }
+                    }
+                }
+            } else {
+                for (int y = 0; y < k; y++) {
+                    const float2 a = *(const float2*)(tile + (oy * k + y) * TS + ox * k);
+                    s += a.x; s += a.y;
+                }
+            }
             out[off + (size_t)pl * h * w + (size_t)(ty * n + oy) * w + tx * n + ox] = s / (float)(k * k);
         }
         off += (size_t)planes * h * w;
