@@ -189,7 +189,9 @@ class CCTrainer:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: only the capturing thread's calls are policed -- a process-group watchdog thread (multi-GPU runs)
+        # polling its events must not invalidate the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.losses = self._fwd_bwd(self.static_batch)
         LF.pyramid_cache.clear()
 
