@@ -10,6 +10,8 @@ MI355X-first structure around that body:
   * forward + backward of a step are captured once into a hipGraph (static shapes, no host syncs on the path)
     and replayed, which removes the ~1.5 k kernel-launch and Python/autograd dispatch costs from the step.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -191,7 +193,7 @@ class CCTrainer:
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: only the capturing thread's calls are policed -- a process-group watchdog thread (multi-GPU runs)
         # polling its events must not invalidate the capture
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        with torch.cuda.graph(self.graph, capture_error_mode=os.environ.get("CC_CAPTURE_MODE", "thread_local")):
             self.losses = self._fwd_bwd(self.static_batch)
         LF.pyramid_cache.clear()
 
