@@ -1,0 +1,87 @@
+"""The drop-in contract of SURVEY.md 8b on the Python module surface: state_dict keys/shapes, constructor signatures,
+train()/eval() return conventions, the reference's assertion messages and argument errors, checkpoint layout.
+(The oracle nets are pinned to the unmodified reference by tests/test_oracle_golden.py.)"""
+import io
+
+import pytest
+import torch
+
+from cc_amd import models, inverse_warp as IW, loss_functions as LF, synthetic as syn
+from hipemu.emu import emulated_engine
+from oracle import nets as ON
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _emu():
+    with emulated_engine():
+        yield
+
+
+NETS = [("DispResNet6", {}), ("DispNetS", {}), ("PoseNetB6", dict(nb_ref_imgs=4)), ("MaskNet6", dict(nb_ref_imgs=4, output_exp=True)),
+        ("PoseExpNet", dict(nb_ref_imgs=4, output_exp=True)), ("Back2Future", dict(nlevels=6))]
+
+
+@pytest.mark.parametrize("name,kw", NETS)
+def test_state_dict_contract(name, kw):
+    ours, ref = getattr(models, name)(**kw), getattr(ON, name)(**kw)
+    a, b = ours.state_dict(), ref.state_dict()
+    assert list(a.keys()) == list(b.keys())
+    assert [tuple(v.shape) for v in a.values()] == [tuple(v.shape) for v in b.values()]
+    # utils.py:55-63 checkpoint layout {'epoch', 'state_dict'} round-trips through torch.save / load_state_dict
+    buf = io.BytesIO()
+    torch.save({"epoch": 3, "state_dict": b}, buf)
+    buf.seek(0)
+    ck = torch.load(buf)
+    ours.load_state_dict(ck["state_dict"])
+    assert ck["epoch"] == 3
+
+
+def test_train_eval_return_conventions():
+    B, H, W = 2, 64, 128
+    tgt, refs, K, Kinv = syn.sample(B, H, W, seed=1, smooth=2)
+    disp, pose = models.DispResNet6(), models.PoseNetB6(nb_ref_imgs=4)
+    disp.init_weights(), pose.init_weights()
+    out = disp.train()(tgt)
+    assert isinstance(out, tuple) and len(out) == 6 and [tuple(o.shape[2:]) for o in out][:3] == [(64, 128), (32, 64), (16, 32)]
+    with torch.no_grad():
+        assert torch.is_tensor(disp.eval()(tgt)) and disp.eval()(tgt).shape == (B, 1, H, W)      # DispResNet6.py:191-194
+    assert pose.train()(tgt, refs).shape == (B, 4, 6)                                                # PoseNetB6.py:83
+    m = models.MaskNet6(nb_ref_imgs=4, output_exp=True)
+    m.init_weights()
+    masks = m.train()(tgt, refs)
+    assert len(masks) == 6 and masks[0].shape == (B, 4, H, W)
+
+
+def test_reference_assertion_messages():
+    img, depth = torch.zeros(2, 3, 8, 10), torch.ones(2, 8, 10)
+    pose, K = torch.zeros(2, 6), torch.eye(3).repeat(2, 1, 1)
+    with pytest.raises(AssertionError, match=r"wrong size for depth, expected BxHxW, got  \[2, 1, 8, 10\]"):
+        IW.inverse_warp(img, depth.unsqueeze(1), pose, K, K)                                        # inverse_warp.py:23-28,263
+    with pytest.raises(AssertionError, match=r"wrong size for pose, expected Bx6"):
+        IW.inverse_warp(img, depth, torch.zeros(2, 7), K, K)
+    with pytest.raises(AssertionError, match=r"wrong size for flow, expected Bx2xHxW"):
+        IW.flow_warp(img, torch.zeros(2, 3, 8, 10))
+    with pytest.raises(AssertionError, match=r"wrong size for flow, expected Bx2xHxW"):
+        IW.flow2oob(torch.zeros(2, 8, 10))
+
+
+def test_argument_errors_of_the_losses():
+    B, H, W = 2, 16, 24
+    tgt, refs, K, Kinv = syn.sample(B, H, W, seed=1)
+    depth = [torch.ones(B, 1, H, W)]
+    with pytest.raises(IndexError):           # depth_occlusion_masks indexes 4 reference poses (loss_functions.py:132-137)
+        LF.photometric_reconstruction_loss(tgt, refs[:2], K, Kinv, depth, [None], torch.zeros(B, 2, 6))
+    with pytest.raises(IndexError):           # occlusion_masks(flows[0], flows[1]) needs two flows (:70)
+        LF.photometric_flow_loss(tgt, refs[:1], [[torch.zeros(B, 2, H, W)]], [None])
+    with pytest.raises(AssertionError, match="wrong size for depth"):
+        # B = 1: depth.squeeze() drops the batch dimension as well (loss_functions.py:133)
+        LF.depth_occlusion_masks(torch.ones(1, 1, H, W), torch.zeros(1, 4, 6), K[:1], Kinv[:1])
+
+
+def test_flow2oob_matches_definition():
+    flow = torch.zeros(1, 2, 4, 6)
+    flow[0, 0, 1, 5] = 0.5          # x + u = 5.5 > w - 1
+    flow[0, 1, 0, 2] = -0.25        # y + v < 0
+    oob = IW.flow2oob(flow)
+    assert oob.dtype == torch.bool and oob.shape == (1, 4, 6)
+    assert bool(oob[0, 1, 5]) and bool(oob[0, 0, 2]) and int(oob.sum()) == 2
