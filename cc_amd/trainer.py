@@ -135,6 +135,34 @@ class FlatAdam:
         engine().call("cc_adam_step", self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.step_dev, self.n,
                       float(self.lr), float(self.betas[0]), float(self.betas[1]), 1e-8, float(grad_scale), STREAM)
 
+    def state_dict(self):
+        """The layout of ``torch.optim.Adam.state_dict()`` (what train.py:408-410 stores in optimizer_checkpoint.pth.tar):
+        per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` cut out of the flat buckets, one param group."""
+        state, off = {}, 0
+        for i, p in enumerate(self.params):
+            k = p.numel()
+            state[i] = {"step": self.step_dev.detach().clone().reshape(()),
+                        "exp_avg": self.exp_avg[off:off + k].view_as(p).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + k].view_as(p).clone()}
+            off += k
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
+                 "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        """Accepts a ``torch.optim.Adam`` state dict over the same parameter order (chain of the four nets)."""
+        off = 0
+        for i, p in enumerate(self.params):
+            k = p.numel()
+            st = sd["state"].get(i)
+            if st is not None:
+                self.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                self.step_dev.fill_(float(st["step"]))
+            off += k
+        g = sd["param_groups"][0]
+        self.lr, self.betas = g["lr"], tuple(g["betas"])
+
     def broadcast_from_rank0(self):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.broadcast(self.flat_p, 0)
@@ -196,6 +224,14 @@ class CCTrainer:
         with torch.cuda.graph(self.graph, capture_error_mode=os.environ.get("CC_CAPTURE_MODE", "thread_local")):
             self.losses = self._fwd_bwd(self.static_batch)
         LF.pyramid_cache.clear()
+
+    def save_checkpoint(self, save_path, epoch, is_best=False):
+        """train.py:396-413: the five ``{'epoch', 'state_dict'}`` files of utils.save_checkpoint."""
+        from . import utils
+        sd = [({"epoch": epoch + 1, "state_dict": n.state_dict()} if n is not None else {"epoch": epoch + 1, "state_dict": {}})
+              for n in self.nets]
+        utils.save_checkpoint(save_path, sd[0], sd[1], sd[2], sd[3], {"epoch": epoch + 1, "state_dict": self.opt.state_dict()},
+                              is_best)
 
     def step(self, batch):
         """train.py:445-568 for one mini-batch: returns the (device) loss tensors of this step."""

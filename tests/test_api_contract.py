@@ -85,3 +85,40 @@ def test_flow2oob_matches_definition():
     oob = IW.flow2oob(flow)
     assert oob.dtype == torch.bool and oob.shape == (1, 4, 6)
     assert bool(oob[0, 1, 5]) and bool(oob[0, 0, 2]) and int(oob.sum()) == 2
+
+
+def test_checkpoint_wire_format(tmp_path):
+    """utils.py:55-63 + train.py:286-295,396-413: five files, {'epoch','state_dict'}, *_model_best copies; the files load
+    with the reference's own torch.load + load_state_dict lines (here into the oracle nets, which carry the reference's
+    keys) and back; the optimizer file has torch.optim.Adam's layout."""
+    import os
+    from cc_amd import trainer as T, utils
+    torch.manual_seed(0)
+    nets = T.build_nets("cpu")
+    tr = T.CCTrainer(nets, T.StepConfig(), use_graph=False)
+    tr.opt.exp_avg.normal_()                 # stand-in for the moments after one optimizer step
+    tr.opt.exp_avg_sq.uniform_()
+    tr.opt.step_dev.fill_(1.0)
+    tr.save_checkpoint(tmp_path, epoch=4, is_best=True)
+    names = sorted(os.listdir(tmp_path))
+    assert names == sorted(["%s_%s" % (p, s) for p in utils.FILE_PREFIXES for s in ("checkpoint.pth.tar", "model_best.pth.tar")])
+    # the reference's resume lines (train.py:288-295) against nets that carry the reference's keys
+    ref_nets = [ON.DispResNet6(), ON.PoseNetB6(nb_ref_imgs=4), ON.MaskNet6(nb_ref_imgs=4, output_exp=True), ON.Back2Future(nlevels=6)]
+    for prefix, net, ours in zip(utils.FILE_PREFIXES, ref_nets, nets):
+        w = torch.load(os.path.join(tmp_path, prefix + "_checkpoint.pth.tar"))
+        assert set(w.keys()) == {"epoch", "state_dict"} and w["epoch"] == 5
+        net.load_state_dict(w["state_dict"])
+        for (k, a), b in zip(net.state_dict().items(), ours.state_dict().values()):
+            assert torch.equal(a, b), k
+    # optimizer file: loadable by a real torch.optim.Adam over the same parameter chain
+    params = [p for n in ref_nets for p in n.parameters()]
+    opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.999))
+    osd = torch.load(os.path.join(tmp_path, "optimizer_checkpoint.pth.tar"))["state_dict"]
+    opt.load_state_dict(osd)
+    assert float(opt.state[params[0]]["step"]) == 1.0 and opt.state[params[0]]["exp_avg"].shape == params[0].shape
+    # and back into a fresh engine trainer
+    nets2 = T.build_nets("cpu")
+    assert utils.resume(tmp_path, *nets2) == 5
+    tr2 = T.CCTrainer(nets2, T.StepConfig(), use_graph=False)
+    tr2.opt.load_state_dict(opt.state_dict())
+    assert torch.equal(tr2.opt.exp_avg, tr.opt.exp_avg) and torch.equal(tr2.opt.flat_p, tr.opt.flat_p)
