@@ -207,6 +207,34 @@ def net_and_step_level(ac):
     return g
 
 
+AB, AH, AW = 2, 64, 128           # alternative-architecture case (kept small: the CPU suite runs it under the HIP emulator)
+ALT_NETS = (("DispNetS6", {}), ("DispResNetS6", {}), ("PoseNet6", dict(nb_ref_imgs=4)),
+            ("MaskResNet6", dict(nb_ref_imgs=4, output_exp=True)))
+
+
+def alt_nets_level():
+    """The alternative architectures of train.py:84-91 from the unmodified reference modules:
+    train-mode outputs and parameter-gradient norms on the seeded sample with seeded weights."""
+    import importlib.util
+    ref_import.load(None)
+    g = {}
+    tgt, refs, K, Kinv = syn.sample(AB, AH, AW, seed=1)
+    for name, kw in ALT_NETS:
+        spec = importlib.util.spec_from_file_location("ccref_alt_" + name, os.path.join(ref_import.REF_ROOT, "models", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        net = getattr(mod, name)(**kw)
+        net.load_state_dict(syn.seeded_state_dict(net, 0))
+        net.train()
+        out = net(tgt) if name.startswith("Disp") else net(tgt, refs)
+        outs = list(out) if isinstance(out, (tuple, list)) else [out]
+        _coarse(name, outs, g)
+        loss = sum((o * o).mean() for o in outs)
+        loss.backward()
+        g[name + ".gradnorm"] = np.float64(sum(float(p.grad.double().pow(2).sum()) for p in net.parameters() if p.grad is not None) ** 0.5)
+    return g
+
+
 def metric_inputs(seed=21, B=2, H=48, W=64, h=24, w=32):
     """Seeded inputs of the validation metrics: KITTI-like flow ground truth (u, v, valid), two predictions at half
     resolution, a soft rigidity mask, and depth ground truth / prediction with invalid (0 / > 80 m) pixels."""
@@ -245,6 +273,10 @@ def main():
     np.savez_compressed(os.path.join(OUT, "metrics.npz"), **metrics_level())
     print("wrote metrics")
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":
+        return
+    np.savez_compressed(os.path.join(OUT, "altnets.npz"), **alt_nets_level())
+    print("wrote altnets")
+    if len(sys.argv) > 1 and sys.argv[1] == "altnets":
         return
     for tag, ac in (("acF", None), ("acT", True)):
         np.savez_compressed(os.path.join(OUT, "functions_%s.npz" % tag), **function_level(ac))

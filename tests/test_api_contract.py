@@ -37,14 +37,15 @@ def test_state_dict_contract(name, kw):
 
 
 def test_train_eval_return_conventions():
-    B, H, W = 2, 64, 128
+    B, H, W = 2, 64, 64
     tgt, refs, K, Kinv = syn.sample(B, H, W, seed=1, smooth=2)
     disp, pose = models.DispResNet6(), models.PoseNetB6(nb_ref_imgs=4)
     disp.init_weights(), pose.init_weights()
-    out = disp.train()(tgt)
-    assert isinstance(out, tuple) and len(out) == 6 and [tuple(o.shape[2:]) for o in out][:3] == [(64, 128), (32, 64), (16, 32)]
     with torch.no_grad():
-        assert torch.is_tensor(disp.eval()(tgt)) and disp.eval()(tgt).shape == (B, 1, H, W)      # DispResNet6.py:191-194
+        out = disp.train()(tgt)
+        assert isinstance(out, tuple) and len(out) == 6 and [tuple(o.shape[2:]) for o in out][:3] == [(64, 64), (32, 32), (16, 16)]
+        one = disp.eval()(tgt)
+        assert torch.is_tensor(one) and one.shape == (B, 1, H, W)                                   # DispResNet6.py:191-194
     assert pose.train()(tgt, refs).shape == (B, 4, 6)                                                # PoseNetB6.py:83
     m = models.MaskNet6(nb_ref_imgs=4, output_exp=True)
     m.init_weights()
