@@ -48,7 +48,7 @@ struct GG {
 
 __device__ __forceinline__ float apply_act(float v, int act, float a, float b) {
     if (act == ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == ACT_LRELU) return v > 0.f ? v : 0.2f * v;
+    if (act == ACT_LRELU) return v > 0.f ? v : (b != 0.f ? b : 0.2f) * v;       // slope: act_b, 0 -> the 0.2 of Back2Future
     if (act == ACT_SIGMOID) return a * (1.f / (1.f + expf(-v))) + b;
     return v;
 }
@@ -1195,7 +1195,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 // when the plane size allows (HBM-bound: 2 reads + 1 write per element).
 __device__ __forceinline__ float act_grad(float g, float v, int act, float act_a, float act_b) {
     if (act == ACT_RELU) return v > 0.f ? g : 0.f;
-    if (act == ACT_LRELU) return v > 0.f ? g : 0.2f * g;
+    if (act == ACT_LRELU) return v > 0.f ? g : (act_b != 0.f ? act_b : 0.2f) * g;
     const float sg = (v - act_b) / act_a;
     return g * act_a * sg * (1.f - sg);
 }

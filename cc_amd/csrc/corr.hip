@@ -279,6 +279,60 @@ __global__ __launch_bounds__(256) void k_corr_bwd_f2_4(const float* __restrict__
     }
 }
 
+// ---- general P x P displacement grid with dilation D (FlowNetC6: P = 21, D = 2 on the 1/8-resolution features,
+// models/FlowNetC6.py:18-30).  Off the BASELINE path: simple gather kernels, one work-item per output element,
+// channel / displacement sums in index order (deterministic).
+//   out[b, i*P + j, y, x] = (1/C) sum_c f1[b,c,y,x] * f2[b,c, y + (i-r)*D, x + (j-r)*D],  r = (P-1)/2, zero outside
+__global__ __launch_bounds__(256) void k_corrp_fwd(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                   float* __restrict__ out, int C, int H, int W, int P, int D) {
+    const int HW = H * W, ND2 = P * P, r = (P - 1) / 2;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (t >= (long)HW * ND2) return;
+    const int d = (int)(t / HW), p = (int)(t - (long)d * HW);
+    const int i = d / P, j = d - i * P;
+    const int y = p / W, x = p - y * W;
+    const int yy = y + (i - r) * D, xx = x + (j - r) * D;
+    float acc = 0.f;
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const float* a = f1 + (size_t)b * C * HW + p;
+        const float* bb = f2 + (size_t)b * C * HW + yy * W + xx;
+        for (int c = 0; c < C; c++) acc = fmaf(a[(size_t)c * HW], bb[(size_t)c * HW], acc);
+    }
+    out[((size_t)b * ND2 + d) * HW + p] = acc / (float)C;
+}
+
+// g1[b,c,p] = (1/C) sum_d gout[b,d,p] * f2[b,c,p + disp(d)];   g2[b,c,q] = (1/C) sum_d gout[b,d,q - disp(d)] * f1[b,c,q - disp(d)]
+__global__ __launch_bounds__(256) void k_corrp_bwd(const float* __restrict__ gout, const float* __restrict__ f1,
+                                                   const float* __restrict__ f2, float* __restrict__ g1, float* __restrict__ g2,
+                                                   int C, int H, int W, int P, int D) {
+    const int HW = H * W, ND2 = P * P, r = (P - 1) / 2;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    const float* g = gout + (size_t)b * ND2 * HW;
+    const float* s1 = f1 + ((size_t)b * C + c) * HW;
+    const float* s2 = f2 + ((size_t)b * C + c) * HW;
+    float a1 = 0.f, a2 = 0.f;
+    for (int i = 0; i < P; i++) {
+        const int dy = (i - r) * D;
+        for (int j = 0; j < P; j++) {
+            const int dx = (j - r) * D, d = i * P + j;
+            const int yy = y + dy, xx = x + dx;              // f2 sample of output pixel p
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) a1 = fmaf(g[(size_t)d * HW + p], s2[yy * W + xx], a1);
+            const int ys = y - dy, xs = x - dx;              // output pixel whose f2 sample is p
+            if (ys >= 0 && ys < H && xs >= 0 && xs < W) {
+                const int q = ys * W + xs;
+                a2 = fmaf(g[(size_t)d * HW + q], s1[q], a2);
+            }
+        }
+    }
+    const size_t o = ((size_t)b * C + c) * HW + p;
+    if (g1) g1[o] = a1 / (float)C;
+    if (g2) g2[o] = a2 / (float)C;
+}
+
 }  // namespace
 
 extern "C" {
@@ -323,6 +377,27 @@ int cc_corr9x9_bwd(const float* gout, const float* f1, const float* f2, float* g
     if (g2_or_null)
         hipLaunchKernelGGL(k_corr_bwd_f2, g, dim3(256), 0, s, gout, f1, g2_or_null, chan_of_disp_or_null, C, H, W,
                            g_channels_total, g_channel_offset);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+/* spatial_correlation_sample(f1, f2, kernel_size=1, patch_size=P, dilation_patch=D) / C  -> [B, P*P, H, W]
+ * (models/FlowNetC6.py:18-30: P = 21, D = 2) */
+int cc_corr_patch_fwd(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int patch, int dilation,
+                      void* stream) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || patch < 1 || (patch & 1) == 0 || dilation < 1) return CC_ERR_ARG;
+    const long n = (long)H * W * patch * patch;
+    hipLaunchKernelGGL(k_corrp_fwd, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, f1, f2, out, C, H, W,
+                       patch, dilation);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_corr_patch_bwd(const float* gout, const float* f1, const float* f2, float* g1_or_null, float* g2_or_null, int B, int C,
+                      int H, int W, int patch, int dilation, void* stream) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || patch < 1 || (patch & 1) == 0 || dilation < 1) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_corrp_bwd, dim3((H * W + 255) / 256, C, B), dim3(256), 0, (hipStream_t)stream, gout, f1, f2, g1_or_null,
+                       g2_or_null, C, H, W, patch, dilation);
     CC_CHECK_LAUNCH();
     return CC_OK;
 }

@@ -169,7 +169,8 @@ class _Conv2dFn(torch.autograd.Function):
 
 
 def conv2d(x, w, bias=None, stride=1, padding=0, act=None, residual=None, act_a=1.0, act_b=0.0):
-    """act(conv2d(x, w, bias) + residual): nn.Conv2d (+ fused ReLU/LeakyReLU(0.2)/a*sigmoid+b epilogue)."""
+    """act(conv2d(x, w, bias) + residual): nn.Conv2d (+ fused ReLU / LeakyReLU / a*sigmoid+b epilogue).
+    act='lrelu': act_b is the negative slope (0 -> the 0.2 of Back2Future)."""
     if config.conv_backend == "miopen":
         y = F.conv2d(x, w, bias, stride, padding)
         if residual is not None:
@@ -180,7 +181,7 @@ def conv2d(x, w, bias=None, stride=1, padding=0, act=None, residual=None, act_a=
 
 class _ConvT2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, out_pad, act):
+    def forward(ctx, x, w, bias, stride, pad, out_pad, act, act_b=0.0):
         x, w = _c(x), _c(w)
         B, Cin, IH, IW = x.shape
         _, Cout, R, S = w.shape
@@ -193,9 +194,10 @@ class _ConvT2dFn(torch.autograd.Function):
         ws = _ws(E.call("cc_conv2d_dgrad_ws_bytes", B, Cin, IH, IW, Cout, R, S, stride, pad, OH, OW), x)
         pk = packs.get("dgrad", w, (B, Cin, IH, IW, Cout, R, S, stride, pad, OH, OW, Cout * R * S, R * S))
         E.call("cc_conv2d_dgrad", x, w, bias_c, y, ws, pk, B, Cin, IH, IW, Cin * IH * IW, Cout, R, S, stride, pad, OH, OW,
-               Cout * OH * OW, Cout * R * S, R * S, act, 1.0, 0.0, STREAM)
+               Cout * OH * OW, Cout * R * S, R * S, act, 1.0, float(act_b), STREAM)
         ctx.save_for_backward(x, w, y if act != 0 else None)
         ctx.cfg = (stride, pad, act, bias is not None)
+        ctx.act_b = float(act_b)
         ctx.bias_ptr = bias_c.data_ptr() if bias_c is not None else 0
         return y
 
@@ -216,7 +218,7 @@ class _ConvT2dFn(torch.autograd.Function):
         if act != 0 or gbias is not None:
             geff = torch.empty_like(gy) if act != 0 else None
             E.call("cc_act_bwd_bias", gy, y, geff, gbias, _ws(E.call("cc_act_bwd_ws_bytes", Cout), x), B, Cout, OH, OW,
-                   Cout * OH * OW, Cout * OH * OW, Cout * OH * OW, act, 1.0, 0.0, int(bsink is not None), STREAM)
+                   Cout * OH * OW, Cout * OH * OW, Cout * OH * OW, act, 1.0, ctx.act_b, int(bsink is not None), STREAM)
             if geff is not None:
                 gy = geff
         if bsink is not None:
@@ -237,20 +239,21 @@ class _ConvT2dFn(torch.autograd.Function):
                    stride, pad, Cout * R * S, R * S, int(wsink is not None), STREAM)
             if wsink is not None:
                 gw = None
-        return gx, gw, gbias, None, None, None, None
+        return gx, gw, gbias, None, None, None, None, None
 
 
-def conv_transpose2d(x, w, bias=None, stride=1, padding=0, output_padding=0, act=None):
+def conv_transpose2d(x, w, bias=None, stride=1, padding=0, output_padding=0, act=None, act_b=0.0):
+    """act='lrelu': act_b is the negative slope (0 -> 0.2)."""
     if config.conv_backend == "miopen":
-        return _torch_act(F.conv_transpose2d(x, w, bias, stride, padding, output_padding), act, 1.0, 0.0)
-    return _ConvT2dFn.apply(x, w, bias, int(stride), int(padding), int(output_padding), ACT[act])
+        return _torch_act(F.conv_transpose2d(x, w, bias, stride, padding, output_padding), act, 1.0, act_b)
+    return _ConvT2dFn.apply(x, w, bias, int(stride), int(padding), int(output_padding), ACT[act], float(act_b))
 
 
 def _torch_act(y, act, a, b):
     if act == "relu":
         return F.relu(y)
     if act == "lrelu":
-        return F.leaky_relu(y, 0.2)
+        return F.leaky_relu(y, b if b != 0 else 0.2)
     if act == "sigmoid":
         return a * torch.sigmoid(y) + b
     return y
@@ -385,3 +388,29 @@ class _CorrFn(torch.autograd.Function):
         ga, gb = torch.empty_like(a), torch.empty_like(b)
         engine().call("cc_corr9x9_bwd", _c(g), a, b, ga, gb, None, B, C, H, W, 81, 0, 0, STREAM)
         return ga, gb
+
+
+class _CorrPatchFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, patch, dilation):
+        a, b = _c(a), _c(b)
+        B, C, H, W = a.shape
+        out = torch.empty(B, patch * patch, H, W, device=a.device, dtype=torch.float32)
+        engine().call("cc_corr_patch_fwd", a, b, out, B, C, H, W, patch, dilation, STREAM)
+        ctx.save_for_backward(a, b)
+        ctx.geom = (patch, dilation)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        B, C, H, W = a.shape
+        ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        engine().call("cc_corr_patch_bwd", _c(g), a, b, ga, gb, B, C, H, W, ctx.geom[0], ctx.geom[1], STREAM)
+        return ga, gb, None, None
+
+
+def correlate_patch(input1, input2, patch_size=21, dilation_patch=2):
+    """models/FlowNetC6.py:18-30 `correlate`: [B, patch^2, H, W], already divided by C."""
+    return _CorrPatchFn.apply(input1, input2, int(patch_size), int(dilation_patch))

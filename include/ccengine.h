@@ -166,6 +166,11 @@ int cc_corr9x9_fwd(const float* f1, const float* f2, float* out, const int* chan
 int cc_corr9x9_bwd(const float* gout, const float* f1, const float* f2, float* g1, float* g2_or_null,
                    const int* chan_of_disp_or_null, int B, int C, int H, int W, int g_channels_total,
                    int g_channel_offset, int accumulate_g1, void* stream);
+/* general odd patch P with dilation D (models/FlowNetC6.py:18-30: P = 21, D = 2): out [B, P*P, H, W] = sample / C */
+int cc_corr_patch_fwd(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int patch, int dilation,
+                      void* stream);
+int cc_corr_patch_bwd(const float* gout, const float* f1, const float* f2, float* g1_or_null, float* g2_or_null, int B, int C,
+                      int H, int W, int patch, int dilation, void* stream);
 
 /* ---------------------------------------------------------------- convolutions (nn.Conv2d / nn.ConvTranspose2d of models/ *.py)
  * fp32 implicit GEMM on v_mfma_f32_32x32x2_f32.  act: 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 act_a*sigmoid+act_b.

@@ -209,7 +209,16 @@ def net_and_step_level(ac):
 
 AB, AH, AW = 2, 64, 128           # alternative-architecture case (kept small: the CPU suite runs it under the HIP emulator)
 ALT_NETS = (("DispNetS6", {}), ("DispResNetS6", {}), ("PoseNet6", dict(nb_ref_imgs=4)),
-            ("MaskResNet6", dict(nb_ref_imgs=4, output_exp=True)))
+            ("MaskResNet6", dict(nb_ref_imgs=4, output_exp=True)), ("FlowNetC6", dict(nlevels=6)))
+
+
+def alt_net_args(name, tgt, refs):
+    """Call signature per architecture: disparity nets (tgt), pose / mask nets (tgt, refs), FlowNetC6 (tgt, ref+)."""
+    if name.startswith("Disp"):
+        return (tgt,)
+    if name == "FlowNetC6":
+        return (tgt, refs[2])
+    return (tgt, refs)
 
 
 def alt_nets_level():
@@ -219,14 +228,17 @@ def alt_nets_level():
     ref_import.load(None)
     g = {}
     tgt, refs, K, Kinv = syn.sample(AB, AH, AW, seed=1)
+    root = os.path.join(ref_import.REF_ROOT, "models")        # as a package: FlowNetC6 imports .submodules
+    spec = importlib.util.spec_from_file_location("ccref_models_pkg", os.path.join(root, "__init__.py"),
+                                                  submodule_search_locations=[root])
+    pkg = importlib.util.module_from_spec(spec)
+    sys.modules["ccref_models_pkg"] = pkg
+    spec.loader.exec_module(pkg)
     for name, kw in ALT_NETS:
-        spec = importlib.util.spec_from_file_location("ccref_alt_" + name, os.path.join(ref_import.REF_ROOT, "models", name + ".py"))
-        mod = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(mod)
-        net = getattr(mod, name)(**kw)
+        net = getattr(pkg, name)(**kw)
         net.load_state_dict(syn.seeded_state_dict(net, 0))
         net.train()
-        out = net(tgt) if name.startswith("Disp") else net(tgt, refs)
+        out = net(*alt_net_args(name, tgt, refs))
         outs = list(out) if isinstance(out, (tuple, list)) else [out]
         _coarse(name, outs, g)
         loss = sum((o * o).mean() for o in outs)

@@ -479,3 +479,20 @@ def check_batch_norm(dev, cases=((2, 5, 7, 12), (3, 16, 9, 13), (2, 8, 32, 64)))
         g0 = torch.autograd.grad(r, [xc, wc, bc], go)
         errs = [rel(a, b) for a, b in zip(g1, g0)]
         assert max(errs) < 1e-5, ("bn grads", (B, C, H, W), errs)
+
+
+def check_corr_patch(dev, cases=((2, 6, 9, 14, 5, 1), (1, 4, 12, 10, 7, 2), (1, 3, 6, 7, 21, 2))):
+    """General P x P / dilation-D cost volume (FlowNetC6) vs the oracle's restatement of spatial_correlation_sample."""
+    from cc_amd import ops
+    from oracle.corr import correlation_volume
+    g = torch.Generator().manual_seed(11)
+    for (B, C, H, W, P, D) in cases:
+        a0, b0 = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+        ad, bd, ac, bc = leaf(a0, dev), leaf(b0, dev), leaf(a0, "cpu"), leaf(b0, "cpu")
+        o = ops.correlate_patch(ad, bd, P, D)
+        r = correlation_volume(ac, bc, P, D).reshape(B, P * P, H, W) / C
+        assert rel(o, r) < 2e-6, ("corr patch", (B, C, H, W, P, D), rel(o, r))
+        go = torch.randn(r.shape, generator=g)
+        g1 = torch.autograd.grad(o, [ad, bd], go.to(dev))
+        g0 = torch.autograd.grad(r, [ac, bc], go)
+        assert max(rel(x, y) for x, y in zip(g1, g0)) < 5e-6, ("corr patch grads", (B, C, H, W, P, D))

@@ -61,6 +61,7 @@ def test_convs_thin_wgrad(monkeypatch):
 
 def test_cost_volume():
     parity.check_corr("cpu")
+    parity.check_corr_patch("cpu")
 
 
 def test_batch_norm():

@@ -78,6 +78,7 @@ def test_convs_full_size_thin_layers():
 
 def test_cost_volume():
     parity.check_corr("cuda")
+    parity.check_corr_patch("cuda")
     parity.check_corr("cuda", cases=((2, 32, 64, 208), (2, 196, 8, 26)))
 
 
