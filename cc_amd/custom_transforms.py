@@ -1,0 +1,198 @@
+"""Input pipeline of the reference (custom_transforms.py).
+
+Host side: the transform classes train.py:166-190 composes, same names, arguments, random-number draws (so the same seeds
+give the same augmentations) and intrinsics updates.  ``scipy.misc.imresize`` / ``imrotate`` -- removed from SciPy in 1.3
+and absent here -- are restated from SciPy 1.1's ``scipy/misc/pilutil.py`` (``toimage`` byte-scales float arrays to their
+own min..max before PIL's resize; bilinear resampling).  **Parity unpinned** for those two functions: the dependency the
+reference imports no longer exists, so there is nothing to run them against.
+
+Device side: ``DeviceFrames`` fuses ArrayToTensor + Normalize (+ the mirror of RandomHorizontalFlip and the crop of
+RandomScaleCrop) for a whole batch of frames into one HIP launch (``cc_frames_to_tensor``) -- HWC uint8 / float32 frames go
+to HBM as they are (4x less PCIe traffic for uint8) and come out as the normalised fp32 NCHW tensors the nets consume."""
+import random
+
+import numpy as np
+import torch
+
+from ._lib import engine, STREAM
+
+
+# ----------------------------------------------------------------------------- scipy.misc restatements (parity unpinned)
+def _bytescale(data, cmin=None, cmax=None, high=255, low=0):
+    """scipy 1.1 misc/pilutil.py bytescale."""
+    if data.dtype == np.uint8:
+        return data
+    if cmin is None:
+        cmin = data.min()
+    if cmax is None:
+        cmax = data.max()
+    cscale = cmax - cmin
+    if cscale == 0:
+        cscale = 1
+    scale = float(high - low) / cscale
+    bytedata = (data - cmin) * scale + low
+    return (bytedata.clip(low, high) + 0.5).astype(np.uint8)
+
+
+def _toimage(arr):
+    from PIL import Image
+    data = np.asarray(arr)
+    if data.ndim == 2:
+        return Image.fromarray(_bytescale(data), mode='L')
+    assert data.ndim == 3 and data.shape[2] in (3, 4), "imresize: expected HxW or HxWx{3,4}"
+    return Image.fromarray(np.ascontiguousarray(_bytescale(data)), mode='RGB' if data.shape[2] == 3 else 'RGBA')
+
+
+def imresize(arr, size, interp='bilinear'):
+    """scipy.misc.imresize(arr, (h, w)) -> uint8 array."""
+    from PIL import Image
+    func = {'nearest': Image.NEAREST, 'lanczos': Image.LANCZOS, 'bilinear': Image.BILINEAR, 'bicubic': Image.BICUBIC}
+    im = _toimage(arr)
+    if isinstance(size, int):
+        size = tuple((np.array(im.size) * (size / 100.0)).astype(int))
+    elif isinstance(size, float):
+        size = tuple((np.array(im.size) * size).astype(int))
+    else:
+        size = (size[1], size[0])
+    return np.array(im.resize(size, resample=func[interp]))
+
+
+def imrotate(arr, angle, interp='bilinear'):
+    """scipy.misc.imrotate(arr, angle) -> uint8 array (counter-clockwise, same size)."""
+    from PIL import Image
+    func = {'nearest': Image.NEAREST, 'bilinear': Image.BILINEAR, 'bicubic': Image.BICUBIC}
+    return np.array(_toimage(arr).rotate(angle, resample=func[interp]))
+
+
+# ----------------------------------------------------------------------------- host transforms (custom_transforms.py)
+class Compose(object):
+    def __init__(self, transforms):
+        self.transforms = transforms
+
+    def __call__(self, images, intrinsics):
+        for t in self.transforms:
+            images, intrinsics = t(images, intrinsics)
+        return images, intrinsics
+
+
+class Normalize(object):
+    def __init__(self, mean, std):
+        self.mean = mean
+        self.std = std
+
+    def __call__(self, images, intrinsics):
+        for tensor in images:
+            for t, m, s in zip(tensor, self.mean, self.std):
+                t.sub_(m).div_(s)
+        return images, intrinsics
+
+
+class NormalizeLocally(object):
+    def __call__(self, images, intrinsics):
+        image_tensor = torch.stack(images)
+        assert image_tensor.size(1) == 3
+        mean = image_tensor.transpose(0, 1).contiguous().view(3, -1).mean(1)
+        std = image_tensor.transpose(0, 1).contiguous().view(3, -1).std(1)
+        for tensor in images:
+            for t, m, s in zip(tensor, mean, std):
+                t.sub_(m).div_(s)
+        return images, intrinsics
+
+
+class ArrayToTensor(object):
+    """list of HxWxC arrays -> list of CxHxW float tensors / 255."""
+
+    def __call__(self, images, intrinsics):
+        return [torch.from_numpy(np.transpose(im, (2, 0, 1))).float() / 255 for im in images], intrinsics
+
+
+class RandomHorizontalFlip(object):
+    def __call__(self, images, intrinsics):
+        assert intrinsics is not None
+        if random.random() < 0.5:
+            output_intrinsics = np.copy(intrinsics)
+            output_images = [np.copy(np.fliplr(im)) for im in images]
+            w = output_images[0].shape[1]
+            output_intrinsics[0, 2] = w - output_intrinsics[0, 2]
+        else:
+            output_images, output_intrinsics = images, intrinsics
+        return output_images, output_intrinsics
+
+
+class RandomRotate(object):
+    def __call__(self, images, intrinsics):
+        if np.random.random() > 0.5:
+            return images, intrinsics
+        assert intrinsics is not None
+        rot = np.random.uniform(0, 10)
+        return [imrotate(im, rot) for im in images], intrinsics
+
+
+class RandomScaleCrop(object):
+    def __init__(self, h=0, w=0):
+        self.h, self.w = h, w
+
+    def draw(self, in_h, in_w):
+        """The random decisions of __call__ in its order: -> (scaled_h, scaled_w, x_scaling, y_scaling, off_y, off_x, out_h, out_w)."""
+        x_scaling, y_scaling = np.random.uniform(1, 1.1, 2)
+        scaled_h, scaled_w = int(in_h * y_scaling), int(in_w * x_scaling)
+        out_h, out_w = (self.h, self.w) if (self.h and self.w) else (in_h, in_w)
+        offset_y = np.random.randint(scaled_h - out_h + 1)
+        offset_x = np.random.randint(scaled_w - out_w + 1)
+        return scaled_h, scaled_w, x_scaling, y_scaling, offset_y, offset_x, out_h, out_w
+
+    def __call__(self, images, intrinsics):
+        assert intrinsics is not None
+        output_intrinsics = np.copy(intrinsics)
+        in_h, in_w, _ = images[0].shape
+        scaled_h, scaled_w, xs, ys, offset_y, offset_x, out_h, out_w = self.draw(in_h, in_w)
+        output_intrinsics[0] *= xs
+        output_intrinsics[1] *= ys
+        scaled_images = [imresize(im, (scaled_h, scaled_w)) for im in images]
+        cropped_images = [im[offset_y:offset_y + out_h, offset_x:offset_x + out_w] for im in scaled_images]
+        output_intrinsics[0, 2] -= offset_x
+        output_intrinsics[1, 2] -= offset_y
+        return cropped_images, output_intrinsics
+
+
+class Scale(object):
+    def __init__(self, h, w):
+        self.h, self.w = h, w
+
+    def __call__(self, images, intrinsics):
+        assert intrinsics is not None
+        output_intrinsics = np.copy(intrinsics)
+        in_h, in_w, _ = images[0].shape
+        output_intrinsics[0] *= (self.w / in_w)
+        output_intrinsics[1] *= (self.h / in_h)
+        return [imresize(im, (self.h, self.w)) for im in images], output_intrinsics
+
+
+# ----------------------------------------------------------------------------- device side
+class DeviceFrames(object):
+    """ArrayToTensor + Normalize(mean, std) (+ per-frame mirror / crop window) for a batch of equally sized HWC frames in
+    one launch.  frames: list of N arrays [H,W,3] (uint8 or float32 0..255) or one [N,H,W,3] array / tensor;
+    flips / offsets: per-frame (bool, (off_y, off_x)) or None.  -> fp32 [N,3,h,w] on `device`."""
+
+    def __init__(self, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), device="cuda"):
+        self.mean, self.std, self.device = [float(m) for m in mean], [float(s) for s in std], torch.device(device)
+
+    def __call__(self, frames, out_hw=None, flips=None, offsets=None):
+        if not torch.is_tensor(frames):
+            frames = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(f) for f in frames])
+                                                           if isinstance(frames, (list, tuple)) else frames))
+        assert frames.dim() == 4 and frames.shape[3] == 3 and frames.dtype in (torch.uint8, torch.float32)
+        src = frames.to(self.device, non_blocking=True).contiguous()
+        N, H, W, _ = src.shape
+        h, w = out_hw if out_hw is not None else (H, W)
+        geo = np.zeros((N, 3), dtype=np.int32)
+        if flips is not None:
+            geo[:, 0] = np.asarray(flips, dtype=np.int32)
+        if offsets is not None:
+            geo[:, 1:] = np.asarray(offsets, dtype=np.int32)
+        assert (geo[:, 1] >= 0).all() and (geo[:, 2] >= 0).all() and (geo[:, 1] + h <= H).all() and (geo[:, 2] + w <= W).all()
+        geo_d = torch.from_numpy(geo).to(self.device)
+        dst = torch.empty(N, 3, h, w, device=self.device, dtype=torch.float32)
+        engine().call("cc_frames_to_tensor", src, int(src.dtype == torch.uint8), dst, geo_d, N, H, W, h, w, self.mean[0],
+                      self.mean[1], self.mean[2], self.std[0], self.std[1], self.std[2], STREAM)
+        return dst

@@ -223,6 +223,13 @@ int cc_act_bwd_bias(const float* gy, const float* y_or_null, float* geff_or_null
                     int C, int H, int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b,
                     int accumulate_bias, void* stream);
 
+/* ---------------------------------------------------------------- input pipeline, device side
+ * custom_transforms.py:21-30,47-57 ArrayToTensor + Normalize with the crop of RandomScaleCrop (:93-121) and the mirror of
+ * RandomHorizontalFlip (:60-73) folded in.  src: [N,H,W,3] uint8 or float32 (0..255); dst: [N,3,h,w];
+ * geo: int32 [N,3] = (flip, off_y, off_x) per frame. */
+int cc_frames_to_tensor(const void* src, int src_is_u8, float* dst, const int* geo, int N, int H, int W, int h, int w, float mean0,
+                        float mean1, float mean2, float std0, float std1, float std2, void* stream);
+
 /* ---------------------------------------------------------------- BatchNorm2d, training mode
  * (models/DispResNet6.py:53-56: the Conv1x1 + BatchNorm2d shortcut of every ResNet stage; 13 per forward)
  * y = (x - mean_c) / sqrt(var_c + eps) * w_c + b_c with batch statistics over (B,H,W); running stats updated with

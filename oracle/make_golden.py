@@ -247,6 +247,59 @@ def alt_nets_level():
     return g
 
 
+def transform_inputs(seed=31, n=3, H=40, W=56):
+    """Seeded 'decoded JPEG' frames as datasets/sequence_folders.py:27-28 hands them to the transforms (float32 HWC 0..255)
+    and a KITTI-like intrinsics matrix."""
+    r = np.random.RandomState(seed)
+    frames = [np.floor(r.rand(H, W, 3) * 256).clip(0, 255).astype(np.float32) for _ in range(n)]
+    K = np.array([[0.58 * W, 0, 0.49 * W], [0, 1.92 * H, 0.5 * H], [0, 0, 1]], dtype=np.float32)
+    return frames, K
+
+
+def load_reference_transforms():
+    """The unmodified custom_transforms.py; `scipy.misc.imresize/imrotate` (gone from SciPy) are provided by the
+    restatement in cc_amd/custom_transforms.py -- everything else in the fixture is the reference's own arithmetic."""
+    import importlib.util
+    import types
+    from cc_amd import custom_transforms as mine
+    shim = types.ModuleType("scipy.misc")
+    shim.imresize, shim.imrotate = mine.imresize, mine.imrotate
+    import scipy
+    sys.modules["scipy.misc"] = shim
+    scipy.misc = shim
+    spec = importlib.util.spec_from_file_location("ccref_custom_transforms", os.path.join(ref_import.REF_ROOT, "custom_transforms.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def run_train_transform(ct, seed):
+    """train.py:166-177 pipeline with Normalize(0.5, 0.5) on the seeded frames; both RNGs seeded like SequenceFolder does."""
+    import random
+    frames, K = transform_inputs()
+    random.seed(seed)
+    np.random.seed(seed)
+    t = ct.Compose([ct.RandomHorizontalFlip(), ct.RandomScaleCrop(), ct.ArrayToTensor(),
+                    ct.Normalize(mean=[0.5, 0.5, 0.5], std=[0.5, 0.5, 0.5])])
+    imgs, Kout = t([f.copy() for f in frames], np.copy(K))
+    return imgs, Kout
+
+
+def transforms_level():
+    ct = load_reference_transforms()
+    g = {}
+    for seed in (0, 1, 2, 3):
+        imgs, Kout = run_train_transform(ct, seed)
+        g["seed%d.K" % seed] = np.asarray(Kout, dtype=np.float32)
+        for i, im in enumerate(imgs):
+            g["seed%d.img%d" % (seed, i)] = npy(im)
+    frames, K = transform_inputs()
+    sc, Ks = ct.Compose([ct.Scale(h=24, w=32), ct.ArrayToTensor()])([f.copy() for f in frames], np.copy(K))
+    g["scale.K"] = np.asarray(Ks, dtype=np.float32)
+    g["scale.img0"] = npy(sc[0])
+    return g
+
+
 def metric_inputs(seed=21, B=2, H=48, W=64, h=24, w=32):
     """Seeded inputs of the validation metrics: KITTI-like flow ground truth (u, v, valid), two predictions at half
     resolution, a soft rigidity mask, and depth ground truth / prediction with invalid (0 / > 80 m) pixels."""
@@ -286,6 +339,11 @@ def main():
     print("wrote metrics")
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "transforms":
+        np.savez_compressed(os.path.join(OUT, "transforms.npz"), **transforms_level())
+        print("wrote transforms")
+        return
+    np.savez_compressed(os.path.join(OUT, "transforms.npz"), **transforms_level())
     np.savez_compressed(os.path.join(OUT, "altnets.npz"), **alt_nets_level())
     print("wrote altnets")
     if len(sys.argv) > 1 and sys.argv[1] == "altnets":

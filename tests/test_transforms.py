@@ -1,0 +1,60 @@
+"""Input pipeline: cc_amd.custom_transforms against fixtures the unmodified reference
+custom_transforms.py produced (tests/golden/transforms.npz; its two removed SciPy imports are served by the restatement, so
+the fixture pins the reference's own arithmetic: RNG draw order, flip, crop, intrinsics updates, /255, normalise), and the
+fused device kernel against the host classes, bit for bit."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from cc_amd import custom_transforms as CT
+from oracle.make_golden import run_train_transform, transform_inputs
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "transforms.npz"))
+
+
+def test_host_transforms_match_reference(gold):
+    for seed in (0, 1, 2, 3):
+        imgs, K = run_train_transform(CT, seed)
+        assert np.array_equal(np.asarray(K, dtype=np.float32), gold["seed%d.K" % seed])
+        for i, im in enumerate(imgs):
+            assert np.array_equal(im.numpy(), gold["seed%d.img%d" % (seed, i)]), (seed, i)
+    frames, K = transform_inputs()
+    sc, Ks = CT.Compose([CT.Scale(h=24, w=32), CT.ArrayToTensor()])([f.copy() for f in frames], np.copy(K))
+    assert np.array_equal(np.asarray(Ks, dtype=np.float32), gold["scale.K"]) and np.array_equal(sc[0].numpy(), gold["scale.img0"])
+
+
+def _device_vs_host(dev):
+    frames, K = transform_inputs(seed=5, n=4, H=36, W=52)
+    u8 = [f.astype(np.uint8) for f in frames]
+    prep = CT.DeviceFrames(mean=(0.5, 0.45, 0.4), std=(0.5, 0.25, 0.2), device=dev)
+    flips, offs, hw = [1, 0, 1, 0], [(3, 5), (0, 0), (4, 20), (2, 1)], (32, 32)
+    for src in (u8, frames):
+        out = prep(src, out_hw=hw, flips=flips, offsets=offs).cpu()
+        for n, f in enumerate(src):
+            a = np.copy(np.fliplr(f)) if flips[n] else f                              # RandomHorizontalFlip, :66
+            a = a[offs[n][0]:offs[n][0] + hw[0], offs[n][1]:offs[n][1] + hw[1]]      # RandomScaleCrop's crop, :116
+            t, _ = CT.Compose([CT.ArrayToTensor(), CT.Normalize(prep.mean, prep.std)])([np.ascontiguousarray(a)], None)
+            assert torch.equal(out[n], t[0]), n
+
+
+def test_device_frames_emulated():
+    from hipemu.emu import emulated_engine
+    with emulated_engine():
+        _device_vs_host("cpu")
+
+
+@pytest.mark.gpu
+def test_device_frames_gpu():
+    _device_vs_host("cuda")
+    # one training sample's worth of full-size frames (5 x 256 x 832 uint8) in a single launch
+    r = np.random.RandomState(0)
+    big = r.randint(0, 256, size=(5, 256, 832, 3)).astype(np.uint8)
+    out = CT.DeviceFrames(device="cuda")(big)
+    ref = (torch.from_numpy(big).permute(0, 3, 1, 2).float() / 255 - 0.5) / 0.5
+    assert torch.equal(out.cpu(), ref)
