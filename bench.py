@@ -45,12 +45,30 @@ def parse():
     ap.add_argument("--elide-occ", action="store_true",
                     help="NOT the default metric: skip Back2Future's occlusion decoders, whose output train.py:463 discards "
                          "(SURVEY.md 8a D1); reported separately in DESIGN.md")
+    ap.add_argument("--freeze", action="store_true",
+                    help="README.md:59-65 training variant --fix-masknet --fix-flownet (train.py:332-346): all four nets run "
+                         "forward, only DispResNet6 + PoseNetB6 are trained (227 MB gradient bucket); reported beside the metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--conv-backend", default="hip", choices=["hip", "miopen"])
-    ap.add_argument("--cpu-steps", type=int, default=1)
-    ap.add_argument("--cpu-threads", type=int, default=64)
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU steps after one warm-up (median is reported)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every host thread (os.cpu_count())")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside a launcher: re-exec under torch.distributed.run, one rank per GPU (the driver's
+    own command line for N > 1), and pass the ranks' output through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log("self-launch: " + " ".join(cmd))
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 # ----------------------------------------------------------------------------- per-call instrumentation
@@ -195,6 +213,11 @@ def pmc_traffic(kernel):
     try:
         with open(path) as f:
             t = json.load(f)
+        from cc_amd import _lib
+        have = int(_lib.engine().call("cc_version"))
+        if int(t.get("cc_version", -1)) != have:
+            return None, "profiles/pmc_traffic.json is stale (kernels %s, library %s): rerun tools/gpu_pmc2.sh" % (
+                t.get("cc_version"), have)
         ent = t["kernels"].get(kernel.split("+")[0])
         if ent:
             return round(ent["hbm_bytes_per_launch"]), "profiles/pmc_traffic.json (%s)" % t.get("command", "")
@@ -203,34 +226,56 @@ def pmc_traffic(kernel):
     return None, None
 
 
-def cpu_baseline(batch_cpu, args):
-    """The oracle (CPU port of the reference step) on this box's host cores -- reported beside, never the target."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(batch_cpu, init_sd, args):
+    """The oracle (CPU port of the reference step, pinned bit-exact to the reference by tests/golden) on this box's host
+    cores -- reported beside the metric, never the target.  It starts from the SAME initial weights as the GPU run, so its
+    first two steps double as the bench-time parity gate.  -> (baseline dict, [losses per step])"""
     from oracle import step as S
-    n = min(os.cpu_count() or 1, args.cpu_threads)
+    n = args.cpu_threads if args.cpu_threads > 0 else (os.cpu_count() or 1)
     torch.set_num_threads(n)
-    torch.manual_seed(0)
     nets = S.build_nets("oracle", flow=(args.config == "c3"), mask=(args.config == "c3"))
-    for m in nets:
+    for m, sd in zip(nets, init_sd):
         if m is not None:
-            m.init_weights()
+            m.load_state_dict(sd)
+    if args.freeze:
+        for m in nets[2:]:
+            if m is not None:
+                for p_ in m.parameters():
+                    p_.requires_grad = False              # train.py:332-339
     cfg = S.StepConfig()
     opt = S.make_optimizer(nets, cfg)
-    t0 = time.time()
-    S.cc_step(nets, opt, batch_cpu, cfg)          # warm-up
-    log("cpu baseline warm-up step %.1f s (%d threads)" % (time.time() - t0, n))
-    t0 = time.time()
-    for _ in range(args.cpu_steps):
-        S.cc_step(nets, opt, batch_cpu, cfg)
-    dt = (time.time() - t0) / args.cpu_steps
+    losses, times = [], []
+    for i in range(1 + args.cpu_steps):
+        t0 = time.time()
+        losses.append(S.cc_step(nets, opt, batch_cpu, cfg))
+        times.append(time.time() - t0)
+        log("cpu baseline step %d: %.1f s (%d threads)" % (i, times[-1], n))
+    timed = sorted(times[1:])
+    dt = timed[len(timed) // 2] if timed else times[0]
     return {"value": round(batch_cpu[0].shape[0] / dt, 4), "unit": "images/s", "cores": n, "kind": "port",
-            "sample": "%d full CC steps (fwd+bwd+Adam) after 1 warm-up, B=%d %dx%d, torch %s CPU, %d threads"
-                      % (args.cpu_steps, batch_cpu[0].shape[0], batch_cpu[0].shape[3], batch_cpu[0].shape[2],
+            "cpu": cpu_model(),
+            "sample": "median of %d full CC steps (fwd+bwd+Adam) after 1 warm-up, B=%d %dx%d, oracle/step.py (the CPU port "
+                      "of train.py:445-568, pinned to the reference by tests/golden), torch %s, %d threads"
+                      % (len(timed), batch_cpu[0].shape[0], batch_cpu[0].shape[3], batch_cpu[0].shape[2],
                          torch.__version__, n),
-            "s_per_step": round(dt, 3)}
+            "s_per_step": round(dt, 3), "s_per_step_all": [round(t, 3) for t in times]}, losses
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -242,8 +287,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)     # nccl == RCCL on ROCm
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
-    from cc_amd import config, synthetic as syn, trainer as T, _lib
-    config.conv_backend = args.conv_backend
+    from cc_amd import synthetic as syn, trainer as T, _lib
     eng = _lib.engine()
 
     torch.manual_seed(0)                                             # train.py:152
@@ -251,6 +295,14 @@ def main():
     cfg = T.StepConfig()
     if args.elide_occ and nets[3] is not None:
         nets[3].elide_occ = True
+    if args.freeze:
+        for n_ in nets[2:]:
+            if n_ is not None:
+                for p_ in n_.parameters():
+                    p_.requires_grad = False                             # train.py:332-339
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    init_sd = [({k: v.detach().cpu().clone() for k, v in n_.state_dict().items()} if n_ is not None else None)
+               for n_ in nets] if want_cpu else None
     B, H, W = args.batch, args.height, args.width
     batch_cpu = syn.sample(B, H, W, seed=1 + rank, smooth=3)
     batch = (batch_cpu[0].to(dev), [r.to(dev) for r in batch_cpu[1]], batch_cpu[2].to(dev), batch_cpu[3].to(dev))
@@ -263,10 +315,13 @@ def main():
             torch.cuda.synchronize()
 
     t_w = time.perf_counter()
+    first_losses = []
     for i in range(args.warmup):
         losses = tr.step(batch)
         if rank == 0:
             torch.cuda.synchronize()
+            if i < 2:
+                first_losses.append({k: float(v) for k, v in losses.items()})
             log("warm-up step %d done at %.1f s" % (i, time.perf_counter() - t_w))
     sync()
     t0 = time.perf_counter()
@@ -281,8 +336,7 @@ def main():
     loss_val = float(losses["loss"])
     if rank == 0:
         log("timed %d steps: %.2f ms/step, loss %.6f" % (args.steps, 1e3 * dt / args.steps, loss_val))
-    from cc_amd import loss_functions as LF
-    LF.check_finite()
+    tr.check_finite()
 
     kernels, roof = None, None
     if not args.no_kernel_timing:
@@ -318,7 +372,7 @@ def main():
     if rank == 0:
         imgs = B * world * args.steps
         line = {
-            "metric": "train images/sec (832x256, 5-frame sample, 6-scale CC step)",
+            "metric": "train images/sec (%dx%d, 5-frame sample, 6-scale CC step)" % (W, H),
             "value": round(imgs / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -326,12 +380,24 @@ def main():
                                     if args.config == "c3" else "DispResNet6+PoseNetB6, photometric+smoothness"),
                        "per_gpu_batch": B, "global_batch": B * world, "height": H, "width": W, "scales": 6,
                        "frames": 5, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph,
-                       "conv_backend": args.conv_backend, "loss": round(loss_val, 6),
+                       "trained_nets": "disp+pose (mask, flow frozen: README --fix-masknet --fix-flownet)" if args.freeze else "all",
+                       "loss": round(loss_val, 6), "rccl_ranks": world,
                        "dead_occlusion_decoders_elided": bool(args.elide_occ)},
             "roofline": roof, "kernels": kernels,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(syn.sample(B, H, W, seed=1, smooth=3), args)
+        if want_cpu:
+            base, cpu_losses = cpu_baseline(batch_cpu, init_sd, args)
+            line["cpu_baseline"] = base
+            # bench-time parity gate: the engine's first steps against the oracle's on identical weights and data
+            par = {"tolerance": 1e-4, "steps_compared": min(len(first_losses), len(cpu_losses))}
+            worst = 0.0
+            for i, (g_, c_) in enumerate(zip(first_losses, cpu_losses)):
+                rels = {k: abs(g_[k] - c_[k]) / max(abs(c_[k]), 1e-12) for k in c_ if k in g_}
+                par["step%d" % i] = {k: float("%.3e" % v) for k, v in sorted(rels.items())}
+                worst = max([worst] + list(rels.values()))
+            par["loss_rel"] = float("%.3e" % worst)
+            par["ok"] = bool(worst <= 1e-4)
+            line["parity"] = par
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

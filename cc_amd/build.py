@@ -30,16 +30,32 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_hash():
+    """First 32 bits of the SHA-1 over the kernel sources + headers (-> cc_version())."""
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) +
+                   glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return int(h.hexdigest()[:8], 16)
+
+
 def build(verbose=False, force=False):
     os.makedirs(OBJ, exist_ok=True)
     headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h"))
     jobs = []
     objs = []
+    sh = source_hash()
+    stamp = os.path.join(OBJ, "version.hash")
+    hash_changed = not os.path.exists(stamp) or open(stamp).read().strip() != str(sh)
     for src in sources():
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if force or _stale(obj, [src] + headers):
-            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+        is_ver = os.path.basename(src) == "version.hip"
+        if force or _stale(obj, [src] + headers) or (is_ver and hash_changed):
+            jobs.append([HIPCC] + FLAGS + (["-DCC_SRC_HASH=%du" % sh] if is_ver else []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -53,6 +69,8 @@ def build(verbose=False, force=False):
         list(ex.map(run, jobs))
     if force or jobs or _stale(OUT, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    with open(stamp, "w") as f:
+        f.write(str(sh))
     return OUT
 
 

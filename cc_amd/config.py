@@ -9,7 +9,3 @@ align_corners = False
 # True: check every photometric term for NaN eagerly (AssertionError, one host sync per term, the
 # reference's behaviour, loss_functions.py:60,105,115).  False: device flag, see loss_functions.check_finite().
 strict_nan_checks = False
-
-# 'hip'    : hand-written fp32 MFMA implicit-GEMM kernels (cc_amd/csrc/conv.hip) -- the product path
-# 'miopen' : torch's F.conv2d (MIOpen) -- kept only as an A/B reference for benchmarking
-conv_backend = "hip"

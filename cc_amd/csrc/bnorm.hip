@@ -159,6 +159,100 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     }
 }
 
+// ---- small maps (B*H*W <= BN_SMALL_MAX values per channel: the 9 deep shortcut branches, 128-512 channels on <= 32x104 maps)
+// ONE launch per direction: a workgroup owns a channel, reduces its B*HW values (second pass re-reads them from L1/L2),
+// finalises the statistics itself and applies them.  Same formulas / summation structure as the three-kernel path above
+// (per-thread strided partial sums -> wave shuffles -> 4-wave sum), fixed order -> deterministic.
+constexpr int BN_SMALL_MAX = 16384;
+
+__global__ __launch_bounds__(256) void k_bn_small_fwd(const float* __restrict__ x, const float* __restrict__ weight,
+                                                      const float* __restrict__ bias, float* __restrict__ running_mean,
+                                                      float* __restrict__ running_var, float* __restrict__ y,
+                                                      float* __restrict__ save_mean, float* __restrict__ save_invstd, int B,
+                                                      int C, int HW, float momentum, float eps) {
+    __shared__ float red[8];
+    __shared__ float bc[2];
+    const int c = blockIdx.x;
+    const long bs = (long)C * HW;
+    const float k = x[(long)c * HW];
+    float s[2] = {0.f, 0.f};
+    for (int n = 0; n < B; n++) {
+        const float* __restrict__ xp = x + (long)n * bs + (long)c * HW;
+        for (int e = threadIdx.x; e < HW; e += 256) {
+            const float d = xp[e] - k;
+            s[0] += d;
+            s[1] += d * d;
+        }
+    }
+    cc::block_sum_256<2>(s, red);
+    if (threadIdx.x == 0) {
+        const float count = (float)((long)B * HW);
+        const float md = s[0] / count;
+        const float mean = k + md;
+        float var = s[1] / count - md * md;
+        var = var < 0.f ? 0.f : var;
+        const float invstd = 1.f / sqrtf(var + eps);
+        save_mean[c] = mean;
+        save_invstd[c] = invstd;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        if (running_var) {
+            const float unbiased = count > 1.f ? var * (count / (count - 1.f)) : var;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        }
+        const float w = weight ? weight[c] : 1.f, b = bias ? bias[c] : 0.f;
+        bc[0] = w * invstd;
+        bc[1] = b - mean * (w * invstd);
+    }
+    __syncthreads();
+    const float sc = bc[0], sh = bc[1];
+    for (int n = 0; n < B; n++) {
+        const float* __restrict__ xp = x + (long)n * bs + (long)c * HW;
+        float* __restrict__ yp = y + (long)n * bs + (long)c * HW;
+        for (int e = threadIdx.x; e < HW; e += 256) yp[e] = fmaf(xp[e], sc, sh);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_small_bwd(const float* __restrict__ gy, const float* __restrict__ x,
+                                                      const float* __restrict__ weight, const float* __restrict__ save_mean,
+                                                      const float* __restrict__ save_invstd, float* __restrict__ gx,
+                                                      float* __restrict__ gweight, float* __restrict__ gbias, int B, int C,
+                                                      int HW, int accumulate) {
+    __shared__ float red[8];
+    __shared__ float bc[3];
+    const int c = blockIdx.x;
+    const long bs = (long)C * HW;
+    const float m = save_mean[c];
+    float s[2] = {0.f, 0.f};
+    for (int n = 0; n < B; n++) {
+        const float* __restrict__ xp = x + (long)n * bs + (long)c * HW;
+        const float* __restrict__ gp = gy + (long)n * bs + (long)c * HW;
+        for (int e = threadIdx.x; e < HW; e += 256) {
+            const float g = gp[e];
+            s[0] += g;
+            s[1] += g * (xp[e] - m);
+        }
+    }
+    cc::block_sum_256<2>(s, red);
+    if (threadIdx.x == 0) {
+        const float count = (float)((long)B * HW);
+        const float invstd = save_invstd[c], w = weight ? weight[c] : 1.f;
+        const float gb = s[0], gw = s[1] * invstd;
+        if (gbias) gbias[c] = accumulate ? gbias[c] + gb : gb;
+        if (gweight) gweight[c] = accumulate ? gweight[c] + gw : gw;
+        bc[0] = w * invstd;
+        bc[1] = s[0] / count;
+        bc[2] = s[1] * invstd * invstd / count;
+    }
+    __syncthreads();
+    const float c1 = bc[0], c2 = bc[1], c3 = bc[2];
+    for (int n = 0; n < B; n++) {
+        const float* __restrict__ xp = x + (long)n * bs + (long)c * HW;
+        const float* __restrict__ gp = gy + (long)n * bs + (long)c * HW;
+        float* __restrict__ op = gx + (long)n * bs + (long)c * HW;
+        for (int e = threadIdx.x; e < HW; e += 256) op[e] = c1 * (gp[e] - c2 - (xp[e] - m) * c3);
+    }
+}
+
 inline int bn_cpp(int B, int HW) {
     int cpp = (HW + 8191) / 8192;
     const int cap = BN_MAXCHUNK / B > 0 ? BN_MAXCHUNK / B : 1;
@@ -177,9 +271,16 @@ size_t cc_bn_ws_bytes(int C) { return (size_t)C * (2 * BN_MAXCHUNK + 3) * sizeof
 int cc_bn_train_fwd(const float* x, const float* weight_or_null, const float* bias_or_null, float* running_mean_or_null,
                     float* running_var_or_null, float* y, float* save_mean, float* save_invstd, float* ws, int B, int C,
                     int H, int W, float momentum, float eps, void* stream) {
-    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || B > BN_MAXCHUNK) return CC_ERR_ARG;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int HW = H * W;
+    if ((long)B * HW <= BN_SMALL_MAX) {
+        hipLaunchKernelGGL(k_bn_small_fwd, dim3(C), dim3(256), 0, s, x, weight_or_null, bias_or_null, running_mean_or_null,
+                           running_var_or_null, y, save_mean, save_invstd, B, C, HW, momentum, eps);
+        CC_CHECK_LAUNCH();
+        return CC_OK;
+    }
+    if (B > BN_MAXCHUNK) return CC_ERR_ARG;
     const long bs = (long)C * HW;
     const int cpp = bn_cpp(B, HW), nchunk = cpp * B;
     float* partial = ws;
@@ -201,9 +302,16 @@ int cc_bn_train_fwd(const float* x, const float* weight_or_null, const float* bi
 int cc_bn_train_bwd(const float* gy, const float* x, const float* weight_or_null, const float* save_mean,
                     const float* save_invstd, float* gx, float* gweight_or_null, float* gbias_or_null, float* ws, int B, int C,
                     int H, int W, int accumulate_wb, void* stream) {
-    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || B > BN_MAXCHUNK) return CC_ERR_ARG;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int HW = H * W;
+    if ((long)B * HW <= BN_SMALL_MAX) {
+        hipLaunchKernelGGL(k_bn_small_bwd, dim3(C), dim3(256), 0, s, gy, x, weight_or_null, save_mean, save_invstd, gx,
+                           gweight_or_null, gbias_or_null, B, C, HW, accumulate_wb);
+        CC_CHECK_LAUNCH();
+        return CC_OK;
+    }
+    if (B > BN_MAXCHUNK) return CC_ERR_ARG;
     const long bs = (long)C * HW;
     const int cpp = bn_cpp(B, HW), nchunk = cpp * B;
     float* partial = ws;

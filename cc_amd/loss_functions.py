@@ -71,11 +71,20 @@ def _empty(n, ref):
 _nan_flags = []
 
 
-def check_finite():
-    """Deferred form of the reference's ``assert((loss == loss).item() == 1)`` (one host sync)."""
-    bad = any(bool(f.item() != 0) for f in _nan_flags)
+def check_finite(persistent=()):
+    """Deferred form of the reference's ``assert((loss == loss).item() == 1)`` (one host sync).  `persistent`: flag
+    tensors that a captured hipGraph step rewrites at every replay (CCTrainer keeps them; they are never dropped)."""
+    flags = list(_nan_flags) + list(persistent)
     del _nan_flags[:]
+    bad = bool(torch.stack([f.reshape(()) for f in flags]).ne(0).any().item()) if flags else False
     assert not bad, "NaN encountered in a photometric loss term"
+
+
+def take_nan_flags():
+    """Hand the flags registered since the last check to the caller (the trainer, right after capturing a step)."""
+    out = list(_nan_flags)
+    del _nan_flags[:]
+    return out
 
 
 def _register_nan_flag(flag):

@@ -108,8 +108,8 @@ class Model(nn.Module):
                 s = self.WARP_SCALE[lvl]
                 bw = self.warp(feats[(lvl - 1, "b")], s * up_f[lvl])
                 cw = self.warp(feats[(lvl - 1, "c")], -s * up_f[lvl])      # the FORWARD flow for both (Q9)
-        ff = [self.FULL_SCALE[l] * up(up_f[l]) for l in range(2, 7)]
-        fb = [-self.FULL_SCALE[l] * up(up_b[l]) for l in range(2, 7)]
+        ff = [up(up_f[l], self.FULL_SCALE[l]) for l in range(2, 7)]         # scale fused into the up-sampling launch
+        fb = [up(up_b[l], -self.FULL_SCALE[l]) for l in range(2, 7)]
         oc = None if self.elide_occ else [F.interpolate(occ[l], scale_factor=4) for l in range(2, 7)]
         if self.training:
             if self.nlevels == 6:

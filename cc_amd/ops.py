@@ -2,13 +2,11 @@
 (convolutions on fp32 MFMA, the 9x9 cost volume, feature warp) behind the C ABI.
 
 Everything heavy is a HIP kernel.  What is still stock ATen (tiny tensors, listed in DESIGN.md as "torch
-plumbing"): BatchNorm of the 13 residual shortcuts, x2 bilinear / nearest upsampling of 1-2 channel maps,
-channel softmax of the (unused-by-training) occlusion head, torch.cat.
+plumbing"): nearest upsampling + channel softmax of the (unused-by-training) occlusion head, torch.cat.
 """
 import torch
 import torch.nn.functional as F
 
-from . import config
 from ._lib import engine, STREAM
 
 ACT = {None: 0, "relu": 1, "lrelu": 2, "sigmoid": 3}
@@ -32,6 +30,7 @@ class PackRegistry:
     def __init__(self):
         self.entries = {}
         self.valid = False
+        self.recording = False      # new layers are registered only inside a trainer step (not by eval passes at other sizes)
         self.epoch = 0
         self.dirty = False
         self.table = None
@@ -42,7 +41,8 @@ class PackRegistry:
         key = (kind, w.data_ptr(), geom)
         ent = self.entries.get(key)
         if ent is None:
-            self._register(key, kind, w, geom)
+            if self.recording:
+                self._register(key, kind, w, geom)
             return None
         if ent is False or not self.valid or ent["epoch"] != self.epoch:
             return None
@@ -57,14 +57,17 @@ class PackRegistry:
             self.entries[key] = False
             return
         buf = torch.zeros(int(n), device=w.device, dtype=torch.float32)
-        host = (ctypes.c_long * 64)()
+        stride = int(geom[7])
+        host = (ctypes.c_long * (16 * max(4, stride * stride)))()       # one 16-long descriptor per output parity class
         nd = E.fn[fn + "_desc"](*geom, w.data_ptr(), buf.data_ptr(), ctypes.addressof(host))
         descs = [[int(host[16 * i + k]) for k in range(16)] for i in range(nd)]
         self.entries[key] = {"buf": buf, "descs": descs, "epoch": -1, "w": w}
         self.dirty = True
 
     def prepack_all(self):
+        """Start of a trainer step: refresh every registered image (the weights changed in Adam) and open registration."""
         live = [e for e in self.entries.values() if e]
+        self.recording = True
         if not live:
             return
         if self.dirty or self.table is None:
@@ -86,6 +89,7 @@ class PackRegistry:
 
     def invalidate(self):
         self.valid = False
+        self.recording = False
 
     def reset(self):
         """Forget every registered layer (tests; a new set of networks)."""
@@ -171,11 +175,6 @@ class _Conv2dFn(torch.autograd.Function):
 def conv2d(x, w, bias=None, stride=1, padding=0, act=None, residual=None, act_a=1.0, act_b=0.0):
     """act(conv2d(x, w, bias) + residual): nn.Conv2d (+ fused ReLU / LeakyReLU / a*sigmoid+b epilogue).
     act='lrelu': act_b is the negative slope (0 -> the 0.2 of Back2Future)."""
-    if config.conv_backend == "miopen":
-        y = F.conv2d(x, w, bias, stride, padding)
-        if residual is not None:
-            y = y + residual
-        return _torch_act(y, act, act_a, act_b)
     return _Conv2dFn.apply(x, w, bias, residual, int(stride), int(padding), ACT[act], float(act_a), float(act_b))
 
 
@@ -244,22 +243,10 @@ class _ConvT2dFn(torch.autograd.Function):
 
 def conv_transpose2d(x, w, bias=None, stride=1, padding=0, output_padding=0, act=None, act_b=0.0):
     """act='lrelu': act_b is the negative slope (0 -> 0.2)."""
-    if config.conv_backend == "miopen":
-        return _torch_act(F.conv_transpose2d(x, w, bias, stride, padding, output_padding), act, 1.0, act_b)
     return _ConvT2dFn.apply(x, w, bias, int(stride), int(padding), int(output_padding), ACT[act], float(act_b))
 
 
-def _torch_act(y, act, a, b):
-    if act == "relu":
-        return F.relu(y)
-    if act == "lrelu":
-        return F.leaky_relu(y, b if b != 0 else 0.2)
-    if act == "sigmoid":
-        return a * torch.sigmoid(y) + b
-    return y
-
-
-# ----------------------------------------------------------------------------- small ATen-backed pieces
+# ----------------------------------------------------------------------------- batch norm / upsampling
 class _BNTrainFn(torch.autograd.Function):
     """nn.BatchNorm2d in training mode on the HIP kernels (csrc/bnorm.hip)."""
 
@@ -302,20 +289,42 @@ class _BNTrainFn(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None
 
 
-BN_HIP_MIN_PER_CHANNEL = 16384      # below this the vendor's one-launch kernel is as fast (3 launches here)
-
-
 def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps):
-    if training and num_batches_tracked is not None:
+    """nn.BatchNorm2d.forward.  Training mode always runs on csrc/bnorm.hip (three launches for >= 16 k values per channel,
+    one workgroup-per-channel launch below); eval mode is the affine map of the running statistics (stock torch)."""
+    if not training:
+        return F.batch_norm(x, running_mean, running_var, weight, bias, False, 0.0, eps)
+    if num_batches_tracked is not None:
         num_batches_tracked.add_(1)
-    if (training and config.conv_backend == "hip" and x.dim() == 4 and x.dtype == torch.float32 and momentum is not None
-            and x.shape[0] * x.shape[2] * x.shape[3] >= BN_HIP_MIN_PER_CHANNEL and x.shape[0] <= 64):
-        return _BNTrainFn.apply(x, weight, bias, running_mean, running_var, momentum, eps)
-    return F.batch_norm(x, running_mean, running_var, weight, bias, training, momentum, eps)
+    if x.dim() != 4 or momentum is None:
+        raise NotImplementedError("ccengine BatchNorm: 4-d input and a fixed momentum (the reference's nn.BatchNorm2d use)")
+    return _BNTrainFn.apply(x, weight, bias, running_mean, running_var, momentum, eps)
 
 
-def upsample_bilinear2x(x):
-    return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+class _Up2xFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = _c(x)
+        B, C, H, W = x.shape
+        y = torch.empty(B, C, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
+        engine().call("cc_upsample2x_fwd", x, y, B, C, H, W, C * H * W, 4 * C * H * W, float(scale), STREAM)
+        ctx.geom = (B, C, H, W, float(scale))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, C, H, W, scale = ctx.geom
+        gy = _c(gy)
+        gx = torch.empty(B, C, H, W, device=gy.device, dtype=torch.float32)
+        engine().call("cc_upsample2x_bwd", gy, gx, B, C, H, W, 4 * C * H * W, C * H * W, scale, 0, STREAM)
+        return gx, None
+
+
+def upsample_bilinear2x(x, scale=1.0):
+    """scale * F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False) in one launch (csrc/resize.hip)."""
+    if x.shape[3] % 2:
+        return scale * F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    return _Up2xFn.apply(x, float(scale))
 
 
 # ----------------------------------------------------------------------------- cost volume

@@ -50,13 +50,30 @@ def build_nets(device, flow=True, mask=True, init=True):
     return nets
 
 
-def cc_forward(nets, batch, cfg, keep=False):
-    """train.py:454-509.  batch = (tgt, [4 refs], K, Kinv)."""
+def cc_forward(nets, batch, cfg, keep=False, cut=None):
+    """train.py:454-509.  batch = (tgt, [4 refs], K, Kinv).
+    cut: optional dict; when given, the losses are computed on detached copies of the network outputs and
+    cut['dp'] / cut['mf'] receive the (output, detached copy) pairs of DispResNet6 + PoseNetB6 / MaskNet6 + Back2Future, so
+    that the backward pass can be run in stages (losses -> copies, then each network group from its outputs)."""
     disp_net, pose_net, mask_net, flow_net = nets
     tgt, refs, K, Kinv = batch
-    disparities = disp_net(tgt)                                                        # :454
+
+    def _cut(group, ts):
+        if cut is None:
+            return ts
+        outs = []
+        for t in ts:
+            if t.requires_grad:
+                d = t.detach().requires_grad_(True)
+                cut.setdefault(group, []).append((t, d))
+                outs.append(d)
+            else:
+                outs.append(t)
+        return outs
+
+    disparities = _cut("dp", list(disp_net(tgt)))                                      # :454
     depth = [1 / d for d in disparities]                                               # :458
-    pose = pose_net(tgt, refs)                                                         # :459
+    pose = _cut("dp", [pose_net(tgt, refs)])[0]                                        # :459
     out = {}
     if mask_net is None or flow_net is None:                                           # BASELINE config 2
         l1 = LF.photometric_reconstruction_loss(tgt, refs, K, Kinv, depth, [None] * len(depth), pose,
@@ -66,8 +83,9 @@ def cc_forward(nets, batch, cfg, keep=False):
         if keep:
             out.update(disparities=disparities, pose=pose)
         return out
-    exp_mask = mask_net(tgt, refs)                                                     # :460
+    exp_mask = _cut("mf", list(mask_net(tgt, refs)))                                   # :460
     flow_fwd, flow_bwd, _ = flow_net(tgt, refs[1:3])                                   # :463
+    flow_fwd, flow_bwd = _cut("mf", list(flow_fwd)), _cut("mf", list(flow_bwd))
     cam_fwd = [pose2flow(d.squeeze(1), pose[:, 2], K, Kinv) for d in depth]            # :470
     cam_bwd = [pose2flow(d.squeeze(1), pose[:, 1], K, Kinv) for d in depth]            # :471
     target = LF.consensus_exp_masks(cam_fwd, cam_bwd, flow_fwd, flow_bwd, tgt, refs[2], refs[1],
@@ -121,15 +139,25 @@ class FlatAdam:
         # conv weights / biases: the wgrad and bias-gradient kernels accumulate straight into the flat bucket
         # (the trainer switches ops.grad_sinks to this table for the duration of its own forward+backward only)
         self.sinks = {p.data_ptr(): p.grad for p in params}
+        ops.packs.reset()          # weight images registered against the pre-bucket storages are stale now
 
     def zero_grad(self):
         engine().call("cc_fill", self.flat_g, self.flat_g.numel(), 0.0, STREAM)
 
-    def all_reduce(self):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat_g)          # RCCL over xGMI: one collective per step
-            return 1.0 / dist.get_world_size()
-        return 1.0
+    @staticmethod
+    def world():
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+    def all_reduce(self, lo=0, hi=None, async_op=False):
+        """SUM-all-reduce flat_g[lo:hi] over the ranks (RCCL over xGMI; gloo in the CPU tests).  -> work handle or None."""
+        if self.world() > 1:
+            hi = self.flat_g.numel() if hi is None else hi
+            if hi > lo:
+                return dist.all_reduce(self.flat_g[lo:hi], async_op=async_op)
+        return None
+
+    def grad_scale(self):
+        return 1.0 / self.world()
 
     def step(self, grad_scale=1.0):
         engine().call("cc_adam_step", self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.step_dev, self.n,
@@ -171,7 +199,7 @@ class FlatAdam:
 class CCTrainer:
     """One rank of the data-parallel CC training job."""
 
-    def __init__(self, nets, cfg, use_graph=True):
+    def __init__(self, nets, cfg, use_graph=True, split_graphs=None):
         self.nets, self.cfg = nets, cfg
         for n in nets:
             if n is not None:
@@ -180,27 +208,68 @@ class CCTrainer:
         self.opt.broadcast_from_rank0()
         self.use_graph = use_graph
         self.graph = None
+        self.graph_b = None
+        # gradient segments of the flat bucket: [DispResNet6 | PoseNetB6] [MaskNet6 | Back2Future] (parameter order of
+        # FlatAdam = train.py:305's chain)
+        self.n_dp = sum(p.numel() for n in nets[:2] if n is not None for p in n.parameters() if p.requires_grad)
+        self.split_graphs = self.opt.world() > 1 if split_graphs is None else bool(split_graphs)
+        self.comm_ms = None
         self.static_batch = None
         self.losses = None
+        self.nan_flags = []
 
-    def _fwd_bwd(self, batch):
+    # The step is cut into stages so that the gradient exchange of the big DispResNet6 + PoseNetB6 segment (227 MB of the
+    # 297 MB bucket) runs UNDER the backward pass of Back2Future + MaskNet6 (the longest stage):
+    #   A: weight images, zero grads, forward of the four nets + losses (train.py:454-509), d loss / d (net outputs),
+    #      backward of DispResNet6 + PoseNetB6                                   -> all-reduce(flat_g[:n_dp]) starts
+    #   B: backward of MaskNet6 + Back2Future                                    -> all-reduce(flat_g[n_dp:]) (exposed)
+    # The nets only meet in the losses, so the two backward stages are independent given the output gradients.
+    def _stage_a(self, batch):
         LF.pyramid_cache.clear()
         ops.packs.prepack_all()            # every conv layer's [tap][c][m] weight images, one launch (weights changed in Adam)
         self.opt.zero_grad()                                                # :566
         ops.grad_sinks = self.opt.sinks
         LF.scalar_pool.begin(batch[0].device)
+        cut = {}
+        out = cc_forward(self.nets, batch, self.cfg, cut=cut)
+        pairs = cut.get("dp", []) + cut.get("mf", [])
+        g = torch.autograd.grad(out["loss"], [d for _, d in pairs], allow_unused=True) if pairs else ()   # :567, losses only
+        ndp = len(cut.get("dp", []))
+        dp = [(t, gt) for (t, _), gt in zip(pairs[:ndp], g[:ndp]) if gt is not None]
+        mf = [(t, gt) for (t, _), gt in zip(pairs[ndp:], g[ndp:]) if gt is not None]
+        if dp:
+            torch.autograd.backward([t for t, _ in dp], [gt for _, gt in dp])
+        losses = {k: v.detach() for k, v in out.items() if torch.is_tensor(v) and k.startswith("loss")}
+        return losses, mf
+
+    def _stage_b(self, mf):
+        if mf:
+            torch.autograd.backward([t for t, _ in mf], [gt for _, gt in mf])
+
+    def _stage_end(self):
+        LF.scalar_pool.end()
+        ops.grad_sinks = {}
+        ops.packs.invalidate()
+
+    def _fwd_bwd(self, batch, between=None):
+        """forward + backward of one mini-batch; `between()` runs between the two backward stages."""
         try:
-            out = cc_forward(self.nets, batch, self.cfg)
-            out["loss"].backward()                                          # :567
+            losses, mf = self._stage_a(batch)
+            if between is not None:
+                between()
+            self._stage_b(mf)
         finally:
-            LF.scalar_pool.end()
-            ops.grad_sinks = {}
-            ops.packs.invalidate()
-        return {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
+            self._stage_end()
+        return losses
 
     def _copy_in(self, batch):
         tgt, refs, K, Kinv = batch
         s_tgt, s_refs, s_K, s_Kinv = self.static_batch
+        # the captured graph has static shapes: a smaller last batch would silently broadcast into the buffers
+        assert tgt.shape == s_tgt.shape and len(refs) == len(s_refs) and all(a.shape == b.shape for a, b in zip(refs, s_refs)) \
+            and K.shape == s_K.shape and Kinv.shape == s_Kinv.shape, \
+            "batch shapes differ from the captured step's (%s vs %s): use a fixed batch size / drop_last" % (
+                tuple(tgt.shape), tuple(s_tgt.shape))
         s_tgt.copy_(tgt)
         for a, b in zip(s_refs, refs):
             a.copy_(b)
@@ -209,8 +278,12 @@ class CCTrainer:
 
     def capture(self, batch, warmup=2):
         """Warm up eagerly on a side stream, then capture forward+backward of one step into a hipGraph."""
+        assert not config.strict_nan_checks, "config.strict_nan_checks syncs the host per loss term: use use_graph=False with it"
         tgt, refs, K, Kinv = batch
         self.static_batch = (tgt.clone(), [r.clone() for r in refs], K.clone(), Kinv.clone())
+        # the eager warm-up passes must leave no trace: BatchNorm running statistics / num_batches_tracked would otherwise
+        # absorb the first batch three times where the reference absorbs it once (train.py:454 runs each batch once)
+        bn_state = [(b, b.detach().clone()) for n in self.nets if n is not None for b in n.buffers()]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -218,31 +291,85 @@ class CCTrainer:
                 self._fwd_bwd(self.static_batch)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
+        for b, saved in bn_state:
+            b.copy_(saved)
+        LF.check_finite()                   # the warm-up's own flags (and drop them: the captured step registers its own)
         # thread_local: only the capturing thread's calls are policed -- a process-group watchdog thread (multi-GPU runs)
         # polling its events must not invalidate the capture
-        with torch.cuda.graph(self.graph, capture_error_mode=os.environ.get("CC_CAPTURE_MODE", "thread_local")):
-            self.losses = self._fwd_bwd(self.static_batch)
+        mode = os.environ.get("CC_CAPTURE_MODE", "thread_local")
+        self.graph = torch.cuda.CUDAGraph()
+        if self.split_graphs:
+            # two graphs sharing one memory pool: the collective of the first gradient segment is issued between them
+            self.graph_b = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(self.graph, capture_error_mode=mode):
+                    self.losses, mf = self._stage_a(self.static_batch)
+                with torch.cuda.graph(self.graph_b, pool=self.graph.pool(), capture_error_mode=mode):
+                    self._stage_b(mf)
+            finally:
+                self._stage_end()
+        else:
+            with torch.cuda.graph(self.graph, capture_error_mode=mode):
+                self.losses = self._fwd_bwd(self.static_batch)
+        # the NaN flags of the captured step live in the graph's private pool and are rewritten by every replay: keep them
+        # as persistent handles (the reference asserts on NaN at every step, loss_functions.py:60,105,115)
+        self.nan_flags = LF.take_nan_flags()
         LF.pyramid_cache.clear()
+
+    def check_finite(self):
+        """Deferred NaN assert of the most recent step (one host sync); works in eager and in hipGraph mode."""
+        LF.check_finite(self.nan_flags)
+
+    def grad_norms(self):
+        """L2 norm of the most recent step's (all-reduced, unscaled) gradient per network, from the flat bucket
+        -> {'disp'|'pose'|'mask'|'flow': 0-dim float64 device tensor}.  Diagnostic / parity-test hook."""
+        out, off = {}, 0
+        for name, n in zip(("disp", "pose", "mask", "flow"), self.nets):
+            if n is None:
+                continue
+            k = sum(p.numel() for p in n.parameters() if p.requires_grad)
+            if k:
+                out[name] = self.opt.flat_g[off:off + k].double().pow(2).sum().sqrt()
+            off += k
+        return out
 
     def save_checkpoint(self, save_path, epoch, is_best=False):
         """train.py:396-413: the five ``{'epoch', 'state_dict'}`` files of utils.save_checkpoint."""
         from . import utils
-        sd = [({"epoch": epoch + 1, "state_dict": n.state_dict()} if n is not None else {"epoch": epoch + 1, "state_dict": {}})
+        # parameters are views into the 297 MB flat bucket: torch.save would write the WHOLE storage behind every view
+        # (each net file 297 MB, carrying the other nets' weights) -> clone to per-tensor storages first
+        def own(n):
+            return {k: v.detach().clone() for k, v in n.state_dict().items()}
+        sd = [({"epoch": epoch + 1, "state_dict": own(n)} if n is not None else {"epoch": epoch + 1, "state_dict": {}})
               for n in self.nets]
         utils.save_checkpoint(save_path, sd[0], sd[1], sd[2], sd[3], {"epoch": epoch + 1, "state_dict": self.opt.state_dict()},
                               is_best)
 
     def step(self, batch):
         """train.py:445-568 for one mini-batch: returns the (device) loss tensors of this step."""
+        opt = self.opt
+        works = []
+
+        def reduce_dp():            # 227 MB segment: in flight while MaskNet6 + Back2Future run their backward pass
+            works.append(opt.all_reduce(0, self.n_dp, async_op=True))
+
         if self.use_graph:
             if self.graph is None:
                 self.capture(batch)
             self._copy_in(batch)
             self.graph.replay()
+            if self.graph_b is not None:
+                reduce_dp()
+                self.graph_b.replay()
             losses = self.losses
         else:
-            losses = self._fwd_bwd(batch)
-        scale = self.opt.all_reduce()
-        self.opt.step(scale)                                                # :568
+            losses = self._fwd_bwd(batch, between=reduce_dp if opt.world() > 1 else None)
+        if opt.world() > 1:
+            if not works:
+                works.append(opt.all_reduce(0, self.n_dp, async_op=True))
+            works.append(opt.all_reduce(self.n_dp, None, async_op=True))      # mask + flow segment (70 MB): exposed
+            for w in works:
+                if w is not None:
+                    w.wait()
+        opt.step(opt.grad_scale())                                          # :568
         return losses

@@ -243,6 +243,15 @@ int cc_bn_train_bwd(const float* gy, const float* x, const float* weight_or_null
                     const float* save_invstd, float* gx, float* gweight_or_null, float* gbias_or_null, float* ws, int B, int C,
                     int H, int W, int accumulate_wb, void* stream);
 
+/* ---------------------------------------------------------------- x2 bilinear up-sampling
+ * F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) of the prediction maps, with the constant the callers
+ * multiply in afterwards fused (models/DispResNet6.py:170-186 disp_up; models/back2future.py:196-285 `up_flow`,
+ * `20 * upsample(...)`, `-0.625 * ...`):  y[B,C,2H,2W] = scale * up(x[B,C,H,W]).  x_bs / y_bs: batch strides in floats
+ * (y may be a channel slice of a wider concat buffer; W even, y 16-byte aligned).  bwd: gx (+)= scale * up^T(gy), gather form. */
+int cc_upsample2x_fwd(const float* x, float* y, int B, int C, int H, int W, long x_bs, long y_bs, float scale, void* stream);
+int cc_upsample2x_bwd(const float* gy, float* gx, int B, int C, int H, int W, long gy_bs, long gx_bs, float scale, int accumulate,
+                      void* stream);
+
 /* ---------------------------------------------------------------- optimizer (train.py:307-310,568)
  * torch.optim.Adam(betas, eps, weight_decay=0) on the flat fp32 bucket; grads are multiplied by grad_scale first
  * (1/world_size after the RCCL all-reduce).  step_dev: device float, incremented by the call. */

@@ -332,8 +332,59 @@ def metrics_level():
     return g
 
 
+HEADLINE = (("c3_b4", True, 4, 256, 832),      # BASELINE.json configs[2]: the configuration the metric is quoted on
+            ("c2_b4", False, 4, 256, 832),     # configs[1]
+            ("c5_b2", True, 2, 512, 1664))     # configs[4] per-GPU shape
+
+
+def headline_level(only=None):
+    """Step-level goldens AT THE BENCHMARKED SIZES from the unmodified reference (as-run align_corners): the six loss
+    scalars, per-net gradient norms after loss.backward(), and the loss after one Adam step (train.py:454-509,566-568).
+    Inputs = what bench.py feeds (syn.sample(B, H, W, seed=1, smooth=3)), weights = syn.seeded_state_dict(net, 0).
+    Scalars only: the fixture stays tiny although the run is full-size (minutes of CPU)."""
+    import time
+    ref = ref_import.load(None)
+    g = {}
+    for tag, full, B, H, W in HEADLINE:
+        if only and tag not in only:
+            continue
+        t0 = time.time()
+        batch = syn.sample(B, H, W, seed=1, smooth=3)
+        nets = S.build_nets("ref", ref, flow=full, mask=full)
+        for n in nets:
+            if n is not None:
+                n.load_state_dict(syn.seeded_state_dict(n, 0))
+                n.train()
+        cfg = S.StepConfig()
+        out = S.cc_forward(nets, batch, cfg, impl=ref)
+        for k, v in out.items():
+            if k.startswith("loss"):
+                g["%s.%s" % (tag, k)] = np.float64(float(v))
+        out["loss"].backward()
+        for name, n in zip(("disp", "pose", "mask", "flow"), nets):
+            if n is None:
+                continue
+            sq = sum(float(p.grad.double().pow(2).sum()) for p in n.parameters() if p.grad is not None)
+            g["%s.gradnorm.%s" % (tag, name)] = np.float64(sq ** 0.5)
+        opt = S.make_optimizer(nets, cfg)
+        opt.step()
+        with torch.no_grad():
+            out2 = S.cc_forward(nets, batch, cfg, impl=ref)
+        g["%s.loss_after_adam" % tag] = np.float64(float(out2["loss"]))
+        print("headline %s: loss %.8f  (%.0f s)" % (tag, float(out["loss"]), time.time() - t0), flush=True)
+    return g
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "headline":
+        torch.set_num_threads(os.cpu_count() or 1)      # scalars at 1e-4: thread-count rounding is irrelevant here
+        path = os.path.join(OUT, "headline.npz")
+        g = dict(np.load(path)) if os.path.exists(path) and len(sys.argv) > 2 else {}
+        g.update(headline_level(sys.argv[2:] or None))
+        np.savez_compressed(path, **g)
+        print("wrote headline")
+        return
     torch.set_num_threads(1)   # run-to-run bit reproducibility of the fixtures
     np.savez_compressed(os.path.join(OUT, "metrics.npz"), **metrics_level())
     print("wrote metrics")

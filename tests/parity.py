@@ -375,6 +375,17 @@ CONVT_CASES = [  # B, Cin, H, W, Cout, k, stride, pad, output_padding, act
 ]
 
 
+def _torch_act(y, act, a, b):
+    import torch.nn.functional as F
+    if act == "relu":
+        return F.relu(y)
+    if act == "lrelu":
+        return F.leaky_relu(y, b if b != 0 else 0.2)
+    if act == "sigmoid":
+        return a * torch.sigmoid(y) + b
+    return y
+
+
 def check_convs(dev, cases=CONV_CASES, tcases=CONVT_CASES, tol=2e-5, seed=0, prepack=False):
     """conv2d / conv_transpose2d forward (+ fused bias / residual / activation epilogue) and all gradients, max-abs
     error relative to the largest reference magnitude <= tol (fp32 MFMA accumulation order differs from the CPU's).
@@ -399,7 +410,7 @@ def check_convs(dev, cases=CONV_CASES, tcases=CONVT_CASES, tol=2e-5, seed=0, pre
         r = F.conv2d(ins_c[0], ins_c[1], ins_c[2], st, pad)
         if hr:
             r = r + ins_c[3]
-        r = ops._torch_act(r, act, aa, ab)
+        r = _torch_act(r, act, aa, ab)
         go = rn(*r.shape)
         g0 = torch.autograd.grad(r, [t for t in ins_c if t is not None], go)
         for ps in range(passes):
@@ -414,7 +425,7 @@ def check_convs(dev, cases=CONV_CASES, tcases=CONVT_CASES, tol=2e-5, seed=0, pre
         x0, w0, b0 = rn(B, Cin, H, W), rn(Cin, Cout, k, k) * 0.2, rn(Cout)
         ins_d = [leaf(t, dev) for t in (x0, w0, b0)]
         ins_c = [leaf(t, "cpu") for t in (x0, w0, b0)]
-        r = ops._torch_act(F.conv_transpose2d(ins_c[0], ins_c[1], ins_c[2], st, pad, op), act, 1.0, 0.0)
+        r = _torch_act(F.conv_transpose2d(ins_c[0], ins_c[1], ins_c[2], st, pad, op), act, 1.0, 0.0)
         go = rn(*r.shape)
         g0 = torch.autograd.grad(r, ins_c, go)
         for ps in range(passes):
@@ -458,8 +469,26 @@ def check_corr(dev, cases=((2, 8, 6, 12), (1, 5, 7, 13), (2, 12, 5, 8), (1, 33, 
         assert max(rel(x, y) for x, y in zip(g1, g0)) < 5e-6, ("pair grads", (B, C, H, W), [rel(x, y) for x, y in zip(g1, g0)])
 
 
-def check_batch_norm(dev, cases=((2, 5, 7, 12), (3, 16, 9, 13), (2, 8, 32, 64))):
-    """Training-mode BatchNorm2d (csrc/bnorm.hip) vs ATen on the CPU: output, running statistics and all gradients."""
+def check_upsample2x(dev, cases=((2, 1, 5, 8, 1.0), (1, 2, 3, 6, -0.625), (2, 2, 16, 26, 20.0), (1, 1, 1, 2, 1.0))):
+    """scale * F.interpolate(x, scale_factor=2, 'bilinear', align_corners=False) (csrc/resize.hip) and its adjoint vs ATen."""
+    import torch.nn.functional as F
+    from cc_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for (B, C, H, W, sc) in cases:
+        x0 = torch.randn(B, C, H, W, generator=g)
+        xd, xc = leaf(x0, dev), leaf(x0, "cpu")
+        y = ops.upsample_bilinear2x(xd, sc)
+        r = sc * F.interpolate(xc, scale_factor=2, mode="bilinear", align_corners=False)
+        assert rel(y, r) < 1e-6, ("up2x", (B, C, H, W), rel(y, r))
+        go = torch.randn(r.shape, generator=g)
+        g1 = torch.autograd.grad(y, [xd], go.to(dev))[0]
+        g0 = torch.autograd.grad(r, [xc], go)[0]
+        assert rel(g1, g0) < 2e-6, ("up2x grad", (B, C, H, W), rel(g1, g0))
+
+
+def check_batch_norm(dev, cases=((2, 5, 7, 12), (3, 16, 9, 13), (2, 8, 32, 64), (2, 3, 96, 128), (4, 2, 80, 104))):
+    """Training-mode BatchNorm2d (csrc/bnorm.hip) vs ATen on the CPU: output, running statistics and all gradients;
+    cases on both sides of the 16 k values-per-channel switch between the one-launch and the three-launch kernels."""
     import torch.nn.functional as F
     from cc_amd import ops
     g = torch.Generator().manual_seed(5)

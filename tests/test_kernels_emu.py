@@ -66,3 +66,7 @@ def test_cost_volume():
 
 def test_batch_norm():
     parity.check_batch_norm("cpu")
+
+
+def test_upsample2x():
+    parity.check_upsample2x("cpu")

@@ -84,4 +84,9 @@ def test_cost_volume():
 
 def test_batch_norm():
     parity.check_batch_norm("cuda")
-    parity.check_batch_norm("cuda", cases=((4, 16, 256, 832), (4, 64, 64, 208)))
+    parity.check_batch_norm("cuda", cases=((4, 16, 256, 832), (4, 64, 64, 208), (4, 128, 32, 104), (4, 512, 2, 7)))
+
+
+def test_upsample2x():
+    parity.check_upsample2x("cuda")
+    parity.check_upsample2x("cuda", cases=((4, 2, 64, 208, 20.0), (4, 1, 128, 416, 1.0)))

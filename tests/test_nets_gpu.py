@@ -74,6 +74,23 @@ def test_full_step_against_reference_golden(golden_dir, use_graph):
     got = {k: float(v) for k, v in tr.step(batch).items()}
     for k in ("loss", "loss_1", "loss_2", "loss_3", "loss_4", "loss_5"):
         assert abs(got[k] - float(g[k])) <= 1e-4 * abs(float(g[k])), (k, got[k], float(g[k]))
+    for name, v in tr.grad_norms().items():            # per-network gradient norms of the reference's loss.backward()
+        want = float(g["gradnorm." + name])
+        assert abs(float(v) - want) <= 1e-3 * want, (name, float(v), want)
+    # the small-parameter gradients the fixture stores in full (biases of <= 64 channels)
+    off, worst = 0, (0.0, "")
+    for name, n in zip(("disp", "pose", "mask", "flow"), nets):
+        for pn, p in n.named_parameters():
+            k = p.numel()
+            key = "grad.%s.%s" % (name, pn)
+            if key in g:
+                gw = torch.from_numpy(g[key]).double().reshape(-1)
+                gg = tr.opt.flat_g[off:off + k].detach().cpu().double()
+                r = float((gg - gw).norm()) / (float(gw.norm()) + 1e-12)
+                worst = max(worst, (r, key))
+                assert r <= 1e-2, (key, r)
+            off += k
+    print("worst small-parameter gradient mismatch vs the reference: %.2e (%s)" % worst)
     got2 = {k: float(v) for k, v in tr.step(batch).items()}
     assert abs(got2["loss"] - float(g["loss_after_adam"])) <= 1e-4 * abs(float(g["loss_after_adam"]))
 

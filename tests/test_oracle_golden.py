@@ -209,3 +209,30 @@ def test_c_warp_coords(golden_dir):
                               grid.ctypes.data_as(vp), flow.ctypes.data_as(vp), tap.ctypes.data_as(vp))
     assert np.array_equal(grid, g["grid_zeros"])
     assert np.array_equal(flow, g["pose2flow"])
+
+
+@pytest.mark.slow
+def test_headline_size_step(golden_dir):
+    """The oracle at the size the metric is quoted on (B=4, 832x256; config 2 = DispResNet6 + PoseNetB6, the cheaper of the
+    headline fixtures) against the scalars the unmodified reference wrote (tests/golden/headline.npz): pins the CPU baseline
+    / bench-time parity checker of bench.py at full size, not only at the 128x192 of the step fixtures."""
+    from oracle.make_golden import HEADLINE
+    g = _load(golden_dir, "headline.npz")
+    tag, full, B, H, W = next(c for c in HEADLINE if c[0] == "c2_b4")
+    torch.set_num_threads(os.cpu_count() or 1)
+    batch = syn.sample(B, H, W, seed=1, smooth=3)
+    nets = S.build_nets("oracle", flow=full, mask=full)
+    for n in nets:
+        if n is not None:
+            n.load_state_dict(syn.seeded_state_dict(n, 0))
+            n.train()
+    cfg = S.StepConfig()
+    out = S.cc_forward(nets, batch, cfg)
+    for k in ("loss", "loss_1", "loss_3"):
+        want = float(g["%s.%s" % (tag, k)])
+        assert abs(float(out[k]) - want) <= 1e-6 * abs(want), (k, float(out[k]), want)
+    out["loss"].backward()
+    for name, n in zip(("disp", "pose"), nets):
+        sq = sum(float(p.grad.double().pow(2).sum()) for p in n.parameters() if p.grad is not None)
+        want = float(g["%s.gradnorm.%s" % (tag, name)])
+        assert abs(sq ** 0.5 - want) <= 1e-5 * want, (name, sq ** 0.5, want)

@@ -51,12 +51,20 @@ def test_flat_adam_matches_torch_adam():
         for _ in range(3):
             opt.zero_grad()
             lin(x).pow(2).sum().backward()
-            opt.step(opt.all_reduce())
+            opt.all_reduce()
+            opt.step(opt.grad_scale())
             topt.zero_grad()
             ref(x).pow(2).sum().backward()
             topt.step()
         for a, b in zip(lin.parameters(), ref.parameters()):
             assert float((a - b).abs().max()) < 1e-6
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
 
 def _dp_worker(rank, world, port, ret):
@@ -75,8 +83,8 @@ def _dp_worker(rank, world, port, ret):
         x = torch.randn(2, 3, 8, 8, generator=torch.Generator().manual_seed(10 + rank))   # rank-specific shard
         opt.zero_grad()
         net(x).pow(2).mean().backward()
-        scale = opt.all_reduce()                        # ONE collective on the flat bucket
-        opt.step(scale)
+        opt.all_reduce()                                # ONE collective on the flat bucket
+        opt.step(opt.grad_scale())
         ret[rank] = opt.flat_p.clone()
     dist.destroy_process_group()
 
@@ -84,7 +92,7 @@ def _dp_worker(rank, world, port, ret):
 def test_data_parallel_two_ranks_gloo():
     """world_size-2 gloo run of the DP path: flat-bucket all-reduce + identical fused Adam on every rank
     == single-process training on the mean gradient of the two shards."""
-    world, port = 2, 29533
+    world, port = 2, _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_dp_worker, args=(world, port, ret), nprocs=world, join=True)
@@ -100,3 +108,63 @@ def test_data_parallel_two_ranks_gloo():
     opt.step()
     flat = torch.cat([p.data.reshape(-1) for p in net.parameters()])
     assert float((ret[0][:flat.numel()] - flat).abs().max()) < 1e-6
+
+
+def _cc_dp_worker(rank, world, port, ret):
+    """One rank of the REAL data-parallel CC step (CCTrainer.step: four nets, all losses, staged backward with the
+    DispResNet6 + PoseNetB6 gradient segment reduced while MaskNet6 + Back2Future run backward, fused Adam)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "4"
+    torch.set_num_threads(4)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, H, W = 2, 64, 128
+    batch = syn.sample(B, H, W, seed=1 + rank)               # rank-specific shard, as bench.py draws it
+    with emulated_engine():
+        nets = T.build_nets("cpu", init=False)
+        for n in nets:
+            n.load_state_dict(syn.seeded_state_dict(n, 0))
+            if rank == 1:                                   # the start-up broadcast must bring rank 1 back to rank 0's weights
+                for p in n.parameters():
+                    p.data.mul_(1.01)
+        tr = T.CCTrainer(nets, T.StepConfig(), use_graph=False)
+        assert tr.split_graphs and 0 < tr.n_dp < tr.opt.n
+        p0 = tr.opt.flat_p.clone()
+        local = torch.zeros_like(tr.opt.flat_g)
+        calls = []
+        orig = tr.opt.all_reduce
+
+        def spy(lo=0, hi=None, async_op=False):
+            hi = tr.opt.flat_g.numel() if hi is None else hi
+            local[lo:hi] = tr.opt.flat_g[lo:hi]             # this rank's own gradient segment, complete at issue time
+            calls.append((lo, hi, async_op))
+            return orig(lo, hi, async_op)
+        tr.opt.all_reduce = spy
+        losses = tr.step(batch)
+        ret[rank] = dict(p0=p0, local=local, reduced=tr.opt.flat_g.clone(), p1=tr.opt.flat_p.clone(), calls=calls,
+                         n_dp=tr.n_dp, loss=float(losses["loss"]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_cc_step_data_parallel_two_ranks_gloo():
+    """world_size-2 gloo run of CCTrainer.step (train.py:300-303's DataParallel as one process per GPU): ranks agree bit for
+    bit, the exchanged gradient is the sum of the two ranks' own gradients, the update equals Adam on their mean, and the
+    exchange is issued as two segments with the first one started before the second backward stage."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_cc_dp_worker, args=(world, port, ret), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert torch.equal(r0["p0"], r1["p0"]), "broadcast from rank 0 did not equalise the start weights"
+    assert torch.equal(r0["reduced"], r1["reduced"]) and torch.equal(r0["p1"], r1["p1"]), "ranks diverged"
+    assert torch.equal(r0["reduced"], r0["local"] + r1["local"])
+    assert float(r0["local"].abs().sum()) > 0 and not torch.equal(r0["local"], r1["local"])
+    n_dp, n = r0["n_dp"], r0["p0"].numel()
+    assert [(lo, hi) for lo, hi, _ in r0["calls"]] == [(0, n_dp), (n_dp, n)] and all(a for _, _, a in r0["calls"])
+    # single-process reference: torch.optim.Adam on the mean gradient
+    p = r0["p0"].clone().requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=1e-4, betas=(0.9, 0.999))
+    p.grad = (r0["local"] + r1["local"]) * 0.5
+    opt.step()
+    assert float((p.detach() - r0["p1"]).abs().max()) < 1e-6
