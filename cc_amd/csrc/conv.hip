@@ -44,6 +44,7 @@ struct GG {
     int Rt, St, dy0, dx0, dstep, si;
     int OHt, OWt, so, oy0, ox0, OH, OW; long y_bs, res_bs;
     int act; float act_a, act_b;
+    int res_mul;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float a, float b) {
@@ -51,6 +52,23 @@ __device__ __forceinline__ float apply_act(float v, int act, float a, float b) {
     if (act == ACT_LRELU) return v > 0.f ? v : (b != 0.f ? b : 0.2f) * v;       // slope: act_b, 0 -> the 0.2 of Back2Future
     if (act == ACT_SIGMOID) return a * (1.f / (1.f + expf(-v))) + b;
     return v;
+}
+
+// d act(pre) / d pre expressed through the activation's OUTPUT v, times the upstream gradient g
+__device__ __forceinline__ float act_grad(float g, float v, int act, float act_a, float act_b) {
+    if (act == ACT_RELU) return v > 0.f ? g : 0.f;
+    if (act == ACT_LRELU) return v > 0.f ? g : (act_b != 0.f ? act_b : 0.2f) * g;
+    const float sg = (v - act_b) / act_a;
+    return g * act_a * sg * (1.f - sg);
+}
+
+// epilogue tail shared by every conv kernel: res_mul == 0: act(v + res);  res_mul == 1 (data-gradient calls): the gradient
+// w.r.t. the PRE-activation of the layer that produced this conv's input, v * act'(r), r = that layer's output (= this
+// conv's input, same shape as the gradient) -- the producer's separate activation-backward pass disappears
+__device__ __forceinline__ float conv_tail(float v, bool has_res, float r, int res_mul, int act, float a, float b) {
+    if (has_res && res_mul) return act_grad(v, r, act, a, b);
+    if (has_res) v += r;
+    return apply_act(v, act, a, b);
 }
 
 template <int BM>
@@ -190,8 +208,7 @@ __global__ __launch_bounds__(256) void k_gather_gemm(GG g) {
                 if (m < g.M) {
                     float v = acc[a][b][r];
                     if (g.bias) v += g.bias[m];
-                    if (rbp) v += rbp[(long)m * y_cs];
-                    yb[(long)m * y_cs] = apply_act(v, g.act, g.act_a, g.act_b);
+                    yb[(long)m * y_cs] = conv_tail(v, rbp != nullptr, rbp ? rbp[(long)m * y_cs] : 0.f, g.res_mul, g.act, g.act_a, g.act_b);
                 }
             }
         }
@@ -222,6 +239,7 @@ struct CP {
     int tiles_x, tiles_y;
     int nsplit, cps; long part_stride;
     int act; float act_a, act_b;
+    int res_mul;
 };
 
 // wp[(t*Cpad + c)*Mpad + m] = w[w0 + m*w_sm + c*w_sc + i*w_ri + j*w_sj]  (0 beyond Cin / M), t = i*St + j
@@ -472,8 +490,7 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
                     if (m < g.M) {
                         float v = acc[a][b][r];
                         if (g.bias) v += g.bias[m];
-                        if (rbp) v += rbp[(long)m * y_cs];
-                        yb[(long)m * y_cs] = apply_act(v, g.act, g.act_a, g.act_b);
+                        yb[(long)m * y_cs] = conv_tail(v, rbp != nullptr, rbp ? rbp[(long)m * y_cs] : 0.f, g.res_mul, g.act, g.act_a, g.act_b);
                     }
                 }
         }
@@ -488,17 +505,23 @@ __global__ __launch_bounds__(256) void k_conv_patch(CP g) {
 // The (up to) four output-parity classes of a stride-2 data-gradient / transposed convolution in ONE launch:
 // blockIdx.x ranges over the classes' tiles back to back (each class has its own geometry, weight image and partial
 // slabs; the small-map layers are launch-bound, and four quarter-size grids in a row under-fill the chip).
+// ... and, more generally, up to MAXCLS independent problems of one tile configuration in ONE launch: the G same-shaped
+// convolutions of a network's parallel branches (Back2Future's decoder_fwd / decoder_bwd / decoder_occ at one pyramid level,
+// its a / b / c feature streams) times their parity classes.  The deep pyramid levels are 1-4 GFLOP problems: one launch per
+// group instead of one per branch triples the work per launch, needs a third of the split-K (partial-slab traffic) and
+// removes two thirds of the ~5 us launch floors.
+constexpr int MAXCLS = 12;
 struct CPM {
-    CP c[4];
+    CP c[MAXCLS];
     int n;
-    int bx_end[4];
+    int bx_end[MAXCLS];
 };
 
 template <int BM, int CK, int TPS>
 __global__ __launch_bounds__(256) void k_conv_patch_multi(CPM a) {
     int k = 0, first = 0;
 #pragma unroll
-    for (int q = 0; q < 3; q++)
+    for (int q = 0; q < MAXCLS - 1; q++)
         if (q + 1 < a.n && (int)blockIdx.x >= a.bx_end[q]) { k = q + 1; first = a.bx_end[q]; }
     const CP& g = a.c[k];
     if ((int)blockIdx.z >= g.nsplit) return;
@@ -510,7 +533,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
                                                          const float* __restrict__ bias, const float* __restrict__ res,
                                                          float* __restrict__ y, int M, int OHt, int OWt, int so, int oy0,
                                                          int ox0, int OH, int OW, long y_bs, long res_bs, long total,
-                                                         int act, float act_a, float act_b) {
+                                                         int act, float act_a, float act_b, int res_mul) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     float v = 0.f;
@@ -524,24 +547,23 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
     const int ty = t / OWt, tx = t - ty * OWt;
     const long o = (long)m * OH * OW + (long)(oy0 + so * ty) * OW + (ox0 + so * tx);
     if (bias) v += bias[m];
-    if (res) v += res[(long)n * res_bs + o];
-    y[(long)n * y_bs + o] = apply_act(v, act, act_a, act_b);
+    y[(long)n * y_bs + o] = conv_tail(v, res != nullptr, res ? res[(long)n * res_bs + o] : 0.f, res_mul, act, act_a, act_b);
 }
 
-struct EPC { const float* part; int nsplit; long part_stride; int OHt, OWt, oy0, ox0; long total; };
+struct EPC { const float* part; const float* bias; const float* res; float* y; int nsplit; long part_stride; int OHt, OWt, oy0, ox0; long total; };
 struct EPM {
-    EPC c[4];
+    EPC c[MAXCLS];
     int n;
-    int bx_end[4];
-    const float* bias; float* y;
-    int M, so, OH, OW; long y_bs;
+    int bx_end[MAXCLS];
+    int M, so, OH, OW; long y_bs, res_bs;
     int act; float act_a, act_b;
+    int res_mul;
 };
 
 __global__ __launch_bounds__(256) void k_splitk_epilogue_multi(EPM a) {
     int k = 0, first = 0;
 #pragma unroll
-    for (int q = 0; q < 3; q++)
+    for (int q = 0; q < MAXCLS - 1; q++)
         if (q + 1 < a.n && (int)blockIdx.x >= a.bx_end[q]) { k = q + 1; first = a.bx_end[q]; }
     const EPC& c = a.c[k];
     const long e = (long)((int)blockIdx.x - first) * 256 + threadIdx.x;
@@ -556,8 +578,8 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_multi(EPM a) {
     const int t = (int)(r - (long)m * HWt);
     const int ty = t / c.OWt, tx = t - ty * c.OWt;
     const long o = (long)m * a.OH * a.OW + (long)(c.oy0 + a.so * ty) * a.OW + (c.ox0 + a.so * tx);
-    if (a.bias) v += a.bias[m];
-    a.y[(long)n * a.y_bs + o] = apply_act(v, a.act, a.act_a, a.act_b);
+    if (c.bias) v += c.bias[m];
+    c.y[(long)n * a.y_bs + o] = conv_tail(v, c.res != nullptr, c.res ? c.res[(long)n * a.res_bs + o] : 0.f, a.res_mul, a.act, a.act_a, a.act_b);
 }
 
 static int dbg_flag_early(const char* name) {
@@ -576,7 +598,8 @@ static int env_int_early(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-inline ConvPlan plan_conv(const GG& g) {
+// mult: number of same-shaped problems that share the launch (split-K only has to fill what they leave empty)
+inline ConvPlan plan_conv(const GG& g, int mult = 1) {
     ConvPlan p = {};
     p.bm = pick_bm_fwd(g.M);
     {   // few pixel tiles: halve the channel tile before resorting to split-K (no partial slabs, no epilogue launch)
@@ -611,7 +634,7 @@ inline ConvPlan plan_conv(const GG& g) {
     p.tiles_x = (g.OWt + TW - 1) / TW;
     p.tiles_y = (g.OHt + TH - 1) / TH;
     p.wp_floats = (size_t)g.Rt * g.St * p.Cpad * p.Mpad;
-    const long blocks = (long)g.B * p.tiles_x * p.tiles_y * (p.Mpad / p.bm);
+    const long blocks = (long)g.B * p.tiles_x * p.tiles_y * (p.Mpad / p.bm) * (mult > 1 ? mult : 1);
     const int nchunk = p.Cpad / p.ck;
     p.nsplit = 1;
     p.cps = nchunk;
@@ -631,10 +654,13 @@ inline ConvPlan plan_conv(const GG& g) {
 inline size_t conv_ws_floats(const ConvPlan& p) { return 64 + p.wp_floats + p.part_floats; }
 
 // ------------------------------------------------------------------ weight gradient
+constexpr int MAXGRP = 4;       // same-shaped weight-gradient problems per launch (parallel branches of a network)
 struct WG {
     const float* a;   // "dY-like" tensor [B, M, AH, AW] (batch stride a_bs), sampled on the full lattice (ty, tx)
     const float* x;   // gathered tensor [B, Cin, IH, IW]
     float* out;       // partial tiles ws[split][M][N] (or the final gradient when nsplit == 1 -> strided store)
+    const float* ga[MAXGRP]; const float* gxp[MAXGRP]; float* gout[MAXGRP];   // per-problem pointers (blockIdx.z / nsplit)
+    int nsplit;
     int B, M, AH, AW; long a_bs;
     int Cin, IH, IW; long x_bs;
     int Rt, St, dy0, dx0, dstep, si;
@@ -645,6 +671,10 @@ struct WG {
 
 template <int BM>
 __global__ __launch_bounds__(256) void k_wgrad(WG g) {
+    const int grp = (int)blockIdx.z / g.nsplit, zsplit = (int)blockIdx.z - grp * g.nsplit;
+    const float* __restrict__ a_ = g.ga[grp];
+    const float* __restrict__ x_ = g.gxp[grp];
+    float* __restrict__ out_ = g.gout[grp];
     constexpr int WM = (BM >= 64) ? BM / 2 : 32;
     constexpr int WN = (BM >= 64) ? 64 : 32;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -663,7 +693,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WG g) {
     const int Ntot = g.Cin * RS;
     const int HWa = g.AH * g.AW;
     const long Ptot = (long)g.B * HWa;
-    const long pbeg = (long)blockIdx.z * g.pix_per_split;
+    const long pbeg = (long)zsplit * g.pix_per_split;
     long pend = pbeg + g.pix_per_split;
     if (pend > Ptot) pend = Ptot;
     const int x_cs = g.IH * g.IW;
@@ -706,7 +736,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WG g) {
         for (int q = 0; q < AQ; q++) {
             const int m = m0 + rgp + 16 * q;
             const bool ok = pv && (m < g.M);
-            ra[q] = g.a[ok ? abase + (long)m * HWa : 0];
+            ra[q] = a_[ok ? abase + (long)m * HWa : 0];
             okA |= (ok ? 1u : 0u) << q;
         }
         const int iy0 = g.si * ty, ix0 = g.si * tx;
@@ -715,7 +745,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WG g) {
         for (int q = 0; q < 8; q++) {
             const int iy = iy0 + tdy[q], ix = ix0 + tdx[q];
             const bool ok = pv && ((unsigned)iy < (unsigned)g.IH) && ((unsigned)ix < (unsigned)g.IW);
-            rb[q] = g.x[ok ? xb + xoff[q] : 0];
+            rb[q] = x_[ok ? xb + xoff[q] : 0];
             okB |= (ok ? 1u : 0u) << q;
         }
     };
@@ -775,7 +805,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WG g) {
             const int i = rem / g.St, j = rem - i * g.St;
             obase = (long)c * g.o_sc + i * g.o_ri + j * g.o_sj;
         } else {
-            obase = (long)blockIdx.z * g.M * Ntot + jn;
+            obase = (long)zsplit * g.M * Ntot + jn;
         }
 #pragma unroll
         for (int a = 0; a < TM; a++)
@@ -783,7 +813,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WG g) {
             for (int r = 0; r < 16; r++) {
                 const int m = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (m < g.M) {
-                    float* o = g.out + obase + (g.direct ? (long)m * g.o_sm : (long)m * Ntot);
+                    float* o = out_ + obase + (g.direct ? (long)m * g.o_sm : (long)m * Ntot);
                     *o = (g.direct && g.accum) ? (*o + acc[a][b][r]) : acc[a][b][r];
                 }
             }
@@ -983,6 +1013,7 @@ constexpr int W3_PC = 41;       // chunks per channel in the patch (40 used + 1 
 
 struct W3 {
     const float* a; const float* x; const float* zeros; float* ws;
+    const float* ga[MAXGRP]; const float* gxp[MAXGRP]; float* gws[MAXGRP];      // per-problem pointers (blockIdx.y)
     int B, M, AH, AW; long a_bs;
     int Cin; long x_bs;
     int tiles_x, tiles_y, ntiles, tiles_per_split, nsplit, Cpad, dbg;
@@ -993,6 +1024,9 @@ struct W3 {
 // = 12 (tap row, tile) groups, three per wave = 9 accumulators; every k-step pair costs 4 ds_read_b128 per 12 MFMAs.
 template <int MT, int CT>
 __global__ __launch_bounds__(256, 2) void k_wgrad3x3(W3 g) {
+    const float* __restrict__ a_ = g.ga[blockIdx.y];
+    const float* __restrict__ x_ = g.gxp[blockIdx.y];
+    float* __restrict__ ws_ = g.gws[blockIdx.y];
     constexpr int BM = 32 * MT, BC = 32 * CT;
     constexpr int A_SLOTS = BM * 16;                           // 16-byte slots of the dY tile
     constexpr int P_SLOTS = ((BC * W3_PC + 63) / 64) * 64;     // rounded up so that every DMA instruction runs all 64 lanes
@@ -1041,7 +1075,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3(W3 g) {
             const int ty = ty0 + (pc >> 3), tx = tx0 + 4 * (pc & 7);
             const int m = m0 + mm;
             const bool ok = (m < g.M) && (ty < g.AH) && (tx < g.AW);
-            const float* src = ok ? g.a + (long)n * g.a_bs + (long)m * HW + (long)ty * g.AW + tx : g.zeros;
+            const float* src = ok ? a_ + (long)n * g.a_bs + (long)m * HW + (long)ty * g.AW + tx : g.zeros;
             __builtin_amdgcn_global_load_lds(CC_GLOBAL_PTR(src), CC_LDS_PTR(As + s0), 16, 0, 0);
         }
         // patch: LDS slot s = c*41 + r, r = py*10 + ch (r == 40: pad)
@@ -1052,7 +1086,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3(W3 g) {
             const int iy = ty0 - 1 + py, ix = tx0 - 4 + 4 * ch;
             const int c = c0 + cc;
             const bool ok = (cc < BC) && (r < 40) && (c < g.Cin) && ((unsigned)iy < (unsigned)g.AH) && ((unsigned)ix < (unsigned)g.AW);
-            const float* src = ok ? g.x + (long)n * g.x_bs + (long)c * HW + (long)iy * g.AW + ix : g.zeros;
+            const float* src = ok ? x_ + (long)n * g.x_bs + (long)c * HW + (long)iy * g.AW + ix : g.zeros;
             __builtin_amdgcn_global_load_lds(CC_GLOBAL_PTR(src), CC_LDS_PTR(Ps + s0), 16, 0, 0);
         }
     };
@@ -1092,7 +1126,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3(W3 g) {
     for (int k = 0; k < 3; k++) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            float* o = g.ws + (((long)blockIdx.z * 9 + (g_row[k] * 3 + j)) * g.M) * g.Cpad + c0 + g_ct[k] * 32 + l31;
+            float* o = ws_ + (((long)blockIdx.z * 9 + (g_row[k] * 3 + j)) * g.M) * g.Cpad + c0 + g_ct[k] * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int m = m0 + g_mt[k] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -1104,9 +1138,13 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3(W3 g) {
 
 __global__ void k_zero64(float* p) { p[threadIdx.x] = 0.f; }
 
-// gw[m*o_sm + c*o_sc + t] = sum_z ws[z][t][m][c]
-__global__ __launch_bounds__(256) void k_wgrad_patch_reduce(const float* __restrict__ ws, float* __restrict__ gw, int nsplit,
+struct RG { const float* ws[MAXGRP]; float* gw[MAXGRP]; };
+
+// gw[m*o_sm + c*o_sc + t] = sum_z ws[z][t][m][c]      (blockIdx.y = problem of the group)
+__global__ __launch_bounds__(256) void k_wgrad_patch_reduce(RG rg, int nsplit,
                                                             int T, int M, int Cin, int Cp32, long o_sm, long o_sc, int accum) {
+    const float* __restrict__ ws = rg.ws[blockIdx.y];
+    float* __restrict__ gw = rg.gw[blockIdx.y];
     const long e = (long)blockIdx.x * 256 + threadIdx.x;     // over [t][m][c]
     const long tot = (long)T * M * Cp32;
     if (e >= tot) return;
@@ -1173,10 +1211,12 @@ inline WPlan plan_wgrad(int B, int M, int AH, int AW, int Cin, int R, int S, int
     return p;
 }
 
-// second stage: gw[m, (c,i,j)] = sum_split ws[split][m][(c,i,j)]
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ gw, int nsplit,
+// second stage: gw[m, (c,i,j)] = sum_split ws[split][m][(c,i,j)]      (blockIdx.y = problem of the group)
+__global__ __launch_bounds__(256) void k_wgrad_reduce(RG rg, int nsplit,
                                                       int M, int Ntot, int RS, int St, long o_sm, long o_sc, int o_ri,
                                                       int o_sj, int accum) {
+    const float* __restrict__ ws = rg.ws[blockIdx.y];
+    float* __restrict__ gw = rg.gw[blockIdx.y];
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     const long tot = (long)M * Ntot;
     if (e >= tot) return;
@@ -1193,25 +1233,28 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 // geff = gy * act'(y) (in place allowed);  partial[m][n*cpp + chunk] = sum over the chunk of geff.
 // grid (cpp, C, B): one (image, channel) plane chunk per workgroup -> no per-element index arithmetic, float4 accesses
 // when the plane size allows (HBM-bound: 2 reads + 1 write per element).
-__device__ __forceinline__ float act_grad(float g, float v, int act, float act_a, float act_b) {
-    if (act == ACT_RELU) return v > 0.f ? g : 0.f;
-    if (act == ACT_LRELU) return v > 0.f ? g : (act_b != 0.f ? act_b : 0.2f) * g;
-    const float sg = (v - act_b) / act_a;
-    return g * act_a * sg * (1.f - sg);
-}
+
+struct AB {      // up to MAXGRP same-shaped problems per launch: blockIdx.z = problem * zper + image
+    const float* gy[MAXGRP]; const float* y[MAXGRP]; float* geff[MAXGRP]; float* partial[MAXGRP]; float* gbias_direct[MAXGRP];
+    int zper;
+};
 
 template <bool VEC4>
-__global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ gy, const float* __restrict__ y,
-                                                 float* __restrict__ geff, float* __restrict__ partial, int HW,
-                                                 long gy_bs, long y_bs, long ge_bs, int act, float act_a, float act_b,
-                                                 int nb, float* __restrict__ gbias_direct, int accum) {
+__global__ __launch_bounds__(256) void k_act_bwd(AB t, int HW, long gy_bs, long y_bs, long ge_bs, int act, float act_a,
+                                                 float act_b, int nb, int accum) {
     __shared__ float red[4];
+    const int grp = (int)blockIdx.z / t.zper, zimg = (int)blockIdx.z - grp * t.zper;
+    const float* __restrict__ gy = t.gy[grp];
+    const float* __restrict__ y = t.y[grp];
+    float* __restrict__ geff = t.geff[grp];
+    float* __restrict__ partial = t.partial[grp];
+    float* __restrict__ gbias_direct = t.gbias_direct[grp];
     const int m = blockIdx.y, cpp = gridDim.x;
     float s[1] = {0.f};
-    // nb == 1: this workgroup owns image blockIdx.z; nb == B (small maps, grid.z == 1): it walks all images itself and
+    // nb == 1: this workgroup owns image zimg; nb == B (small maps, zper == 1): it walks all images itself and
     // writes the channel's bias gradient directly (no second-stage launch)
     for (int nn = 0; nn < nb; nn++) {
-        const int n = blockIdx.z + nn;
+        const int n = zimg + nn;
         const float* __restrict__ gp = gy + (long)n * gy_bs + (long)m * HW;
         const float* __restrict__ yp = (act != ACT_NONE) ? y + (long)n * y_bs + (long)m * HW : nullptr;
         float* __restrict__ ep = geff ? geff + (long)n * ge_bs + (long)m * HW : nullptr;
@@ -1241,11 +1284,15 @@ __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ gy, c
     cc::block_sum_256<1>(s, red);
     if (threadIdx.x == 0) {
         if (gbias_direct) gbias_direct[m] = accum ? (gbias_direct[m] + s[0]) : s[0];
-        else if (partial) partial[(long)m * (cpp * gridDim.z) + blockIdx.z * cpp + blockIdx.x] = s[0];
+        else if (partial) partial[(long)m * (cpp * t.zper) + zimg * cpp + blockIdx.x] = s[0];
     }
 }
 
-__global__ __launch_bounds__(64) void k_bias_reduce(const float* __restrict__ partial, float* __restrict__ gbias, int nchunk, int accum) {
+struct BR { const float* partial[MAXGRP]; float* gbias[MAXGRP]; };
+
+__global__ __launch_bounds__(64) void k_bias_reduce(BR t, int nchunk, int accum) {
+    const float* __restrict__ partial = t.partial[blockIdx.y];
+    float* __restrict__ gbias = t.gbias[blockIdx.y];
     const int m = blockIdx.x;
     float s = 0.f;
     for (int k = threadIdx.x; k < nchunk; k += 64) s += partial[(long)m * nchunk + k];
@@ -1327,7 +1374,7 @@ inline CP make_cp(const GG& g, const ConvPlan& p, const float* zeros, const floa
     c.y_bs = g.y_bs; c.res_bs = g.res_bs;
     c.tiles_x = p.tiles_x; c.tiles_y = p.tiles_y;
     c.nsplit = p.nsplit; c.cps = p.cps; c.part_stride = (long)g.B * g.M * g.OHt * g.OWt;
-    c.act = g.act; c.act_a = g.act_a; c.act_b = g.act_b;
+    c.act = g.act; c.act_a = g.act_a; c.act_b = g.act_b; c.res_mul = g.res_mul;
     return c;
 }
 
@@ -1354,28 +1401,33 @@ inline void launch_gg(const GG& g, float* ws, hipStream_t s, const float* prepac
         const long total = c.part_stride;
         hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)part,
                            p.nsplit, c.part_stride, g.bias, g.res, g.y, g.M, g.OHt, g.OWt, g.so, g.oy0, g.ox0, g.OH, g.OW,
-                           g.y_bs, g.res_bs, total, g.act, g.act_a, g.act_b);
+                           g.y_bs, g.res_bs, total, g.act, g.act_a, g.act_b, g.res_mul);
     }
 }
 
-// All parity classes of one stride-s data-gradient in ONE conv launch (+ ONE split-K epilogue launch).  Needs the
-// prepacked weight images (class k's image follows class k-1's) and every class on the patch kernel with the same tile
-// configuration; partial slabs of the classes are laid out back to back in ws.  -> false: caller launches them one by one.
-inline bool launch_gg_classes(const GG* gs, int n, float* ws, hipStream_t s, const float* prepacked) {
-    if (n < 2 || n > 4 || !prepacked || !ws || dbg_flag_early("CC_NO_CLASS_MERGE")) return false;
-    ConvPlan ps[4];
+// n problems (parity classes of one stride-2 data-gradient and / or the same-shaped convolutions of parallel branches) in
+// ONE conv launch (+ ONE split-K epilogue launch).  Needs prepacked weight images and every problem on the patch kernel with
+// the same tile configuration.  zeros[k] / wps[k] / parts[k]: the 64-float zero block, weight image and partial-slab area of
+// problem k.  -> false: caller launches them one by one.
+inline bool launch_gg_classes(const GG* gs, int n, int mult, const float* const* zeros, const float* const* wps,
+                              float* const* parts, hipStream_t s) {
+    if (n < 2 || n > MAXCLS || dbg_flag_early("CC_NO_CLASS_MERGE")) return false;
+    ConvPlan ps[MAXCLS];
     size_t smem = 0;
     int tps = 3, maxsplit = 1;
     for (int k = 0; k < n; k++) {
-        ps[k] = plan_conv(gs[k]);
-        if (!ps[k].use_patch || ps[k].bm != ps[0].bm || ps[k].ck != ps[0].ck || gs[k].res != nullptr) return false;
+        ps[k] = plan_conv(gs[k], mult);
+        if (!ps[k].use_patch || ps[k].bm != ps[0].bm || ps[k].ck != ps[0].ck || !wps[k]) return false;
+        if (gs[k].res != nullptr && !gs[k].res_mul) return false;
+        if (gs[k].M != gs[0].M || gs[k].so != gs[0].so || gs[k].OH != gs[0].OH || gs[k].OW != gs[0].OW || gs[k].y_bs != gs[0].y_bs ||
+            gs[k].res_bs != gs[0].res_bs || gs[k].act != gs[0].act || gs[k].res_mul != gs[0].res_mul)
+            return false;
         if (ps[k].tps != 3) tps = 1;
         if (ps[k].nsplit > maxsplit) maxsplit = ps[k].nsplit;
     }
-    CPM a = {};
+    CPM a = {};        // ~3 KB + ~1 KB of host stack, passed to the launches by value
     EPM e = {};
     a.n = n; e.n = n;
-    long off = 64, poff = 64;
     int bx = 0, ebx = 0, nsplit_any = 0;
     for (int k = 0; k < n; k++) {
         const GG& g = gs[k];
@@ -1383,27 +1435,31 @@ inline bool launch_gg_classes(const GG* gs, int n, float* ws, hipStream_t s, con
         // LDS: A buffers follow the launch-wide TPS, the patch buffers this class's PS
         const size_t sm = (size_t)(2 * tps * p.ck * p.bm + 2 * p.ck * p.PS) * sizeof(float);
         if (sm > smem) smem = sm;
-        a.c[k] = make_cp(g, p, prepacked, prepacked + off, ws + poff);
-        off += (long)p.wp_floats;
+        a.c[k] = make_cp(g, p, zeros[k], wps[k], parts[k]);
         bx += g.B * p.tiles_x * p.tiles_y;
         a.bx_end[k] = bx;
         EPC& c = e.c[k];
-        c.part = ws + poff; c.nsplit = p.nsplit; c.part_stride = a.c[k].part_stride;
+        c.part = parts[k]; c.bias = g.bias; c.res = g.res; c.y = g.y;
+        c.nsplit = p.nsplit; c.part_stride = a.c[k].part_stride;
         c.OHt = g.OHt; c.OWt = g.OWt; c.oy0 = g.oy0; c.ox0 = g.ox0;
         c.total = (p.nsplit > 1) ? a.c[k].part_stride : 0;
         ebx += (int)((c.total + 255) / 256);
         e.bx_end[k] = ebx;
-        if (p.nsplit > 1) { nsplit_any = 1; poff += (long)p.part_floats; }
+        if (p.nsplit > 1) nsplit_any = 1;
     }
     if (smem > 80 * 1024) return false;
     if (dbg_flag_early("CC_CLASS_MERGE_TRACE"))
-        fprintf(stderr, "[conv] %d parity classes in one launch: %d tiles, bm %d ck %d tps %d split %d\n", n, bx, ps[0].bm, ps[0].ck, tps, maxsplit);
+        fprintf(stderr, "[conv] %d problems in one launch: %d tiles, bm %d ck %d tps %d split %d\n", n, bx, ps[0].bm, ps[0].ck, tps, maxsplit);
     dim3 grid((unsigned)bx, (unsigned)(ps[0].Mpad / ps[0].bm), (unsigned)maxsplit);
     dispatch_patch(ps[0].bm, ps[0].ck, tps, a, grid, smem, s);
     if (nsplit_any) {
         const GG& g = gs[0];
-        e.bias = g.bias; e.y = g.y; e.M = g.M; e.so = g.so; e.OH = g.OH; e.OW = g.OW; e.y_bs = g.y_bs;
-        e.act = g.act; e.act_a = g.act_a; e.act_b = g.act_b;
+        e.M = g.M; e.so = g.so; e.OH = g.OH; e.OW = g.OW; e.y_bs = g.y_bs; e.res_bs = g.res_bs;
+        e.act = g.act; e.act_a = g.act_a; e.act_b = g.act_b; e.res_mul = g.res_mul;
+        if (dbg_flag_early("CC_CLASS_MERGE_TRACE"))
+            for (int k = 0; k < n; k++)
+                fprintf(stderr, "[conv]   epi class %d: part %p y %p nsplit %d total %ld bx_end %d\n", k, (const void*)e.c[k].part,
+                        (void*)e.c[k].y, e.c[k].nsplit, e.c[k].total, e.bx_end[k]);
         hipLaunchKernelGGL(k_splitk_epilogue_multi, dim3((unsigned)ebx), dim3(256), 0, s, e);
     }
     return true;
@@ -1473,6 +1529,43 @@ int cc_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, con
     return CC_OK;
 }
 
+/* G same-shaped convolutions (parallel branches of a network) in one launch.  x / w / bias / res / y / prepacked: HOST arrays
+ * of G device addresses (0 = null); ws: G consecutive areas of cc_conv2d_fwd_group_ws_bytes() / G bytes each. */
+size_t cc_conv2d_fwd_group_ws_bytes(int G, int B, int Cin, int IH, int IW, int Cout, int R, int S, int stride, int pad, int OH,
+                                    int OW) {
+    GG g = make_fwd(nullptr, nullptr, nullptr, nullptr, nullptr, B, Cin, IH, IW, 0, Cout, R, S, stride, pad, OH, OW, 0, 0, 0,
+                    1.f, 0.f);
+    const size_t a = conv_ws_floats(plan_conv(g, G)), b = conv_ws_floats(plan_conv(g));
+    return (size_t)G * (a > b ? a : b) * sizeof(float);
+}
+
+int cc_conv2d_fwd_group(int G, const long* x, const long* w, const long* bias, const long* res, const long* y, float* ws,
+                        const long* prepacked, int B, int Cin, int IH, int IW, long x_bs, int Cout, int R, int S, int stride,
+                        int pad, int OH, int OW, long y_bs, long res_bs, int act, float act_a, float act_b, void* stream) {
+    if (G <= 0 || G > MAXCLS || B <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t stride_f = cc_conv2d_fwd_group_ws_bytes(G, B, Cin, IH, IW, Cout, R, S, stride, pad, OH, OW) / sizeof(float) / G;
+    GG gs[MAXCLS];
+    const float *zeros[MAXCLS], *wps[MAXCLS];
+    float* parts[MAXCLS];
+    bool packed = true;
+    for (int k = 0; k < G; k++) {
+        gs[k] = make_fwd((const float*)x[k], (const float*)w[k], bias ? (const float*)bias[k] : nullptr,
+                         res ? (const float*)res[k] : nullptr, (float*)y[k], B, Cin, IH, IW, x_bs, Cout, R, S, stride, pad, OH,
+                         OW, y_bs, res_bs, act, act_a, act_b);
+        const float* pk = prepacked ? (const float*)prepacked[k] : nullptr;
+        if (!pk) packed = false;
+        zeros[k] = pk;
+        wps[k] = pk ? pk + 64 : nullptr;
+        parts[k] = ws + k * stride_f + 64;
+    }
+    if (!(G > 1 && packed && ws && launch_gg_classes(gs, G, G, zeros, wps, parts, s))) {
+        for (int k = 0; k < G; k++) launch_gg(gs[k], ws ? ws + k * stride_f : nullptr, s, wps[k], zeros[k]);
+    }
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
 /* Transposed-convolution arithmetic  gx[n, c, iy, ix] = sum_{k,r,s} wT(k,c,r,s) * gy[n, k, oy, ox],  iy = oy*stride - pad + r.
  * Used for (a) the data-gradient of conv2d (w: [K,C,R,S] -> w_k_stride = C*R*S, w_c_stride = R*S) and
  * (b) ConvTranspose2d forward (w: [Cin=K, Cout=C, R, S] -> w_k_stride = C*R*S, w_c_stride = R*S as well),
@@ -1480,7 +1573,8 @@ int cc_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, con
  * gy: [B,K,OH,OW]; gx: [B,C,IH,IW]. */
 static bool make_dgrad_class(GG& g, int py, int px, const float* gy, const float* w, const float* bias, float* gx, int B,
                              int K, int OH, int OW, long gy_bs, int C, int R, int S, int stride, int pad, int IH, int IW,
-                             long gx_bs, long w_k_stride, long w_c_stride, int act, float act_a, float act_b) {
+                             long gx_bs, long w_k_stride, long w_c_stride, int act, float act_a, float act_b,
+                             const float* mul = nullptr, long mul_bs = 0) {
     // taps r with (py + pad - r) % stride == 0, r ascending: r = r0 + stride*i
     const int r0 = (py + pad) % stride, s0 = (px + pad) % stride;
     const int Rt = (r0 < R) ? (R - r0 + stride - 1) / stride : 0;
@@ -1488,7 +1582,7 @@ static bool make_dgrad_class(GG& g, int py, int px, const float* gy, const float
     const int OHt = (IH - py + stride - 1) / stride, OWt = (IW - px + stride - 1) / stride;
     if (OHt <= 0 || OWt <= 0) return false;
     g = GG();
-    g.x = gy; g.w = w; g.bias = bias; g.res = nullptr; g.y = gx;
+    g.x = gy; g.w = w; g.bias = bias; g.res = mul; g.res_bs = mul_bs; g.res_mul = mul ? 1 : 0; g.y = gx;
     g.B = B; g.Cin = K; g.IH = OH; g.IW = OW; g.x_bs = gy_bs;
     g.M = C; g.w_sm = w_c_stride; g.w_sc = w_k_stride;
     g.w0 = r0 * S + s0; g.w_ri = stride * S; g.w_sj = stride;
@@ -1501,19 +1595,9 @@ static bool make_dgrad_class(GG& g, int py, int px, const float* gy, const float
     return true;
 }
 
+size_t cc_conv2d_dgrad_group_ws_bytes(int G, int B, int K, int OH, int OW, int C, int R, int S, int stride, int pad, int IH, int IW);
 size_t cc_conv2d_dgrad_ws_bytes(int B, int K, int OH, int OW, int C, int R, int S, int stride, int pad, int IH, int IW) {
-    size_t wmax = 0, psum = 0;        // the merged launch keeps every class's partial slabs alive at once
-    for (int py = 0; py < stride; py++)
-        for (int px = 0; px < stride; px++) {
-            GG g;
-            if (!make_dgrad_class(g, py, px, nullptr, nullptr, nullptr, nullptr, B, K, OH, OW, 0, C, R, S, stride, pad, IH, IW,
-                                  0, (long)C * R * S, (long)R * S, 0, 1.f, 0.f))
-                continue;
-            const ConvPlan p = plan_conv(g);
-            if (p.wp_floats > wmax) wmax = p.wp_floats;
-            psum += p.part_floats;
-        }
-    return (64 + wmax + psum) * sizeof(float);
+    return cc_conv2d_dgrad_group_ws_bytes(1, B, K, OH, OW, C, R, S, stride, pad, IH, IW);
 }
 
 size_t cc_conv2d_dgrad_pack_floats(int B, int K, int OH, int OW, int C, int R, int S, int stride, int pad, int IH, int IW,
@@ -1559,45 +1643,103 @@ int cc_repack_table(const long* table_dev, int ndesc, long total_blocks, void* s
     return CC_OK;
 }
 
-int cc_conv2d_dgrad(const float* gy, const float* w, const float* bias_or_null, float* gx, float* ws,
-                    const float* prepacked_or_null, int B, int K, int OH, int OW, long gy_bs, int C, int R, int S, int stride,
-                    int pad, int IH, int IW, long gx_bs, long w_k_stride, long w_c_stride, int act, float act_a, float act_b,
-                    void* stream) {
-    if (B <= 0 || K <= 0 || C <= 0 || stride <= 0) return CC_ERR_ARG;
+/* G same-shaped problems of the transposed-convolution arithmetic in one launch (all parity classes of all problems).
+ * mul (optional, per problem): tensor of gx's shape (batch stride mul_bs); gx = act_grad(sum (+ bias), mul) = the gradient
+ * w.r.t. the pre-activation of the layer whose OUTPUT `mul` is (act / act_a / act_b then describe THAT activation);
+ * without it gx = act(sum + bias) (ConvTranspose2d forward).  Host pointer arrays as in cc_conv2d_fwd_group. */
+size_t cc_conv2d_dgrad_group_ws_bytes(int G, int B, int K, int OH, int OW, int C, int R, int S, int stride, int pad, int IH, int IW) {
+    size_t best = 0;
+    for (int mult = 1; mult <= G; mult += (G > 1 ? G - 1 : 1)) {
+        size_t wmax = 0, psum = 0;        // the merged launch keeps every class's partial slabs alive at once
+        for (int py = 0; py < stride; py++)
+            for (int px = 0; px < stride; px++) {
+                GG g;
+                if (!make_dgrad_class(g, py, px, nullptr, nullptr, nullptr, nullptr, B, K, OH, OW, 0, C, R, S, stride, pad, IH, IW,
+                                      0, (long)C * R * S, (long)R * S, 0, 1.f, 0.f))
+                    continue;
+                const ConvPlan p = plan_conv(g, mult);
+                if (p.wp_floats > wmax) wmax = p.wp_floats;
+                psum += p.part_floats;
+            }
+        const size_t t = 64 + wmax + psum;
+        if (t > best) best = t;
+    }
+    return (size_t)G * best * sizeof(float);
+}
+
+int cc_conv2d_dgrad_group(int G, const long* gy, const long* w, const long* bias, const long* gx, const long* mul, float* ws,
+                          const long* prepacked, int B, int K, int OH, int OW, long gy_bs, int C, int R, int S, int stride,
+                          int pad, int IH, int IW, long gx_bs, long mul_bs, long w_k_stride, long w_c_stride, int act, float act_a,
+                          float act_b, void* stream) {
+    if (G <= 0 || G > MAXCLS || B <= 0 || K <= 0 || C <= 0 || stride <= 0) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    long off = 64;
-    if (stride == 2 && prepacked_or_null) {
-        GG gs[4];
+    const size_t stride_f = cc_conv2d_dgrad_group_ws_bytes(G, B, K, OH, OW, C, R, S, stride, pad, IH, IW) / sizeof(float) / G;
+    bool packed = true;
+    for (int k = 0; k < G; k++)
+        if (!prepacked || !prepacked[k]) packed = false;
+    const int ncls = stride * stride;
+    if (packed && ws && G * ncls >= 2 && G * ncls <= MAXCLS) {
+        GG gs[MAXCLS];
+        const float *zeros[MAXCLS], *wps[MAXCLS];
+        float* parts[MAXCLS];
         int n = 0;
         bool all = true;
-        for (int py = 0; py < stride && all; py++)
-            for (int px = 0; px < stride; px++) {
-                if (!make_dgrad_class(gs[n], py, px, gy, w, bias_or_null, gx, B, K, OH, OW, gy_bs, C, R, S, stride, pad, IH, IW,
-                                      gx_bs, w_k_stride, w_c_stride, act, act_a, act_b)) { all = false; break; }
-                n++;
-            }
-        if (all && launch_gg_classes(gs, n, ws, s, prepacked_or_null)) {
+        for (int k = 0; k < G && all; k++) {
+            const float* pk = (const float*)prepacked[k];
+            long off = 64;
+            float* part = ws + k * stride_f + 64;
+            for (int py = 0; py < stride && all; py++)
+                for (int px = 0; px < stride; px++) {
+                    if (!make_dgrad_class(gs[n], py, px, (const float*)gy[k], (const float*)w[k],
+                                          bias ? (const float*)bias[k] : nullptr, (float*)gx[k], B, K, OH, OW, gy_bs, C, R, S,
+                                          stride, pad, IH, IW, gx_bs, w_k_stride, w_c_stride, act, act_a, act_b,
+                                          mul ? (const float*)mul[k] : nullptr, mul_bs)) { all = false; break; }
+                    const ConvPlan p = plan_conv(gs[n], G);
+                    zeros[n] = pk;
+                    wps[n] = pk + off;
+                    parts[n] = part;
+                    off += (long)p.wp_floats;
+                    part += p.part_floats;
+                    n++;
+                }
+        }
+        if (all && launch_gg_classes(gs, n, G, zeros, wps, parts, s)) {
             CC_CHECK_LAUNCH();
             return CC_OK;
         }
     }
-    for (int py = 0; py < stride; py++) {
-        for (int px = 0; px < stride; px++) {
-            GG g;
-            if (!make_dgrad_class(g, py, px, gy, w, bias_or_null, gx, B, K, OH, OW, gy_bs, C, R, S, stride, pad, IH, IW, gx_bs,
-                                  w_k_stride, w_c_stride, act, act_a, act_b))
-                continue;
-            if (prepacked_or_null) {
-                const ConvPlan p = plan_conv(g);
-                launch_gg(g, ws, s, prepacked_or_null + off, prepacked_or_null);
-                off += (long)p.wp_floats;
-            } else {
-                launch_gg(g, ws, s);
+    for (int k = 0; k < G; k++) {
+        const float* pk = prepacked ? (const float*)prepacked[k] : nullptr;
+        float* wk = ws ? ws + k * stride_f : nullptr;
+        long off = 64;
+        for (int py = 0; py < stride; py++) {
+            for (int px = 0; px < stride; px++) {
+                GG g;
+                if (!make_dgrad_class(g, py, px, (const float*)gy[k], (const float*)w[k], bias ? (const float*)bias[k] : nullptr,
+                                      (float*)gx[k], B, K, OH, OW, gy_bs, C, R, S, stride, pad, IH, IW, gx_bs, w_k_stride,
+                                      w_c_stride, act, act_a, act_b, mul ? (const float*)mul[k] : nullptr, mul_bs))
+                    continue;
+                if (pk) {
+                    const ConvPlan p = plan_conv(g);
+                    launch_gg(g, wk, s, pk + off, pk);
+                    off += (long)p.wp_floats;
+                } else {
+                    launch_gg(g, wk, s);
+                }
             }
         }
     }
     CC_CHECK_LAUNCH();
     return CC_OK;
+}
+
+int cc_conv2d_dgrad(const float* gy, const float* w, const float* bias_or_null, float* gx, float* ws,
+                    const float* prepacked_or_null, int B, int K, int OH, int OW, long gy_bs, int C, int R, int S, int stride,
+                    int pad, int IH, int IW, long gx_bs, long w_k_stride, long w_c_stride, int act, float act_a, float act_b,
+                    void* stream) {
+    const long gyp = (long)gy, wp = (long)w, bp = (long)bias_or_null, gxp = (long)gx, pk = (long)prepacked_or_null;
+    return cc_conv2d_dgrad_group(1, &gyp, &wp, &bp, &gxp, nullptr, ws, &pk, B, K, OH, OW, gy_bs, C, R, S, stride, pad, IH, IW, gx_bs,
+                                 0, w_k_stride, w_c_stride, act, act_a, act_b, stream);
 }
 
 struct W3Plan { bool ok; int mt, nbuf, tiles_x, tiles_y, ntiles, nsplit, tps, Cp32; size_t smem, ws_floats; };
@@ -1607,7 +1749,7 @@ static int env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-inline W3Plan plan_w3(int B, int M, int AH, int AW, int Cin, int R, int S, int si, int pad, int IH, int IW) {
+inline W3Plan plan_w3(int B, int M, int AH, int AW, int Cin, int R, int S, int si, int pad, int IH, int IW, int G = 1) {
     W3Plan p = {};
     p.ok = (R == 3 && S == 3 && si == 1 && pad == 1 && IH == AH && IW == AW && (AW % 4) == 0 && AW >= 16 && Cin >= 32 && M > 64 &&
             !dbg_flag("CC_NO_WGRAD3X3"));   // measured (tools/wgrad_ablate.py): wins for M > 64 (1.2-1.45x), loses below
@@ -1619,7 +1761,7 @@ inline W3Plan plan_w3(int B, int M, int AH, int AW, int Cin, int R, int S, int s
     p.tiles_x = (AW + 31) / 32;
     p.tiles_y = (AH + 1) / 2;
     p.ntiles = B * p.tiles_x * p.tiles_y;
-    const long base = (long)((M + BM - 1) / BM) * (p.Cp32 / BC);
+    const long base = (long)((M + BM - 1) / BM) * (p.Cp32 / BC) * (G > 1 ? G : 1);
     long nsplit = (env_int("CC_W3_SPLIT", 256) + base - 1) / base;
     const long cap = (p.ntiles + 5) / 6;          // >= 6 pixel tiles per split: every split writes a 9*M*Cpad partial slab
     if (nsplit > cap) nsplit = cap;
@@ -1661,67 +1803,88 @@ static size_t wgrad_ws_bytes_base(int B, int M, int AH, int AW, int Cin, int R, 
 
 /* gw[m, c, r, s] (strides o_*) = sum_{n,ty,tx} a[n, m, ty, tx] * x[n, c, si*ty - pad + r, si*tx - pad + s].
  * conv2d weight-gradient: a = dY [B,Cout,OH,OW], x = input, si = stride, o strides of [Cout,Cin,R,S];
- * ConvTranspose2d weight-gradient: a = input [B,Cin,IH,IW], x = dY, si = stride, o strides of [Cin,Cout,R,S]. */
-int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B, int M, int AH, int AW, long a_bs, int Cin,
-                    int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, int accumulate, void* stream) {
-    if (B <= 0 || M <= 0 || Cin <= 0) return CC_ERR_ARG;
+ * ConvTranspose2d weight-gradient: a = input [B,Cin,IH,IW], x = dY, si = stride, o strides of [Cin,Cout,R,S].
+ * Group form: G (<= 4) same-shaped problems in one launch (+ one reduction launch); a / x / gw: HOST arrays of device
+ * addresses; ws: G consecutive areas of cc_conv2d_wgrad_ws_bytes() each. */
+int cc_conv2d_wgrad_group(int G, const long* a, const long* x, const long* gw, float* ws, int B, int M, int AH, int AW, long a_bs,
+                          int Cin, int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, int accumulate,
+                          void* stream) {
+    if (G <= 0 || G > MAXGRP || B <= 0 || M <= 0 || Cin <= 0) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (ccint::wgrad_thin_launch(a, x, gw, ws, B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, accumulate, s)) {
-        CC_CHECK_LAUNCH();
-        return CC_OK;
+    const size_t stride_f = cc_conv2d_wgrad_ws_bytes(B, M, AH, AW, Cin, R, S, si) / sizeof(float);
+    {   // thin layers fill the chip on their own: one launch per problem
+        bool thin = true;
+        for (int k = 0; k < G && thin; k++)
+            thin = ccint::wgrad_thin_launch((const float*)a[k], (const float*)x[k], (float*)gw[k], ws + k * stride_f, B, M, AH, AW, a_bs,
+                                            Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, accumulate, s);
+        // eligibility depends on the geometry (and 16-byte alignment of the pointers): all problems or none, in practice
+        if (thin) {
+            CC_CHECK_LAUNCH();
+            return CC_OK;
+        }
     }
-    const W3Plan q = plan_w3(B, M, AH, AW, Cin, R, S, si, pad, IH, IW);
+    RG rg = {};
+    const W3Plan q = plan_w3(B, M, AH, AW, Cin, R, S, si, pad, IH, IW, G);
     if (q.ok) {
         W3 w = {};
-        w.a = a; w.x = x; w.zeros = ws; w.ws = ws + 64;
+        w.zeros = ws;
+        for (int k = 0; k < G; k++) {
+            w.ga[k] = (const float*)a[k]; w.gxp[k] = (const float*)x[k]; w.gws[k] = ws + k * stride_f + 64;
+            rg.ws[k] = w.gws[k]; rg.gw[k] = (float*)gw[k];
+        }
         w.B = B; w.M = M; w.AH = AH; w.AW = AW; w.a_bs = a_bs; w.Cin = Cin; w.x_bs = x_bs;
         w.tiles_x = q.tiles_x; w.tiles_y = q.tiles_y; w.ntiles = q.ntiles; w.tiles_per_split = q.tps; w.nsplit = q.nsplit;
         w.Cpad = q.Cp32;
         hipLaunchKernelGGL(k_zero64, dim3(1), dim3(64), 0, s, ws);
         const int BM = 32 * q.mt, BC = 32 * (4 / q.mt);
-        dim3 grid((unsigned)(((M + BM - 1) / BM) * (q.Cp32 / BC)), 1, (unsigned)q.nsplit);
+        dim3 grid((unsigned)(((M + BM - 1) / BM) * (q.Cp32 / BC)), (unsigned)G, (unsigned)q.nsplit);
         w.dbg = env_int("CC_W3_DBG", 0);
         if (q.mt == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<4, 1>), grid, dim3(256), q.smem, s, w);
         else if (q.mt == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<2, 2>), grid, dim3(256), q.smem, s, w);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<1, 4>), grid, dim3(256), q.smem, s, w);
         const long tot = (long)9 * M * q.Cp32;
-        hipLaunchKernelGGL(k_wgrad_patch_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const float*)w.ws, gw,
+        hipLaunchKernelGGL(k_wgrad_patch_reduce, dim3((unsigned)((tot + 255) / 256), (unsigned)G), dim3(256), 0, s, rg,
                            q.nsplit, 9, M, Cin, q.Cp32, o_sm, o_sc, accumulate);
         CC_CHECK_LAUNCH();
         return CC_OK;
     }
     const WPlan p = plan_wgrad(B, M, AH, AW, Cin, R, S, si);
-    if (p.ok) {
-        WP w = {};
-        w.a = a; w.x = x; w.zeros = ws; w.ws = ws + 64;
-        w.B = B; w.M = M; w.AH = AH; w.AW = AW; w.a_bs = a_bs; w.Cin = Cin; w.IH = IH; w.IW = IW; w.x_bs = x_bs;
-        w.R = R; w.S = S; w.si = si; w.pad = pad; w.PH = p.PH; w.PWr = p.PWr; w.PSc = p.PSc; w.npos = p.npos;
-        w.tiles_x = p.tiles_x; w.tiles_y = p.tiles_y; w.ntiles = p.ntiles; w.tiles_per_split = p.tps; w.nsplit = p.nsplit;
-        w.TG = p.TG; w.ngroups = p.ngroups; w.Cp32 = p.Cp32; w.nbuf = p.nbuf;
-        { const char* v = getenv("CC_WGRAD_DBG"); w.dbg = v ? atoi(v) : 0; }
-        hipLaunchKernelGGL(k_zero64, dim3(1), dim3(64), 0, s, ws);      // the LDS-DMA halo source (a kernel, not a memset node)
-        dim3 grid((unsigned)(((M + p.bmw - 1) / p.bmw) * (p.Cp32 / 32) * p.ngroups), 1, (unsigned)p.nsplit);
-        if (p.bmw == 64) {
-            if (p.nt == 5) launch_wgrad_patch<64, 5>(w, grid, p.smem, s);
-            else if (p.nt == 4) launch_wgrad_patch<64, 4>(w, grid, p.smem, s);
-            else if (p.nt == 3) launch_wgrad_patch<64, 3>(w, grid, p.smem, s);
-            else if (p.nt == 2) launch_wgrad_patch<64, 2>(w, grid, p.smem, s);
-            else launch_wgrad_patch<64, 1>(w, grid, p.smem, s);
-        } else {
-            if (p.nt >= 3) launch_wgrad_patch<32, 3>(w, grid, p.smem, s);
-            else if (p.nt == 2) launch_wgrad_patch<32, 2>(w, grid, p.smem, s);
-            else launch_wgrad_patch<32, 1>(w, grid, p.smem, s);
+    if (p.ok) {       // experimental per-tap kernel (CC_WGRAD_PATCH=1): one problem at a time
+        for (int k = 0; k < G; k++) {
+            float* wsk = ws + k * stride_f;
+            WP w = {};
+            w.a = (const float*)a[k]; w.x = (const float*)x[k]; w.zeros = wsk; w.ws = wsk + 64;
+            w.B = B; w.M = M; w.AH = AH; w.AW = AW; w.a_bs = a_bs; w.Cin = Cin; w.IH = IH; w.IW = IW; w.x_bs = x_bs;
+            w.R = R; w.S = S; w.si = si; w.pad = pad; w.PH = p.PH; w.PWr = p.PWr; w.PSc = p.PSc; w.npos = p.npos;
+            w.tiles_x = p.tiles_x; w.tiles_y = p.tiles_y; w.ntiles = p.ntiles; w.tiles_per_split = p.tps; w.nsplit = p.nsplit;
+            w.TG = p.TG; w.ngroups = p.ngroups; w.Cp32 = p.Cp32; w.nbuf = p.nbuf;
+            { const char* v = getenv("CC_WGRAD_DBG"); w.dbg = v ? atoi(v) : 0; }
+            hipLaunchKernelGGL(k_zero64, dim3(1), dim3(64), 0, s, wsk);      // the LDS-DMA halo source (a kernel, not a memset node)
+            dim3 grid((unsigned)(((M + p.bmw - 1) / p.bmw) * (p.Cp32 / 32) * p.ngroups), 1, (unsigned)p.nsplit);
+            if (p.bmw == 64) {
+                if (p.nt == 5) launch_wgrad_patch<64, 5>(w, grid, p.smem, s);
+                else if (p.nt == 4) launch_wgrad_patch<64, 4>(w, grid, p.smem, s);
+                else if (p.nt == 3) launch_wgrad_patch<64, 3>(w, grid, p.smem, s);
+                else if (p.nt == 2) launch_wgrad_patch<64, 2>(w, grid, p.smem, s);
+                else launch_wgrad_patch<64, 1>(w, grid, p.smem, s);
+            } else {
+                if (p.nt >= 3) launch_wgrad_patch<32, 3>(w, grid, p.smem, s);
+                else if (p.nt == 2) launch_wgrad_patch<32, 2>(w, grid, p.smem, s);
+                else launch_wgrad_patch<32, 1>(w, grid, p.smem, s);
+            }
+            RG r1 = {};
+            r1.ws[0] = w.ws; r1.gw[0] = (float*)gw[k];
+            const long tot = (long)R * S * M * p.Cp32;
+            hipLaunchKernelGGL(k_wgrad_patch_reduce, dim3((unsigned)((tot + 255) / 256), 1), dim3(256), 0, s, r1,
+                               p.nsplit, R * S, M, Cin, p.Cp32, o_sm, o_sc, accumulate);
         }
-        const long tot = (long)R * S * M * p.Cp32;
-        hipLaunchKernelGGL(k_wgrad_patch_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const float*)w.ws, gw,
-                           p.nsplit, R * S, M, Cin, p.Cp32, o_sm, o_sc, accumulate);
         CC_CHECK_LAUNCH();
         return CC_OK;
     }
     const long Ntot = (long)Cin * R * S;
     const long P = (long)B * AH * AW;
     const int bm = pick_bm(M);
-    const long tiles = ((Ntot + BN - 1) / BN) * ((M + bm - 1) / bm);
+    const long tiles = ((Ntot + BN - 1) / BN) * ((M + bm - 1) / bm) * G;
     long nsplit = (env_int_early("CC_WGRAD_SPLIT_TARGET", 512) + tiles - 1) / tiles;
     const long maxsplit = (P + 63) / 64;      // small maps still need >= 256 workgroups: split down to 64-pixel ranges
     if (nsplit > maxsplit) nsplit = maxsplit;
@@ -1730,25 +1893,37 @@ int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B,
     pps = ((pps + BK - 1) / BK) * BK;
     nsplit = (P + pps - 1) / pps;
     WG g = {};
-    g.a = a; g.x = x; g.B = B; g.M = M; g.AH = AH; g.AW = AW; g.a_bs = a_bs;
+    g.B = B; g.M = M; g.AH = AH; g.AW = AW; g.a_bs = a_bs;
     g.Cin = Cin; g.IH = IH; g.IW = IW; g.x_bs = x_bs;
     g.Rt = R; g.St = S; g.dy0 = -pad; g.dx0 = -pad; g.dstep = 1; g.si = si;
     g.o_sm = o_sm; g.o_sc = o_sc; g.o_ri = S; g.o_sj = 1;
     g.direct = (nsplit == 1);
     g.accum = accumulate;
-    g.out = g.direct ? gw : ws;
+    g.nsplit = (int)nsplit;
+    for (int k = 0; k < G; k++) {
+        g.ga[k] = (const float*)a[k]; g.gxp[k] = (const float*)x[k];
+        g.gout[k] = g.direct ? (float*)gw[k] : ws + k * stride_f;
+        rg.ws[k] = ws + k * stride_f; rg.gw[k] = (float*)gw[k];
+    }
     g.pix_per_split = (int)pps;
-    dim3 grid((unsigned)((Ntot + BN - 1) / BN), (unsigned)((M + bm - 1) / bm), (unsigned)nsplit);
+    dim3 grid((unsigned)((Ntot + BN - 1) / BN), (unsigned)((M + bm - 1) / bm), (unsigned)(nsplit * G));
     if (bm == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<128>), grid, dim3(256), 0, s, g);
     else if (bm == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<64>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<32>), grid, dim3(256), 0, s, g);
     if (!g.direct) {
         const long tot = (long)M * Ntot;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const float*)ws, gw,
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((tot + 255) / 256), (unsigned)G), dim3(256), 0, s, rg,
                            (int)nsplit, M, (int)Ntot, R * S, S, o_sm, o_sc, S, 1, accumulate);
     }
     CC_CHECK_LAUNCH();
     return CC_OK;
+}
+
+int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B, int M, int AH, int AW, long a_bs, int Cin,
+                    int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, int accumulate, void* stream) {
+    const long ap = (long)a, xp = (long)x, gp = (long)gw;
+    return cc_conv2d_wgrad_group(1, &ap, &xp, &gp, ws, B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, accumulate,
+                                 stream);
 }
 
 /* ---- introspection (bench.py groups its per-call timings by the kernel a call dispatches to) */
@@ -1810,38 +1985,59 @@ int cc_conv2d_wgrad_kernel(int B, int M, int AH, int AW, int Cin, int IH, int IW
 
 size_t cc_act_bwd_ws_bytes(int C) { return (size_t)C * 64 * sizeof(float); }
 
-/* geff = gy * act'(y) (geff may alias gy or be null), gbias[c] = sum_{n,p} geff (gbias may be null) */
-int cc_act_bwd_bias(const float* gy, const float* y_or_null, float* geff_or_null, float* gbias_or_null, float* ws, int B,
-                    int C, int H, int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b,
-                    int accumulate_bias, void* stream) {
-    if (B <= 0 || C <= 0) return CC_ERR_ARG;
-    if (act != ACT_NONE && !y_or_null) return CC_ERR_ARG;
+/* geff = gy * act'(y) (geff may alias gy or be null), gbias[c] = sum_{n,p} geff (gbias may be null).
+ * Group form: G (<= 4) same-shaped problems per launch; gy / y / geff / gbias: HOST arrays of device addresses (0 = null,
+ * uniformly over the group); ws: G areas of cc_act_bwd_ws_bytes(C) each. */
+int cc_act_bwd_bias_group(int G, const long* gy, const long* y, const long* geff, const long* gbias, float* ws, int B, int C, int H,
+                          int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b, int accumulate_bias,
+                          void* stream) {
+    if (G <= 0 || G > MAXGRP || B <= 0 || C <= 0) return CC_ERR_ARG;
+    const bool has_y = y && y[0], has_ge = geff && geff[0], has_gb = gbias && gbias[0];
+    if (act != ACT_NONE && !has_y) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int HW = H * W;
     int cpp = (HW + 8191) / 8192;                       // chunks per (image, channel) plane; B * cpp <= 64 partials per channel
     const int cap = 64 / B > 0 ? 64 / B : 1;
     cpp = cpp < 1 ? 1 : (cpp > cap ? cap : cpp);
     if (B > 64) return CC_ERR_ARG;
-    const bool vec4 = (HW % 4 == 0) && (gy_bs % 4 == 0) && (y_bs % 4 == 0) && (geff_bs % 4 == 0) &&
-                      (((uintptr_t)gy | (uintptr_t)y_or_null | (uintptr_t)geff_or_null) % 16 == 0);
+    bool vec4 = (HW % 4 == 0) && (gy_bs % 4 == 0) && (y_bs % 4 == 0) && (geff_bs % 4 == 0);
+    for (int k = 0; k < G; k++)
+        vec4 = vec4 && ((((uintptr_t)gy[k]) | (uintptr_t)(has_y ? y[k] : 0) | (uintptr_t)(has_ge ? geff[k] : 0)) % 16 == 0);
     // small maps with enough channels to occupy the chip: one workgroup per channel, bias gradient written in place
-    const bool single = ((long)B * HW <= 32768) && ((long)C * B * HW <= (1l << 22) || C >= 128);
-    int nb = 1;
-    dim3 grid(cpp, C, B);
-    float* direct = nullptr;
-    if (single) { nb = B; grid = dim3(1, C, 1); direct = gbias_or_null; }
+    const bool single = ((long)B * HW <= 32768) && ((long)C * B * HW * G <= (1l << 22) || (long)C * G >= 128);
+    const int nb = single ? B : 1;
+    const size_t wstride = cc_act_bwd_ws_bytes(C) / sizeof(float);
+    AB t = {};
+    BR r = {};
+    t.zper = single ? 1 : B;
+    for (int k = 0; k < G; k++) {
+        t.gy[k] = (const float*)gy[k];
+        t.y[k] = has_y ? (const float*)y[k] : nullptr;
+        t.geff[k] = has_ge ? (float*)geff[k] : nullptr;
+        t.gbias_direct[k] = (single && has_gb) ? (float*)gbias[k] : nullptr;
+        t.partial[k] = (has_gb && !single) ? ws + k * wstride : nullptr;
+        r.partial[k] = t.partial[k];
+        r.gbias[k] = has_gb ? (float*)gbias[k] : nullptr;
+    }
+    dim3 grid(single ? 1 : cpp, C, (single ? 1 : B) * G);
     const int nchunk = single ? 1 : cpp * B;
-    float* part = (gbias_or_null && !single) ? ws : (float*)nullptr;
     if (vec4)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_act_bwd<true>), grid, dim3(256), 0, s, gy, y_or_null, geff_or_null, part, HW,
-                           gy_bs, y_bs, geff_bs, act, act_a, act_b, nb, direct, accumulate_bias);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_act_bwd<true>), grid, dim3(256), 0, s, t, HW, gy_bs, y_bs, geff_bs, act, act_a, act_b,
+                           nb, accumulate_bias);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_act_bwd<false>), grid, dim3(256), 0, s, gy, y_or_null, geff_or_null, part, HW,
-                           gy_bs, y_bs, geff_bs, act, act_a, act_b, nb, direct, accumulate_bias);
-    if (gbias_or_null && !single)
-        hipLaunchKernelGGL(k_bias_reduce, dim3(C), dim3(64), 0, s, (const float*)ws, gbias_or_null, nchunk, accumulate_bias);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_act_bwd<false>), grid, dim3(256), 0, s, t, HW, gy_bs, y_bs, geff_bs, act, act_a, act_b,
+                           nb, accumulate_bias);
+    if (has_gb && !single)
+        hipLaunchKernelGGL(k_bias_reduce, dim3(C, G), dim3(64), 0, s, r, nchunk, accumulate_bias);
     CC_CHECK_LAUNCH();
     return CC_OK;
+}
+
+int cc_act_bwd_bias(const float* gy, const float* y_or_null, float* geff_or_null, float* gbias_or_null, float* ws, int B,
+                    int C, int H, int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b,
+                    int accumulate_bias, void* stream) {
+    const long a = (long)gy, b = (long)y_or_null, c = (long)geff_or_null, d = (long)gbias_or_null;
+    return cc_act_bwd_bias_group(1, &a, &b, &c, &d, ws, B, C, H, W, gy_bs, y_bs, geff_bs, act, act_a, act_b, accumulate_bias, stream);
 }
 
 }  // extern "C"

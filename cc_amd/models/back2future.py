@@ -77,13 +77,37 @@ class Model(nn.Module):
         """back2future.py:287-321."""
         return feature_warp(x, flo)
 
+    def _decoders(self, decs, ins):
+        """The 6-layer decoder stacks of one pyramid level (decoder_fwd / decoder_bwd [/ decoder_occ]) layer by layer as
+        grouped launches: same-shaped layers of the parallel stacks share one kernel launch per pass; LeakyReLU backward of
+        layers 0-4 is applied by the next layer's data-gradient epilogue (ops.conv2d_group defer / pre_act)."""
+        xs = list(ins)
+        for i in range(6):
+            convs = [d[2 * i] for d in decs]
+            act = "lrelu" if i < 5 else None
+            kw = dict(defer=i < 5, pre_act="lrelu" if i > 0 else None)
+            # the first layer of decoder_occ6 has its own input width (354 vs 162 channels): group by shape
+            shapes = sorted({tuple(c.weight.shape) for c in convs})
+            ys = [None] * len(decs)
+            for shp in shapes:
+                idx = [k for k, c in enumerate(convs) if tuple(c.weight.shape) == shp]
+                out = ops.conv2d_group([xs[k] for k in idx], [convs[k].weight for k in idx], [convs[k].bias for k in idx],
+                                       1, 1, act, **kw)
+                for k, y in zip(idx, out):
+                    ys[k] = y
+            xs = ys
+        return xs
+
     def forward(self, im_tar, im_refs):
         n = self.normalize([im_tar] + list(im_refs))
         feats = {}
-        for s, im in (("a", n[0]), ("b", n[2]), ("c", n[1])):      # b = I+, c = I-  (back2future.py:159,166)
-            x = im
-            for lvl in range(1, 7):
-                x = getattr(self, "conv%d%s" % (lvl, s))(x)
+        xs = [n[0], n[2], n[1]]                                    # a = target, b = I+, c = I-  (back2future.py:159,166)
+        for lvl in range(1, 7):
+            blocks = [getattr(self, "conv%d%s" % (lvl, s)) for s in "abc"]
+            ys = ops.conv2d_group(xs, [b[0].weight for b in blocks], [b[0].bias for b in blocks], 2, 1, "lrelu", defer=True)
+            xs = ops.conv2d_group(ys, [b[2].weight for b in blocks], [b[2].bias for b in blocks], 1, 1, "lrelu",
+                                  pre_act="lrelu")
+            for s, x in zip("abc", xs):
                 feats[(lvl, s)] = x
         flow_f, flow_b, up_f, up_b, occ = {}, {}, {}, {}, {}
         bw, cw = feats[(6, "b")], feats[(6, "c")]
@@ -98,12 +122,17 @@ class Model(nn.Module):
                 in_f = torch.cat((corr, a, up_f[lvl + 1]), 1)
                 in_b = torch.cat((corr, a, up_b[lvl + 1]), 1)
                 in_o = in_f
-            flow_f[lvl] = getattr(self, "decoder_fwd%d" % lvl)(in_f)
+            decs = [getattr(self, "decoder_fwd%d" % lvl), getattr(self, "decoder_bwd%d" % lvl)]
+            ins = [in_f, in_b]
+            if not self.elide_occ:
+                decs.append(getattr(self, "decoder_occ%d" % lvl))
+                ins.append(in_o)
+            outs = self._decoders(decs, ins)
+            flow_f[lvl], flow_b[lvl] = outs[0], outs[1]
             up_f[lvl] = up(flow_f[lvl])
-            flow_b[lvl] = getattr(self, "decoder_bwd%d" % lvl)(in_b)
             up_b[lvl] = up(flow_b[lvl])
             if not self.elide_occ:
-                occ[lvl] = torch.softmax(getattr(self, "decoder_occ%d" % lvl)(in_o), dim=1)
+                occ[lvl] = torch.softmax(outs[2], dim=1)
             if lvl > 2:
                 s = self.WARP_SCALE[lvl]
                 bw = self.warp(feats[(lvl - 1, "b")], s * up_f[lvl])

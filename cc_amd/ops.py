@@ -172,6 +172,144 @@ class _Conv2dFn(torch.autograd.Function):
         return gx, gw, gbias, gres, None, None, None, None, None
 
 
+# ----------------------------------------------------------------------------- grouped convolution (parallel branches)
+def _parr(ts):
+    """HOST array of device addresses (0 = null) for the *_group entry points; keep the returned object alive over the call."""
+    import ctypes
+    return (ctypes.c_long * len(ts))(*[(t.data_ptr() if t is not None else 0) for t in ts])
+
+
+def _addr(arr):
+    import ctypes
+    return ctypes.addressof(arr)
+
+
+class _ConvGroupFn(torch.autograd.Function):
+    """G same-shaped convolutions (with their own inputs, weights, biases) as ONE launch per pass (cc_conv2d_*_group).
+
+    meta = (G, stride, pad, act, act_a, act_b, has_bias, pre_act, pre_b, defer)
+      defer   : this layer's outputs feed ONLY convolutions called with pre_act = this activation; those multiply act'(y)
+                into their data-gradient epilogue, so the gradient arriving here is already w.r.t. the pre-activation
+                (no separate activation-backward pass over gy and y);
+      pre_act : activation (code, slope pre_b) of the deferring layer that produced xs.
+    tensors = xs + weights (+ biases)."""
+
+    @staticmethod
+    def forward(ctx, meta, *tensors):
+        G, stride, pad, act, act_a, act_b, has_bias, pre_act, pre_b, defer = meta
+        xs = [_c(t) for t in tensors[:G]]
+        ws = [_c(t) for t in tensors[G:2 * G]]
+        bs = [_c(t) for t in tensors[2 * G:3 * G]] if has_bias else [None] * G
+        B, Cin, IH, IW = xs[0].shape
+        Cout, _, R, S = ws[0].shape
+        OH = (IH + 2 * pad - R) // stride + 1
+        OW = (IW + 2 * pad - S) // stride + 1
+        E = engine()
+        ys = [torch.empty(B, Cout, OH, OW, device=xs[0].device, dtype=torch.float32) for _ in range(G)]
+        geom = (B, Cin, IH, IW, Cout, R, S, stride, pad, OH, OW)
+        wsb = _ws(E.call("cc_conv2d_fwd_group_ws_bytes", G, *geom), xs[0])
+        pks = [packs.get("fwd", w, geom) for w in ws]
+        ax, aw, ab, ay, ap = _parr(xs), _parr(ws), _parr(bs), _parr(ys), _parr(pks)
+        E.call("cc_conv2d_fwd_group", G, _addr(ax), _addr(aw), _addr(ab), 0, _addr(ay), wsb, _addr(ap), B, Cin, IH, IW,
+               Cin * IH * IW, Cout, R, S, stride, pad, OH, OW, Cout * OH * OW, 0, act, act_a, act_b, STREAM)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(*xs, *ws, *([y for y in ys] if (act != 0 and not defer) else []))
+        ctx.meta = meta
+        ctx.bias_ptrs = [b.data_ptr() if b is not None else 0 for b in bs]
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        G, stride, pad, act, act_a, act_b, has_bias, pre_act, pre_b, defer = ctx.meta
+        saved = ctx.saved_tensors
+        xs, ws = saved[:G], saved[G:2 * G]
+        ys = saved[2 * G:] if len(saved) > 2 * G else [None] * G
+        need = ctx.needs_input_grad
+        E = engine()
+        B, Cin, IH, IW = xs[0].shape
+        Cout, _, R, S = ws[0].shape
+        live = [k for k in range(G) if gys[k] is not None]          # branches nobody differentiates (occlusion decoders) drop out
+        gx_out, gw_out, gb_out = [None] * G, [None] * G, [None] * G
+        if not live:
+            return (None,) + tuple(gx_out + gw_out + (gb_out if has_bias else []))
+        gy = {k: _c(gys[k]) for k in live}
+        OH, OW = gy[live[0]].shape[2], gy[live[0]].shape[3]
+        n = len(live)
+        dev = xs[0].device
+        # ---- activation backward (unless deferred to the consumers' data-gradient epilogues) + bias gradients
+        want_b = [k for k in live if has_bias and need[1 + 2 * G + k]]
+        bsinks = {k: (grad_sinks.get(ctx.bias_ptrs[k]) if grad_sinks else None) for k in want_b}
+        all_sink = bool(want_b) and all(v is not None for v in bsinks.values())
+        do_act = act != 0 and not defer
+        if do_act or want_b:
+            idx = live if do_act else want_b
+            geff = {k: torch.empty_like(gy[k]) for k in idx} if do_act else {}
+            gb = {}
+            for k in idx:
+                if k in want_b:
+                    gb[k] = bsinks[k] if all_sink else torch.empty(Cout, device=dev, dtype=torch.float32)
+            # bias gradients are wanted for all of idx or for none of it (one network: all parameters trainable or all frozen)
+            with_b = len(gb) == len(idx)
+            for c0 in range(0, len(idx), 4):
+                ch = idx[c0:c0 + 4]
+                a1 = _parr([gy[k] for k in ch])
+                a2 = _parr([ys[k] if do_act else None for k in ch])
+                a3 = _parr([geff.get(k) for k in ch])
+                a4 = _parr([gb.get(k) if with_b else None for k in ch])
+                wsb = _ws(E.call("cc_act_bwd_ws_bytes", Cout) * len(ch), xs[0])
+                E.call("cc_act_bwd_bias_group", len(ch), _addr(a1), _addr(a2) if do_act else 0, _addr(a3) if do_act else 0,
+                       _addr(a4) if with_b else 0, wsb, B, Cout, OH, OW, Cout * OH * OW, Cout * OH * OW, Cout * OH * OW,
+                       act if do_act else 0, act_a, act_b, int(all_sink), STREAM)
+            if not with_b and gb:          # mixed case: the remaining bias gradients one by one
+                for k in gb:
+                    E.call("cc_act_bwd_bias", geff.get(k, gy[k]), None, None, gb[k], _ws(E.call("cc_act_bwd_ws_bytes", Cout), xs[0]),
+                           B, Cout, OH, OW, Cout * OH * OW, 0, 0, 0, 1.0, 0.0, int(all_sink), STREAM)
+            if do_act:
+                gy = geff
+            if not all_sink:
+                for k in gb:
+                    gb_out[k] = gb[k]
+        # ---- data gradients
+        dx = [k for k in live if need[1 + k]]
+        if dx:
+            geom = (B, Cout, OH, OW, Cin, R, S, stride, pad, IH, IW)
+            for k in dx:
+                gx_out[k] = torch.empty_like(xs[k])
+            wsb = _ws(E.call("cc_conv2d_dgrad_group_ws_bytes", len(dx), *geom), xs[0])
+            pks = [packs.get("dgrad", ws[k], geom + (Cin * R * S, R * S)) for k in dx]
+            a1, a2, a3 = _parr([gy[k] for k in dx]), _parr([ws[k] for k in dx]), _parr([gx_out[k] for k in dx])
+            a4, a5 = _parr([xs[k] if pre_act else None for k in dx]), _parr(pks)
+            E.call("cc_conv2d_dgrad_group", len(dx), _addr(a1), _addr(a2), 0, _addr(a3), _addr(a4) if pre_act else 0, wsb, _addr(a5),
+                   B, Cout, OH, OW, Cout * OH * OW, Cin, R, S, stride, pad, IH, IW, Cin * IH * IW, Cin * IH * IW, Cin * R * S, R * S,
+                   pre_act, 1.0, pre_b, STREAM)
+        # ---- weight gradients
+        dw = [k for k in live if need[1 + G + k]]
+        if dw:
+            wsinks = {k: _sink(ws[k]) for k in dw}
+            all_wsink = all(v is not None for v in wsinks.values())
+            gw = {k: (wsinks[k] if all_wsink else torch.empty_like(ws[k])) for k in dw}
+            per = E.call("cc_conv2d_wgrad_ws_bytes", B, Cout, OH, OW, Cin, R, S, stride)
+            for c0 in range(0, len(dw), 4):
+                ch = dw[c0:c0 + 4]
+                a1, a2, a3 = _parr([gy[k] for k in ch]), _parr([xs[k] for k in ch]), _parr([gw[k] for k in ch])
+                E.call("cc_conv2d_wgrad_group", len(ch), _addr(a1), _addr(a2), _addr(a3), _ws(per * len(ch), xs[0]), B, Cout, OH, OW,
+                       Cout * OH * OW, Cin, IH, IW, Cin * IH * IW, R, S, stride, pad, Cin * R * S, R * S, int(all_wsink), STREAM)
+            if not all_wsink:
+                for k in dw:
+                    gw_out[k] = gw[k]
+        return (None,) + tuple(gx_out + gw_out + (gb_out if has_bias else []))
+
+
+def conv2d_group(xs, weights, biases=None, stride=1, padding=0, act=None, slope=0.0, pre_act=None, pre_slope=0.0, defer=False):
+    """[act(conv2d(x_k, w_k, b_k)) for k] for same-shaped problems, one launch per pass.  act='lrelu': slope (0 -> 0.2).
+    See _ConvGroupFn for pre_act / defer (activation backward fused into the consumer's data-gradient epilogue)."""
+    G = len(xs)
+    has_bias = biases is not None and biases[0] is not None
+    meta = (G, int(stride), int(padding), ACT[act], 1.0, float(slope), has_bias, ACT[pre_act], float(pre_slope), bool(defer))
+    out = _ConvGroupFn.apply(meta, *xs, *weights, *(biases if has_bias else ()))
+    return list(out)
+
+
 def conv2d(x, w, bias=None, stride=1, padding=0, act=None, residual=None, act_a=1.0, act_b=0.0):
     """act(conv2d(x, w, bias) + residual): nn.Conv2d (+ fused ReLU / LeakyReLU / a*sigmoid+b epilogue).
     act='lrelu': act_b is the negative slope (0 -> the 0.2 of Back2Future)."""

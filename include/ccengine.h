@@ -209,6 +209,31 @@ size_t cc_conv2d_wgrad_ws_bytes(int B, int M, int AH, int AW, int Cin, int R, in
 int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B, int M, int AH, int AW, long a_bs, int Cin,
                     int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, int accumulate,
                     void* stream);
+/* ---- group forms: G same-shaped problems in ONE launch -- the parallel branches of a network that the reference runs as
+ * separate nn.Sequential stacks (models/back2future.py:152-171,186-204: decoder_fwd / decoder_bwd / decoder_occ of a pyramid
+ * level; :27-33,159-169: the conv{l}a / conv{l}b / conv{l}c feature streams).  x / w / bias / res / y / gy / gx / mul / a / gw /
+ * prepacked are HOST arrays of G device addresses (0 = null, uniformly over the group; array pointer null = all null); ws is
+ * G consecutive areas of (*_group_ws_bytes / G) resp. the single-problem *_ws_bytes each.  G <= 12 (fwd, dgrad: G * stride^2
+ * <= 12 for the merged launch) resp. G <= 4 (wgrad, act_bwd); without prepacked weight images the problems run one by one.
+ * cc_conv2d_dgrad_group additionally takes `mul`: tensors of gx's shape; gx = act'(mul) * sum, i.e. the gradient w.r.t. the
+ * PRE-activation of the layer whose output `mul` is (act / act_a / act_b describe that activation): the producer's separate
+ * activation-backward pass over (gy, y) -> geff disappears. */
+size_t cc_conv2d_fwd_group_ws_bytes(int G, int B, int Cin, int IH, int IW, int Cout, int R, int S, int stride, int pad, int OH,
+                                    int OW);
+int cc_conv2d_fwd_group(int G, const long* x, const long* w, const long* bias, const long* res, const long* y, float* ws,
+                        const long* prepacked, int B, int Cin, int IH, int IW, long x_bs, int Cout, int R, int S, int stride,
+                        int pad, int OH, int OW, long y_bs, long res_bs, int act, float act_a, float act_b, void* stream);
+size_t cc_conv2d_dgrad_group_ws_bytes(int G, int B, int K, int OH, int OW, int C, int R, int S, int stride, int pad, int IH, int IW);
+int cc_conv2d_dgrad_group(int G, const long* gy, const long* w, const long* bias, const long* gx, const long* mul, float* ws,
+                          const long* prepacked, int B, int K, int OH, int OW, long gy_bs, int C, int R, int S, int stride,
+                          int pad, int IH, int IW, long gx_bs, long mul_bs, long w_k_stride, long w_c_stride, int act, float act_a,
+                          float act_b, void* stream);
+int cc_conv2d_wgrad_group(int G, const long* a, const long* x, const long* gw, float* ws, int B, int M, int AH, int AW, long a_bs,
+                          int Cin, int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, int accumulate,
+                          void* stream);
+int cc_act_bwd_bias_group(int G, const long* gy, const long* y, const long* geff, const long* gbias, float* ws, int B, int C, int H,
+                          int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b, int accumulate_bias,
+                          void* stream);
 /* introspection: the name of the device kernel the corresponding entry point dispatches to for this geometry (as it
  * appears in a rocprofv3 kernel trace; "+splitk" = followed by the split-K epilogue).  name_out_host: HOST char buffer. */
 int cc_conv2d_fwd_kernel(int B, int Cin, int IH, int IW, int Cout, int R, int S, int stride, int pad, int OH, int OW,

@@ -439,6 +439,70 @@ def check_convs(dev, cases=CONV_CASES, tcases=CONVT_CASES, tol=2e-5, seed=0, pre
     ops.packs.reset()
 
 
+def check_conv_groups(dev, tol=2e-5, prepack=True, cases=((2, 6, 9, 14, 20, 12, 1), (1, 3, 12, 20, 16, 24, 2), (2, 40, 5, 8, 136, 16, 1), (1, 32, 4, 16, 72, 8, 1))):
+    """Grouped convolution chains (cc_conv2d_*_group: the parallel decoder / feature branches of Back2Future as one launch
+    per pass) vs per-branch torch convs: conv(stride s, LeakyReLU, deferred activation backward) -> conv(LeakyReLU) -> conv,
+    G = 3 branches with their own inputs and parameters, one branch's output left out of the loss (no gradient: it must drop
+    out of the backward launches), all input / weight / bias gradients."""
+    import torch.nn.functional as F
+    from cc_amd import ops
+    g = torch.Generator().manual_seed(21)
+    G = 3
+
+    def rn(*s):
+        return torch.randn(*s, generator=g)
+    for (B, Cin, H, W, C1, C2, st) in cases:
+        x0 = [rn(B, Cin, H, W) for _ in range(G)]
+        w1 = [rn(C1, Cin, 3, 3) * 0.2 for _ in range(G)]
+        b1 = [rn(C1) * 0.3 for _ in range(G)]
+        w2 = [rn(C2, C1, 3, 3) * 0.1 for _ in range(G)]
+        b2 = [rn(C2) * 0.3 for _ in range(G)]
+        w3 = [rn(2, C2, 3, 3) * 0.1 for _ in range(G)]
+        b3 = [rn(2) for _ in range(G)]
+        flat = x0 + w1 + b1 + w2 + b2 + w3 + b3
+        td = [leaf(t, dev) for t in flat]
+        tc = [leaf(t, "cpu") for t in flat]
+
+        def split(ts):
+            return [ts[i * G:(i + 1) * G] for i in range(7)]
+        # reference
+        xc, w1c, b1c, w2c, b2c, w3c, b3c = split(tc)
+        outs_c = []
+        for k in range(G):
+            y = F.leaky_relu(F.conv2d(xc[k], w1c[k], b1c[k], st, 1), 0.2)
+            y = F.leaky_relu(F.conv2d(y, w2c[k], b2c[k], 1, 1), 0.2)
+            outs_c.append(F.conv2d(y, w3c[k], b3c[k], 1, 1))
+        go = [rn(*o.shape) for o in outs_c]
+        used = [0, 2]                                     # branch 1 gets no gradient
+        loss_c = sum((outs_c[k] * go[k]).sum() for k in used)
+        wrt_c = [t for i, t in enumerate(tc) if (i % G) in used]
+        g0 = torch.autograd.grad(loss_c, wrt_c)
+        for ps in range(2 if prepack else 1):
+            ops.packs.reset()
+            if ps == 1:
+                ops.packs.prepack_all()                   # opens registration; second prepack below builds the images
+            xd, w1d, b1d, w2d, b2d, w3d, b3d = split(td)
+
+            def run():
+                y = ops.conv2d_group(xd, w1d, b1d, st, 1, "lrelu", defer=True)
+                y = ops.conv2d_group(y, w2d, b2d, 1, 1, "lrelu", pre_act="lrelu", defer=True)
+                return ops.conv2d_group(y, w3d, b3d, 1, 1, None, pre_act="lrelu")
+            if ps == 1:
+                with torch.no_grad():
+                    run()                                 # registers the layers
+                ops.packs.prepack_all()
+            outs_d = run()
+            for k in range(G):
+                assert rel(outs_d[k], outs_c[k]) < tol, ("group fwd", (B, Cin, H, W, C1, C2, st), ps, k, rel(outs_d[k], outs_c[k]))
+            loss_d = sum((outs_d[k] * go[k].to(dev)).sum() for k in used)
+            wrt_d = [t for i, t in enumerate(td) if (i % G) in used]
+            g1 = torch.autograd.grad(loss_d, wrt_d)
+            errs = [rel(a, b) for a, b in zip(g1, g0)]
+            assert max(errs) < tol, ("group grads", (B, Cin, H, W, C1, C2, st), ps, errs)
+            ops.packs.invalidate()
+    ops.packs.reset()
+
+
 def check_corr(dev, cases=((2, 8, 6, 12), (1, 5, 7, 13), (2, 12, 5, 8), (1, 33, 9, 20))):
     """9x9 cost volume (Back2Future): plain `correlate` and the fused pair with the idx_fwd / idx_bwd channel
     permutations, forward and all gradients, vs the oracle; W % 4 == 0 runs the register-blocked kernels, other widths

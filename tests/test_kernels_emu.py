@@ -70,3 +70,7 @@ def test_batch_norm():
 
 def test_upsample2x():
     parity.check_upsample2x("cpu")
+
+
+def test_conv_groups():
+    parity.check_conv_groups("cpu")

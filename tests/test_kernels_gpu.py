@@ -90,3 +90,8 @@ def test_batch_norm():
 def test_upsample2x():
     parity.check_upsample2x("cuda")
     parity.check_upsample2x("cuda", cases=((4, 2, 64, 208, 20.0), (4, 1, 128, 416, 1.0)))
+
+
+def test_conv_groups():
+    parity.check_conv_groups("cuda")
+    parity.check_conv_groups("cuda", cases=((4, 196, 16, 52, 128, 96, 1), (4, 64, 32, 104, 96, 32, 2)))

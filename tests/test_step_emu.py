@@ -33,9 +33,11 @@ def test_full_cc_step_matches_oracle():
         want = S.cc_step(onets, oopt, batch, ocfg)
         for k, v in want.items():
             assert abs(float(got[k]) - v) <= 1e-4 * abs(v), (k, float(got[k]), v)
-        got2 = tr.step(batch)                                   # after one fused-Adam update
-        want2 = S.cc_step(onets, oopt, batch, ocfg)
-        assert abs(float(got2["loss"]) - want2["loss"]) <= 1e-4 * abs(want2["loss"])
+        # the fused-Adam update against torch.optim.Adam's on the oracle nets (first step: |update| = lr for every
+        # parameter whose gradient is not ~0, where the sign of a 1e-12 gradient decides) -- parameter order is the same
+        po = torch.cat([p.detach().reshape(-1) for n in onets for p in n.parameters()])
+        d = (tr.opt.flat_p[:po.numel()] - po).abs()
+        assert float((d > 1e-6).float().mean()) < 1e-3 and float(d.max()) <= 2.001e-4, (float((d > 1e-6).float().mean()), float(d.max()))
 
 
 def test_flat_adam_matches_torch_adam():
