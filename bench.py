@@ -51,7 +51,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU steps after one warm-up (median is reported)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every host thread (os.cpu_count())")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="0 = min(usable threads (affinity / cgroup quota), 64): with all 256 hardware threads of the GPU box the "
+                         "first oracle step did not finish in 13 min (round 2), with 64 threads a step takes ~8 s")
+    ap.add_argument("--cpu-timeout", type=float, default=240.0, help="wall-clock bound of the CPU baseline leg (seconds)")
+    ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -85,6 +89,10 @@ WORK = {   # entry point -> (kind, fn(args dict) -> algorithmic flops or bytes)
     "cc_conv2d_fwd": ("flop", lambda d: 2.0 * d["B"] * d["OH"] * d["OW"] * d["Cout"] * d["Cin"] * d["R"] * d["S"]),
     "cc_conv2d_dgrad": ("flop", lambda d: 2.0 * d["B"] * d["OH"] * d["OW"] * d["K"] * d["C"] * d["R"] * d["S"]),
     "cc_conv2d_wgrad": ("flop", lambda d: 2.0 * d["B"] * d["AH"] * d["AW"] * d["M"] * d["Cin"] * d["R"] * d["S"]),
+    # group forms: G same-shaped problems per launch
+    "cc_conv2d_fwd_group": ("flop", lambda d: 2.0 * d["G"] * d["B"] * d["OH"] * d["OW"] * d["Cout"] * d["Cin"] * d["R"] * d["S"]),
+    "cc_conv2d_dgrad_group": ("flop", lambda d: 2.0 * d["G"] * d["B"] * d["OH"] * d["OW"] * d["K"] * d["C"] * d["R"] * d["S"]),
+    "cc_conv2d_wgrad_group": ("flop", lambda d: 2.0 * d["G"] * d["B"] * d["AH"] * d["AW"] * d["M"] * d["Cin"] * d["R"] * d["S"]),
     # algorithmic bytes per pixel (SURVEY.md 8d conventions: each distinct tensor argument once, fp32)
     "cc_inverse_warp_fwd": ("byte", lambda d: 28.0 * d["B"] * d["H"] * d["W"]),
     "cc_inverse_warp_bwd": ("byte", lambda d: 32.0 * d["B"] * d["H"] * d["W"]),
@@ -105,6 +113,14 @@ def kernel_of(eng, name, d):
     import ctypes
     buf = ctypes.create_string_buffer(96)
     a = ctypes.addressof(buf)
+    if name.endswith("_group"):
+        base = kernel_of(eng, name[:-6], dict(d, prepacked_or_null=d.get("prepacked")))
+        if not base or d["G"] == 1:
+            return base
+        if name == "cc_conv2d_wgrad_group":
+            return base + " xG"
+        # merged launch of the G problems (x their parity classes) on the multi-problem kernel
+        return base.replace("k_conv_patch<", "k_conv_patch_multi<").replace(", 1>+", ">+").replace(", 0>", ">") + " xG"
     if name == "cc_conv2d_fwd":
         eng.fn["cc_conv2d_fwd_kernel"](d["B"], d["Cin"], d["IH"], d["IW"], d["Cout"], d["R"], d["S"], d["stride"], d["pad"],
                                        d["OH"], d["OW"], a, 96)
@@ -121,6 +137,8 @@ def kernel_of(eng, name, d):
 
 def algorithmic_bytes(name, d):
     """fp32 bytes of each distinct tensor argument once (input, weights, output) for one conv call."""
+    if name.endswith("_group"):
+        return d["G"] * algorithmic_bytes(name[:-6], d)
     if name == "cc_conv2d_fwd":
         return 4.0 * (d["B"] * d["Cin"] * d["IH"] * d["IW"] + d["Cout"] * d["Cin"] * d["R"] * d["S"] + d["B"] * d["Cout"] * d["OH"] * d["OW"])
     if name == "cc_conv2d_dgrad":
@@ -218,12 +236,36 @@ def pmc_traffic(kernel):
         if int(t.get("cc_version", -1)) != have:
             return None, "profiles/pmc_traffic.json is stale (kernels %s, library %s): rerun tools/gpu_pmc2.sh" % (
                 t.get("cc_version"), have)
-        ent = t["kernels"].get(kernel.split("+")[0])
+        ent = t["kernels"].get(kernel.replace(" xG", "").split("+")[0])
         if ent:
             return round(ent["hbm_bytes_per_launch"]), "profiles/pmc_traffic.json (%s)" % t.get("command", "")
     except (OSError, ValueError, KeyError):
         pass
     return None, None
+
+
+def usable_cpus():
+    """Threads this process may actually run on: scheduler affinity, capped by a cgroup CPU quota when there is one
+    (os.cpu_count() reports the whole machine inside a container; a thread pool sized by it spin-waits itself to a halt)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(float(parts[0]) / float(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, q // int(g.read().split()[0])))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
 
 
 def cpu_model():
@@ -242,7 +284,7 @@ def cpu_baseline(batch_cpu, init_sd, args):
     cores -- reported beside the metric, never the target.  It starts from the SAME initial weights as the GPU run, so its
     first two steps double as the bench-time parity gate.  -> (baseline dict, [losses per step])"""
     from oracle import step as S
-    n = args.cpu_threads if args.cpu_threads > 0 else (os.cpu_count() or 1)
+    n = args.cpu_threads if args.cpu_threads > 0 else min(usable_cpus(), 64)
     torch.set_num_threads(n)
     nets = S.build_nets("oracle", flow=(args.config == "c3"), mask=(args.config == "c3"))
     for m, sd in zip(nets, init_sd):
@@ -264,7 +306,7 @@ def cpu_baseline(batch_cpu, init_sd, args):
     timed = sorted(times[1:])
     dt = timed[len(timed) // 2] if timed else times[0]
     return {"value": round(batch_cpu[0].shape[0] / dt, 4), "unit": "images/s", "cores": n, "kind": "port",
-            "cpu": cpu_model(),
+            "cpu": cpu_model(), "host_threads": os.cpu_count(), "usable_threads": usable_cpus(),
             "sample": "median of %d full CC steps (fwd+bwd+Adam) after 1 warm-up, B=%d %dx%d, oracle/step.py (the CPU port "
                       "of train.py:445-568, pinned to the reference by tests/golden), torch %s, %d threads"
                       % (len(timed), batch_cpu[0].shape[0], batch_cpu[0].shape[3], batch_cpu[0].shape[2],
@@ -272,8 +314,38 @@ def cpu_baseline(batch_cpu, init_sd, args):
             "s_per_step": round(dt, 3), "s_per_step_all": [round(t, 3) for t in times]}, losses
 
 
+def cpu_baseline_bounded(batch_cpu, init_sd, args):
+    """Run cpu_baseline() in a child process with a wall-clock bound, so that a slow host can never eat the bench line.
+    -> (baseline dict or {'value': None, 'note': ...}, [losses per step])"""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        inp, outp = os.path.join(td, "in.pt"), os.path.join(td, "out.json")
+        torch.save({"batch": batch_cpu, "init_sd": init_sd}, inp)
+        cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--cpu-baseline-child", inp + "," + outp]
+        env = dict(os.environ)
+        env["HIP_VISIBLE_DEVICES"] = ""            # the child is a pure CPU process
+        try:
+            subprocess.run(cmd, env=env, timeout=args.cpu_timeout, check=True, stdout=sys.stderr)
+            with open(outp) as f:
+                r = json.load(f)
+            return r["baseline"], r["losses"]
+        except subprocess.TimeoutExpired:
+            return {"value": None, "unit": "images/s", "kind": "port", "cpu": cpu_model(), "host_threads": os.cpu_count(),
+                    "note": "CPU baseline leg exceeded --cpu-timeout %.0f s" % args.cpu_timeout}, []
+        except (subprocess.CalledProcessError, OSError, ValueError) as e:
+            return {"value": None, "unit": "images/s", "kind": "port", "note": "CPU baseline leg failed: %r" % (e,)}, []
+
+
 def main():
     args = parse()
+    if args.cpu_baseline_child:
+        inp, outp = args.cpu_baseline_child.split(",")
+        d = torch.load(inp)
+        base, losses = cpu_baseline(d["batch"], d["init_sd"], args)
+        with open(outp, "w") as f:
+            json.dump({"baseline": base, "losses": losses}, f)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -386,7 +458,7 @@ def main():
             "roofline": roof, "kernels": kernels,
         }
         if want_cpu:
-            base, cpu_losses = cpu_baseline(batch_cpu, init_sd, args)
+            base, cpu_losses = cpu_baseline_bounded(batch_cpu, init_sd, args)
             line["cpu_baseline"] = base
             # bench-time parity gate: the engine's first steps against the oracle's on identical weights and data
             par = {"tolerance": 1e-4, "steps_compared": min(len(first_losses), len(cpu_losses))}
@@ -395,8 +467,8 @@ def main():
                 rels = {k: abs(g_[k] - c_[k]) / max(abs(c_[k]), 1e-12) for k in c_ if k in g_}
                 par["step%d" % i] = {k: float("%.3e" % v) for k, v in sorted(rels.items())}
                 worst = max([worst] + list(rels.values()))
-            par["loss_rel"] = float("%.3e" % worst)
-            par["ok"] = bool(worst <= 1e-4)
+            par["loss_rel"] = float("%.3e" % worst) if par["steps_compared"] else None
+            par["ok"] = bool(worst <= 1e-4) if par["steps_compared"] else None
             line["parity"] = par
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -4,7 +4,7 @@ import torch.nn as nn
 
 from .. import nn as L
 from .. import ops
-from ._blocks import xavier_zero_bias, crop_like, make_layer
+from ._blocks import xavier_zero_bias, crop_like, make_layer, conv_call
 
 _ENC = [32, 64, 128, 256, 512, 512, 512]
 _DEC = [512, 512, 256, 128, 64, 32, 16]
@@ -39,8 +39,8 @@ class DispResNet6(nn.Module):
         return ops.conv2d(feat, head.weight, head.bias, 1, 1, "sigmoid", None, float(self.alpha), float(self.beta))
 
     def forward(self, x):
-        c = [x]
-        for i in range(1, 8):
+        c = [x, conv_call(self.conv1[2], conv_call(self.conv1[0], x, defer=True), pre_act="relu")]
+        for i in range(2, 8):
             c.append(getattr(self, "conv%d" % i)(c[-1]))
         out, disps, prev = c[7], {}, None
         for lvl in range(7, 0, -1):

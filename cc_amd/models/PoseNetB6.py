@@ -3,7 +3,7 @@ import torch
 import torch.nn as nn
 
 from .. import nn as L
-from ._blocks import xavier_zero_bias, seq_conv_act
+from ._blocks import xavier_zero_bias, seq_conv_act, conv_call
 
 PLANES = [16, 32, 64, 128, 256, 256, 256, 256]
 KS = [7, 5, 3, 3, 3, 3, 3, 3]
@@ -25,7 +25,7 @@ class PoseNetB6(nn.Module):
     def forward(self, target_image, ref_imgs):
         assert len(ref_imgs) == self.nb_ref_imgs
         x = torch.cat([target_image] + list(ref_imgs), 1)       # target first (PoseNetB6.py:67-69)
-        for i in range(8):
-            x = getattr(self, "conv%d" % (i + 1))(x)
-        pose = self.pose_pred(x).mean(3).mean(2)                 # W first, then H (PoseNetB6.py:80)
+        for i in range(8):      # a pure conv -> conv chain: every ReLU backward runs in the next layer's data-gradient epilogue
+            x = conv_call(getattr(self, "conv%d" % (i + 1))[0], x, pre_act="relu" if i else None, defer=True)
+        pose = conv_call(self.pose_pred, x, pre_act="relu").mean(3).mean(2)       # W first, then H (PoseNetB6.py:80)
         return 0.01 * pose.view(pose.size(0), self.nb_ref_imgs, 6)

@@ -27,6 +27,12 @@ def seq_conv_act(cin, cout, k, stride, act):
     return nn.Sequential(L.Conv2d(cin, cout, k, stride, (k - 1) // 2, act=act), L.Act())
 
 
+def conv_call(m, x, pre_act=None, defer=False, residual=None):
+    """L.Conv2d module `m` applied to x as a link of a conv -> conv chain: defer = every consumer of the output is a
+    convolution called with pre_act=m.act (its data-gradient epilogue then applies this layer's activation backward)."""
+    return ops.conv2d(x, m.weight, m.bias, m.stride[0], m.padding[0], m.act, residual, 1.0, m.slope, pre_act=pre_act, defer=defer)
+
+
 class BasicBlock(nn.Module):
     """models/DispResNet6.py:14-43: conv3x3 -> ReLU -> conv3x3 -> (+ shortcut) -> ReLU, no BN on the main path.
     The residual add and the final ReLU run in conv2's epilogue."""
@@ -40,8 +46,8 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         r = x if self.downsample is None else self.downsample(x)
-        y = self.conv1(x)
-        return ops.conv2d(y, self.conv2.weight, None, 1, 1, "relu", residual=r)
+        y = conv_call(self.conv1, x, defer=True)                    # consumed by conv2 only
+        return ops.conv2d(y, self.conv2.weight, None, 1, 1, "relu", residual=r, pre_act="relu")
 
 
 def make_layer(cin, cout, blocks, stride):

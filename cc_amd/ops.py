@@ -112,7 +112,7 @@ def _sink(p):
 # ----------------------------------------------------------------------------- convolution
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, res, stride, pad, act, act_a, act_b):
+    def forward(ctx, x, w, bias, res, stride, pad, act, act_a, act_b, pre_act=0, pre_b=0.0, defer=False):
         x, w = _c(x), _c(w)
         B, Cin, IH, IW = x.shape
         Cout, _, R, S = w.shape
@@ -126,8 +126,11 @@ class _Conv2dFn(torch.autograd.Function):
         pk = packs.get("fwd", w, (B, Cin, IH, IW, Cout, R, S, stride, pad, OH, OW))
         E.call("cc_conv2d_fwd", x, w, bias_c, res_c, y, ws, pk, B, Cin, IH, IW, Cin * IH * IW, Cout, R, S, stride, pad,
                OH, OW, Cout * OH * OW, Cout * OH * OW, act, act_a, act_b, STREAM)
-        ctx.save_for_backward(x, w, y if act != 0 else None)
-        ctx.cfg = (stride, pad, act, act_a, act_b, bias is not None, res is not None)
+        # defer: the consumers of y (convolutions called with pre_act = this activation) apply act'(y) in their data-gradient
+        # epilogue, so the gradient arriving here is already w.r.t. the pre-activation (see _ConvGroupFn)
+        ctx.save_for_backward(x, w, y if (act != 0 and not defer) else None)
+        ctx.cfg = (stride, pad, act if not defer else 0, act_a, act_b, bias is not None, res is not None)
+        ctx.pre = (pre_act, pre_b)
         ctx.bias_ptr = bias_c.data_ptr() if bias_c is not None else 0
         return y
 
@@ -135,6 +138,7 @@ class _Conv2dFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
         stride, pad, act, act_a, act_b, has_bias, has_res = ctx.cfg
+        pre_act, pre_b = ctx.pre
         E = engine()
         gy = _c(gy)
         B, Cin, IH, IW = x.shape
@@ -158,8 +162,14 @@ class _Conv2dFn(torch.autograd.Function):
             gx = torch.empty_like(x)
             ws = _ws(E.call("cc_conv2d_dgrad_ws_bytes", B, Cout, OH, OW, Cin, R, S, stride, pad, IH, IW), x)
             pk = packs.get("dgrad", w, (B, Cout, OH, OW, Cin, R, S, stride, pad, IH, IW, Cin * R * S, R * S))
-            E.call("cc_conv2d_dgrad", gy, w, None, gx, ws, pk, B, Cout, OH, OW, Cout * OH * OW, Cin, R, S, stride, pad, IH, IW,
-                   Cin * IH * IW, Cin * R * S, R * S, 0, 1.0, 0.0, STREAM)
+            if pre_act:       # gradient w.r.t. the producer's pre-activation: act'(x) multiplied in the epilogue
+                a1, a2, a3, a4, a5 = _parr([gy]), _parr([w]), _parr([gx]), _parr([x]), _parr([pk])
+                E.call("cc_conv2d_dgrad_group", 1, _addr(a1), _addr(a2), 0, _addr(a3), _addr(a4), ws, _addr(a5), B, Cout, OH, OW,
+                       Cout * OH * OW, Cin, R, S, stride, pad, IH, IW, Cin * IH * IW, Cin * IH * IW, Cin * R * S, R * S, pre_act, 1.0,
+                       pre_b, STREAM)
+            else:
+                E.call("cc_conv2d_dgrad", gy, w, None, gx, ws, pk, B, Cout, OH, OW, Cout * OH * OW, Cin, R, S, stride, pad, IH, IW,
+                       Cin * IH * IW, Cin * R * S, R * S, 0, 1.0, 0.0, STREAM)
         if need[1]:
             wsink = _sink(w)
             gw = wsink if wsink is not None else torch.empty_like(w)
@@ -169,7 +179,7 @@ class _Conv2dFn(torch.autograd.Function):
             if wsink is not None:
                 gw = None
         gres = gy if (has_res and need[3]) else None
-        return gx, gw, gbias, gres, None, None, None, None, None
+        return gx, gw, gbias, gres, None, None, None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------- grouped convolution (parallel branches)
@@ -310,10 +320,14 @@ def conv2d_group(xs, weights, biases=None, stride=1, padding=0, act=None, slope=
     return list(out)
 
 
-def conv2d(x, w, bias=None, stride=1, padding=0, act=None, residual=None, act_a=1.0, act_b=0.0):
+def conv2d(x, w, bias=None, stride=1, padding=0, act=None, residual=None, act_a=1.0, act_b=0.0, pre_act=None, pre_slope=0.0,
+           defer=False):
     """act(conv2d(x, w, bias) + residual): nn.Conv2d (+ fused ReLU / LeakyReLU / a*sigmoid+b epilogue).
-    act='lrelu': act_b is the negative slope (0 -> the 0.2 of Back2Future)."""
-    return _Conv2dFn.apply(x, w, bias, residual, int(stride), int(padding), ACT[act], float(act_a), float(act_b))
+    act='lrelu': act_b is the negative slope (0 -> the 0.2 of Back2Future).
+    defer / pre_act: activation backward of a layer whose output feeds ONLY convolutions is applied by those consumers'
+    data-gradient epilogue (producer: defer=True; every consumer: pre_act=<the producer's activation>)."""
+    return _Conv2dFn.apply(x, w, bias, residual, int(stride), int(padding), ACT[act], float(act_a), float(act_b),
+                           ACT[pre_act], float(pre_slope), bool(defer))
 
 
 class _ConvT2dFn(torch.autograd.Function):
