@@ -17,9 +17,12 @@
 //   V pass: thread = (column, 4 consecutive rows): 16 ds_read_b32 per moment (conflict-free:
 //           a 32-lane group reads 32 consecutive columns).
 #include "cc_common.h"
+#include "jobs.h"
 #include "../../include/ccengine.h"
 
 namespace {
+
+using ccjobs::JobTab;
 
 constexpr int TS = 32;          // output tile edge
 constexpr int HALO = 6;         // window_size // 2
@@ -56,16 +59,16 @@ __device__ __forceinline__ float robust_pow(float v, float q) {
     return (q == 0.5f) ? sqrtf(v) : powf(v, q);
 }
 
+// one 32x32 tile of image b: (tile_x, tile_y) -> outputs; `blk` = index of this tile's partial sums (MODE_PHOTO)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_ssim_tile(PhotoArgs a, Gauss13 gw) {
+__device__ __forceinline__ void ssim_tile_body(const PhotoArgs& a, const Gauss13& gw, int b, int tile_x, int tile_y, size_t blk) {
     __shared__ __attribute__((aligned(16))) float tx[TIN * TIN];
     __shared__ __attribute__((aligned(16))) float ty[TIN * TIN];
     __shared__ __attribute__((aligned(16))) float hb[5][TIN * TS];
     __shared__ float red[4 * 3];
 
     const int H = a.H, W = a.W, HW = H * W;
-    const int b = blockIdx.z;
-    const int ox0 = blockIdx.x * TS, oy0 = blockIdx.y * TS;
+    const int ox0 = tile_x * TS, oy0 = tile_y * TS;
     const int tid = threadIdx.x;
     const int cx = tid & 31, rg = tid >> 5;
     const int gx = ox0 + cx;
@@ -252,7 +255,6 @@ __global__ __launch_bounds__(256) void k_ssim_tile(PhotoArgs a, Gauss13 gw) {
         __syncthreads();
         cc::block_sum_256<3>(v, red);
         if (tid == 0) {
-            const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
             a.partials[blk * 4 + 0] = v[0];
             a.partials[blk * 4 + 1] = v[1];
             a.partials[blk * 4 + 2] = v[2];
@@ -261,16 +263,73 @@ __global__ __launch_bounds__(256) void k_ssim_tile(PhotoArgs a, Gauss13 gw) {
     }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(256) void k_ssim_tile(PhotoArgs a, Gauss13 gw) {
+    ssim_tile_body<MODE>(a, gw, (int)blockIdx.z, (int)blockIdx.x, (int)blockIdx.y,
+                         ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+}
+
+// job-table forms (jobs.h): every (pyramid level, reference frame) term of a loss in ONE launch; blocks = 32x32 tiles
+__device__ __forceinline__ void tile_of(const JobTab& t, int& j, int& b, int& tile_x, int& tile_y, int& local) {
+    int first;
+    j = ccjobs::find(t, (int)blockIdx.x, first);
+    const int tw = (t.W[j] + TS - 1) / TS, th = (t.H[j] + TS - 1) / TS;
+    local = (int)blockIdx.x - first;
+    b = local / (tw * th);
+    const int r = local - b * (tw * th);
+    tile_y = r / tw;
+    tile_x = r - tile_y * tw;
+}
+
+// photo slots: 0 tgt, 1 warped, 2 mask_a, 3 mask_b, 4 gmask, 5 adjoint maps (adjA, adjB, adjC, g0: 4 x [B,3,H,W]),
+//              6 partials [B*tiles][4], 7 batch strides of mask_a / mask_b / gmask in units of H*W (8 bits each)
+struct PhotoCommon { int b_complement, want_grad; float wssim, q; };
+
+__global__ __launch_bounds__(256) void k_ssim_photo_jobs(JobTab t, PhotoCommon c, Gauss13 gw) {
+    int j, b, tile_x, tile_y, local;
+    tile_of(t, j, b, tile_x, tile_y, local);
+    PhotoArgs a = {};
+    a.H = t.H[j]; a.W = t.W[j];
+    const int HW = a.H * a.W;
+    const long st = t.slot[j][7];
+    a.x = ccjobs::ptr<const float>(t, j, 0);
+    a.y = ccjobs::ptr<const float>(t, j, 1);
+    a.mask_a = ccjobs::ptr<const float>(t, j, 2);
+    a.mask_b = ccjobs::ptr<const float>(t, j, 3);
+    a.gmask = ccjobs::ptr<float>(t, j, 4);
+    a.a_bs = (int)(st & 255) * HW; a.b_bs = (int)((st >> 8) & 255) * HW; a.gm_bs = (int)((st >> 16) & 255) * HW;
+    float* adj = ccjobs::ptr<float>(t, j, 5);
+    const size_t map = (size_t)t.B * 3 * HW;
+    a.adjA = adj; a.adjB = adj + map; a.adjC = adj + 2 * map; a.g0 = adj + 3 * map;
+    a.partials = ccjobs::ptr<float>(t, j, 6);
+    a.b_complement = c.b_complement; a.want_grad = c.want_grad; a.wssim = c.wssim; a.q = c.q;
+    ssim_tile_body<MODE_PHOTO>(a, gw, b, tile_x, tile_y, (size_t)local);
+}
+
+// err slots (consensus_exp_masks): 0 tgt, 1 warped, 2 err [B,1,H,W], 3 valid [B,1,H,W]
+__global__ __launch_bounds__(256) void k_ssim_err_jobs(JobTab t, float wssim, Gauss13 gw) {
+    int j, b, tile_x, tile_y, local;
+    tile_of(t, j, b, tile_x, tile_y, local);
+    PhotoArgs a = {};
+    a.H = t.H[j]; a.W = t.W[j];
+    a.x = ccjobs::ptr<const float>(t, j, 0);
+    a.y = ccjobs::ptr<const float>(t, j, 1);
+    a.out_map = ccjobs::ptr<float>(t, j, 2);
+    a.out_valid = ccjobs::ptr<float>(t, j, 3);
+    a.wssim = wssim;
+    ssim_tile_body<MODE_ERR>(a, gw, b, tile_x, tile_y, 0);
+}
+
 // gy = scale * (g0 + G*adjA + 2*y*(G*adjB) + x*(G*adjC)),  G* = zero-padded 13x13 Gaussian filter
-__global__ __launch_bounds__(256) void k_ssim_adjoint(const float* __restrict__ adjA, const float* __restrict__ adjB,
-                                                      const float* __restrict__ adjC, const float* __restrict__ g0,
-                                                      const float* __restrict__ x, const float* __restrict__ y,
-                                                      const float* __restrict__ scale, float* __restrict__ gy, int H,
-                                                      int W, int accumulate, Gauss13 gw) {
+__device__ __forceinline__ void ssim_adjoint_body(const float* __restrict__ adjA, const float* __restrict__ adjB,
+                                                  const float* __restrict__ adjC, const float* __restrict__ g0,
+                                                  const float* __restrict__ x, const float* __restrict__ y,
+                                                  const float* __restrict__ scale, float* __restrict__ gy, int H,
+                                                  int W, int accumulate, const Gauss13& gw, int b, int tile_x, int tile_y) {
     __shared__ __attribute__((aligned(16))) float tin[3][TIN * TIN];
     __shared__ __attribute__((aligned(16))) float hb[3][TIN * TS];
-    const int HW = H * W, b = blockIdx.z;
-    const int ox0 = blockIdx.x * TS, oy0 = blockIdx.y * TS;
+    const int HW = H * W;
+    const int ox0 = tile_x * TS, oy0 = tile_y * TS;
     const int tid = threadIdx.x, cx = tid & 31, rg = tid >> 5, gx = ox0 + cx;
     const float sc = scale ? scale[0] : 1.f;
     for (int c = 0; c < 3; c++) {
@@ -333,6 +392,67 @@ __global__ __launch_bounds__(256) void k_ssim_adjoint(const float* __restrict__ 
                 gy[o] = accumulate ? gy[o] + r : r;
             }
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ssim_adjoint(const float* __restrict__ adjA, const float* __restrict__ adjB,
+                                                      const float* __restrict__ adjC, const float* __restrict__ g0,
+                                                      const float* __restrict__ x, const float* __restrict__ y,
+                                                      const float* __restrict__ scale, float* __restrict__ gy, int H,
+                                                      int W, int accumulate, Gauss13 gw) {
+    ssim_adjoint_body(adjA, adjB, adjC, g0, x, y, scale, gy, H, W, accumulate, gw, (int)blockIdx.z, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// adjoint slots: 0 adjoint maps (adjA, adjB, adjC, g0), 1 tgt, 2 warped, 3 scale (1 float), 4 gwarped [B,3,H,W]
+__global__ __launch_bounds__(256) void k_ssim_adjoint_jobs(JobTab t, Gauss13 gw) {
+    int j, b, tile_x, tile_y, local;
+    tile_of(t, j, b, tile_x, tile_y, local);
+    const int H = t.H[j], W = t.W[j];
+    const float* adj = ccjobs::ptr<const float>(t, j, 0);
+    const size_t map = (size_t)t.B * 3 * H * W;
+    ssim_adjoint_body(adj, adj + map, adj + 2 * map, adj + 3 * map, ccjobs::ptr<const float>(t, j, 1), ccjobs::ptr<const float>(t, j, 2),
+                      ccjobs::ptr<const float>(t, j, 3), ccjobs::ptr<float>(t, j, 4), H, W, 0, gw, b, tile_x, tile_y);
+}
+
+// all terms of one photometric loss: one wave per job (16 waves), then the terms are added to the loss in job order.
+// slots: 6 partials [B*tiles][4] (as written by k_ssim_photo_jobs); scale_out[j], terms in LDS; nan_flag set on any NaN term
+__global__ __launch_bounds__(1024) void k_photo_finalize_jobs(JobTab t, float wssim, float q, float lambda_oob,
+                                                              float* __restrict__ loss_accum, float* __restrict__ scale_out,
+                                                              float* __restrict__ nan_flag) {
+    __shared__ float terms[ccjobs::MAXJOBS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = wave; j < t.n; j += 16) {
+        const int nblk = t.B * ((t.W[j] + TS - 1) / TS) * ((t.H[j] + TS - 1) / TS);
+        const float* partials = ccjobs::ptr<const float>(t, j, 6);
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        for (int i = lane; i < nblk; i += 64) {
+            v0 += partials[i * 4 + 0];
+            v1 += partials[i * 4 + 1];
+            v2 += partials[i * 4 + 2];
+        }
+        v0 = cc::wave_sum(v0); v1 = cc::wave_sum(v1); v2 = cc::wave_sum(v2);
+        if (lane == 0) {
+            const float n1 = (float)t.B * (float)t.H[j] * (float)t.W[j], n3 = 3.f * n1;
+            const float oob = n1 / v2;
+            float term = (1.f - wssim) * oob * (v0 / n3 + wssim * (v1 / n3));
+            if (lambda_oob != 0.f) {
+                const float hi = powf(1.01f, q), lo = powf(0.01f, q);
+                term += lambda_oob * (((n1 - v2) * hi + v2 * lo) / n1);
+            }
+            terms[j] = term;
+            scale_out[j] = (1.f - wssim) * oob / n3;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float acc = loss_accum[0];
+        bool bad = false;
+        for (int j = 0; j < t.n; j++) {
+            acc += terms[j];
+            bad = bad || !(terms[j] == terms[j]);
+        }
+        loss_accum[0] = acc;
+        if (bad) nan_flag[0] = 1.f;
     }
 }
 
@@ -455,6 +575,41 @@ int cc_ssim_err_fwd(const float* tgt, const float* warped, float* err, float* va
     a.x = tgt; a.y = warped; a.out_map = err; a.out_valid = valid; a.wssim = wssim; a.H = H; a.W = W;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ssim_tile<MODE_ERR>), tile_grid(B, H, W), dim3(256), 0, (hipStream_t)stream, a,
                        make_gauss(gauss13_host));
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+/* ---- job-table forms (jobs: HOST array of njobs x 10 longs {slot0..7, H, W}; njobs <= 24; slots per kernel above) */
+static int tile_blocks(int H, int W) { return ((W + TS - 1) / TS) * ((H + TS - 1) / TS); }
+
+int cc_ssim_photo_fwd_jobs(const long* jobs, int njobs, int B, int mask_b_complement, int want_grad, float wssim, float q,
+                           float lambda_oob, float* loss_accum, float* scale_out, float* nan_flag, const float* gauss13_host,
+                           void* stream) {
+    if (!jobs || njobs <= 0 || njobs > ccjobs::MAXJOBS || B <= 0) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    JobTab t;
+    const int nblk = ccjobs::fill(t, jobs, njobs, B, tile_blocks);
+    PhotoCommon c = {mask_b_complement, want_grad, wssim, q};
+    hipLaunchKernelGGL(k_ssim_photo_jobs, dim3((unsigned)nblk), dim3(256), 0, s, t, c, make_gauss(gauss13_host));
+    hipLaunchKernelGGL(k_photo_finalize_jobs, dim3(1), dim3(1024), 0, s, t, wssim, q, lambda_oob, loss_accum, scale_out, nan_flag);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_ssim_photo_bwd_jobs(const long* jobs, int njobs, int B, const float* gauss13_host, void* stream) {
+    if (!jobs || njobs <= 0 || njobs > ccjobs::MAXJOBS || B <= 0) return CC_ERR_ARG;
+    JobTab t;
+    const int nblk = ccjobs::fill(t, jobs, njobs, B, tile_blocks);
+    hipLaunchKernelGGL(k_ssim_adjoint_jobs, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, t, make_gauss(gauss13_host));
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_ssim_err_fwd_jobs(const long* jobs, int njobs, int B, float wssim, const float* gauss13_host, void* stream) {
+    if (!jobs || njobs <= 0 || njobs > ccjobs::MAXJOBS || B <= 0) return CC_ERR_ARG;
+    JobTab t;
+    const int nblk = ccjobs::fill(t, jobs, njobs, B, tile_blocks);
+    hipLaunchKernelGGL(k_ssim_err_jobs, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, t, wssim, make_gauss(gauss13_host));
     CC_CHECK_LAUNCH();
     return CC_OK;
 }

@@ -12,9 +12,12 @@
 // so depth/flow/out accesses are fully coalesced and the 4-tap gathers hit
 // neighbouring lines (L1/L2-resident for the small motions of this workload).
 #include "cc_common.h"
+#include "jobs.h"
 #include "../../include/ccengine.h"
 
 namespace {
+
+using ccjobs::JobTab;
 
 struct Bilinear {
     float w, e, n, s;     // distances to the west/east/north/south tap (ATen cpu/GridSamplerKernel naming)
@@ -397,6 +400,173 @@ __global__ __launch_bounds__(256) void k_rigid_noocc_fused(const float* __restri
     o[3 * HW] = m03;
 }
 
+// ------------------------------------------------------------------ job-table forms (all pyramid levels x reference frames
+// of one loss in ONE launch; jobs.h).  Same per-pixel arithmetic as the single-call kernels above (shared device functions).
+// rigid fwd slots: 0 img [B,C,H,W], 1 depth [B,H,W], 2 P [B,12], 3 Kinv [B,9], 4 out
+template <bool AC, bool BORDER>
+__global__ __launch_bounds__(256) void k_inverse_warp_fwd_jobs(JobTab t, int C) {
+    int first;
+    const int j = ccjobs::find(t, (int)blockIdx.x, first);
+    const int H = t.H[j], W = t.W[j], HW = H * W, nb = (HW + 255) >> 8;
+    const int local = (int)blockIdx.x - first;
+    const int b = local / nb, p = (local - b * nb) * 256 + (int)threadIdx.x;
+    if (p >= HW) return;
+    const float* __restrict__ img = ccjobs::ptr<const float>(t, j, 0);
+    const float* __restrict__ depth = ccjobs::ptr<const float>(t, j, 1);
+    const float* __restrict__ P = ccjobs::ptr<const float>(t, j, 2);
+    const float* __restrict__ Kinv = ccjobs::ptr<const float>(t, j, 3);
+    float* __restrict__ out = ccjobs::ptr<float>(t, j, 4);
+    const int y = p / W, x = p - y * W;
+    Rigid r;
+    rigid_project(P + 12 * b, Kinv + 9 * b, (float)x, (float)y, depth[(size_t)b * HW + p], W, H, !BORDER, r);
+    Bilinear bl;
+    bilinear_setup<AC, BORDER>(r.xn, r.yn, W, H, bl);
+    const float* src = img + (size_t)b * C * HW;
+    float* dst = out + (size_t)b * C * HW + p;
+    for (int c = 0; c < C; c++) {
+        float nw, ne, sw, se;
+        gather4(src + (size_t)c * HW, W, bl, nw, ne, sw, se);
+        dst[(size_t)c * HW] = blend(bl, nw, ne, sw, se);
+    }
+}
+
+// rigid bwd slots: 0 gout, 1 img, 2 depth, 3 P, 4 Kinv, 5 gdepth [B,H,W], 6 gP partials [B][nb][12]
+template <bool AC, bool BORDER>
+__global__ __launch_bounds__(256) void k_inverse_warp_bwd_jobs(JobTab t, int C) {
+    __shared__ float red[4 * 12];
+    int first;
+    const int j = ccjobs::find(t, (int)blockIdx.x, first);
+    const int H = t.H[j], W = t.W[j], HW = H * W, nb = (HW + 255) >> 8;
+    const int local = (int)blockIdx.x - first;
+    const int b = local / nb, blk = local - b * nb, p = blk * 256 + (int)threadIdx.x;
+    const float* __restrict__ gout = ccjobs::ptr<const float>(t, j, 0);
+    const float* __restrict__ img = ccjobs::ptr<const float>(t, j, 1);
+    const float* __restrict__ depth = ccjobs::ptr<const float>(t, j, 2);
+    const float* __restrict__ P = ccjobs::ptr<const float>(t, j, 3);
+    const float* __restrict__ Kinv = ccjobs::ptr<const float>(t, j, 4);
+    float* __restrict__ gdepth = ccjobs::ptr<float>(t, j, 5);
+    float* __restrict__ gP_part = ccjobs::ptr<float>(t, j, 6);
+    float gP[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) gP[i] = 0.f;
+    if (p < HW) {
+        const int y = p / W, x = p - y * W;
+        Rigid r;
+        rigid_project(P + 12 * b, Kinv + 9 * b, (float)x, (float)y, depth[(size_t)b * HW + p], W, H, !BORDER, r);
+        Bilinear bl;
+        bilinear_setup<AC, BORDER>(r.xn, r.yn, W, H, bl);
+        float gix, giy, gd;
+        sample_grad(img + (size_t)b * C * HW, gout + (size_t)b * C * HW + p, C, HW, W, bl, nullptr, gix, giy);
+        rigid_backward(P + 12 * b, r, gix * bl.gmx, giy * bl.gmy, W, H, gd, gP);
+        gdepth[(size_t)b * HW + p] = gd;
+    }
+    cc::block_sum_256<12>(gP, red);
+    if (threadIdx.x == 0) {
+        float* o = gP_part + ((size_t)b * nb + blk) * 12;
+#pragma unroll
+        for (int i = 0; i < 12; i++) o[i] = gP[i];
+    }
+}
+
+// flow fwd slots: 0 img, 1 flow [B,2,H,W], 2 out;   flow bwd slots: 0 gout, 1 img, 2 flow, 3 gflow
+template <bool AC, bool BORDER>
+__global__ __launch_bounds__(256) void k_flow_warp_fwd_jobs(JobTab t, int C) {
+    int first;
+    const int j = ccjobs::find(t, (int)blockIdx.x, first);
+    const int H = t.H[j], W = t.W[j], HW = H * W, nb = (HW + 255) >> 8;
+    const int local = (int)blockIdx.x - first;
+    const int b = local / nb, p = (local - b * nb) * 256 + (int)threadIdx.x;
+    if (p >= HW) return;
+    const float* __restrict__ img = ccjobs::ptr<const float>(t, j, 0);
+    const float* __restrict__ flow = ccjobs::ptr<const float>(t, j, 1);
+    float* __restrict__ out = ccjobs::ptr<float>(t, j, 2);
+    const int y = p / W, x = p - y * W;
+    float xn, yn, dxn, dyn;
+    flow_coords<false>((float)x, (float)y, flow[((size_t)b * 2) * HW + p], flow[((size_t)b * 2 + 1) * HW + p], W, H, xn, yn, dxn, dyn);
+    Bilinear bl;
+    bilinear_setup<AC, BORDER>(xn, yn, W, H, bl);
+    const float* src = img + (size_t)b * C * HW;
+    float* dst = out + (size_t)b * C * HW + p;
+    for (int c = 0; c < C; c++) {
+        float nw, ne, sw, se;
+        gather4(src + (size_t)c * HW, W, bl, nw, ne, sw, se);
+        dst[(size_t)c * HW] = blend(bl, nw, ne, sw, se);
+    }
+}
+
+template <bool AC, bool BORDER>
+__global__ __launch_bounds__(256) void k_flow_warp_bwd_jobs(JobTab t, int C) {
+    int first;
+    const int j = ccjobs::find(t, (int)blockIdx.x, first);
+    const int H = t.H[j], W = t.W[j], HW = H * W, nb = (HW + 255) >> 8;
+    const int local = (int)blockIdx.x - first;
+    const int b = local / nb, p = (local - b * nb) * 256 + (int)threadIdx.x;
+    if (p >= HW) return;
+    const float* __restrict__ gout = ccjobs::ptr<const float>(t, j, 0);
+    const float* __restrict__ img = ccjobs::ptr<const float>(t, j, 1);
+    const float* __restrict__ flow = ccjobs::ptr<const float>(t, j, 2);
+    float* __restrict__ gflow = ccjobs::ptr<float>(t, j, 3);
+    const int y = p / W, x = p - y * W;
+    float xn, yn, dxn, dyn;
+    flow_coords<false>((float)x, (float)y, flow[((size_t)b * 2) * HW + p], flow[((size_t)b * 2 + 1) * HW + p], W, H, xn, yn, dxn, dyn);
+    Bilinear bl;
+    bilinear_setup<AC, BORDER>(xn, yn, W, H, bl);
+    float gix, giy;
+    sample_grad(img + (size_t)b * C * HW, gout + (size_t)b * C * HW + p, C, HW, W, bl, nullptr, gix, giy);
+    gflow[((size_t)b * 2) * HW + p] = gix * bl.gmx * dxn;
+    gflow[((size_t)b * 2 + 1) * HW + p] = giy * bl.gmy * dyn;
+}
+
+// depth_occlusion_masks of every level: slots 0 depth [B,H,W], 1 P4 [4,B,12] (full-resolution K, Q4), 2 Kinv, 3 out [B,4,H,W]
+__global__ __launch_bounds__(256) void k_rigid_noocc_jobs(JobTab t) {
+    int first;
+    const int j = ccjobs::find(t, (int)blockIdx.x, first);
+    const int H = t.H[j], W = t.W[j], HW = H * W, nb = (HW + 255) >> 8;
+    const int local = (int)blockIdx.x - first;
+    const int b = local / nb, p = (local - b * nb) * 256 + (int)threadIdx.x;
+    if (p >= HW) return;
+    const float* __restrict__ depth = ccjobs::ptr<const float>(t, j, 0);
+    const float* __restrict__ P4 = ccjobs::ptr<const float>(t, j, 1);
+    const float* __restrict__ Kinv = ccjobs::ptr<const float>(t, j, 2);
+    float* __restrict__ out = ccjobs::ptr<float>(t, j, 3);
+    const int y = p / W, x = p - y * W;
+    const float d = depth[(size_t)b * HW + p];
+    float u[4], v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        Rigid rg;
+        rigid_project(P4 + ((size_t)r * t.B + b) * 12, Kinv + 9 * b, (float)x, (float)y, d, W, H, false, rg);
+        u[r] = (float)(W - 1) * (rg.xn / 2.0f + 0.5f) - (float)x;
+        v[r] = (float)(H - 1) * (rg.yn / 2.0f + 0.5f) - (float)y;
+    }
+    const float m12 = noocc_pair(u[1], v[1], u[2], v[2]);
+    const float m03 = noocc_pair(u[0], v[0], u[3], v[3]);
+    float* o = out + (size_t)b * 4 * HW + p;
+    o[0] = m03;
+    o[HW] = m12;
+    o[2 * HW] = m12;
+    o[3 * HW] = m03;
+}
+
+// pose2flow of every level (train.py:470-471 flows_cam_fwd / _bwd): slots 0 depth, 1 P [B,12], 2 Kinv, 3 flow [B,2,H,W]
+__global__ __launch_bounds__(256) void k_pose2flow_fwd_jobs(JobTab t, int rewrite) {
+    int first;
+    const int j = ccjobs::find(t, (int)blockIdx.x, first);
+    const int H = t.H[j], W = t.W[j], HW = H * W, nb = (HW + 255) >> 8;
+    const int local = (int)blockIdx.x - first;
+    const int b = local / nb, p = (local - b * nb) * 256 + (int)threadIdx.x;
+    if (p >= HW) return;
+    const float* __restrict__ depth = ccjobs::ptr<const float>(t, j, 0);
+    const float* __restrict__ P = ccjobs::ptr<const float>(t, j, 1);
+    const float* __restrict__ Kinv = ccjobs::ptr<const float>(t, j, 2);
+    float* __restrict__ flow = ccjobs::ptr<float>(t, j, 3);
+    const int y = p / W, x = p - y * W;
+    Rigid r;
+    rigid_project(P + 12 * b, Kinv + 9 * b, (float)x, (float)y, depth[(size_t)b * HW + p], W, H, rewrite != 0, r);
+    flow[((size_t)b * 2 + 0) * HW + p] = (float)(W - 1) * (r.xn / 2.0f + 0.5f) - (float)x;
+    flow[((size_t)b * 2 + 1) * HW + p] = (float)(H - 1) * (r.yn / 2.0f + 0.5f) - (float)y;
+}
+
 inline dim3 pix_grid(int B, int H, int W) { return dim3((unsigned)((H * W + 255) / 256), (unsigned)B); }
 
 }  // namespace
@@ -526,6 +696,71 @@ int cc_feature_warp_bwd(const float* gout, const float* feat, const float* flow,
     }
     if (align_corners) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<true, true, true>), g, dim3(256), 0, s, gout, feat, flow, gflow_or_null, gfeat_or_null, C, H, W);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<false, true, true>), g, dim3(256), 0, s, gout, feat, flow, gflow_or_null, gfeat_or_null, C, H, W);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+/* ---- job-table forms: `jobs` = HOST array of njobs x 10 longs {slot0..slot7, H, W} (slot meaning per entry point, see
+ * include/ccengine.h); every job spans B batch items; njobs <= 24. */
+static int warp_jobs_tab(ccjobs::JobTab& t, const long* jobs, int njobs, int B) {
+    if (!jobs || njobs <= 0 || njobs > ccjobs::MAXJOBS || B <= 0) return -1;
+    return ccjobs::fill(t, jobs, njobs, B, ccjobs::pix_blocks);
+}
+
+int cc_inverse_warp_fwd_jobs(const long* jobs, int njobs, int B, int C, int padding_border, int align_corners, void* stream) {
+    ccjobs::JobTab t;
+    const int nblk = warp_jobs_tab(t, jobs, njobs, B);
+    if (nblk <= 0) return CC_ERR_ARG;
+    CC_DISPATCH_AC_PAD(k_inverse_warp_fwd_jobs, align_corners, padding_border, dim3((unsigned)nblk), dim3(256), 0,
+                       (hipStream_t)stream, t, C);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_inverse_warp_bwd_jobs(const long* jobs, int njobs, int B, int C, int padding_border, int align_corners, void* stream) {
+    ccjobs::JobTab t;
+    const int nblk = warp_jobs_tab(t, jobs, njobs, B);
+    if (nblk <= 0) return CC_ERR_ARG;
+    CC_DISPATCH_AC_PAD(k_inverse_warp_bwd_jobs, align_corners, padding_border, dim3((unsigned)nblk), dim3(256), 0,
+                       (hipStream_t)stream, t, C);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_flow_warp_fwd_jobs(const long* jobs, int njobs, int B, int C, int padding_border, int align_corners, void* stream) {
+    ccjobs::JobTab t;
+    const int nblk = warp_jobs_tab(t, jobs, njobs, B);
+    if (nblk <= 0) return CC_ERR_ARG;
+    CC_DISPATCH_AC_PAD(k_flow_warp_fwd_jobs, align_corners, padding_border, dim3((unsigned)nblk), dim3(256), 0,
+                       (hipStream_t)stream, t, C);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_flow_warp_bwd_jobs(const long* jobs, int njobs, int B, int C, int padding_border, int align_corners, void* stream) {
+    ccjobs::JobTab t;
+    const int nblk = warp_jobs_tab(t, jobs, njobs, B);
+    if (nblk <= 0) return CC_ERR_ARG;
+    CC_DISPATCH_AC_PAD(k_flow_warp_bwd_jobs, align_corners, padding_border, dim3((unsigned)nblk), dim3(256), 0,
+                       (hipStream_t)stream, t, C);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_rigid_noocc_jobs(const long* jobs, int njobs, int B, void* stream) {
+    ccjobs::JobTab t;
+    const int nblk = warp_jobs_tab(t, jobs, njobs, B);
+    if (nblk <= 0) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_rigid_noocc_jobs, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, t);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_pose2flow_fwd_jobs(const long* jobs, int njobs, int B, int rewrite_oob, void* stream) {
+    ccjobs::JobTab t;
+    const int nblk = warp_jobs_tab(t, jobs, njobs, B);
+    if (nblk <= 0) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_pose2flow_fwd_jobs, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, t, rewrite_oob);
     CC_CHECK_LAUNCH();
     return CC_OK;
 }
