@@ -268,6 +268,39 @@ int cc_bn_train_bwd(const float* gy, const float* x, const float* weight_or_null
                     const float* save_invstd, float* gx, float* gweight_or_null, float* gbias_or_null, float* ws, int B, int C,
                     int H, int W, int accumulate_wb, void* stream);
 
+/* ---------------------------------------------------------------- job-table forms of the loss path
+ * loss_functions.py runs every photometric / consensus term once per (pyramid scale, reference frame): `for scale ... for ref`
+ * loops of 24 (:80-128), 12 (:27-77) and 18 (:160-202) warp + SSIM evaluations per step, five of the six scales being
+ * launch-latency sized.  A job-table call evaluates ALL terms of one loss in ONE launch: `jobs` is a HOST array of
+ * njobs x 10 longs {slot0 .. slot7, H, W} (device addresses / packed integers, meaning per call below), every job spans B batch
+ * items, njobs <= 24; blocks are dealt to jobs through a prefix table carried in the kernel arguments.
+ *   cc_inverse_warp_fwd_jobs  slots: img, depth, P, Kinv, out                      (cc_inverse_warp_fwd per job)
+ *   cc_inverse_warp_bwd_jobs  slots: gout, img, depth, P, Kinv, gdepth, gP partials [B][ceil(HW/256)][12]
+ *   cc_flow_warp_fwd_jobs     slots: img, flow, out;      cc_flow_warp_bwd_jobs    slots: gout, img, flow, gflow
+ *   cc_rigid_noocc_jobs       slots: depth, P4 [4,B,12], Kinv, out [B,4,H,W]       (loss_functions.py:132-137 per scale)
+ *   cc_pose2flow_fwd_jobs     slots: depth, P, Kinv, flow                          (train.py:470-471 per scale)
+ *   cc_ssim_photo_fwd_jobs    slots: tgt, warped, mask_a, mask_b, gmask, adjoint maps (4 x [B,3,H,W]), partials [B*tiles][4],
+ *                             batch strides of mask_a | mask_b << 8 | gmask << 16 in units of H*W; + one finalize launch:
+ *                             loss_accum += sum_j term_j (job order), scale_out[j], nan_flag
+ *   cc_ssim_photo_bwd_jobs    slots: adjoint maps, tgt, warped, scale (1 float), gwarped
+ *   cc_ssim_err_fwd_jobs      slots: tgt, warped, err [B,1,H,W], valid [B,1,H,W]   (loss_functions.py:181-188)
+ *   cc_pose_proj_levels       pose [B,R,6], K [B,9] -> P_all [L][R][B][12], level l with K rows 0,1 / kdiv_host[l]
+ *   cc_pose_grad_jobs         jobs (level-major, njobs = L*R) slot 0 = the gP partials of cc_inverse_warp_bwd_jobs -> gpose [B,R,6] */
+int cc_inverse_warp_fwd_jobs(const long* jobs, int njobs, int B, int C, int padding_border, int align_corners, void* stream);
+int cc_inverse_warp_bwd_jobs(const long* jobs, int njobs, int B, int C, int padding_border, int align_corners, void* stream);
+int cc_flow_warp_fwd_jobs(const long* jobs, int njobs, int B, int C, int padding_border, int align_corners, void* stream);
+int cc_flow_warp_bwd_jobs(const long* jobs, int njobs, int B, int C, int padding_border, int align_corners, void* stream);
+int cc_rigid_noocc_jobs(const long* jobs, int njobs, int B, void* stream);
+int cc_pose2flow_fwd_jobs(const long* jobs, int njobs, int B, int rewrite_oob, void* stream);
+int cc_ssim_photo_fwd_jobs(const long* jobs, int njobs, int B, int mask_b_complement, int want_grad, float wssim, float q,
+                           float lambda_oob, float* loss_accum, float* scale_out, float* nan_flag, const float* gauss13_host,
+                           void* stream);
+int cc_ssim_photo_bwd_jobs(const long* jobs, int njobs, int B, const float* gauss13_host, void* stream);
+int cc_ssim_err_fwd_jobs(const long* jobs, int njobs, int B, float wssim, const float* gauss13_host, void* stream);
+int cc_pose_proj_levels(const float* pose, const float* K, float* P_all, int L, int R, int B, const float* kdiv_host, void* stream);
+int cc_pose_grad_jobs(const long* jobs, int njobs, int L, int R, int B, const float* pose, const float* K, float* gpose,
+                      const float* kdiv_host, void* stream);
+
 /* ---------------------------------------------------------------- x2 bilinear up-sampling
  * F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) of the prediction maps, with the constant the callers
  * multiply in afterwards fused (models/DispResNet6.py:170-186 disp_up; models/back2future.py:196-285 `up_flow`,
