@@ -105,7 +105,24 @@ WORK = {   # entry point -> (kind, fn(args dict) -> algorithmic flops or bytes)
     "cc_ssim_photo_bwd": ("byte", lambda d: 84.0 * d["B"] * d["H"] * d["W"]),
     "cc_ssim_err_fwd": ("byte", lambda d: 32.0 * d["B"] * d["H"] * d["W"]),
     "cc_adam_step": ("byte", lambda d: 28.0 * d["n"]),
+    # job-table forms: one launch = every (scale, reference frame) term of a loss; bytes/pixel as above, summed over the jobs
+    "cc_inverse_warp_fwd_jobs": ("byte", lambda d: 28.0 * d["B"] * job_pixels(d)),
+    "cc_inverse_warp_bwd_jobs": ("byte", lambda d: 32.0 * d["B"] * job_pixels(d)),
+    "cc_flow_warp_fwd_jobs": ("byte", lambda d: 32.0 * d["B"] * job_pixels(d)),
+    "cc_flow_warp_bwd_jobs": ("byte", lambda d: 40.0 * d["B"] * job_pixels(d)),
+    "cc_pose2flow_fwd_jobs": ("byte", lambda d: 12.0 * d["B"] * job_pixels(d)),
+    "cc_ssim_photo_fwd_jobs": ("byte", lambda d: (32.0 + (52.0 if d["want_grad"] else 0.0)) * d["B"] * job_pixels(d)),
+    "cc_ssim_photo_bwd_jobs": ("byte", lambda d: 84.0 * d["B"] * job_pixels(d)),
+    "cc_ssim_err_fwd_jobs": ("byte", lambda d: 32.0 * d["B"] * job_pixels(d)),
 }
+
+
+def job_pixels(d):
+    """sum of H*W over the jobs of a *_jobs call (the host job table: njobs x {8 slots, H, W} longs)."""
+    import ctypes
+    n = d["njobs"]
+    arr = (ctypes.c_long * (10 * n)).from_address(d["jobs"])
+    return float(sum(arr[10 * j + 8] * arr[10 * j + 9] for j in range(n)))
 
 
 def kernel_of(eng, name, d):

@@ -5,9 +5,12 @@
 //   as the forward value is) and with deterministic two-stage reductions (no float atomics).
 // Replaces the per-scale Python loops of loss_functions.py:132-137,148-155,221-261,287-352.
 #include "cc_common.h"
+#include "jobs.h"
 #include "../../include/ccengine.h"
 
 namespace {
+
+using ccjobs::JobTab;
 
 // ------------------------------------------------------------------ pyramid
 // F.adaptive_avg_pool2d(img, (h, w)) (loss_functions.py:36-37,89-90,163-165,315): window
@@ -281,6 +284,173 @@ __global__ __launch_bounds__(256) void k_scale_by_scalar(const float* __restrict
     if (i < n) out[i] = a[i] * s[0];
 }
 
+// ------------------------------------------------------------------ job-table forms (all pyramid levels in one launch, jobs.h)
+#define CC_JOB_PIXEL(t, j, b, p, HW)                                        \
+    int first__;                                                            \
+    const int j = ccjobs::find(t, (int)blockIdx.x, first__);                \
+    const int HW = t.H[j] * t.W[j], nb__ = (HW + 255) >> 8;                 \
+    const int local__ = (int)blockIdx.x - first__;                          \
+    const int b = local__ / nb__, p = (local__ - b * nb__) * 256 + (int)threadIdx.x;
+
+// occlusion_masks per level: slots 0 flow_bw [B,2,H,W], 1 flow_fw, 2 out [B,1,H,W]
+__global__ __launch_bounds__(256) void k_flow_noocc_jobs(JobTab t) {
+    CC_JOB_PIXEL(t, j, b, p, HW)
+    if (p >= HW) return;
+    const float* fb = ccjobs::ptr<const float>(t, j, 0) + (size_t)b * 2 * HW + p;
+    const float* ff = ccjobs::ptr<const float>(t, j, 1) + (size_t)b * 2 * HW + p;
+    ccjobs::ptr<float>(t, j, 2)[(size_t)b * HW + p] = noocc(fb[0], fb[HW], ff[0], ff[HW]);
+}
+
+// consensus target per level: slots 0 err_cam_fwd, 1 err_cam_bwd, 2 err_flow_fwd, 3 valid_cam_fwd, 4 valid_cam_bwd, 5 target
+__global__ __launch_bounds__(256) void k_consensus_combine_jobs(JobTab t, float wrig) {
+    CC_JOB_PIXEL(t, j, b, p, HW)
+    if (p >= HW) return;
+    const size_t i = (size_t)b * HW + p;
+    const float vcf = ccjobs::ptr<const float>(t, j, 3)[i], vcb = ccjobs::ptr<const float>(t, j, 4)[i];
+    const float valid = 1.f - (1.f - vcf) * (1.f - vcb);
+    const float cam_err = fminf(ccjobs::ptr<const float>(t, j, 0)[i], ccjobs::ptr<const float>(t, j, 1)[i]) * valid;
+    ccjobs::ptr<float>(t, j, 5)[i] = (wrig * cam_err <= (ccjobs::ptr<const float>(t, j, 2)[i] + 1e-8f)) ? 1.f : 0.f;
+}
+
+// end of a photometric loss's gradient pass, per level: gdepth = sum over reference frames of the per-frame depth gradients
+// (reference order r = 0..R-1), gmask[:, c] *= scale[c] (the per-term normalisers known only after the reduction).
+// slots 0 gd_all [R][B][HW] (or 0), 1 gdepth [B][HW], 2 gmask [B][MC][HW] (or 0), 3 scales (MC floats)
+__global__ __launch_bounds__(256) void k_sum_refs_scale_jobs(JobTab t, int R, int MC) {
+    CC_JOB_PIXEL(t, j, b, p, HW)
+    if (p >= HW) return;
+    const float* gd = ccjobs::ptr<const float>(t, j, 0);
+    if (gd) {
+        float s = gd[(size_t)b * HW + p];
+        for (int r = 1; r < R; r++) s += gd[((size_t)r * t.B + b) * HW + p];
+        ccjobs::ptr<float>(t, j, 1)[(size_t)b * HW + p] = s;
+    }
+    float* gm = ccjobs::ptr<float>(t, j, 2);
+    if (gm) {
+        const float* sc = ccjobs::ptr<const float>(t, j, 3);
+        for (int c = 0; c < MC; c++) gm[((size_t)b * MC + c) * HW + p] *= sc[c];
+    }
+}
+
+// deterministic finalize shared by the per-level losses below: accum[0] += coef * sum(partials[0..n))  (one workgroup)
+// (the partials of all levels are contiguous, level after level, block after block)
+
+// edge-aware smoothness, all levels: slots 0 img level [B,3,H,W], 1 pred [B,C,H,W], 2 gpred (or 0), 3 partials of this job
+// table B = batch * C (one (image, channel) plane per "batch item")
+__global__ __launch_bounds__(256) void k_edge_smooth_jobs(JobTab t, int C, float gscale) {
+    __shared__ float red[4];
+    CC_JOB_PIXEL(t, j, bc, p, HW)
+    const int H = t.H[j], W = t.W[j], b = bc / C;
+    const float inv_nx = 1.f / ((float)t.B * (H - 1) * W), inv_ny = 1.f / ((float)t.B * H * (W - 1));
+    float part[1] = {0.f};
+    if (p < HW) {
+        const int y = p / W, x = p - y * W;
+        const float* im = ccjobs::ptr<const float>(t, j, 0) + (size_t)b * 3 * HW;
+        const float* pr = ccjobs::ptr<const float>(t, j, 1) + (size_t)bc * HW;
+        float* gpred = ccjobs::ptr<float>(t, j, 2);
+        const float v = pr[p];
+        float g = 0.f;
+        if (y + 1 < H) {
+            const float d = v - pr[p + W];
+            const float w = edge_w(im, HW, p, p + W);
+            part[0] += fabsf(d) * w * inv_nx;
+            g += sgn(d) * w * inv_nx;
+        }
+        if (y > 0) {
+            const float d = pr[p - W] - v;
+            g -= sgn(d) * edge_w(im, HW, p - W, p) * inv_nx;
+        }
+        if (x + 1 < W) {
+            const float d = v - pr[p + 1];
+            const float w = edge_w(im, HW, p, p + 1);
+            part[0] += fabsf(d) * w * inv_ny;
+            g += sgn(d) * w * inv_ny;
+        }
+        if (x > 0) {
+            const float d = pr[p - 1] - v;
+            g -= sgn(d) * edge_w(im, HW, p - 1, p) * inv_ny;
+        }
+        if (gpred) gpred[(size_t)bc * HW + p] = g * gscale;
+    }
+    cc::block_sum_256<1>(part, red);
+    if (threadIdx.x == 0) ccjobs::ptr<float>(t, j, 3)[local__] = part[0];
+}
+
+// explainability BCE, all levels: slots 0 mask (n = B*C*H*W elements: table B = batch * C), 1 gmask (or 0), 2 partials
+__global__ __launch_bounds__(256) void k_bce_ones_jobs(JobTab t, float gscale) {
+    __shared__ float red[4];
+    CC_JOB_PIXEL(t, j, bc, p, HW)
+    const float inv_n = 1.f / ((float)t.B * HW);
+    float part[1] = {0.f};
+    if (p < HW) {
+        const size_t i = (size_t)bc * HW + p;
+        const float m = ccjobs::ptr<const float>(t, j, 0)[i];
+        const float lg = fmaxf(logf(m), -100.f);
+        part[0] = -lg * inv_n;
+        float* gmask = ccjobs::ptr<float>(t, j, 1);
+        if (gmask) gmask[i] = ((m - 1.f) / fmaxf((1.f - m) * m, 1e-12f)) * inv_n * gscale;
+    }
+    cc::block_sum_256<1>(part, red);
+    if (threadIdx.x == 0) ccjobs::ptr<float>(t, j, 2)[local__] = part[0];
+}
+
+// consensus weighted BCE, all levels: slots 0 exp_mask [B,4,H,W], 1 census_bwd [B,2,H,W], 2 census_fwd, 3 tgt_bwd [B,1,H,W],
+// 4 tgt_fwd, 5 gmask (or 0), 6 partials
+__global__ __launch_bounds__(256) void k_consensus_bce_jobs(JobTab t, float thresh, float w0, float w1, float gscale) {
+    __shared__ float red[4];
+    CC_JOB_PIXEL(t, j, b, p, HW)
+    const float inv_n = 1.f / ((float)t.B * 4 * HW);
+    float part[1] = {0.f};
+    if (p < HW) {
+        const float* exp_mask = ccjobs::ptr<const float>(t, j, 0);
+        const float* census_bwd = ccjobs::ptr<const float>(t, j, 1);
+        const float* census_fwd = ccjobs::ptr<const float>(t, j, 2);
+        float* gmask = ccjobs::ptr<float>(t, j, 5);
+        const size_t f = (size_t)b * 2 * HW + p;
+        const float cb = (census_bwd[f] < thresh && census_bwd[f + HW] < thresh) ? 1.f : 0.f;
+        const float cf = (census_fwd[f] < thresh && census_fwd[f + HW] < thresh) ? 1.f : 0.f;
+        const float tb = 1.f - (1.f - cb) * (1.f - ccjobs::ptr<const float>(t, j, 3)[(size_t)b * HW + p]);
+        const float tf = 1.f - (1.f - cf) * (1.f - ccjobs::ptr<const float>(t, j, 4)[(size_t)b * HW + p]);
+        const float tg[4] = {tb, tb, tf, tf};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const size_t o = ((size_t)b * 4 + c) * HW + p;
+            const float e = exp_mask[o];
+            const float a1 = e + 1e-8f, a0 = (1.f - e) + 1e-8f;
+            part[0] -= (w1 * (tg[c] * logf(a1)) + w0 * ((1.f - tg[c]) * logf(a0))) * inv_n;
+            if (gmask) gmask[o] = -(w1 * tg[c] / a1 - w0 * (1.f - tg[c]) / a0) * inv_n * gscale;
+        }
+    }
+    cc::block_sum_256<1>(part, red);
+    if (threadIdx.x == 0) ccjobs::ptr<float>(t, j, 6)[local__] = part[0];
+}
+
+// small element-wise glue of train.py:458,475-476,488 over all pyramid levels in one launch (table B = planes per job):
+//   op 0: out = 1 / a                      slots a, out            (depth = 1 / disparity, :458)
+//   op 1: ga = -g * (y * y)                slots g, y, ga          (its backward; y = the forward result)
+//   op 2: out = |a - b|                    slots a, b, out         (rigidity masks |flow_cam - flow|, :475-476)
+//   op 3: out[b, c] = 1 - m[b, c0 + c]     slots m, out            (flow_exp_mask = 1 - exp_mask[:, 1:3], :488; planes = B * nc)
+//   op 4: gm[b, c] = -g[b, c - c0] inside [c0, c0 + nc), 0 outside   slots g, gm   (its backward; planes = B * MC)
+__global__ __launch_bounds__(256) void k_elementwise_jobs(JobTab t, int op, int c0, int nc, int MC) {
+    CC_JOB_PIXEL(t, j, q, p, HW)
+    if (p >= HW) return;
+    const size_t i = (size_t)q * HW + p;
+    if (op == 0) {
+        ccjobs::ptr<float>(t, j, 1)[i] = 1.0f / ccjobs::ptr<const float>(t, j, 0)[i];
+    } else if (op == 1) {
+        const float y = ccjobs::ptr<const float>(t, j, 1)[i];
+        ccjobs::ptr<float>(t, j, 2)[i] = -ccjobs::ptr<const float>(t, j, 0)[i] * (y * y);
+    } else if (op == 2) {
+        ccjobs::ptr<float>(t, j, 2)[i] = fabsf(ccjobs::ptr<const float>(t, j, 0)[i] - ccjobs::ptr<const float>(t, j, 1)[i]);
+    } else if (op == 3) {
+        const int b = q / nc, c = q - b * nc;
+        ccjobs::ptr<float>(t, j, 1)[i] = 1.0f - ccjobs::ptr<const float>(t, j, 0)[((size_t)b * MC + c0 + c) * HW + p];
+    } else {
+        const int b = q / MC, c = q - b * MC;
+        const bool in = (c >= c0) && (c < c0 + nc);
+        ccjobs::ptr<float>(t, j, 1)[i] = in ? -ccjobs::ptr<const float>(t, j, 0)[((size_t)b * nc + (c - c0)) * HW + p] : 0.f;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -403,6 +573,91 @@ int cc_consensus_bce_fwd_bwd(const float* exp_mask, const float* census_bwd, con
 int cc_scale_by_scalar(const float* a, const float* scalar_dev, float* out, int n, void* stream) {
     if (n <= 0) return CC_ERR_ARG;
     hipLaunchKernelGGL(k_scale_by_scalar, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, scalar_dev, out, n);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+/* ---- job-table forms (jobs: HOST array of njobs x 10 longs {slot0..7, H, W}; njobs <= 24; slots per kernel above).
+ * The *_fwd_bwd_jobs losses write one partial sum per block into the per-job partial areas, which the caller lays out
+ * back to back (job after job) starting at `partials`; one finalize launch adds their sum to loss_accum. */
+static int loss_jobs_tab(ccjobs::JobTab& t, const long* jobs, int njobs, int B) {
+    if (!jobs || njobs <= 0 || njobs > ccjobs::MAXJOBS || B <= 0) return -1;
+    return ccjobs::fill(t, jobs, njobs, B, ccjobs::pix_blocks);
+}
+
+int cc_flow_noocc_jobs(const long* jobs, int njobs, int B, void* stream) {
+    ccjobs::JobTab t;
+    const int nblk = loss_jobs_tab(t, jobs, njobs, B);
+    if (nblk <= 0) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_flow_noocc_jobs, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, t);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_consensus_target_jobs(const long* jobs, int njobs, int B, float wrig, void* stream) {
+    ccjobs::JobTab t;
+    const int nblk = loss_jobs_tab(t, jobs, njobs, B);
+    if (nblk <= 0) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_consensus_combine_jobs, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, t, wrig);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_sum_refs_scale_jobs(const long* jobs, int njobs, int B, int R, int MC, void* stream) {
+    ccjobs::JobTab t;
+    const int nblk = loss_jobs_tab(t, jobs, njobs, B);
+    if (nblk <= 0) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_sum_refs_scale_jobs, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, t, R, MC);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_elementwise_jobs(const long* jobs, int njobs, int planes, int op, int c0, int nc, int MC, void* stream) {
+    ccjobs::JobTab t;
+    const int nblk = loss_jobs_tab(t, jobs, njobs, planes);
+    if (nblk <= 0 || op < 0 || op > 4) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_elementwise_jobs, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, t, op, c0, nc, MC);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+size_t cc_loss_jobs_num_blocks(const long* jobs, int njobs, int planes) {
+    ccjobs::JobTab t;
+    const int nblk = loss_jobs_tab(t, jobs, njobs, planes);
+    return nblk > 0 ? (size_t)nblk : 0;
+}
+
+int cc_edge_smooth_fwd_bwd_jobs(const long* jobs, int njobs, int B, int C, float* partials, float* loss_accum, float gscale,
+                                void* stream) {
+    ccjobs::JobTab t;
+    const int nblk = loss_jobs_tab(t, jobs, njobs, B * C);
+    if (nblk <= 0 || C <= 0) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_edge_smooth_jobs, dim3((unsigned)nblk), dim3(256), 0, s, t, C, gscale);
+    hipLaunchKernelGGL(k_reduce_add, dim3(1), dim3(256), 0, s, (const float*)partials, nblk, 1.0f, loss_accum);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_bce_ones_fwd_bwd_jobs(const long* jobs, int njobs, int planes, float* partials, float* loss_accum, float gscale, void* stream) {
+    ccjobs::JobTab t;
+    const int nblk = loss_jobs_tab(t, jobs, njobs, planes);
+    if (nblk <= 0) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bce_ones_jobs, dim3((unsigned)nblk), dim3(256), 0, s, t, gscale);
+    hipLaunchKernelGGL(k_reduce_add, dim3(1), dim3(256), 0, s, (const float*)partials, nblk, 1.0f, loss_accum);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_consensus_bce_fwd_bwd_jobs(const long* jobs, int njobs, int B, float* partials, float* loss_accum, float thresh, float wbce,
+                                  float gscale, void* stream) {
+    ccjobs::JobTab t;
+    const int nblk = loss_jobs_tab(t, jobs, njobs, B);
+    if (nblk <= 0) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_consensus_bce_jobs, dim3((unsigned)nblk), dim3(256), 0, s, t, thresh, wbce, 1.f - wbce, gscale);
+    hipLaunchKernelGGL(k_reduce_add, dim3(1), dim3(256), 0, s, (const float*)partials, nblk, 1.0f, loss_accum);
     CC_CHECK_LAUNCH();
     return CC_OK;
 }

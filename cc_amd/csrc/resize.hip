@@ -16,12 +16,13 @@ __device__ __forceinline__ void up2_src(int o, int N, int& i0, int& i1, float& l
     l1 = s - (float)i0;
 }
 
-// one work-item per OUTPUT pixel quad (4 consecutive x): float4 stores
+// one work-item per group of VEC consecutive output pixels of a row (VEC = 4: float4 stores, even W; VEC = 2: any W)
+template <int VEC>
 __global__ __launch_bounds__(256) void k_upsample2x_fwd(const float* __restrict__ x, float* __restrict__ y, int C, int H, int W,
                                                         long x_bs, long y_bs, float scale, long total) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;        // over [n][c][oy][ox/4]
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;        // over [n][c][oy][ox/VEC]
     if (e >= total) return;
-    const int OW = 2 * W, OH = 2 * H, q4 = OW >> 2;
+    const int OW = 2 * W, OH = 2 * H, q4 = OW / VEC;
     const int oxq = (int)(e % q4);
     long r = e / q4;
     const int oy = (int)(r % OH);
@@ -32,17 +33,23 @@ __global__ __launch_bounds__(256) void k_upsample2x_fwd(const float* __restrict_
     up2_src(oy, H, y0, y1, ly);
     const float* __restrict__ r0 = x + (long)n * x_bs + ((long)c * H + y0) * W;
     const float* __restrict__ r1 = x + (long)n * x_bs + ((long)c * H + y1) * W;
-    float o[4];
+    float o[VEC];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < VEC; k++) {
         int x0, x1;
         float lx;
-        up2_src(4 * oxq + k, W, x0, x1, lx);
+        up2_src(VEC * oxq + k, W, x0, x1, lx);
         const float top = (1.f - lx) * r0[x0] + lx * r0[x1];
         const float bot = (1.f - lx) * r1[x0] + lx * r1[x1];
         o[k] = scale * ((1.f - ly) * top + ly * bot);
     }
-    *reinterpret_cast<float4*>(y + (long)n * y_bs + ((long)c * OH + oy) * OW + 4 * oxq) = make_float4(o[0], o[1], o[2], o[3]);
+    float* dst = y + (long)n * y_bs + ((long)c * OH + oy) * OW + VEC * oxq;
+    if (VEC == 4) {
+        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[VEC - 1]);
+    } else {
+        dst[0] = o[0];
+        dst[1] = o[1];
+    }
 }
 
 __device__ __forceinline__ float up2_w(int o, int i, int N) {
@@ -94,10 +101,16 @@ __global__ __launch_bounds__(256) void k_upsample2x_bwd(const float* __restrict_
 extern "C" {
 
 int cc_upsample2x_fwd(const float* x, float* y, int B, int C, int H, int W, long x_bs, long y_bs, float scale, void* stream) {
-    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (W & 1) || (y_bs & 3) || ((uintptr_t)y & 15)) return CC_ERR_ARG;
-    const long total = (long)B * C * (2 * H) * (W >> 1);
-    hipLaunchKernelGGL(k_upsample2x_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, C, H, W,
-                       x_bs, y_bs, scale, total);
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return CC_ERR_ARG;
+    if (!(W & 1) && !(y_bs & 3) && !((uintptr_t)y & 15)) {
+        const long total = (long)B * C * (2 * H) * (W >> 1);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_upsample2x_fwd<4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, x, y, C, H, W, x_bs, y_bs, scale, total);
+    } else {
+        const long total = (long)B * C * (2 * H) * W;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_upsample2x_fwd<2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, x, y, C, H, W, x_bs, y_bs, scale, total);
+    }
     CC_CHECK_LAUNCH();
     return CC_OK;
 }

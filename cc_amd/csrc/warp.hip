@@ -280,15 +280,16 @@ __device__ __forceinline__ void flow_coords(float x, float y, float u, float v, 
     }
 }
 
+// fs: constant the flow is multiplied by first (Back2Future warps with `up_flow * 0.625 ...` / its negation, back2future.py:196-285)
 template <bool AC, bool BORDER, bool FEATURE>
 __global__ __launch_bounds__(256) void k_flow_warp_fwd(const float* __restrict__ img, const float* __restrict__ flow,
-                                                       float* __restrict__ out, int C, int H, int W) {
+                                                       float* __restrict__ out, int C, int H, int W, float fs) {
     const int b = blockIdx.y, HW = H * W;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= HW) return;
     const int y = p / W, x = p - y * W;
     float xn, yn, dxn, dyn;
-    flow_coords<FEATURE>((float)x, (float)y, flow[((size_t)b * 2) * HW + p], flow[((size_t)b * 2 + 1) * HW + p], W, H, xn,
+    flow_coords<FEATURE>((float)x, (float)y, flow[((size_t)b * 2) * HW + p] * fs, flow[((size_t)b * 2 + 1) * HW + p] * fs, W, H, xn,
                          yn, dxn, dyn);
     Bilinear t;
     bilinear_setup<AC, BORDER>(xn, yn, W, H, t);
@@ -307,13 +308,13 @@ __global__ __launch_bounds__(256) void k_flow_warp_fwd(const float* __restrict__
 template <bool AC, bool BORDER, bool FEATURE>
 __global__ __launch_bounds__(256) void k_flow_warp_bwd(const float* __restrict__ gout, const float* __restrict__ img,
                                                        const float* __restrict__ flow, float* __restrict__ gflow,
-                                                       float* __restrict__ gimg, int C, int H, int W) {
+                                                       float* __restrict__ gimg, int C, int H, int W, float fs) {
     const int b = blockIdx.y, HW = H * W;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= HW) return;
     const int y = p / W, x = p - y * W;
     float xn, yn, dxn, dyn;
-    flow_coords<FEATURE>((float)x, (float)y, flow[((size_t)b * 2) * HW + p], flow[((size_t)b * 2 + 1) * HW + p], W, H, xn,
+    flow_coords<FEATURE>((float)x, (float)y, flow[((size_t)b * 2) * HW + p] * fs, flow[((size_t)b * 2 + 1) * HW + p] * fs, W, H, xn,
                          yn, dxn, dyn);
     Bilinear t;
     bilinear_setup<AC, BORDER>(xn, yn, W, H, t);
@@ -321,8 +322,8 @@ __global__ __launch_bounds__(256) void k_flow_warp_bwd(const float* __restrict__
     sample_grad(img + (size_t)b * C * HW, gout + (size_t)b * C * HW + p, C, HW, W, t,
                 gimg ? gimg + (size_t)b * C * HW : nullptr, gix, giy);
     if (gflow) {
-        gflow[((size_t)b * 2) * HW + p] = gix * t.gmx * dxn;
-        gflow[((size_t)b * 2 + 1) * HW + p] = giy * t.gmy * dyn;
+        gflow[((size_t)b * 2) * HW + p] = gix * t.gmx * dxn * fs;
+        gflow[((size_t)b * 2 + 1) * HW + p] = giy * t.gmy * dyn * fs;
     }
 }
 
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256) void k_flow_warp_bwd(const float* __restrict__
 template <bool AC>
 __global__ __launch_bounds__(256) void k_feature_warp_bwd4(const float* __restrict__ gout, const float* __restrict__ img,
                                                            const float* __restrict__ flow, float* __restrict__ gflow,
-                                                           float* __restrict__ gimg, int C, int H, int W) {
+                                                           float* __restrict__ gimg, int C, int H, int W, float fs) {
     __shared__ float part[4][64][2];
     const int b = blockIdx.y, HW = H * W;
     const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(256) void k_feature_warp_bwd4(const float* __restri
     if (p < HW) {
         const int y = p / W, x = p - y * W;
         float xn, yn;
-        flow_coords<true>((float)x, (float)y, flow[((size_t)b * 2) * HW + p], flow[((size_t)b * 2 + 1) * HW + p], W, H, xn, yn,
+        flow_coords<true>((float)x, (float)y, flow[((size_t)b * 2) * HW + p] * fs, flow[((size_t)b * 2 + 1) * HW + p] * fs, W, H, xn, yn,
                           dxn, dyn);
         Bilinear t;
         bilinear_setup<AC, true>(xn, yn, W, H, t);
@@ -360,8 +361,8 @@ __global__ __launch_bounds__(256) void k_feature_warp_bwd4(const float* __restri
     if (cg == 0 && p < HW && gflow) {
         const float sx = ((part[0][lane][0] + part[1][lane][0]) + part[2][lane][0]) + part[3][lane][0];
         const float sy = ((part[0][lane][1] + part[1][lane][1]) + part[2][lane][1]) + part[3][lane][1];
-        gflow[((size_t)b * 2) * HW + p] = sx * gmx * dxn;
-        gflow[((size_t)b * 2 + 1) * HW + p] = sy * gmy * dyn;
+        gflow[((size_t)b * 2) * HW + p] = sx * gmx * dxn * fs;
+        gflow[((size_t)b * 2 + 1) * HW + p] = sy * gmy * dyn * fs;
     }
 }
 
@@ -642,11 +643,11 @@ int cc_flow_warp_fwd(const float* img, const float* flow, float* out, int B, int
     hipStream_t s = (hipStream_t)stream;
     dim3 g = pix_grid(B, H, W);
     if (align_corners) {
-        if (padding_border) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_fwd<true, true, false>), g, dim3(256), 0, s, img, flow, out, C, H, W);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_fwd<true, false, false>), g, dim3(256), 0, s, img, flow, out, C, H, W);
+        if (padding_border) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_fwd<true, true, false>), g, dim3(256), 0, s, img, flow, out, C, H, W, 1.f);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_fwd<true, false, false>), g, dim3(256), 0, s, img, flow, out, C, H, W, 1.f);
     } else {
-        if (padding_border) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_fwd<false, true, false>), g, dim3(256), 0, s, img, flow, out, C, H, W);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_fwd<false, false, false>), g, dim3(256), 0, s, img, flow, out, C, H, W);
+        if (padding_border) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_fwd<false, true, false>), g, dim3(256), 0, s, img, flow, out, C, H, W, 1.f);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_fwd<false, false, false>), g, dim3(256), 0, s, img, flow, out, C, H, W, 1.f);
     }
     CC_CHECK_LAUNCH();
     return CC_OK;
@@ -658,11 +659,11 @@ int cc_flow_warp_bwd(const float* gout, const float* img, const float* flow, flo
     hipStream_t s = (hipStream_t)stream;
     dim3 g = pix_grid(B, H, W);
     if (align_corners) {
-        if (padding_border) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<true, true, false>), g, dim3(256), 0, s, gout, img, flow, gflow_or_null, gimg_or_null, C, H, W);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<true, false, false>), g, dim3(256), 0, s, gout, img, flow, gflow_or_null, gimg_or_null, C, H, W);
+        if (padding_border) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<true, true, false>), g, dim3(256), 0, s, gout, img, flow, gflow_or_null, gimg_or_null, C, H, W, 1.f);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<true, false, false>), g, dim3(256), 0, s, gout, img, flow, gflow_or_null, gimg_or_null, C, H, W, 1.f);
     } else {
-        if (padding_border) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<false, true, false>), g, dim3(256), 0, s, gout, img, flow, gflow_or_null, gimg_or_null, C, H, W);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<false, false, false>), g, dim3(256), 0, s, gout, img, flow, gflow_or_null, gimg_or_null, C, H, W);
+        if (padding_border) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<false, true, false>), g, dim3(256), 0, s, gout, img, flow, gflow_or_null, gimg_or_null, C, H, W, 1.f);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<false, false, false>), g, dim3(256), 0, s, gout, img, flow, gflow_or_null, gimg_or_null, C, H, W, 1.f);
     }
     CC_CHECK_LAUNCH();
     return CC_OK;
@@ -670,32 +671,32 @@ int cc_flow_warp_bwd(const float* gout, const float* img, const float* flow, flo
 
 // models/back2future.py:287-321 Model.warp (border padding, grid = 2(x+u)/max(W-1,1) - 1)
 int cc_feature_warp_fwd(const float* feat, const float* flow, float* out, int B, int C, int H, int W, int align_corners,
-                        void* stream) {
+                        float flow_scale, void* stream) {
     if (B <= 0 || C <= 0 || H < 1 || W < 1) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     dim3 g = pix_grid(B, H, W);
     if (C >= 16) g.z = 4;
-    if (align_corners) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_fwd<true, true, true>), g, dim3(256), 0, s, feat, flow, out, C, H, W);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_fwd<false, true, true>), g, dim3(256), 0, s, feat, flow, out, C, H, W);
+    if (align_corners) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_fwd<true, true, true>), g, dim3(256), 0, s, feat, flow, out, C, H, W, flow_scale);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_fwd<false, true, true>), g, dim3(256), 0, s, feat, flow, out, C, H, W, flow_scale);
     CC_CHECK_LAUNCH();
     return CC_OK;
 }
 
 // gfeat must be zero-filled by the caller (scatter-add with float atomics)
 int cc_feature_warp_bwd(const float* gout, const float* feat, const float* flow, float* gflow_or_null,
-                        float* gfeat_or_null, int B, int C, int H, int W, int align_corners, void* stream) {
+                        float* gfeat_or_null, int B, int C, int H, int W, int align_corners, float flow_scale, void* stream) {
     if (B <= 0 || C <= 0 || H < 1 || W < 1) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     dim3 g = pix_grid(B, H, W);
     if (C >= 16) {
         dim3 g4((unsigned)((H * W + 63) / 64), (unsigned)B);
-        if (align_corners) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feature_warp_bwd4<true>), g4, dim3(256), 0, s, gout, feat, flow, gflow_or_null, gfeat_or_null, C, H, W);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feature_warp_bwd4<false>), g4, dim3(256), 0, s, gout, feat, flow, gflow_or_null, gfeat_or_null, C, H, W);
+        if (align_corners) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feature_warp_bwd4<true>), g4, dim3(256), 0, s, gout, feat, flow, gflow_or_null, gfeat_or_null, C, H, W, flow_scale);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feature_warp_bwd4<false>), g4, dim3(256), 0, s, gout, feat, flow, gflow_or_null, gfeat_or_null, C, H, W, flow_scale);
         CC_CHECK_LAUNCH();
         return CC_OK;
     }
-    if (align_corners) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<true, true, true>), g, dim3(256), 0, s, gout, feat, flow, gflow_or_null, gfeat_or_null, C, H, W);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<false, true, true>), g, dim3(256), 0, s, gout, feat, flow, gflow_or_null, gfeat_or_null, C, H, W);
+    if (align_corners) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<true, true, true>), g, dim3(256), 0, s, gout, feat, flow, gflow_or_null, gfeat_or_null, C, H, W, flow_scale);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<false, true, true>), g, dim3(256), 0, s, gout, feat, flow, gflow_or_null, gfeat_or_null, C, H, W, flow_scale);
     CC_CHECK_LAUNCH();
     return CC_OK;
 }

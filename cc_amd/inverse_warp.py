@@ -148,10 +148,13 @@ class _Pose2FlowFn(torch.autograd.Function):
         engine().call("cc_pose2flow_fwd", depth, P, Kinv, flow, B, H, W, rewrite, STREAM)
         ctx.save_for_backward(depth, P, Kinv)
         ctx.rewrite = rewrite
+        ctx.set_materialize_grads(False)       # a consumer that returns no gradient (thresholds) must not cost a backward pass
         return flow
 
     @staticmethod
     def backward(ctx, gflow):
+        if gflow is None:
+            return None, None, None, None
         depth, P, Kinv = ctx.saved_tensors
         B, H, W = depth.shape
         E = engine()
@@ -164,12 +167,13 @@ class _Pose2FlowFn(torch.autograd.Function):
 
 class _FlowWarpFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, flow, border, ac, feature):
+    def forward(ctx, img, flow, border, ac, feature, fscale=1.0):
         img, flow = _f32c(img), _f32c(flow)
+        ctx.fscale = fscale
         B, C, H, W = img.shape
         out = torch.empty_like(img)
         if feature:
-            engine().call("cc_feature_warp_fwd", img, flow, out, B, C, H, W, ac, STREAM)
+            engine().call("cc_feature_warp_fwd", img, flow, out, B, C, H, W, ac, float(fscale), STREAM)
         else:
             engine().call("cc_flow_warp_fwd", img, flow, out, B, C, H, W, border, ac, STREAM)
         ctx.save_for_backward(img, flow)
@@ -184,10 +188,10 @@ class _FlowWarpFn(torch.autograd.Function):
         gflow = torch.empty_like(flow) if ctx.needs_input_grad[1] else None
         gimg = torch.zeros_like(img) if ctx.needs_input_grad[0] else None
         if feature:
-            engine().call("cc_feature_warp_bwd", _f32c(gout), img, flow, gflow, gimg, B, C, H, W, ac, STREAM)
+            engine().call("cc_feature_warp_bwd", _f32c(gout), img, flow, gflow, gimg, B, C, H, W, ac, float(ctx.fscale), STREAM)
         else:
             engine().call("cc_flow_warp_bwd", _f32c(gout), img, flow, gflow, gimg, B, C, H, W, border, ac, STREAM)
-        return gimg, gflow, None, None, None
+        return gimg, gflow, None, None, None, None
 
 
 def _border(padding_mode):
@@ -230,9 +234,9 @@ def flow_warp(img, flow, padding_mode='zeros', align_corners=None):
     return _FlowWarpFn.apply(img, flow, _border(padding_mode), _ac(align_corners), False)
 
 
-def feature_warp(x, flo, align_corners=None):
-    """models/back2future.py:287-321 Model.warp (border padding)."""
-    return _FlowWarpFn.apply(x, flo, 1, _ac(align_corners), True)
+def feature_warp(x, flo, align_corners=None, flow_scale=1.0):
+    """models/back2future.py:287-321 Model.warp (border padding) of x by flo * flow_scale."""
+    return _FlowWarpFn.apply(x, flo, 1, _ac(align_corners), True, float(flow_scale))
 
 
 def flow2oob(flow):

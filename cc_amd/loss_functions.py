@@ -68,6 +68,42 @@ def _empty(n, ref):
     return torch.empty(max(int(n), 1), device=ref.device, dtype=torch.float32)
 
 
+class _Jobs:
+    """Host-side job table of a *_jobs entry point: rows of 8 slots (tensors -> device addresses, ints, None) + (H, W)."""
+
+    def __init__(self):
+        self.rows = []
+
+    def add(self, slots, H, W):
+        self.rows.append((list(slots) + [None] * (8 - len(slots)), int(H), int(W)))
+
+    def __len__(self):
+        return len(self.rows)
+
+    def pack(self):
+        import ctypes
+        E = engine()
+        arr = (ctypes.c_long * (10 * len(self.rows)))()
+        for j, (slots, H, W) in enumerate(self.rows):
+            for k, v in enumerate(slots):
+                if v is None:
+                    arr[10 * j + k] = 0
+                elif torch.is_tensor(v):
+                    arr[10 * j + k] = E._ptr(v, "job", k)
+                else:
+                    arr[10 * j + k] = int(v)
+            arr[10 * j + 8], arr[10 * j + 9] = H, W
+        self._keep = arr
+        return ctypes.addressof(arr)
+
+
+def _off(t, nfloats):
+    """Device address of element `nfloats` of a contiguous fp32 tensor."""
+    return engine()._ptr(t, "job", 0) + 4 * int(nfloats)
+
+
+MAX_JOBS = 24
+
 _nan_flags = []
 
 
@@ -174,6 +210,120 @@ class _GradArena:
         return [self.view(i, out) for i in range(len(self.spans))]
 
 
+# ----------------------------------------------------------------------------- engine extensions: per-scale glue of train.py
+# (not part of the reference's module surface; cc_amd.trainer.cc_forward uses them in place of the per-scale Python list
+# comprehensions of train.py:458,470-471,475-476,488 -- same values, one launch for all scales)
+def _ew_jobs(op, rows, planes, c0=0, nc=0, MC=0):
+    jb = _Jobs()
+    for slots, h, w in rows:
+        jb.add(slots, h, w)
+    engine().call("cc_elementwise_jobs", jb.pack(), len(jb), planes, op, c0, nc, MC, STREAM)
+
+
+class _RecipLevelsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [_f32c(x) for x in xs]
+        ys = [torch.empty_like(x) for x in xs]
+        _ew_jobs(0, [([x, y], x.shape[2], x.shape[3]) for x, y in zip(xs, ys)], xs[0].shape[0] * xs[0].shape[1])
+        ctx.save_for_backward(*ys)
+        ctx.set_materialize_grads(False)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ys = ctx.saved_tensors
+        out = [None] * len(ys)
+        rows = []
+        for k, (g, y) in enumerate(zip(gs, ys)):
+            if g is not None:
+                out[k] = torch.empty_like(y)
+                rows.append(([_f32c(g), y, out[k]], y.shape[2], y.shape[3]))
+        if rows:
+            _ew_jobs(1, rows, ys[0].shape[0] * ys[0].shape[1])
+        return tuple(out)
+
+
+def reciprocal_levels(xs):
+    """[1 / x for x in xs] (train.py:458 depth = 1 / disparity) for same-(B, C) maps of all scales in one launch."""
+    xs = list(xs)
+    if len(xs) > MAX_JOBS or len({(x.shape[0], x.shape[1]) for x in xs}) != 1:
+        return [1 / x for x in xs]
+    return list(_RecipLevelsFn.apply(*xs))
+
+
+def abs_diff_levels(a_list, b_list):
+    """[(a - b).abs() ...] WITHOUT gradient (train.py:475-476: the rigidity masks only ever enter `< THRESH` comparisons)."""
+    with torch.no_grad():
+        a_list, b_list = [_f32c(a) for a in a_list], [_f32c(b) for b in b_list]
+        if len(a_list) > MAX_JOBS or len({(a.shape[0], a.shape[1]) for a in a_list}) != 1:
+            return [(a - b).abs() for a, b in zip(a_list, b_list)]
+        outs = [torch.empty_like(a) for a in a_list]
+        _ew_jobs(2, [([a, b, o], a.shape[2], a.shape[3]) for a, b, o in zip(a_list, b_list, outs)],
+                 a_list[0].shape[0] * a_list[0].shape[1])
+        return outs
+
+
+class _ComplementSliceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, c0, c1, *ms):
+        ms = [_f32c(m) for m in ms]
+        B, MC, nc = ms[0].shape[0], ms[0].shape[1], c1 - c0
+        outs = [torch.empty(B, nc, m.shape[2], m.shape[3], device=m.device, dtype=torch.float32) for m in ms]
+        _ew_jobs(3, [([m, o], m.shape[2], m.shape[3]) for m, o in zip(ms, outs)], B * nc, c0, nc, MC)
+        ctx.geom = (c0, nc, MC, B, [tuple(m.shape) for m in ms])
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        c0, nc, MC, B, shapes = ctx.geom
+        out = [None] * len(shapes)
+        rows = []
+        for k, g in enumerate(gs):
+            if g is not None:
+                out[k] = torch.empty(shapes[k], device=g.device, dtype=torch.float32)
+                rows.append(([_f32c(g), out[k]], shapes[k][2], shapes[k][3]))
+        if rows:
+            _ew_jobs(4, rows, B * MC, c0, nc, MC)
+        return (None, None) + tuple(out)
+
+
+def complement_slice_levels(masks, c0, c1):
+    """[1 - m[:, c0:c1] for m in masks] (train.py:488 flow_exp_mask) for all scales in one launch (and one for the backward)."""
+    masks = list(masks)
+    if len(masks) > MAX_JOBS or len({(m.shape[0], m.shape[1]) for m in masks}) != 1:
+        return [1 - m[:, c0:c1] for m in masks]
+    return list(_ComplementSliceFn.apply(int(c0), int(c1), *masks))
+
+
+def rigid_flows_levels(depths, pose, ref_ids, intrinsics, intrinsics_inv):
+    """[[pose2flow(d.squeeze(1), pose[:, r], K, Kinv) for d in depths] for r in ref_ids] WITHOUT gradient (train.py:470-471:
+    flows_cam_fwd / flows_cam_bwd feed thresholds and the non-differentiable consensus target only) -- one pose launch + one
+    launch for all scales and reference frames."""
+    import ctypes
+    E = engine()
+    with torch.no_grad():
+        S, R, B = len(depths), pose.shape[1], pose.shape[0]
+        if S * len(ref_ids) > MAX_JOBS:
+            return [[pose2flow(d.squeeze(1), pose[:, r], intrinsics, intrinsics_inv) for d in depths] for r in ref_ids]
+        one = (ctypes.c_float * 1)(1.0)
+        P = torch.empty(1, R, B, 12, device=pose.device, dtype=torch.float32)
+        Kinv_c = _f32c(intrinsics_inv)
+        E.call("cc_pose_proj_levels", _f32c(pose), _f32c(intrinsics), P, 1, R, B, ctypes.addressof(one), STREAM)
+        out, jb = [], _Jobs()
+        for r in ref_ids:
+            fl = []
+            for dpt in depths:
+                dd = _f32c(dpt.detach()[:, 0])
+                f = torch.empty(B, 2, dd.shape[1], dd.shape[2], device=pose.device, dtype=torch.float32)
+                jb.add([dd, P[0][r], Kinv_c, f], dd.shape[1], dd.shape[2])
+                fl.append(f)
+            out.append(fl)
+        E.call("cc_pose2flow_fwd_jobs", jb.pack(), len(jb), B, 0, STREAM)
+        return out
+
+
 # ----------------------------------------------------------------------------- small public helpers
 def spatial_normalize(disp):
     """loss_functions.py:13-16."""
@@ -247,6 +397,119 @@ def _photo_term(E, tgt_s, warped, mask_a, a_bs, mask_b, b_bs, gmask, gm_bs, want
     return adj, scale
 
 
+_colscale_cache = {}
+
+
+def _kinv_levels(Kinv_c, downs):
+    """intrinsics_inv[:, :, 0:2] * downscale for every level (loss_functions.py:92) in one launch -> [S,B,3,3]."""
+    key = (str(Kinv_c.device), tuple(downs))
+    cs = _colscale_cache.get(key)
+    if cs is None:
+        cs = torch.tensor([[d, d, 1.0] for d in downs], dtype=torch.float32).to(Kinv_c.device).view(len(downs), 1, 1, 3)
+        _colscale_cache[key] = cs
+    return (Kinv_c.unsqueeze(0) * cs).contiguous()
+
+
+def _carve(sizes, ref):
+    """One allocation, consecutive views of the given element counts."""
+    flat = torch.empty(max(sum(sizes), 1), device=ref.device, dtype=torch.float32)
+    out, off = [], 0
+    for n in sizes:
+        out.append(flat[off:off + n])
+        off += n
+    return out
+
+
+def _photo_rigid_jobs(ctx, cfg, tgt_img, intrinsics, intrinsics_inv, pose, refs, depths, masks, need):
+    """loss_functions.py:80-128 with every (scale, reference frame) term of a pass in ONE launch (job tables, csrc/jobs.h):
+    ~10 launches for the 24 terms (pose -> P, occlusion masks, warp, SSIM + robust-L1 + masks, finalize, SSIM adjoint, warp
+    backward, pose gradient, per-scale sums) instead of ~14 per term."""
+    import ctypes
+    E = engine()
+    R, S = cfg.n_refs, cfg.n_scales
+    B = tgt_img.shape[0]
+    want_grad = any(need)
+    loss_acc, nan_flag = _zeros1(tgt_img), _zeros1(tgt_img)
+    arena = _GradArena([pose] + list(refs) + list(depths) + list(masks), [need[4]] + [False] * R + list(need[5 + R:]))
+    hw = []
+    for s in range(S):
+        assert masks[s] is None or depths[s].size()[2:] == masks[s].size()[2:]
+        assert pose.size(1) == R
+        hw.append((depths[s].shape[2], depths[s].shape[3]))
+    px = [h * w for h, w in hw]
+    downs = [tgt_img.size(2) / h for h, _ in hw]
+    pose_c, K_c, Kinv_c = _f32c(pose.detach()), _f32c(intrinsics.detach()), _f32c(intrinsics_inv.detach())
+    kdiv = (ctypes.c_float * (S + 1))(*(downs + [1.0]))
+    P_all = torch.empty(S + 1, R, B, 12, device=tgt_img.device, dtype=torch.float32)
+    E.call("cc_pose_proj_levels", pose_c, K_c, P_all, S + 1, R, B, ctypes.addressof(kdiv), STREAM)
+    Kinv_all = _kinv_levels(Kinv_c, downs)
+    d = [_f32c(depths[s].detach()[:, 0]) for s in range(S)]
+    m = [None if masks[s] is None else _f32c(masks[s].detach()) for s in range(S)]
+    tgt_l = [pyramid_cache.get(tgt_img, h, w) for h, w in hw]
+    ref_l = [[pyramid_cache.get(refs[r], h, w) for h, w in hw] for r in range(R)]
+    # ---- occlusion masks of all scales (full-resolution K at every scale, Q4)
+    no = _carve([B * 4 * n for n in px], tgt_img)
+    jb = _Jobs()
+    for s in range(S):
+        jb.add([d[s], P_all[S], Kinv_c, no[s]], *hw[s])
+    E.call("cc_rigid_noocc_jobs", jb.pack(), len(jb), B, STREAM)
+    # ---- warps
+    warped = _carve([B * 3 * px[s] for s in range(S) for _ in range(R)], tgt_img)
+    jb = _Jobs()
+    for s in range(S):
+        for r in range(R):
+            jb.add([ref_l[r][s], d[s], P_all[s][r], Kinv_all[s], warped[s * R + r]], *hw[s])
+    E.call("cc_inverse_warp_fwd_jobs", jb.pack(), len(jb), B, 3, cfg.border, cfg.ac, STREAM)
+    # ---- fused SSIM + robust-L1 + masks, partial sums, adjoint maps; finalize (loss, per-term normalisers, NaN flag)
+    nblk = [E.call("cc_ssim_num_blocks", B, h, w) for h, w in hw]
+    partials = _carve([4 * nblk[s] for s in range(S) for _ in range(R)], tgt_img)
+    adj = _carve([4 * B * 3 * px[s] for s in range(S) for _ in range(R)], tgt_img) if want_grad else None
+    gm = [arena.view(1 + R + S + s) if (m[s] is not None and want_grad) else None for s in range(S)]
+    scales = torch.empty(S * R, device=tgt_img.device, dtype=torch.float32)
+    jb = _Jobs()
+    for s in range(S):
+        MC = 0 if m[s] is None else m[s].shape[1]
+        for r in range(R):
+            jb.add([tgt_l[s], warped[s * R + r], _off(no[s], r * px[s]),
+                    None if m[s] is None else _off(m[s], r * px[s]),
+                    None if gm[s] is None else _off(gm[s], r * px[s]),
+                    None if adj is None else adj[s * R + r], partials[s * R + r], 4 | (MC << 8) | (MC << 16)], *hw[s])
+    E.call("cc_ssim_photo_fwd_jobs", jb.pack(), len(jb), B, 0, 1 if want_grad else 0, float(cfg.wssim), float(cfg.qch),
+           float(cfg.lambda_oob), loss_acc, scales, nan_flag, gauss13_ptr(), STREAM)
+    if want_grad:
+        gw = _carve([B * 3 * px[s] for s in range(S) for _ in range(R)], tgt_img)
+        jb = _Jobs()
+        for s in range(S):
+            for r in range(R):
+                j = s * R + r
+                jb.add([adj[j], tgt_l[s], warped[j], _off(scales, j), gw[j]], *hw[s])
+        E.call("cc_ssim_photo_bwd_jobs", jb.pack(), len(jb), B, gauss13_ptr(), STREAM)
+        gd_all = _carve([R * B * px[s] for s in range(S)], tgt_img)
+        nb = [(n + 255) // 256 for n in px]
+        gpp = _carve([B * nb[s] * 12 for s in range(S) for _ in range(R)], tgt_img)
+        jb, jp = _Jobs(), _Jobs()
+        for s in range(S):
+            for r in range(R):
+                j = s * R + r
+                jb.add([gw[j], ref_l[r][s], d[s], P_all[s][r], Kinv_all[s], _off(gd_all[s], r * B * px[s]), gpp[j]], *hw[s])
+                jp.add([gpp[j]], *hw[s])
+        E.call("cc_inverse_warp_bwd_jobs", jb.pack(), len(jb), B, 3, cfg.border, cfg.ac, STREAM)
+        if need[4]:
+            E.call("cc_pose_grad_jobs", jp.pack(), len(jp), S, R, B, pose_c, K_c, arena.view(0), ctypes.addressof(kdiv), STREAM)
+        jb = _Jobs()
+        for s in range(S):
+            gdv = arena.view(1 + R + s)
+            if gdv is None and gm[s] is None:
+                continue
+            jb.add([gd_all[s] if gdv is not None else None, gdv, gm[s], _off(scales, s * R)], *hw[s])
+        if len(jb):
+            E.call("cc_sum_refs_scale_jobs", jb.pack(), len(jb), B, R, R, STREAM)
+    _register_nan_flag(nan_flag)
+    ctx.arena = arena
+    ctx.need = need
+    return loss_acc.reshape(())
+
+
 class _PhotoRigidFn(torch.autograd.Function):
     """loss_functions.py:80-128 over all scales and reference frames."""
 
@@ -259,6 +522,9 @@ class _PhotoRigidFn(torch.autograd.Function):
         E = engine()
         dev = tgt_img.device
         need = ctx.needs_input_grad
+        if (cfg.rotation_mode == 'euler' and R * S <= MAX_JOBS and R == 4
+                and all(mk is None or mk.shape[1] == R for mk in masks)):
+            return _photo_rigid_jobs(ctx, cfg, tgt_img, intrinsics, intrinsics_inv, pose, refs, depths, masks, need)
         want_grad = any(need)
         loss_acc, nan_flag = _zeros1(tgt_img), _zeros1(tgt_img)
         Kinv_full = _f32c(intrinsics_inv.detach())
@@ -360,6 +626,80 @@ def photometric_reconstruction_loss(tgt_img, ref_imgs, intrinsics, intrinsics_in
     return _PhotoRigidFn.apply(cfg, tgt_img, intrinsics, intrinsics_inv, pose, *ref_imgs, *depth, *explainability_mask)
 
 
+def _photo_flow_jobs(ctx, cfg, tgt_img, refs, flows, masks, need, rest):
+    """loss_functions.py:27-77, every (scale, reference frame) term of a pass in one launch (see _photo_rigid_jobs)."""
+    E = engine()
+    R, S = cfg.n_refs, cfg.n_scales
+    B = tgt_img.shape[0]
+    want_grad = any(need)
+    loss_acc, nan_flag = _zeros1(tgt_img), _zeros1(tgt_img)
+    arena = _GradArena(list(rest), [False] * R + list(need[2 + R:]))      # refs (no gradient), flows, masks
+    fl = [[_f32c(flows[i][s].detach()) for s in range(S)] for i in range(R)]
+    hw = [(fl[0][s].shape[2], fl[0][s].shape[3]) for s in range(S)]
+    px = [h * w for h, w in hw]
+    for s in range(S):
+        assert masks[s] is None or fl[0][s].size()[2:] == masks[s].size()[2:]
+    m = [None if masks[s] is None else _f32c(masks[s].detach()) for s in range(S)]
+    tgt_l = [pyramid_cache.get(tgt_img, h, w) for h, w in hw]
+    ref_l = [[pyramid_cache.get(refs[i], h, w) for h, w in hw] for i in range(R)]
+    no = _carve([B * n for n in px], tgt_img)
+    jb = _Jobs()
+    for s in range(S):
+        jb.add([fl[0][s], fl[1][s], no[s]], *hw[s])                        # occlusion_masks(flow[0], flow[1]), :70
+    E.call("cc_flow_noocc_jobs", jb.pack(), len(jb), B, STREAM)
+    warped = _carve([B * 3 * px[s] for s in range(S) for _ in range(R)], tgt_img)
+    jb = _Jobs()
+    for s in range(S):
+        for i in range(R):
+            jb.add([ref_l[i][s], fl[i][s], warped[s * R + i]], *hw[s])
+    E.call("cc_flow_warp_fwd_jobs", jb.pack(), len(jb), B, 3, 0, cfg.ac, STREAM)
+    nblk = [E.call("cc_ssim_num_blocks", B, h, w) for h, w in hw]
+    partials = _carve([4 * nblk[s] for s in range(S) for _ in range(R)], tgt_img)
+    adj = _carve([4 * B * 3 * px[s] for s in range(S) for _ in range(R)], tgt_img) if want_grad else None
+    gm = []
+    for s in range(S):
+        g = arena.view(R + R * S + s) if (m[s] is not None and want_grad) else None
+        if g is None and m[s] is not None and want_grad:
+            g = torch.empty_like(m[s])                 # the mask itself needs no gradient: scratch for the kernel
+        gm.append(g)
+    scales = torch.empty(S * R, device=tgt_img.device, dtype=torch.float32)
+    jb = _Jobs()
+    for s in range(S):
+        MC = 0 if m[s] is None else m[s].shape[1]
+        for i in range(R):
+            jb.add([tgt_l[s], warped[s * R + i], no[s], None if m[s] is None else _off(m[s], i * px[s]),
+                    None if gm[s] is None else _off(gm[s], i * px[s]), None if adj is None else adj[s * R + i],
+                    partials[s * R + i], 1 | (MC << 8) | (MC << 16)], *hw[s])
+    E.call("cc_ssim_photo_fwd_jobs", jb.pack(), len(jb), B, 0, 1 if want_grad else 0, float(cfg.wssim), float(cfg.qch),
+           float(cfg.lambda_oob), loss_acc, scales, nan_flag, gauss13_ptr(), STREAM)
+    if want_grad:
+        gw = _carve([B * 3 * px[s] for s in range(S) for _ in range(R)], tgt_img)
+        jb = _Jobs()
+        for s in range(S):
+            for i in range(R):
+                j = s * R + i
+                jb.add([adj[j], tgt_l[s], warped[j], _off(scales, j), gw[j]], *hw[s])
+        E.call("cc_ssim_photo_bwd_jobs", jb.pack(), len(jb), B, gauss13_ptr(), STREAM)
+        jb = _Jobs()
+        for s in range(S):
+            for i in range(R):
+                gf = arena.view(R + i * S + s)
+                if gf is not None:
+                    jb.add([gw[s * R + i], ref_l[i][s], fl[i][s], gf], *hw[s])
+        if len(jb):
+            E.call("cc_flow_warp_bwd_jobs", jb.pack(), len(jb), B, 3, 0, cfg.ac, STREAM)
+        jb = _Jobs()
+        for s in range(S):
+            if gm[s] is not None:
+                jb.add([None, None, gm[s], _off(scales, s * R)], *hw[s])
+        if len(jb):
+            E.call("cc_sum_refs_scale_jobs", jb.pack(), len(jb), B, R, R, STREAM)      # per-reference normalisers
+    _register_nan_flag(nan_flag)
+    ctx.arena = arena
+    ctx.need = need
+    return loss_acc.reshape(())
+
+
 class _PhotoFlowFn(torch.autograd.Function):
     """loss_functions.py:27-77 over all scales; flows = [flow list of ref 0, flow list of ref 1]."""
 
@@ -371,6 +711,8 @@ class _PhotoFlowFn(torch.autograd.Function):
         masks = rest[R + R * S:]
         E = engine()
         need = ctx.needs_input_grad
+        if R * S <= MAX_JOBS and all(mk is None or mk.shape[1] == R for mk in masks):
+            return _photo_flow_jobs(ctx, cfg, tgt_img, refs, flows, masks, need, rest)
         want_grad = any(need)
         loss_acc, nan_flag = _zeros1(tgt_img), _zeros1(tgt_img)
         arena = _GradArena(list(rest), [False] * R + list(need[2 + R:]))      # refs (no gradient), flows, masks
@@ -469,11 +811,48 @@ class _PerScaleFn(torch.autograd.Function):
         return (None,) + tuple(ctx.arena.scaled(gout))
 
 
+class _ScaleJobsFn(torch.autograd.Function):
+    """Sum over scales of a fused value+gradient kernel, ALL scales in one launch + one finalize (job tables).
+    build(preds_detached, grad_views, partial_offsets_fn) -> issues the call; see the users below."""
+
+    @staticmethod
+    def forward(ctx, issue, *preds):
+        need = ctx.needs_input_grad
+        loss_acc = _zeros1(preds[0])
+        arena = _GradArena(list(preds), list(need[1:]))
+        issue([_f32c(p.detach()) for p in preds], [arena.view(s) for s in range(len(preds))], loss_acc)
+        ctx.arena = arena
+        return loss_acc.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        return (None,) + tuple(ctx.arena.scaled(gout))
+
+
+def _partials_for(shapes, planes_of):
+    """Per-job partial-sum areas laid out back to back: -> (flat buffer allocator, [float offsets])."""
+    offs, tot = [], 0
+    for shp in shapes:
+        offs.append(tot)
+        tot += ((shp[2] * shp[3] + 255) // 256) * planes_of(shp)
+    return offs, tot
+
+
 def explainability_loss(mask):
     """loss_functions.py:148-155: sum over scales of BCE(mask, ones)."""
     if type(mask) not in [tuple, list]:
         mask = [mask]
     E = engine()
+    if len(mask) <= MAX_JOBS and len({(mk.shape[0], mk.shape[1]) for mk in mask}) == 1:
+        def issue(ps, gs, acc):
+            planes = ps[0].shape[0] * ps[0].shape[1]
+            offs, tot = _partials_for([p.shape for p in ps], lambda shp: planes)
+            part = _empty(tot, ps[0])
+            jb = _Jobs()
+            for p, g, o in zip(ps, gs, offs):
+                jb.add([p, g, _off(part, o)], p.shape[2], p.shape[3])
+            E.call("cc_bce_ones_fwd_bwd_jobs", jb.pack(), len(jb), planes, part, acc, 1.0, STREAM)
+        return _ScaleJobsFn.apply(issue, *mask)
 
     def launch(s, p, g, acc):
         n = p.numel()
@@ -484,6 +863,16 @@ def explainability_loss(mask):
 def edge_aware_smoothness_loss(img, pred_disp):
     """loss_functions.py:287-319."""
     E = engine()
+    if len(pred_disp) <= MAX_JOBS and len({(p.shape[0], p.shape[1]) for p in pred_disp}) == 1:
+        def issue(ps, gs, acc):
+            B, C = ps[0].shape[0], ps[0].shape[1]
+            offs, tot = _partials_for([p.shape for p in ps], lambda shp: B * C)
+            part = _empty(tot, ps[0])
+            jb = _Jobs()
+            for p, g, o in zip(ps, gs, offs):
+                jb.add([pyramid_cache.get(img, p.shape[2], p.shape[3]), p, g, _off(part, o)], p.shape[2], p.shape[3])
+            E.call("cc_edge_smooth_fwd_bwd_jobs", jb.pack(), len(jb), B, C, part, acc, 1.0, STREAM)
+        return _ScaleJobsFn.apply(issue, *pred_disp)
 
     def launch(s, p, g, acc):
         B, C, h, w = p.shape
@@ -513,6 +902,33 @@ def consensus_exp_masks(cam_flows_fwd, cam_flows_bwd, flows_fwd, flows_bwd, tgt_
     E = engine()
     ac = _ac(align_corners)
     out = []
+    S = len(cam_flows_fwd)
+    if 3 * S <= MAX_JOBS:
+        # the 3 warps + 3 error maps of every scale (18 of each per step) as one launch each, then all targets in one launch
+        with torch.no_grad():
+            B = tgt_img.shape[0]
+            cf = [_f32c(t) for t in cam_flows_fwd]
+            cb = [_f32c(t) for t in cam_flows_bwd]
+            ff = [_f32c(t) for t in flows_fwd]
+            hw = [(t.shape[2], t.shape[3]) for t in cf]
+            px = [h * w for h, w in hw]
+            tgt_l = [pyramid_cache.get(tgt_img, h, w) for h, w in hw]
+            rf = [pyramid_cache.get(ref_img_fwd, h, w) for h, w in hw]
+            rb = [pyramid_cache.get(ref_img_bwd, h, w) for h, w in hw]
+            warped = _carve([B * 3 * px[s] for s in range(S) for _ in range(3)], tgt_img)
+            ev = _carve([B * px[s] for s in range(S) for _ in range(6)], tgt_img)       # err x3, valid x3 per scale
+            jw, je, jc = _Jobs(), _Jobs(), _Jobs()
+            for s in range(S):
+                for k, (src, flow) in enumerate(((rf[s], cf[s]), (rb[s], cb[s]), (rf[s], ff[s]))):
+                    jw.add([src, flow, warped[3 * s + k]], *hw[s])
+                    je.add([tgt_l[s], warped[3 * s + k], ev[6 * s + k], ev[6 * s + 3 + k]], *hw[s])
+                target = torch.empty(B, 1, hw[s][0], hw[s][1], device=tgt_img.device, dtype=torch.float32)
+                jc.add([ev[6 * s], ev[6 * s + 1], ev[6 * s + 2], ev[6 * s + 3], ev[6 * s + 4], target], *hw[s])
+                out.append(target)
+            E.call("cc_flow_warp_fwd_jobs", jw.pack(), len(jw), B, 3, 0, ac, STREAM)
+            E.call("cc_ssim_err_fwd_jobs", je.pack(), len(je), B, float(wssim), gauss13_ptr(), STREAM)
+            E.call("cc_consensus_target_jobs", jc.pack(), len(jc), B, float(wrig), STREAM)
+        return out
     with torch.no_grad():
         for i in range(len(cam_flows_fwd)):
             cf, cb, ff = _f32c(cam_flows_fwd[i]), _f32c(cam_flows_bwd[i]), _f32c(flows_fwd[i])
@@ -560,6 +976,21 @@ class _ConsensusBCEFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         loss_acc = _zeros1(masks[0])
         arena = _GradArena(list(masks), list(need[1:1 + S]))
+        if S <= MAX_JOBS:
+            B = masks[0].shape[0]
+            offs, tot = _partials_for([mk.shape for mk in masks], lambda shp: B)
+            part = _empty(tot, masks[0])
+            jb = _Jobs()
+            for s in range(S):
+                e = _f32c(masks[s].detach())
+                assert e.shape[1] == 4
+                jb.add([e, _f32c(cb[s].detach()), _f32c(cf[s].detach()), _f32c(tb[s].detach()), _f32c(tf[s].detach()),
+                        arena.view(s), _off(part, offs[s])], e.shape[2], e.shape[3])
+            E.call("cc_consensus_bce_fwd_bwd_jobs", jb.pack(), len(jb), B, part, loss_acc, float(cfg.THRESH), float(cfg.wbce), 1.0,
+                   STREAM)
+            ctx.arena = arena
+            ctx.n_rest = len(rest)
+            return loss_acc.reshape(())
         for s in range(S):
             e = _f32c(masks[s].detach())
             B, C, h, w = e.shape

@@ -73,9 +73,9 @@ class Model(nn.Module):
         """back2future.py:118-132: [-1,1] -> ImageNet-normalised, on copies."""
         return [((im * 0.5 + 0.5) - self._im_mean) / self._im_std for im in ims]
 
-    def warp(self, x, flo):
-        """back2future.py:287-321."""
-        return feature_warp(x, flo)
+    def warp(self, x, flo, flow_scale=1.0):
+        """back2future.py:287-321 (flow_scale: the constant the reference multiplies into the flow before the call)."""
+        return feature_warp(x, flo, flow_scale=flow_scale)
 
     def _decoders(self, decs, ins):
         """The 6-layer decoder stacks of one pyramid level (decoder_fwd / decoder_bwd [/ decoder_occ]) layer by layer as
@@ -135,8 +135,8 @@ class Model(nn.Module):
                 occ[lvl] = torch.softmax(outs[2], dim=1)
             if lvl > 2:
                 s = self.WARP_SCALE[lvl]
-                bw = self.warp(feats[(lvl - 1, "b")], s * up_f[lvl])
-                cw = self.warp(feats[(lvl - 1, "c")], -s * up_f[lvl])      # the FORWARD flow for both (Q9)
+                bw = self.warp(feats[(lvl - 1, "b")], up_f[lvl], s)
+                cw = self.warp(feats[(lvl - 1, "c")], up_f[lvl], -s)       # the FORWARD flow for both (Q9)
         ff = [up(up_f[l], self.FULL_SCALE[l]) for l in range(2, 7)]         # scale fused into the up-sampling launch
         fb = [up(up_b[l], -self.FULL_SCALE[l]) for l in range(2, 7)]
         oc = None if self.elide_occ else [F.interpolate(occ[l], scale_factor=4) for l in range(2, 7)]

@@ -474,8 +474,6 @@ class _Up2xFn(torch.autograd.Function):
 
 def upsample_bilinear2x(x, scale=1.0):
     """scale * F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False) in one launch (csrc/resize.hip)."""
-    if x.shape[3] % 2:
-        return scale * F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
     return _Up2xFn.apply(x, float(scale))
 
 

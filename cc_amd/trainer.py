@@ -72,7 +72,7 @@ def cc_forward(nets, batch, cfg, keep=False, cut=None):
         return outs
 
     disparities = _cut("dp", list(disp_net(tgt)))                                      # :454
-    depth = [1 / d for d in disparities]                                               # :458
+    depth = LF.reciprocal_levels(disparities)                                          # :458  [1 / d for d in disparities]
     pose = _cut("dp", [pose_net(tgt, refs)])[0]                                        # :459
     out = {}
     if mask_net is None or flow_net is None:                                           # BASELINE config 2
@@ -86,13 +86,12 @@ def cc_forward(nets, batch, cfg, keep=False, cut=None):
     exp_mask = _cut("mf", list(mask_net(tgt, refs)))                                   # :460
     flow_fwd, flow_bwd, _ = flow_net(tgt, refs[1:3])                                   # :463
     flow_fwd, flow_bwd = _cut("mf", list(flow_fwd)), _cut("mf", list(flow_bwd))
-    cam_fwd = [pose2flow(d.squeeze(1), pose[:, 2], K, Kinv) for d in depth]            # :470
-    cam_bwd = [pose2flow(d.squeeze(1), pose[:, 1], K, Kinv) for d in depth]            # :471
+    cam_fwd, cam_bwd = LF.rigid_flows_levels(depth, pose, (2, 1), K, Kinv)             # :470-471  pose2flow per scale
     target = LF.consensus_exp_masks(cam_fwd, cam_bwd, flow_fwd, flow_bwd, tgt, refs[2], refs[1],
                                     wssim=cfg.wssim, wrig=cfg.wrig, ws=cfg.w3)         # :473
-    rig_fwd = [(a - b).abs() for a, b in zip(cam_fwd, flow_fwd)]                       # :475
-    rig_bwd = [(a - b).abs() for a, b in zip(cam_bwd, flow_bwd)]                       # :476
-    flow_exp_mask = [1 - m[:, 1:3] for m in exp_mask]                                  # :488
+    rig_fwd = LF.abs_diff_levels(cam_fwd, flow_fwd)                                    # :475  (a - b).abs(), thresholded only
+    rig_bwd = LF.abs_diff_levels(cam_bwd, flow_bwd)                                    # :476
+    flow_exp_mask = LF.complement_slice_levels(exp_mask, 1, 3)                         # :488  1 - m[:, 1:3]
     l1 = LF.photometric_reconstruction_loss(tgt, refs, K, Kinv, depth, exp_mask, pose,
                                             lambda_oob=cfg.lambda_oob, qch=cfg.qch, wssim=cfg.wssim)   # :490
     l2 = LF.explainability_loss(exp_mask) if cfg.w2 > 0 else 0                         # :492-495

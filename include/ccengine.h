@@ -58,11 +58,12 @@ int cc_flow_warp_bwd(const float* gout, const float* img, const float* flow, flo
                      void* stream);
 
 /* models/back2future.py:287-321 Model.warp: border-padded feature warp, grads to features
- * (atomics, gfeat zero-filled by the caller) and flow. */
+ * (atomics, gfeat zero-filled by the caller) and flow.  flow_scale: constant multiplied into the flow first (the callers'
+ * `up_flow * 0.625` ... `* 5.0` and their negations, back2future.py:196-285, folded in). */
 int cc_feature_warp_fwd(const float* feat, const float* flow, float* out, int B, int C, int H, int W,
-                        int align_corners, void* stream);
+                        int align_corners, float flow_scale, void* stream);
 int cc_feature_warp_bwd(const float* gout, const float* feat, const float* flow, float* gflow_or_null,
-                        float* gfeat_or_null, int B, int C, int H, int W, int align_corners, void* stream);
+                        float* gfeat_or_null, int B, int C, int H, int W, int align_corners, float flow_scale, void* stream);
 
 /* inverse_warp.py:82-119,146-162,214,278 (+ loss_functions.py:91): P[n] = K_s[n] . [Rx.Ry.Rz | t] for pose[n] =
  * (tx,ty,tz,rx,ry,rz) at pose + n*pose_stride, K_s = K with rows 0,1 divided by k_div (the pyramid downscale).
@@ -297,6 +298,29 @@ int cc_ssim_photo_fwd_jobs(const long* jobs, int njobs, int B, int mask_b_comple
                            void* stream);
 int cc_ssim_photo_bwd_jobs(const long* jobs, int njobs, int B, const float* gauss13_host, void* stream);
 int cc_ssim_err_fwd_jobs(const long* jobs, int njobs, int B, float wssim, const float* gauss13_host, void* stream);
+/*   cc_flow_noocc_jobs        slots: flow_bw, flow_fw, out [B,1,H,W]              (loss_functions.py:343-352 per scale)
+ *   cc_consensus_target_jobs  slots: err_cam_fwd, err_cam_bwd, err_flow_fwd, valid_cam_fwd, valid_cam_bwd, target (:189-193)
+ *   cc_sum_refs_scale_jobs    slots: gd_all [R][B][HW] (or 0), gdepth [B][HW], gmask [B][MC][HW] (or 0), scales (MC floats):
+ *                             gdepth = sum_r gd_all[r]; gmask[:, c] *= scales[c]
+ *   cc_edge_smooth_fwd_bwd_jobs  slots: img level, pred [B,C,H,W], gpred (or 0), this job's partials  (:287-319, all scales)
+ *   cc_bce_ones_fwd_bwd_jobs     slots: mask, gmask (or 0), partials; planes = B * C                  (:148-155)
+ *   cc_consensus_bce_fwd_bwd_jobs slots: exp_mask, census_bwd, census_fwd, tgt_bwd, tgt_fwd, gmask (or 0), partials (:221-261)
+ *   The three losses expect the per-job partial areas back to back starting at `partials` (cc_loss_jobs_num_blocks floats in
+ *   total for `planes` planes per job) and add the sum to loss_accum in one finalize launch. */
+/*   cc_elementwise_jobs       the element-wise glue of train.py:458,475-476,488 over all scales (planes per job):
+ *                             op 0 out = 1/a (slots a, out); 1 ga = -g*y*y (g, y, ga); 2 out = |a-b| (a, b, out);
+ *                             3 out[b,c] = 1 - m[b,c0+c] (m, out; planes = B*nc); 4 gm[b,c] = -g[b,c-c0] in [c0,c0+nc) else 0
+ *                             (g, gm; planes = B*MC) */
+int cc_elementwise_jobs(const long* jobs, int njobs, int planes, int op, int c0, int nc, int MC, void* stream);
+int cc_flow_noocc_jobs(const long* jobs, int njobs, int B, void* stream);
+int cc_consensus_target_jobs(const long* jobs, int njobs, int B, float wrig, void* stream);
+int cc_sum_refs_scale_jobs(const long* jobs, int njobs, int B, int R, int MC, void* stream);
+size_t cc_loss_jobs_num_blocks(const long* jobs, int njobs, int planes);
+int cc_edge_smooth_fwd_bwd_jobs(const long* jobs, int njobs, int B, int C, float* partials, float* loss_accum, float gscale,
+                                void* stream);
+int cc_bce_ones_fwd_bwd_jobs(const long* jobs, int njobs, int planes, float* partials, float* loss_accum, float gscale, void* stream);
+int cc_consensus_bce_fwd_bwd_jobs(const long* jobs, int njobs, int B, float* partials, float* loss_accum, float thresh, float wbce,
+                                  float gscale, void* stream);
 int cc_pose_proj_levels(const float* pose, const float* K, float* P_all, int L, int R, int B, const float* kdiv_host, void* stream);
 int cc_pose_grad_jobs(const long* jobs, int njobs, int L, int R, int B, const float* pose, const float* K, float* gpose,
                       const float* kdiv_host, void* stream);

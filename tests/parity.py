@@ -533,7 +533,7 @@ def check_corr(dev, cases=((2, 8, 6, 12), (1, 5, 7, 13), (2, 12, 5, 8), (1, 33, 
         assert max(rel(x, y) for x, y in zip(g1, g0)) < 5e-6, ("pair grads", (B, C, H, W), [rel(x, y) for x, y in zip(g1, g0)])
 
 
-def check_upsample2x(dev, cases=((2, 1, 5, 8, 1.0), (1, 2, 3, 6, -0.625), (2, 2, 16, 26, 20.0), (1, 1, 1, 2, 1.0))):
+def check_upsample2x(dev, cases=((2, 1, 5, 8, 1.0), (1, 2, 3, 6, -0.625), (2, 2, 16, 26, 20.0), (1, 1, 1, 2, 1.0), (2, 2, 4, 13, 0.625), (1, 1, 3, 1, 1.0))):
     """scale * F.interpolate(x, scale_factor=2, 'bilinear', align_corners=False) (csrc/resize.hip) and its adjoint vs ATen."""
     import torch.nn.functional as F
     from cc_amd import ops
