@@ -29,8 +29,14 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-inline int pick_bm_fwd(int M) { return M > 64 ? 128 : (M > 32 ? 64 : 32); }
+// BM = 16 (layers with <= 16 output channels: the full-resolution ends of the nets, prediction heads, their data-gradients):
+// v_mfma_f32_16x16x4_f32 tiles, so that no MFMA row is spent on channels that do not exist (a 32-row tile wastes half)
+inline int pick_bm_fwd(int M) {
+    static const int no16 = []() { const char* v = getenv("CC_CONV_NO_BM16"); return (v && v[0] == '1') ? 1 : 0; }();
+    return M > 64 ? 128 : (M > 32 ? 64 : ((M > 16 || no16) ? 32 : 16));
+}
 
 constexpr int BN = 128;   // pixels per workgroup tile
 constexpr int BK = 16;    // reduction chunk
@@ -394,7 +400,7 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
 #pragma unroll
                 for (int q = 0; q < (N4 + 255) / 256; q++) {
                     const int w4 = q * 256 + wid * 64;         // first float4 of this wave (uniform)
-                    if (w4 < N4) {
+                    if (w4 < N4 && (N4 % 64 == 0 || w4 + lane < N4)) {        // BM = 16, CK = 8: half a wave (EXEC-masked DMA)
                         const int f = 4 * (w4 + lane);
                         const int kk = f / BM, mm = f - kk * BM;
                         __builtin_amdgcn_global_load_lds(CC_GLOBAL_PTR(base + (long)kk * g.Mpad + mm), CC_LDS_PTR(dst + 4 * w4), 16, 0, 0);
@@ -411,6 +417,7 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
         for (int b = 0; b < TN; b++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+    f32x4 acc16[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // BM == 16 only
 
     if (c_beg < c_end) {
         load_patch(c_beg, c_beg & 1);
@@ -431,6 +438,27 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
                     if (tap0 + tt < T) {
                         const float* Ab = As + ((s & 1) * TPS + tt) * CK * BM;
                         const int tapoff = (g.dy_base + ti * g.dstep) * g.PWr + (g.dx_base + tj * g.dstep) + g.shift;
+                        if constexpr (BM == 16) {
+                            // 16x16x4: lane (i = lane & 15, k = lane >> 4) feeds A[m = i][k] and B[k][pixel = i]; two 16-pixel
+                            // halves of the wave's lattice row -> two independent accumulators (40-cycle dependent latency)
+                            const int l15 = lane & 15, l4 = lane >> 4;
+                            const float* Pl = Pb + l4 * g.PS + (g.si * row0) * g.PWr + g.si * l15 + tapoff;
+                            const float* Al = Ab + l4 * BM + l15;
+                            float af[CK / 4], bf[CK / 4][2];
+#pragma unroll
+                            for (int ks = 0; ks < CK / 4; ks++) {
+                                af[ks] = Al[(4 * ks) * BM];
+                                bf[ks][0] = Pl[(4 * ks) * g.PS];
+                                bf[ks][1] = Pl[(4 * ks) * g.PS + g.si * 16];
+                            }
+#pragma unroll
+                            for (int ks = 0; ks < CK / 4; ks++) {
+                                acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks], bf[ks][0], acc16[0], 0, 0, 0);
+                                acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks], bf[ks][1], acc16[1], 0, 0, 0);
+                            }
+                            if (++tj == g.St) { tj = 0; ti++; }
+                            continue;
+                        }
                         const float* Pl = Pb + lk * g.PS + (g.si * row0) * g.PWr + g.si * l31 + tapoff;
                         const float* Al = Ab + lk * BM + wm * WM + l31;
                         // all fragments of a tap are fetched up front (2*(TM+TN)*CK/2 VGPRs): one exposed LDS latency per
@@ -460,8 +488,34 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
         }
     }
 
-    // ---- epilogue: D col = lane&31 -> tx, row -> channel
     const int y_cs = g.OH * g.OW;
+    if constexpr (BM == 16) {
+        // D col = lane & 15 -> pixel of the half, row = 4 * (lane >> 4) + r -> channel
+        const int ty = ty0 + row0;
+        const int HWt = g.OHt * g.OWt;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int tx = tx0 + 16 * h + (lane & 15);
+            if (ty >= g.OHt || tx >= g.OWt) continue;
+            const long pix = (long)(g.oy0 + g.so * ty) * g.OW + (g.ox0 + g.so * tx);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = m0 + 4 * (lane >> 4) + r;
+                if (m >= g.M) continue;
+                if (SPLIT == 1 || (SPLIT == 2 && g.nsplit > 1)) {
+                    g.part[(long)blockIdx.z * g.part_stride + ((long)n * g.M + m) * HWt + (long)ty * g.OWt + tx] = acc16[h][r];
+                } else {
+                    float v = acc16[h][r];
+                    if (g.bias) v += g.bias[m];
+                    const long o = (long)n * g.y_bs + pix + (long)m * y_cs;
+                    const bool hr = g.res != nullptr;
+                    g.y[o] = conv_tail(v, hr, hr ? g.res[(long)n * g.res_bs + pix + (long)m * y_cs] : 0.f, g.res_mul, g.act, g.act_a, g.act_b);
+                }
+            }
+        }
+        return;
+    }
+    // ---- epilogue: D col = lane&31 -> tx, row -> channel
     const int tx = tx0 + l31;
 #pragma unroll
     for (int b = 0; b < TN; b++) {
@@ -1345,20 +1399,24 @@ inline void dispatch_patch(int bm, int ck, int tps, const ARGS& c, dim3 grid, si
         if (ck == 16) {
             if (bm == 128) launch_patch<128, 16, 3>(c, grid, smem, s);
             else if (bm == 64) launch_patch<64, 16, 3>(c, grid, smem, s);
-            else launch_patch<32, 16, 3>(c, grid, smem, s);
+            else if (bm == 32) launch_patch<32, 16, 3>(c, grid, smem, s);
+            else launch_patch<16, 16, 3>(c, grid, smem, s);
         } else {
             if (bm == 128) launch_patch<128, 8, 3>(c, grid, smem, s);
             else if (bm == 64) launch_patch<64, 8, 3>(c, grid, smem, s);
-            else launch_patch<32, 8, 3>(c, grid, smem, s);
+            else if (bm == 32) launch_patch<32, 8, 3>(c, grid, smem, s);
+            else launch_patch<16, 8, 3>(c, grid, smem, s);
         }
     } else if (ck == 16) {
         if (bm == 128) launch_patch<128, 16, 1>(c, grid, smem, s);
         else if (bm == 64) launch_patch<64, 16, 1>(c, grid, smem, s);
-        else launch_patch<32, 16, 1>(c, grid, smem, s);
+        else if (bm == 32) launch_patch<32, 16, 1>(c, grid, smem, s);
+        else launch_patch<16, 16, 1>(c, grid, smem, s);
     } else {
         if (bm == 128) launch_patch<128, 8, 1>(c, grid, smem, s);
         else if (bm == 64) launch_patch<64, 8, 1>(c, grid, smem, s);
-        else launch_patch<32, 8, 1>(c, grid, smem, s);
+        else if (bm == 32) launch_patch<32, 8, 1>(c, grid, smem, s);
+        else launch_patch<16, 8, 1>(c, grid, smem, s);
     }
 }
 

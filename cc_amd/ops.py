@@ -109,6 +109,43 @@ def _sink(p):
     return grad_sinks.get(p.data_ptr()) if grad_sinks else None
 
 
+class _WgradQueue:
+    """Weight gradients of same-shaped layers (the four 3x3 convolutions of a DispResNet6 stage, ...) are independent of the
+    rest of the backward pass once their operands exist: when the trainer enables the queue, a layer's weight-gradient call
+    is parked (operands kept alive) and launched together with its shape-mates as ONE cc_conv2d_wgrad_group launch (+ one
+    reduction) -- more workgroups per launch, fewer partial slabs -- when 4 have gathered or at the end of the backward stage.
+    Only for gradients that are accumulated into the optimizer's flat bucket (nothing is returned to autograd)."""
+    GROUP = 4
+
+    def __init__(self):
+        self.enabled = False
+        self.pending = {}
+
+    def push(self, key, a, x, gw):
+        q = self.pending.setdefault(key, [])
+        q.append((a, x, gw))
+        if len(q) >= self.GROUP:
+            self._launch(key)
+
+    def _launch(self, key):
+        q = self.pending.pop(key, None)
+        if not q:
+            return
+        B, M, AH, AW, Cin, IH, IW, R, S, si, pad, o_sm, o_sc = key
+        E = engine()
+        per = E.call("cc_conv2d_wgrad_ws_bytes", B, M, AH, AW, Cin, R, S, si)
+        a1, a2, a3 = _parr([t[0] for t in q]), _parr([t[1] for t in q]), _parr([t[2] for t in q])
+        E.call("cc_conv2d_wgrad_group", len(q), _addr(a1), _addr(a2), _addr(a3), _ws(per * len(q), q[0][0]), B, M, AH, AW, M * AH * AW,
+               Cin, IH, IW, Cin * IH * IW, R, S, si, pad, o_sm, o_sc, 1, STREAM)
+
+    def flush(self):
+        for key in list(self.pending):
+            self._launch(key)
+
+
+wgrad_queue = _WgradQueue()
+
+
 # ----------------------------------------------------------------------------- convolution
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
@@ -172,12 +209,15 @@ class _Conv2dFn(torch.autograd.Function):
                        Cin * IH * IW, Cin * R * S, R * S, 0, 1.0, 0.0, STREAM)
         if need[1]:
             wsink = _sink(w)
-            gw = wsink if wsink is not None else torch.empty_like(w)
-            ws = _ws(E.call("cc_conv2d_wgrad_ws_bytes", B, Cout, OH, OW, Cin, R, S, stride), x)
-            E.call("cc_conv2d_wgrad", gy, x, gw, ws, B, Cout, OH, OW, Cout * OH * OW, Cin, IH, IW, Cin * IH * IW, R, S,
-                   stride, pad, Cin * R * S, R * S, int(wsink is not None), STREAM)
-            if wsink is not None:
-                gw = None
+            if wsink is not None and wgrad_queue.enabled:
+                wgrad_queue.push((B, Cout, OH, OW, Cin, IH, IW, R, S, stride, pad, Cin * R * S, R * S), gy, x, wsink)
+            else:
+                gw = wsink if wsink is not None else torch.empty_like(w)
+                ws = _ws(E.call("cc_conv2d_wgrad_ws_bytes", B, Cout, OH, OW, Cin, R, S, stride), x)
+                E.call("cc_conv2d_wgrad", gy, x, gw, ws, B, Cout, OH, OW, Cout * OH * OW, Cin, IH, IW, Cin * IH * IW, R, S,
+                       stride, pad, Cin * R * S, R * S, int(wsink is not None), STREAM)
+                if wsink is not None:
+                    gw = None
         gres = gy if (has_res and need[3]) else None
         return gx, gw, gbias, gres, None, None, None, None, None, None, None, None
 

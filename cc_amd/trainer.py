@@ -236,16 +236,21 @@ class CCTrainer:
         ndp = len(cut.get("dp", []))
         dp = [(t, gt) for (t, _), gt in zip(pairs[:ndp], g[:ndp]) if gt is not None]
         mf = [(t, gt) for (t, _), gt in zip(pairs[ndp:], g[ndp:]) if gt is not None]
+        ops.wgrad_queue.enabled = os.environ.get("CC_NO_WGRAD_QUEUE", "0") != "1"        # A/B switch (tools/)
         if dp:
             torch.autograd.backward([t for t, _ in dp], [gt for _, gt in dp])
+        ops.wgrad_queue.flush()              # the segment's gradients are complete before its all-reduce is issued
         losses = {k: v.detach() for k, v in out.items() if torch.is_tensor(v) and k.startswith("loss")}
         return losses, mf
 
     def _stage_b(self, mf):
         if mf:
             torch.autograd.backward([t for t, _ in mf], [gt for _, gt in mf])
+        ops.wgrad_queue.flush()
 
     def _stage_end(self):
+        ops.wgrad_queue.flush()
+        ops.wgrad_queue.enabled = False
         LF.scalar_pool.end()
         ops.grad_sinks = {}
         ops.packs.invalidate()
