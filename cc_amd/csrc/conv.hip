@@ -232,6 +232,9 @@ __global__ __launch_bounds__(256) void k_gather_gemm(GG g) {
 //     double-buffered: A per (chunk, tap) stage, patch per chunk; one barrier per stage (= CK/2 MFMA k-steps
 //     x TM x TN MFMAs per wave);
 //   * deep layers on small maps get split-K over channel chunks (grid.z) with a deterministic second pass.
+// Two tile shapes of 128 lattice pixels: 4 rows x 32 columns, or 8 x 16 (CP::tw16) -- whichever pads the map less
+// (208 columns = 6.5 x 32 but 13 x 16; 104 = 3.25 x 32 but 6.5 x 16).  The 32 MFMA columns of a wave are one row of 32 pixels
+// or two rows of 16: only the per-lane patch offset differs.
 constexpr int TH = 4, TW = 32;
 
 struct CP {
@@ -240,6 +243,7 @@ struct CP {
     int M, Mpad, Cpad;
     int Rt, St, si, dstep, dy_base, dx_base, ymin, xmin;
     int PH, PWr, PS;
+    int tw16;              // tile = 8 rows x 16 columns instead of 4 x 32
     int aligned, shift;    // aligned: patch rows start on a 16-byte boundary of x (PWr = padded row length) -> dwordx4 LDS-DMA
     int OHt, OWt, so, oy0, ox0, OH, OW; long y_bs, res_bs;
     int tiles_x, tiles_y;
@@ -275,23 +279,17 @@ inline long repack_blocks(int Mpad, int Cpad, int T) {
     return (long)((Mpad + 63) / 64) * ((Cpad + ct - 1) / ct);
 }
 
-__global__ __launch_bounds__(256) void k_repack_table(const long* __restrict__ desc, int ndesc) {
-    __shared__ float tile[72 * 65 + 64 * 65];
-    // binary search the descriptor whose block range contains blockIdx.x
-    int lo = 0, hi = ndesc - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (desc[16 * mid + 14] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
-    const long* d = desc + 16 * lo;
+// TC > 0: the tap count as a compile-time constant (the index arithmetic of the two loops is three integer divisions per
+// element: with run-time divisors they -- not memory -- bound the kernel, 0.6 ms per step for 890 MB)
+template <int TC>
+__device__ __forceinline__ void repack_body(const long* __restrict__ d, float* tile, int bid) {
     const float* __restrict__ w = reinterpret_cast<const float*>(d[0]);
     float* __restrict__ wp = reinterpret_cast<float*>(d[1]);
-    const int M = (int)d[2], Cin = (int)d[3], Mpad = (int)d[4], Cpad = (int)d[5], T = (int)d[6], St = (int)d[7];
+    const int M = (int)d[2], Cin = (int)d[3], Mpad = (int)d[4], Cpad = (int)d[5], St = (int)d[7];
+    const int T = TC > 0 ? TC : (int)d[6];
     const long w_sm = d[8], w_sc = d[9], w0 = d[10], w_ri = d[11], w_sj = d[12];
     const int CT = repack_ct(T);
     const int nmt = (Mpad + 63) / 64;
-    const int bid = (int)((long)blockIdx.x - d[14]);
-    if (bid >= (int)d[15]) return;
     const int m0 = (bid % nmt) * 64, c0 = (bid / nmt) * CT;
     const int CTT = CT * T, n = 64 * CTT;
     const bool m_slow = w_sm > w_sc;
@@ -312,6 +310,31 @@ __global__ __launch_bounds__(256) void k_repack_table(const long* __restrict__ d
         const int m_ = e & 63, r = e >> 6;
         const int t = r / CT, c_ = r - t * CT;
         if (m0 + m_ < Mpad && c0 + c_ < Cpad) wp[((long)t * Cpad + c0 + c_) * Mpad + m0 + m_] = tile[r * 65 + m_];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_repack_table(const long* __restrict__ desc, int ndesc) {
+    __shared__ float tile[72 * 65 + 64 * 65];
+    // binary search the descriptor whose block range contains blockIdx.x
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[16 * mid + 14] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long* d = desc + 16 * lo;
+    const int bid = (int)((long)blockIdx.x - d[14]);
+    if (bid >= (int)d[15]) return;
+    switch ((int)d[6]) {                       // tap counts of the CC networks (3x3, 7x7, 5x5, 4x4 and their parity classes)
+        case 9: repack_body<9>(d, tile, bid); break;
+        case 1: repack_body<1>(d, tile, bid); break;
+        case 2: repack_body<2>(d, tile, bid); break;
+        case 4: repack_body<4>(d, tile, bid); break;
+        case 49: repack_body<49>(d, tile, bid); break;
+        case 25: repack_body<25>(d, tile, bid); break;
+        case 16: repack_body<16>(d, tile, bid); break;
+        case 6: repack_body<6>(d, tile, bid); break;
+        case 12: repack_body<12>(d, tile, bid); break;
+        default: repack_body<0>(d, tile, bid); break;
     }
 }
 
@@ -339,7 +362,9 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
     bx /= g.tiles_x;
     const int tile_y = bx % g.tiles_y;
     const int n = bx / g.tiles_y;
-    const int ty0 = tile_y * TH, tx0 = tile_x * TW;
+    const int rowstep = g.tw16 ? 2 : 1;                         // lattice rows per MFMA column group
+    const int lr = g.tw16 ? (l31 >> 4) : 0, lc = g.tw16 ? (l31 & 15) : l31;     // this lane's row / column inside the group
+    const int ty0 = tile_y * (g.tw16 ? 8 : TH), tx0 = tile_x * (g.tw16 ? 16 : TW);
     const int gy0 = g.si * ty0 + g.ymin, gx0 = g.si * tx0 + g.xmin;
     const int m0 = blockIdx.y * BM;
     const int T = g.Rt * g.St;
@@ -442,14 +467,15 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
                             // 16x16x4: lane (i = lane & 15, k = lane >> 4) feeds A[m = i][k] and B[k][pixel = i]; two 16-pixel
                             // halves of the wave's lattice row -> two independent accumulators (40-cycle dependent latency)
                             const int l15 = lane & 15, l4 = lane >> 4;
-                            const float* Pl = Pb + l4 * g.PS + (g.si * row0) * g.PWr + g.si * l15 + tapoff;
+                            const float* Pl = Pb + l4 * g.PS + (g.si * rowstep * row0) * g.PWr + g.si * l15 + tapoff;
                             const float* Al = Ab + l4 * BM + l15;
+                            const int half = g.tw16 ? g.si * g.PWr : g.si * 16;      // second 16-pixel half: next row / next 16 columns
                             float af[CK / 4], bf[CK / 4][2];
 #pragma unroll
                             for (int ks = 0; ks < CK / 4; ks++) {
                                 af[ks] = Al[(4 * ks) * BM];
                                 bf[ks][0] = Pl[(4 * ks) * g.PS];
-                                bf[ks][1] = Pl[(4 * ks) * g.PS + g.si * 16];
+                                bf[ks][1] = Pl[(4 * ks) * g.PS + half];
                             }
 #pragma unroll
                             for (int ks = 0; ks < CK / 4; ks++) {
@@ -459,7 +485,7 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
                             if (++tj == g.St) { tj = 0; ti++; }
                             continue;
                         }
-                        const float* Pl = Pb + lk * g.PS + (g.si * row0) * g.PWr + g.si * l31 + tapoff;
+                        const float* Pl = Pb + lk * g.PS + (g.si * (rowstep * row0 + lr)) * g.PWr + g.si * lc + tapoff;
                         const float* Al = Ab + lk * BM + wm * WM + l31;
                         // all fragments of a tap are fetched up front (2*(TM+TN)*CK/2 VGPRs): one exposed LDS latency per
                         // tap instead of one per k-step; the MFMAs then issue back to back behind counted lgkmcnt waits
@@ -469,7 +495,7 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
 #pragma unroll
                             for (int a = 0; a < TM; a++) af[ks][a] = Al[(2 * ks) * BM + a * 32];
 #pragma unroll
-                            for (int b = 0; b < TN; b++) bf[ks][b] = Pl[(2 * ks) * g.PS + (g.si * b) * g.PWr];
+                            for (int b = 0; b < TN; b++) bf[ks][b] = Pl[(2 * ks) * g.PS + (g.si * rowstep * b) * g.PWr];
                         }
 #pragma unroll
                         for (int ks = 0; ks < CK / 2; ks++) {
@@ -491,11 +517,11 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
     const int y_cs = g.OH * g.OW;
     if constexpr (BM == 16) {
         // D col = lane & 15 -> pixel of the half, row = 4 * (lane >> 4) + r -> channel
-        const int ty = ty0 + row0;
         const int HWt = g.OHt * g.OWt;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const int tx = tx0 + 16 * h + (lane & 15);
+            const int ty = ty0 + rowstep * row0 + (g.tw16 ? h : 0);
+            const int tx = tx0 + (g.tw16 ? 0 : 16 * h) + (lane & 15);
             if (ty >= g.OHt || tx >= g.OWt) continue;
             const long pix = (long)(g.oy0 + g.so * ty) * g.OW + (g.ox0 + g.so * tx);
 #pragma unroll
@@ -516,10 +542,10 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
         return;
     }
     // ---- epilogue: D col = lane&31 -> tx, row -> channel
-    const int tx = tx0 + l31;
+    const int tx = tx0 + lc;
 #pragma unroll
     for (int b = 0; b < TN; b++) {
-        const int ty = ty0 + row0 + b;
+        const int ty = ty0 + rowstep * (row0 + b) + lr;
         if (ty >= g.OHt || tx >= g.OWt) continue;
         const long pix = (long)(g.oy0 + g.so * ty) * g.OW + (g.ox0 + g.so * tx);
         if (SPLIT == 1 || (SPLIT == 2 && g.nsplit > 1)) {
@@ -643,6 +669,7 @@ static int dbg_flag_early(const char* name) {
 
 struct ConvPlan {
     bool use_patch;
+    int tw16;
     int bm, ck, tps, Mpad, Cpad, PH, PWr, PS, ymin, xmin, tiles_x, tiles_y, nsplit, cps, aligned, shift;
     size_t smem, wp_floats, part_floats;
 };
@@ -656,8 +683,14 @@ static int env_int_early(const char* name, int dflt) {
 inline ConvPlan plan_conv(const GG& g, int mult = 1) {
     ConvPlan p = {};
     p.bm = pick_bm_fwd(g.M);
+    {   // tile shape: 4 x 32 or 8 x 16 lattice pixels, whichever covers the map with fewer padded pixels
+        const long a32 = (long)((g.OWt + 31) / 32) * 32 * (((g.OHt + 3) / 4) * 4);
+        const long a16 = (long)((g.OWt + 15) / 16) * 16 * (((g.OHt + 7) / 8) * 8);
+        p.tw16 = (a16 < a32 && !dbg_flag_early("CC_CONV_NO_TW16")) ? 1 : 0;
+    }
+    const int th = p.tw16 ? 8 : TH, tw = p.tw16 ? 16 : TW;
     {   // few pixel tiles: halve the channel tile before resorting to split-K (no partial slabs, no epilogue launch)
-        const long tiles = (long)g.B * ((g.OWt + TW - 1) / TW) * ((g.OHt + TH - 1) / TH);
+        const long tiles = (long)g.B * ((g.OWt + tw - 1) / tw) * ((g.OHt + th - 1) / th);
         const int thr = env_int_early("CC_CONV_BM64_BELOW", 0);
         if (p.bm == 128 && tiles * ((g.M + 127) / 128) < thr) p.bm = 64;
     }
@@ -665,8 +698,8 @@ inline ConvPlan plan_conv(const GG& g, int mult = 1) {
     p.ymin = g.dy0 < ylast ? g.dy0 : ylast;
     p.xmin = g.dx0 < xlast ? g.dx0 : xlast;
     const int ymax = g.dy0 < ylast ? ylast : g.dy0, xmax = g.dx0 < xlast ? xlast : g.dx0;
-    p.PH = (TH - 1) * g.si + (ymax - p.ymin) + 1;
-    p.PWr = (TW - 1) * g.si + (xmax - p.xmin) + 1;
+    p.PH = (th - 1) * g.si + (ymax - p.ymin) + 1;
+    p.PWr = (tw - 1) * g.si + (xmax - p.xmin) + 1;
     // 16-byte aligned variant: start every patch row at the 4-float boundary at or below its first column
     p.aligned = (g.IW % 4 == 0) && !dbg_flag_early("CC_NO_ALIGNED_PATCH");
     p.shift = 0;
@@ -685,8 +718,8 @@ inline ConvPlan plan_conv(const GG& g, int mult = 1) {
     p.use_patch = (p.smem <= 150 * 1024) && g.Cin > 0;
     p.Mpad = ((g.M + p.bm - 1) / p.bm) * p.bm;
     p.Cpad = ((g.Cin + p.ck - 1) / p.ck) * p.ck;
-    p.tiles_x = (g.OWt + TW - 1) / TW;
-    p.tiles_y = (g.OHt + TH - 1) / TH;
+    p.tiles_x = (g.OWt + tw - 1) / tw;
+    p.tiles_y = (g.OHt + th - 1) / th;
     p.wp_floats = (size_t)g.Rt * g.St * p.Cpad * p.Mpad;
     const long blocks = (long)g.B * p.tiles_x * p.tiles_y * (p.Mpad / p.bm) * (mult > 1 ? mult : 1);
     const int nchunk = p.Cpad / p.ck;
@@ -1427,7 +1460,7 @@ inline CP make_cp(const GG& g, const ConvPlan& p, const float* zeros, const floa
     c.M = g.M; c.Mpad = p.Mpad; c.Cpad = p.Cpad;
     c.Rt = g.Rt; c.St = g.St; c.si = g.si; c.dstep = g.dstep;
     c.dy_base = g.dy0 - p.ymin; c.dx_base = g.dx0 - p.xmin; c.ymin = p.ymin; c.xmin = p.xmin;
-    c.PH = p.PH; c.PWr = p.PWr; c.PS = p.PS; c.aligned = p.aligned; c.shift = p.shift;
+    c.PH = p.PH; c.PWr = p.PWr; c.PS = p.PS; c.tw16 = p.tw16; c.aligned = p.aligned; c.shift = p.shift;
     c.OHt = g.OHt; c.OWt = g.OWt; c.so = g.so; c.oy0 = g.oy0; c.ox0 = g.ox0; c.OH = g.OH; c.OW = g.OW;
     c.y_bs = g.y_bs; c.res_bs = g.res_bs;
     c.tiles_x = p.tiles_x; c.tiles_y = p.tiles_y;

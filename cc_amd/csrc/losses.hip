@@ -430,6 +430,8 @@ __global__ __launch_bounds__(256) void k_consensus_bce_jobs(JobTab t, float thre
 //   op 2: out = |a - b|                    slots a, b, out         (rigidity masks |flow_cam - flow|, :475-476)
 //   op 3: out[b, c] = 1 - m[b, c0 + c]     slots m, out            (flow_exp_mask = 1 - exp_mask[:, 1:3], :488; planes = B * nc)
 //   op 4: gm[b, c] = -g[b, c - c0] inside [c0, c0 + nc), 0 outside   slots g, gm   (its backward; planes = B * MC)
+//   op 5: out = ((a * 0.5 + 0.5) - mean_c) / std_c, ImageNet statistics, c = plane % 3   slots a, out
+//         (Back2Future.normalize, models/back2future.py:118-132: three images of one step in one launch)
 __global__ __launch_bounds__(256) void k_elementwise_jobs(JobTab t, int op, int c0, int nc, int MC) {
     CC_JOB_PIXEL(t, j, q, p, HW)
     if (p >= HW) return;
@@ -441,6 +443,10 @@ __global__ __launch_bounds__(256) void k_elementwise_jobs(JobTab t, int op, int 
         ccjobs::ptr<float>(t, j, 2)[i] = -ccjobs::ptr<const float>(t, j, 0)[i] * (y * y);
     } else if (op == 2) {
         ccjobs::ptr<float>(t, j, 2)[i] = fabsf(ccjobs::ptr<const float>(t, j, 0)[i] - ccjobs::ptr<const float>(t, j, 1)[i]);
+    } else if (op == 5) {
+        const int c = q % 3;
+        const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f), sd = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
+        ccjobs::ptr<float>(t, j, 1)[i] = ((ccjobs::ptr<const float>(t, j, 0)[i] * 0.5f + 0.5f) - mean) / sd;
     } else if (op == 3) {
         const int b = q / nc, c = q - b * nc;
         ccjobs::ptr<float>(t, j, 1)[i] = 1.0f - ccjobs::ptr<const float>(t, j, 0)[((size_t)b * MC + c0 + c) * HW + p];
@@ -615,7 +621,7 @@ int cc_sum_refs_scale_jobs(const long* jobs, int njobs, int B, int R, int MC, vo
 int cc_elementwise_jobs(const long* jobs, int njobs, int planes, int op, int c0, int nc, int MC, void* stream) {
     ccjobs::JobTab t;
     const int nblk = loss_jobs_tab(t, jobs, njobs, planes);
-    if (nblk <= 0 || op < 0 || op > 4) return CC_ERR_ARG;
+    if (nblk <= 0 || op < 0 || op > 5) return CC_ERR_ARG;
     hipLaunchKernelGGL(k_elementwise_jobs, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, t, op, c0, nc, MC);
     CC_CHECK_LAUNCH();
     return CC_OK;

@@ -62,8 +62,9 @@ __device__ __forceinline__ float robust_pow(float v, float q) {
 // one 32x32 tile of image b: (tile_x, tile_y) -> outputs; `blk` = index of this tile's partial sums (MODE_PHOTO)
 template <int MODE>
 __device__ __forceinline__ void ssim_tile_body(const PhotoArgs& a, const Gauss13& gw, int b, int tile_x, int tile_y, size_t blk) {
-    __shared__ __attribute__((aligned(16))) float tx[TIN * TIN];
-    __shared__ __attribute__((aligned(16))) float ty[TIN * TIN];
+    // The horizontal pass reads its 16-pixel input windows straight from global memory (8-byte loads, 16 in flight per work
+    // item) instead of staging the two 44x44 input tiles in LDS first: 28 KB of LDS instead of 43 KB, one barrier less per
+    // channel, no scalar staging loop with an integer division per element.
     __shared__ __attribute__((aligned(16))) float hb[5][TIN * TS];
     __shared__ float red[4 * 3];
 
@@ -105,29 +106,38 @@ __device__ __forceinline__ void ssim_tile_body(const PhotoArgs& a, const Gauss13
 
     float s_rob = 0.f, s_sl = 0.f;
 
+    // even width + 8-byte aligned planes: rows start 8-byte aligned and a pair never straddles the image edge
+    const bool pairs = !(W & 1) && ((((uintptr_t)a.x) | ((uintptr_t)a.y)) & 7) == 0;
     for (int c = 0; c < 3; c++) {
         const float* xp = a.x + ((size_t)b * 3 + c) * HW;
         const float* yp = a.y + ((size_t)b * 3 + c) * HW;
         if (c > 0) __syncthreads();          // everyone is done with the previous channel's V pass
-        for (int i = tid; i < TIN * TIN; i += 256) {
-            const int r = i / TIN, col = i - r * TIN;
-            const int yy = oy0 - HALO + r, xx = ox0 - HALO + col;
-            const bool in = (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
-            tx[i] = in ? xp[yy * W + xx] : 0.f;
-            ty[i] = in ? yp[yy * W + xx] : 0.f;
-        }
-        __syncthreads();
         // ---- H pass
         for (int it = tid; it < TIN * (TS / 4); it += 256) {
             const int r = it >> 3, cg = it & 7;
+            const int yy = oy0 - HALO + r, x0 = ox0 - HALO + 4 * cg;
+            const bool rowin = (yy >= 0) && (yy < H);
+            const float* xr = xp + (long)yy * W;
+            const float* yr = yp + (long)yy * W;
             float xv[16], yv[16];
-            const float4* px = reinterpret_cast<const float4*>(&tx[r * TIN + 4 * cg]);
-            const float4* py = reinterpret_cast<const float4*>(&ty[r * TIN + 4 * cg]);
+            if (pairs) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float4 vx = px[k], vy = py[k];
-                xv[4 * k] = vx.x; xv[4 * k + 1] = vx.y; xv[4 * k + 2] = vx.z; xv[4 * k + 3] = vx.w;
-                yv[4 * k] = vy.x; yv[4 * k + 1] = vy.y; yv[4 * k + 2] = vy.z; yv[4 * k + 3] = vy.w;
+                for (int k = 0; k < 8; k++) {
+                    const int xx = x0 + 2 * k;
+                    const bool in = rowin && (xx >= 0) && (xx < W);
+                    const float2 vx = in ? *reinterpret_cast<const float2*>(xr + xx) : make_float2(0.f, 0.f);
+                    const float2 vy = in ? *reinterpret_cast<const float2*>(yr + xx) : make_float2(0.f, 0.f);
+                    xv[2 * k] = vx.x; xv[2 * k + 1] = vx.y;
+                    yv[2 * k] = vy.x; yv[2 * k + 1] = vy.y;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int xx = x0 + k;
+                    const bool in = rowin && (xx >= 0) && (xx < W);
+                    xv[k] = in ? xr[xx] : 0.f;
+                    yv[k] = in ? yr[xx] : 0.f;
+                }
             }
             float o[5][4];
 #pragma unroll
@@ -197,8 +207,7 @@ __device__ __forceinline__ void ssim_tile_body(const PhotoArgs& a, const Gauss13
                 a.adjA[o] = gS * (2.f * mu1 * (num2 - num1) / D - 2.f * mu2 * S * (1.f / den1 - 1.f / den2));
                 continue;
             }
-            const float xc = tx[(4 * rg + j + HALO) * TIN + cx + HALO];
-            const float yc = ty[(4 * rg + j + HALO) * TIN + cx + HALO];
+            const float xc = xp[p], yc = yp[p];
             if (MODE == MODE_ERR) {
                 // loss_functions.py:181-188: robust_l1_per_pix(tgt - warped) and (1 - ssim), channel means
                 const float d = xc - yc;
@@ -326,35 +335,38 @@ __device__ __forceinline__ void ssim_adjoint_body(const float* __restrict__ adjA
                                                   const float* __restrict__ x, const float* __restrict__ y,
                                                   const float* __restrict__ scale, float* __restrict__ gy, int H,
                                                   int W, int accumulate, const Gauss13& gw, int b, int tile_x, int tile_y) {
-    __shared__ __attribute__((aligned(16))) float tin[3][TIN * TIN];
     __shared__ __attribute__((aligned(16))) float hb[3][TIN * TS];
     const int HW = H * W;
     const int ox0 = tile_x * TS, oy0 = tile_y * TS;
     const int tid = threadIdx.x, cx = tid & 31, rg = tid >> 5, gx = ox0 + cx;
     const float sc = scale ? scale[0] : 1.f;
+    const bool pairs = !(W & 1) && ((((uintptr_t)adjA) | ((uintptr_t)adjB) | ((uintptr_t)adjC)) & 7) == 0;
     for (int c = 0; c < 3; c++) {
         const size_t plane = ((size_t)b * 3 + c) * HW;
         if (c > 0) __syncthreads();
-        for (int i = tid; i < TIN * TIN; i += 256) {
-            const int r = i / TIN, col = i - r * TIN;
-            const int yy = oy0 - HALO + r, xx = ox0 - HALO + col;
-            const bool in = (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
-            const size_t o = plane + (size_t)yy * W + xx;
-            tin[0][i] = in ? adjA[o] : 0.f;
-            tin[1][i] = in ? adjB[o] : 0.f;
-            tin[2][i] = in ? adjC[o] : 0.f;
-        }
-        __syncthreads();
+        // H pass straight from global memory (see ssim_tile_body)
         for (int it = tid; it < TIN * (TS / 4); it += 256) {
             const int r = it >> 3, cg = it & 7;
+            const int yy = oy0 - HALO + r, x0 = ox0 - HALO + 4 * cg;
+            const bool rowin = (yy >= 0) && (yy < H);
 #pragma unroll
             for (int mi = 0; mi < 3; mi++) {
+                const float* src = (mi == 0 ? adjA : (mi == 1 ? adjB : adjC)) + plane + (long)yy * W;
                 float v[16];
-                const float4* pv = reinterpret_cast<const float4*>(&tin[mi][r * TIN + 4 * cg]);
+                if (pairs) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const float4 q = pv[k];
-                    v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+                    for (int k = 0; k < 8; k++) {
+                        const int xx = x0 + 2 * k;
+                        const bool in = rowin && (xx >= 0) && (xx < W);
+                        const float2 q = in ? *reinterpret_cast<const float2*>(src + xx) : make_float2(0.f, 0.f);
+                        v[2 * k] = q.x; v[2 * k + 1] = q.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        const int xx = x0 + k;
+                        v[k] = (rowin && (xx >= 0) && (xx < W)) ? src[xx] : 0.f;
+                    }
                 }
                 float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -71,6 +71,9 @@ class Model(nn.Module):
 
     def normalize(self, ims):
         """back2future.py:118-132: [-1,1] -> ImageNet-normalised, on copies."""
+        if all(im.shape[1] == 3 and not im.requires_grad for im in ims) and len({tuple(im.shape) for im in ims}) == 1:
+            from ..loss_functions import imagenet_normalize_levels
+            return imagenet_normalize_levels(ims)
         return [((im * 0.5 + 0.5) - self._im_mean) / self._im_std for im in ims]
 
     def warp(self, x, flo, flow_scale=1.0):

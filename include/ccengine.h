@@ -310,7 +310,8 @@ int cc_ssim_err_fwd_jobs(const long* jobs, int njobs, int B, float wssim, const 
 /*   cc_elementwise_jobs       the element-wise glue of train.py:458,475-476,488 over all scales (planes per job):
  *                             op 0 out = 1/a (slots a, out); 1 ga = -g*y*y (g, y, ga); 2 out = |a-b| (a, b, out);
  *                             3 out[b,c] = 1 - m[b,c0+c] (m, out; planes = B*nc); 4 gm[b,c] = -g[b,c-c0] in [c0,c0+nc) else 0
- *                             (g, gm; planes = B*MC) */
+ *                             (g, gm; planes = B*MC); 5 out = ((a*0.5+0.5) - mean_c)/std_c with the ImageNet statistics, c = plane % 3
+ *                             (models/back2future.py:118-132 normalize of the three input images) */
 int cc_elementwise_jobs(const long* jobs, int njobs, int planes, int op, int c0, int nc, int MC, void* stream);
 int cc_flow_noocc_jobs(const long* jobs, int njobs, int B, void* stream);
 int cc_consensus_target_jobs(const long* jobs, int njobs, int B, float wrig, void* stream);
