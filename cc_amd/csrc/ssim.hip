@@ -335,38 +335,35 @@ __device__ __forceinline__ void ssim_adjoint_body(const float* __restrict__ adjA
                                                   const float* __restrict__ x, const float* __restrict__ y,
                                                   const float* __restrict__ scale, float* __restrict__ gy, int H,
                                                   int W, int accumulate, const Gauss13& gw, int b, int tile_x, int tile_y) {
+    __shared__ __attribute__((aligned(16))) float tin[3][TIN * TIN];
     __shared__ __attribute__((aligned(16))) float hb[3][TIN * TS];
     const int HW = H * W;
     const int ox0 = tile_x * TS, oy0 = tile_y * TS;
     const int tid = threadIdx.x, cx = tid & 31, rg = tid >> 5, gx = ox0 + cx;
     const float sc = scale ? scale[0] : 1.f;
-    const bool pairs = !(W & 1) && ((((uintptr_t)adjA) | ((uintptr_t)adjB) | ((uintptr_t)adjC)) & 7) == 0;
     for (int c = 0; c < 3; c++) {
         const size_t plane = ((size_t)b * 3 + c) * HW;
         if (c > 0) __syncthreads();
-        // H pass straight from global memory (see ssim_tile_body)
+        for (int i = tid; i < TIN * TIN; i += 256) {
+            const int r = i / TIN, col = i - r * TIN;
+            const int yy = oy0 - HALO + r, xx = ox0 - HALO + col;
+            const bool in = (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
+            const size_t o = plane + (size_t)yy * W + xx;
+            tin[0][i] = in ? adjA[o] : 0.f;
+            tin[1][i] = in ? adjB[o] : 0.f;
+            tin[2][i] = in ? adjC[o] : 0.f;
+        }
+        __syncthreads();
         for (int it = tid; it < TIN * (TS / 4); it += 256) {
             const int r = it >> 3, cg = it & 7;
-            const int yy = oy0 - HALO + r, x0 = ox0 - HALO + 4 * cg;
-            const bool rowin = (yy >= 0) && (yy < H);
 #pragma unroll
             for (int mi = 0; mi < 3; mi++) {
-                const float* src = (mi == 0 ? adjA : (mi == 1 ? adjB : adjC)) + plane + (long)yy * W;
                 float v[16];
-                if (pairs) {
+                const float4* pv = reinterpret_cast<const float4*>(&tin[mi][r * TIN + 4 * cg]);
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const int xx = x0 + 2 * k;
-                        const bool in = rowin && (xx >= 0) && (xx < W);
-                        const float2 q = in ? *reinterpret_cast<const float2*>(src + xx) : make_float2(0.f, 0.f);
-                        v[2 * k] = q.x; v[2 * k + 1] = q.y;
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 16; k++) {
-                        const int xx = x0 + k;
-                        v[k] = (rowin && (xx >= 0) && (xx < W)) ? src[xx] : 0.f;
-                    }
+                for (int k = 0; k < 4; k++) {
+                    const float4 q = pv[k];
+                    v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
                 }
                 float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -568,6 +568,52 @@ __global__ __launch_bounds__(256) void k_pose2flow_fwd_jobs(JobTab t, int rewrit
     flow[((size_t)b * 2 + 1) * HW + p] = (float)(H - 1) * (r.yn / 2.0f + 0.5f) - (float)y;
 }
 
+// inverse_warp.py:31-45 pixel2cam and :48-79 cam2pixel as stand-alone maps (the training path uses the fused kernels above;
+// these share their arithmetic -- ray = Kinv.(x, y, 1) by the same fmaf chain, cam = ray * depth; projection by the same
+// chain as rigid_project -- so their composition reproduces the fused kernels' sampling coordinates bit for bit)
+__global__ __launch_bounds__(256) void k_pixel2cam(const float* __restrict__ depth, const float* __restrict__ Kinv,
+                                                   float* __restrict__ cam, int H, int W) {
+    const int b = blockIdx.y, HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    const float* Ki = Kinv + 9 * b;
+    const float d = depth[(size_t)b * HW + p];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float ray = fmaf(Ki[3 * i + 2], 1.0f, fmaf(Ki[3 * i + 1], (float)y, Ki[3 * i] * (float)x));
+        cam[((size_t)b * 3 + i) * HW + p] = ray * d;
+    }
+}
+
+// P: [B,12] rows (rot | tr); has_rot / has_tr: the reference's `is not None` switches; mode: 0 none, 1 'zeros' (OOB -> 2)
+__global__ __launch_bounds__(256) void k_cam2pixel(const float* __restrict__ cam, const float* __restrict__ P,
+                                                   float* __restrict__ out, int H, int W, int has_rot, int has_tr, int rewrite) {
+    const int b = blockIdx.y, HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const float c0 = cam[((size_t)b * 3 + 0) * HW + p], c1 = cam[((size_t)b * 3 + 1) * HW + p], c2 = cam[((size_t)b * 3 + 2) * HW + p];
+    const float* Pb = P + 12 * b;
+    float q[3] = {c0, c1, c2};
+    if (has_rot) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) q[i] = fmaf(Pb[4 * i + 2], c2, fmaf(Pb[4 * i + 1], c1, Pb[4 * i] * c0));
+    }
+    if (has_tr) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) q[i] = q[i] + Pb[4 * i + 3];
+    }
+    const float Z = fmaxf(q[2], 1e-3f);
+    float xn = (2.0f * (q[0] / Z)) / (float)(W - 1) - 1.0f;
+    float yn = (2.0f * (q[1] / Z)) / (float)(H - 1) - 1.0f;
+    if (rewrite) {
+        if (xn > 1.f || xn < -1.f) xn = 2.f;
+        if (yn > 1.f || yn < -1.f) yn = 2.f;
+    }
+    out[((size_t)b * HW + p) * 2] = xn;
+    out[((size_t)b * HW + p) * 2 + 1] = yn;
+}
+
 inline dim3 pix_grid(int B, int H, int W) { return dim3((unsigned)((H * W + 255) / 256), (unsigned)B); }
 
 }  // namespace
@@ -584,6 +630,22 @@ inline dim3 pix_grid(int B, int H, int W) { return dim3((unsigned)((H * W + 255)
     } while (0)
 
 extern "C" {
+
+int cc_pixel2cam(const float* depth, const float* Kinv, float* cam, int B, int H, int W, void* stream) {
+    if (B <= 0 || H < 1 || W < 1) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_pixel2cam, pix_grid(B, H, W), dim3(256), 0, (hipStream_t)stream, depth, Kinv, cam, H, W);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_cam2pixel(const float* cam, const float* P, float* grid, int B, int H, int W, int has_rot, int has_tr, int rewrite_oob,
+                 void* stream) {
+    if (B <= 0 || H < 2 || W < 2) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_cam2pixel, pix_grid(B, H, W), dim3(256), 0, (hipStream_t)stream, cam, P, grid, H, W, has_rot, has_tr,
+                       rewrite_oob);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
 
 size_t cc_warp_partials_bytes(int B, int H, int W) { return (size_t)B * ((H * W + 255) / 256) * 12 * sizeof(float); }
 

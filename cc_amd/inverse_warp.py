@@ -29,6 +29,91 @@ def check_sizes(input, input_name, expected):
         input_name, 'x'.join(expected), list(input.size()))
 
 
+# ------------------------------------------------------------------ pixel2cam / cam2pixel (stand-alone halves of the fused warp)
+def _pixel2cam_torch(depth, intrinsics_inv):
+    b, h, w = depth.size()
+    i = torch.arange(0, h, device=depth.device, dtype=depth.dtype).view(1, h, 1).expand(1, h, w)
+    j = torch.arange(0, w, device=depth.device, dtype=depth.dtype).view(1, 1, w).expand(1, h, w)
+    pix = torch.stack((j, i, torch.ones_like(i)), dim=1).expand(b, 3, h, w).contiguous().view(b, 3, -1)
+    return intrinsics_inv.bmm(pix).view(b, 3, h, w) * depth.unsqueeze(1)
+
+
+def _cam2pixel_torch(cam_coords, proj_c2p_rot, proj_c2p_tr, padding_mode):
+    b, _, h, w = cam_coords.size()
+    flat = cam_coords.reshape(b, 3, -1)
+    pc = proj_c2p_rot.bmm(flat) if proj_c2p_rot is not None else flat
+    if proj_c2p_tr is not None:
+        pc = pc + proj_c2p_tr
+    X, Y, Z = pc[:, 0], pc[:, 1], pc[:, 2].clamp(min=1e-3)
+    Xn = 2 * (X / Z) / (w - 1) - 1
+    Yn = 2 * (Y / Z) / (h - 1) - 1
+    if padding_mode == 'zeros':
+        Xn = torch.where(((Xn > 1) | (Xn < -1)).detach(), torch.full_like(Xn, 2), Xn)
+        Yn = torch.where(((Yn > 1) | (Yn < -1)).detach(), torch.full_like(Yn, 2), Yn)
+    return torch.stack([Xn, Yn], dim=2).view(b, h, w, 2)
+
+
+class _Pixel2CamFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, Kinv):
+        d, Ki = _f32c(depth), _f32c(Kinv)
+        B, H, W = d.shape
+        cam = torch.empty(B, 3, H, W, device=d.device, dtype=torch.float32)
+        engine().call("cc_pixel2cam", d, Ki, cam, B, H, W, STREAM)
+        ctx.save_for_backward(d, Ki)
+        return cam
+
+    @staticmethod
+    def backward(ctx, g):        # off the training path: differentiate the reference's own formula
+        d, Ki = ctx.saved_tensors
+        with torch.enable_grad():
+            dd, kk = d.detach().requires_grad_(True), Ki.detach().requires_grad_(True)
+            gd, gk = torch.autograd.grad(_pixel2cam_torch(dd, kk), [dd, kk], g)
+        return gd, gk
+
+
+class _Cam2PixelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cam, rot, tr, mode):
+        c = _f32c(cam)
+        B, _, H, W = c.shape
+        P = torch.zeros(B, 3, 4, device=c.device, dtype=torch.float32)
+        if rot is not None:
+            P[:, :, :3] = rot
+        if tr is not None:
+            P[:, :, 3:] = tr
+        grid = torch.empty(B, H, W, 2, device=c.device, dtype=torch.float32)
+        engine().call("cc_cam2pixel", c, P.reshape(B, 12), grid, B, H, W, int(rot is not None), int(tr is not None),
+                      1 if mode == 'zeros' else 0, STREAM)
+        ctx.save_for_backward(c, rot, tr)
+        ctx.mode = mode
+        return grid
+
+    @staticmethod
+    def backward(ctx, g):
+        c, rot, tr = ctx.saved_tensors
+        with torch.enable_grad():
+            ins = [t.detach().requires_grad_(True) if t is not None else None for t in (c, rot, tr)]
+            out = _cam2pixel_torch(ins[0], ins[1], ins[2], ctx.mode)
+            live = [t for t in ins if t is not None]
+            gs = list(torch.autograd.grad(out, live, g, allow_unused=True))
+        res = [gs.pop(0) if t is not None else None for t in ins]
+        return res[0], res[1], res[2], None
+
+
+def pixel2cam(depth, intrinsics_inv):
+    """inverse_warp.py:31-45: depth [B,H,W], intrinsics_inv [B,3,3] -> camera-frame points [B,3,H,W]."""
+    check_sizes(depth, 'depth', 'BHW')
+    check_sizes(intrinsics_inv, 'intrinsics', 'B33')
+    return _Pixel2CamFn.apply(depth, intrinsics_inv)
+
+
+def cam2pixel(cam_coords, proj_c2p_rot, proj_c2p_tr, padding_mode):
+    """inverse_warp.py:48-79: camera-frame points [B,3,H,W] -> normalised sampling grid [B,H,W,2] (padding_mode 'zeros':
+    out-of-range coordinates rewritten to 2)."""
+    return _Cam2PixelFn.apply(cam_coords, proj_c2p_rot, proj_c2p_tr, padding_mode)
+
+
 # ------------------------------------------------------------------ pose algebra (tiny, torch)
 def euler2mat(angle):
     """inverse_warp.py:82-119: R = Rx.Ry.Rz, [B,3] -> [B,3,3]."""

@@ -28,6 +28,14 @@ size_t cc_version(void);
 
 /* ---------------------------------------------------------------- geometry (inverse_warp.py) */
 
+/* inverse_warp.py:31-45 pixel2cam: cam[B,3,H,W] = (Kinv . (x, y, 1)) * depth, and :48-79 cam2pixel: grid[B,H,W,2] in [-1,1]
+ * from cam and P[B,12] = rows (rot | tr) (has_rot / has_tr: the reference's `is not None` switches; rewrite_oob: padding_mode
+ * 'zeros' sets out-of-range coordinates to 2, :72-76).  Stand-alone forms of the two halves the fused warp kernels compute
+ * in registers (same fmaf chains: their composition gives the fused kernels' coordinates bit for bit). */
+int cc_pixel2cam(const float* depth, const float* Kinv, float* cam, int B, int H, int W, void* stream);
+int cc_cam2pixel(const float* cam, const float* P, float* grid, int B, int H, int W, int has_rot, int has_tr, int rewrite_oob,
+                 void* stream);
+
 /* scratch for the per-workgroup partial sums of dL/dP: B * ceil(H*W/256) * 12 floats */
 size_t cc_warp_partials_bytes(int B, int H, int W);
 

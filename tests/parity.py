@@ -236,8 +236,25 @@ def check_warps_bit_exact_vs_golden(dev, golden_dir):
         feat = torch.cat([feat, feat.flip(1), feat * 0.5], 1)[:, :8].contiguous()
         flo = syn.kernel_inputs(FB, 16, 24, seed=8)["flow_fwd"]
         ft = IW.feature_warp(feat.to(dev), flo.to(dev), align_corners=bool(ac)).cpu().numpy()
+        # the stand-alone halves (inverse_warp.py:31-79): pixel2cam -> cam2pixel with the reference's P reproduce its grid
+        P34 = torch.from_numpy(g["P"]).to(dev)
+        grid = IW.cam2pixel(IW.pixel2cam(d0, Kinv.to(dev)), P34[:, :, :3].contiguous(), P34[:, :, 3:].contiguous(), "zeros")
+        # tap-flip rate: how many pixels sample a different 2x2 neighbourhood when P comes from THIS device's sin/cos
+        # (cc_pose_proj_fwd) instead of the reference's CPU matrices -- the number behind the flip-tolerant gradient bars
+        pose = syn.kernel_inputs(FB, 8, 8, seed=2)["pose"] * 3.0
+        P_dev = IW.projection_matrix(pose[:, 0].to(dev), K.to(dev)).reshape(-1, 3, 4)
+        grid_dev = IW.cam2pixel(IW.pixel2cam(d0, Kinv.to(dev)), P_dev[:, :, :3].contiguous(), P_dev[:, :, 3:].contiguous(), "zeros")
+
+        def taps(gr):
+            x = torch.floor((gr[..., 0] + 1) * (FW / 2.0) - 0.5) if not ac else torch.floor((gr[..., 0] + 1) / 2 * (FW - 1))
+            y = torch.floor((gr[..., 1] + 1) * (FH / 2.0) - 0.5) if not ac else torch.floor((gr[..., 1] + 1) / 2 * (FH - 1))
+            return x, y
+        (xa, ya), (xb, yb) = taps(grid), taps(grid_dev)
         out[tag] = dict(inverse_warp=float(np.mean(w == g["inverse_warp"])), pose2flow=float(np.mean(f == g["pose2flow"])),
                         flow_warp=float(np.mean(fw == g["flow_warp"])), feature_warp=float(np.mean(ft == g["feature_warp"])),
+                        grid=float(np.mean(grid.cpu().numpy() == g["grid_zeros"])),
+                        tap_flip_rate_device_P=float(((xa != xb) | (ya != yb)).float().mean()),
+                        P_max_rel_diff=float((P_dev - P34).abs().max() / P34.abs().max()),
                         maxabs=float(np.abs(w - g["inverse_warp"]).max()))
     return out
 

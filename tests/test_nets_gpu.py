@@ -107,3 +107,28 @@ def test_config2_against_reference_golden(golden_dir):
             n.train()
     out = T.cc_forward(nets, batch, T.StepConfig())
     assert abs(float(out["loss"]) - float(g["c2.loss"])) <= 1e-4 * abs(float(g["c2.loss"]))
+
+
+def test_training_step_reaches_no_vendor_conv_or_batchnorm_kernel():
+    """One eager CC step under the profiler: every convolution / BatchNorm runs on libccengine.so -- no MIOpen kernel
+    (the round-1 step still dispatched 9 of 13 BatchNorms to MIOpen) and no ATen convolution / batch-norm kernel."""
+    from torch.profiler import profile, ProfilerActivity
+    dev = torch.device("cuda")
+    bc = syn.sample(2, 64, 128, seed=1)
+    batch = (bc[0].to(dev), [r.to(dev) for r in bc[1]], bc[2].to(dev), bc[3].to(dev))
+    nets = T.build_nets(dev, init=False)
+    for n in nets:
+        n.load_state_dict(syn.seeded_state_dict(n, 0))
+    tr = T.CCTrainer(nets, T.StepConfig(), use_graph=False)
+    tr.step(batch)
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        tr.step(batch)
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    kernels = [n for n in names if n.startswith("k_") or "Kernel" in n or "kernel" in n or "MIOpen" in n or "miopen" in n]
+    if not any(n.startswith("k_") or "k_conv" in n for n in names):
+        pytest.skip("the profiler returned no device kernel names on this box")
+    bad = [n for n in names if "miopen" in n.lower() or "batch_norm" in n.lower() or "cudnn" in n.lower()
+           or n in ("aten::convolution", "aten::conv2d", "aten::miopen_convolution", "aten::native_batch_norm")]
+    assert not bad, bad
+    print("device kernels seen: %d distinct, e.g. %s" % (len(kernels), kernels[:6]))
