@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "ccengine.h")
-LIB_PATH = os.path.join(_HERE, "libccengine.so")
+LIB_PATH = os.environ.get("CC_LIB_PATH") or os.path.join(_HERE, "libccengine.so")      # CC_LIB_PATH: A/B builds (tools/)
 
 _CT = {"long": ctypes.c_long, "int": ctypes.c_int, "float": ctypes.c_float, "size_t": ctypes.c_size_t, "double": ctypes.c_double}
 

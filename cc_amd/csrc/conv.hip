@@ -577,8 +577,13 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
     }
 }
 
+// min 4 waves per SIMD (<= 128 registers): the accumulators then live in VGPRs (95-99 registers in total, no spill) instead of
+// 64 AGPRs + 72-85 VGPRs, and four 40 KB workgroups fit a CU (CC_PATCH_LB: A/B builds, tools/)
+#ifndef CC_PATCH_LB
+#define CC_PATCH_LB 4
+#endif
 template <int BM, int CK, int TPS, int SPLIT>
-__global__ __launch_bounds__(256) void k_conv_patch(CP g) {
+__global__ __launch_bounds__(256, CC_PATCH_LB) void k_conv_patch(CP g) {
     conv_patch_body<BM, CK, TPS, SPLIT>(g, (int)blockIdx.x);
 }
 
@@ -598,7 +603,7 @@ struct CPM {
 };
 
 template <int BM, int CK, int TPS>
-__global__ __launch_bounds__(256) void k_conv_patch_multi(CPM a) {
+__global__ __launch_bounds__(256, CC_PATCH_LB) void k_conv_patch_multi(CPM a) {
     int k = 0, first = 0;
 #pragma unroll
     for (int q = 0; q < MAXCLS - 1; q++)
@@ -709,9 +714,12 @@ inline ConvPlan plan_conv(const GG& g, int mult = 1) {
     }
     p.PS = ((p.PH * p.PWr + 63) / 64) * 64;
     if (p.aligned) p.PS = ((p.PH * p.PWr + 255) / 256) * 256;     // whole 64-lane x 16-byte DMA instructions per channel
-    p.ck = 16;
+    // 8-channel chunks: 20-40 KB of LDS per workgroup -> 3 (BM = 128, register-limited) to 7 workgroups per CU.  Measured
+    // against 16-channel chunks (80 KB, two per CU, half as many barriers): -0.8 ms/step in total (r02g-r02i A/Bs);
+    // CC_CONV_CK16=1 restores the round-1 plan (16 wherever one stage fits in 64 KB).
+    p.ck = 8;
     auto smem_of = [&](int ck, int tps) { return (size_t)(2 * tps * ck * p.bm + 2 * ck * p.PS) * sizeof(float); };
-    if (smem_of(16, 1) > 64 * 1024) p.ck = 8;
+    if (dbg_flag_early("CC_CONV_CK16") && smem_of(16, 1) <= 64 * 1024) p.ck = 16;
     // three taps per pipeline stage when the extra weight buffers still leave two workgroups per CU (2 x 80 KB)
     p.tps = (g.Rt * g.St >= 3 && smem_of(p.ck, 3) <= 80 * 1024 && !dbg_flag_early("CC_CONV_TPS1")) ? 3 : 1;
     p.smem = smem_of(p.ck, p.tps);
@@ -1853,7 +1861,7 @@ inline W3Plan plan_w3(int B, int M, int AH, int AW, int Cin, int R, int S, int s
     p.tiles_y = (AH + 1) / 2;
     p.ntiles = B * p.tiles_x * p.tiles_y;
     const long base = (long)((M + BM - 1) / BM) * (p.Cp32 / BC) * (G > 1 ? G : 1);
-    long nsplit = (env_int("CC_W3_SPLIT", 256) + base - 1) / base;
+    long nsplit = (env_int("CC_W3_SPLIT", 512) + base - 1) / base;      // 512: measured -0.27 ms/step vs 256 (r02f A/B)
     const long cap = (p.ntiles + 5) / 6;          // >= 6 pixel tiles per split: every split writes a 9*M*Cpad partial slab
     if (nsplit > cap) nsplit = cap;
     if (nsplit > p.ntiles) nsplit = p.ntiles;
