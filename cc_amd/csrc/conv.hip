@@ -250,7 +250,6 @@ struct CP {
     int nsplit, cps; long part_stride;
     int act; float act_a, act_b;
     int res_mul;
-    int* tickets;          // split-K arrival counters of this launch (zero on entry, zero again on exit), or null: 2-launch form
 };
 
 // wp[(t*Cpad + c)*Mpad + m] = w[w0 + m*w_sm + c*w_sc + i*w_ri + j*w_sj]  (0 beyond Cin / M), t = i*St + j
@@ -516,96 +515,6 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
     }
 
     const int y_cs = g.OH * g.OW;
-    // ---- split-K, one launch: every slice stores its partial tile, takes a ticket, and the LAST arriver of the tile sums the
-    // slabs in slice order (deterministic) and runs the fused epilogue itself -- no second launch, no epilogue-grid re-read.
-    // Visibility (MI355X guide, Guideline 16): plain stores -> every wave drains its own stores -> barrier -> one lane:
-    // agent-scope release, asm vmcnt(0), relaxed agent atomic;  last arriver: one lane agent-scope acquire -> barrier -> plain loads.
-    bool reduce_here = false;
-    if ((SPLIT == 1 || (SPLIT == 2 && g.nsplit > 1)) && g.tickets != nullptr) {
-        __shared__ int last_flag;
-        const int HWt = g.OHt * g.OWt;
-        if constexpr (BM == 16) {
-            const int ty = ty0 + rowstep * row0;
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int tyy = ty + (g.tw16 ? h : 0), txx = tx0 + (g.tw16 ? 0 : 16 * h) + (lane & 15);
-                if (tyy >= g.OHt || txx >= g.OWt) continue;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int m = m0 + 4 * (lane >> 4) + r;
-                    if (m < g.M) g.part[(long)blockIdx.z * g.part_stride + ((long)n * g.M + m) * HWt + (long)tyy * g.OWt + txx] = acc16[h][r];
-                }
-            }
-        } else {
-            const int txx = tx0 + lc;
-#pragma unroll
-            for (int b = 0; b < TN; b++) {
-                const int tyy = ty0 + rowstep * (row0 + b) + lr;
-                if (tyy >= g.OHt || txx >= g.OWt) continue;
-                float* pb = g.part + (long)blockIdx.z * g.part_stride + ((long)n * g.M) * HWt + (long)tyy * g.OWt + txx;
-#pragma unroll
-                for (int a = 0; a < TM; a++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int m = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                        if (m < g.M) pb[(long)m * HWt] = acc[a][b][r];
-                    }
-            }
-        }
-        CC_ASM_WAIT_VMCNT0();
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            CC_ASM_WAIT_VMCNT0();
-            int* tk = g.tickets + ((long)bx_in * gridDim.y + blockIdx.y);
-            const int t = atomicAdd(tk, 1);
-            const int last = (t == g.nsplit - 1) ? 1 : 0;
-            if (last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                *tk = 0;                                  // leave the counters zero for the next launch that uses them
-            }
-            last_flag = last;
-        }
-        __syncthreads();
-        if (!last_flag) return;
-        // re-read this thread's own elements from every slice (same addresses it and its peers wrote: coalesced), slice order
-        if constexpr (BM == 16) {
-            const int ty = ty0 + rowstep * row0;
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int tyy = ty + (g.tw16 ? h : 0), txx = tx0 + (g.tw16 ? 0 : 16 * h) + (lane & 15);
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int m = m0 + 4 * (lane >> 4) + r;
-                    float sacc = 0.f;
-                    if (tyy < g.OHt && txx < g.OWt && m < g.M) {
-                        const float* ps = g.part + ((long)n * g.M + m) * HWt + (long)tyy * g.OWt + txx;
-                        for (int z = 0; z < g.nsplit; z++) sacc += ps[(long)z * g.part_stride];
-                    }
-                    acc16[h][r] = sacc;
-                }
-            }
-        } else {
-            const int txx = tx0 + lc;
-#pragma unroll
-            for (int b = 0; b < TN; b++) {
-                const int tyy = ty0 + rowstep * (row0 + b) + lr;
-                const bool pin = tyy < g.OHt && txx < g.OWt;
-                const float* pb = g.part + ((long)n * g.M) * HWt + (long)tyy * g.OWt + txx;
-#pragma unroll
-                for (int a = 0; a < TM; a++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int m = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                        float sacc = 0.f;
-                        if (pin && m < g.M)
-                            for (int z = 0; z < g.nsplit; z++) sacc += pb[(long)z * g.part_stride + (long)m * HWt];
-                        acc[a][b][r] = sacc;
-                    }
-            }
-        }
-        reduce_here = true;
-    }
     if constexpr (BM == 16) {
         // D col = lane & 15 -> pixel of the half, row = 4 * (lane >> 4) + r -> channel
         const int HWt = g.OHt * g.OWt;
@@ -619,7 +528,7 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
             for (int r = 0; r < 4; r++) {
                 const int m = m0 + 4 * (lane >> 4) + r;
                 if (m >= g.M) continue;
-                if (!reduce_here && (SPLIT == 1 || (SPLIT == 2 && g.nsplit > 1))) {
+                if (SPLIT == 1 || (SPLIT == 2 && g.nsplit > 1)) {
                     g.part[(long)blockIdx.z * g.part_stride + ((long)n * g.M + m) * HWt + (long)ty * g.OWt + tx] = acc16[h][r];
                 } else {
                     float v = acc16[h][r];
@@ -639,7 +548,7 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
         const int ty = ty0 + rowstep * (row0 + b) + lr;
         if (ty >= g.OHt || tx >= g.OWt) continue;
         const long pix = (long)(g.oy0 + g.so * ty) * g.OW + (g.ox0 + g.so * tx);
-        if (!reduce_here && (SPLIT == 1 || (SPLIT == 2 && g.nsplit > 1))) {
+        if (SPLIT == 1 || (SPLIT == 2 && g.nsplit > 1)) {
             // partial slabs are dense over the LATTICE: [split][n][m][ty*OWt + tx]
             const int HWt = g.OHt * g.OWt;
             float* pb = g.part + (long)blockIdx.z * g.part_stride + ((long)n * g.M) * HWt + (long)ty * g.OWt + tx;
@@ -687,7 +596,6 @@ __global__ __launch_bounds__(256, CC_PATCH_LB) void k_conv_patch(CP g) {
 // group instead of one per branch triples the work per launch, needs a third of the split-K (partial-slab traffic) and
 // removes two thirds of the ~5 us launch floors.
 constexpr int MAXCLS = 12;
-constexpr int TICKETS = 2048;      // split-K arrival counters appended to every prepacked weight-image buffer (ints)
 struct CPM {
     CP c[MAXCLS];
     int n;
@@ -1553,9 +1461,8 @@ inline void dispatch_patch(int bm, int ck, int tps, const ARGS& c, dim3 grid, si
     }
 }
 
-inline CP make_cp(const GG& g, const ConvPlan& p, const float* zeros, const float* wp, float* part, int* tickets = nullptr) {
+inline CP make_cp(const GG& g, const ConvPlan& p, const float* zeros, const float* wp, float* part) {
     CP c = {};
-    c.tickets = tickets;
     c.x = g.x; c.wp = wp; c.zeros = zeros; c.bias = g.bias; c.res = g.res; c.y = g.y; c.part = part;
     c.B = g.B; c.Cin = g.Cin; c.IH = g.IH; c.IW = g.IW; c.x_bs = g.x_bs;
     c.M = g.M; c.Mpad = p.Mpad; c.Cpad = p.Cpad;
@@ -1572,8 +1479,7 @@ inline CP make_cp(const GG& g, const ConvPlan& p, const float* zeros, const floa
 
 // ws: [64 zeros][repacked weights][split-K partial slabs]; sized by conv_ws_floats(plan_conv(g))
 // prepacked (optional): {64 zeros, wp} produced earlier by k_repack_table -> no repack launch here
-inline void launch_gg(const GG& g, float* ws, hipStream_t s, const float* prepacked = nullptr, const float* pre_zeros = nullptr,
-                      int* tickets = nullptr) {
+inline void launch_gg(const GG& g, float* ws, hipStream_t s, const float* prepacked = nullptr, const float* pre_zeros = nullptr) {
     const ConvPlan p = plan_conv(g);
     if (!p.use_patch || ws == nullptr) { launch_gg_flat(g, s); return; }
     const float* zeros = ws;
@@ -1587,11 +1493,10 @@ inline void launch_gg(const GG& g, float* ws, hipStream_t s, const float* prepac
         hipLaunchKernelGGL(k_repack_w, dim3((unsigned)((p.wp_floats + 255) / 256)), dim3(256), 0, s, g.w, ws + 64, ws, g.M, g.Cin,
                            p.Mpad, p.Cpad, T, g.St, g.w_sm, g.w_sc, g.w0, g.w_ri, g.w_sj);
     }
+    const CP c = make_cp(g, p, zeros, wp, part);
     dim3 grid((unsigned)(g.B * p.tiles_x * p.tiles_y), (unsigned)(p.Mpad / p.bm), (unsigned)p.nsplit);
-    if ((long)grid.x * grid.y > TICKETS || dbg_flag_early("CC_CONV_SPLITK_2LAUNCH")) tickets = nullptr;
-    const CP c = make_cp(g, p, zeros, wp, part, p.nsplit > 1 ? tickets : nullptr);
     dispatch_patch(p.bm, p.ck, p.tps, c, grid, p.smem, s);
-    if (p.nsplit > 1 && !c.tickets) {
+    if (p.nsplit > 1) {
         const long total = c.part_stride;
         hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)part,
                            p.nsplit, c.part_stride, g.bias, g.res, g.y, g.M, g.OHt, g.OWt, g.so, g.oy0, g.ox0, g.OH, g.OW,
@@ -1604,7 +1509,7 @@ inline void launch_gg(const GG& g, float* ws, hipStream_t s, const float* prepac
 // the same tile configuration.  zeros[k] / wps[k] / parts[k]: the 64-float zero block, weight image and partial-slab area of
 // problem k.  -> false: caller launches them one by one.
 inline bool launch_gg_classes(const GG* gs, int n, int mult, const float* const* zeros, const float* const* wps,
-                              float* const* parts, hipStream_t s, int* tickets = nullptr) {
+                              float* const* parts, hipStream_t s) {
     if (n < 2 || n > MAXCLS || dbg_flag_early("CC_NO_CLASS_MERGE")) return false;
     ConvPlan ps[MAXCLS];
     size_t smem = 0;
@@ -1623,19 +1528,13 @@ inline bool launch_gg_classes(const GG* gs, int n, int mult, const float* const*
     EPM e = {};
     a.n = n; e.n = n;
     int bx = 0, ebx = 0, nsplit_any = 0;
-    {   // in-kernel split-K reduction needs one arrival counter per output tile of the launch
-        long tiles = 0;
-        for (int k = 0; k < n; k++) tiles += (long)gs[k].B * ps[k].tiles_x * ps[k].tiles_y;
-        if (tiles * (ps[0].Mpad / ps[0].bm) > TICKETS || dbg_flag_early("CC_CONV_SPLITK_2LAUNCH")) tickets = nullptr;
-    }
-    const int gy_tiles = ps[0].Mpad / ps[0].bm;
     for (int k = 0; k < n; k++) {
         const GG& g = gs[k];
         const ConvPlan& p = ps[k];
         // LDS: A buffers follow the launch-wide TPS, the patch buffers this class's PS
         const size_t sm = (size_t)(2 * tps * p.ck * p.bm + 2 * p.ck * p.PS) * sizeof(float);
         if (sm > smem) smem = sm;
-        a.c[k] = make_cp(g, p, zeros[k], wps[k], parts[k], (tickets && p.nsplit > 1) ? tickets + (long)bx * gy_tiles : nullptr);
+        a.c[k] = make_cp(g, p, zeros[k], wps[k], parts[k]);
         bx += g.B * p.tiles_x * p.tiles_y;
         a.bx_end[k] = bx;
         EPC& c = e.c[k];
@@ -1652,7 +1551,7 @@ inline bool launch_gg_classes(const GG* gs, int n, int mult, const float* const*
         fprintf(stderr, "[conv] %d problems in one launch: %d tiles, bm %d ck %d tps %d split %d\n", n, bx, ps[0].bm, ps[0].ck, tps, maxsplit);
     dim3 grid((unsigned)bx, (unsigned)(ps[0].Mpad / ps[0].bm), (unsigned)maxsplit);
     dispatch_patch(ps[0].bm, ps[0].ck, tps, a, grid, smem, s);
-    if (nsplit_any && !tickets) {
+    if (nsplit_any) {
         const GG& g = gs[0];
         e.M = g.M; e.so = g.so; e.OH = g.OH; e.OW = g.OW; e.y_bs = g.y_bs; e.res_bs = g.res_bs;
         e.act = g.act; e.act_a = g.act_a; e.act_b = g.act_b; e.res_mul = g.res_mul;
@@ -1697,7 +1596,7 @@ size_t cc_conv2d_fwd_pack_floats(int B, int Cin, int IH, int IW, int Cout, int R
     GG g = make_fwd(nullptr, nullptr, nullptr, nullptr, nullptr, B, Cin, IH, IW, 0, Cout, R, S, stride, pad, OH, OW, 0, 0, 0,
                     1.f, 0.f);
     const ConvPlan p = plan_conv(g);
-    return (p.use_patch && R * S <= 136) ? 64 + p.wp_floats + TICKETS : 0;      // 136 = tile rows of k_repack_table
+    return (p.use_patch && R * S <= 136) ? 64 + p.wp_floats : 0;      // 136 = tile rows of k_repack_table
 }
 
 int cc_conv2d_fwd_pack_desc(int B, int Cin, int IH, int IW, int Cout, int R, int S, int stride, int pad, int OH, int OW,
@@ -1724,9 +1623,7 @@ int cc_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, con
     if (B <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0) return CC_ERR_ARG;
     GG g = make_fwd(x, w, bias_or_null, res_or_null, y, B, Cin, IH, IW, x_bs, Cout, R, S, stride, pad, OH, OW, y_bs, res_bs,
                     act, act_a, act_b);
-    int* tickets = nullptr;
-    if (prepacked_or_null) tickets = (int*)(prepacked_or_null + 64 + plan_conv(g).wp_floats);
-    launch_gg(g, ws, (hipStream_t)stream, prepacked_or_null ? prepacked_or_null + 64 : nullptr, prepacked_or_null, tickets);
+    launch_gg(g, ws, (hipStream_t)stream, prepacked_or_null ? prepacked_or_null + 64 : nullptr, prepacked_or_null);
     CC_CHECK_LAUNCH();
     return CC_OK;
 }
@@ -1761,12 +1658,8 @@ int cc_conv2d_fwd_group(int G, const long* x, const long* w, const long* bias, c
         wps[k] = pk ? pk + 64 : nullptr;
         parts[k] = ws + k * stride_f + 64;
     }
-    const size_t wpf = plan_conv(gs[0]).wp_floats;
-    int* tk0 = packed ? (int*)(const_cast<float*>(zeros[0]) + 64 + wpf) : nullptr;
-    if (!(G > 1 && packed && ws && launch_gg_classes(gs, G, G, zeros, wps, parts, s, tk0))) {
-        for (int k = 0; k < G; k++)
-            launch_gg(gs[k], ws ? ws + k * stride_f : nullptr, s, wps[k], zeros[k],
-                      zeros[k] ? (int*)(const_cast<float*>(zeros[k]) + 64 + wpf) : nullptr);
+    if (!(G > 1 && packed && ws && launch_gg_classes(gs, G, G, zeros, wps, parts, s))) {
+        for (int k = 0; k < G; k++) launch_gg(gs[k], ws ? ws + k * stride_f : nullptr, s, wps[k], zeros[k]);
     }
     CC_CHECK_LAUNCH();
     return CC_OK;
@@ -1820,7 +1713,7 @@ size_t cc_conv2d_dgrad_pack_floats(int B, int K, int OH, int OW, int C, int R, i
             if (!p.use_patch) return 0;
             tot += p.wp_floats;
         }
-    return tot + TICKETS;
+    return tot;
 }
 
 int cc_conv2d_dgrad_pack_desc(int B, int K, int OH, int OW, int C, int R, int S, int stride, int pad, int IH, int IW,
@@ -1890,7 +1783,6 @@ int cc_conv2d_dgrad_group(int G, const long* gy, const long* w, const long* bias
         float* parts[MAXCLS];
         int n = 0;
         bool all = true;
-        int* tk0 = nullptr;
         for (int k = 0; k < G && all; k++) {
             const float* pk = (const float*)prepacked[k];
             long off = 64;
@@ -1909,9 +1801,8 @@ int cc_conv2d_dgrad_group(int G, const long* gy, const long* w, const long* bias
                     part += p.part_floats;
                     n++;
                 }
-            if (k == 0) tk0 = (int*)(const_cast<float*>(pk) + off);       // the ticket area follows the last class image
         }
-        if (all && launch_gg_classes(gs, n, G, zeros, wps, parts, s, tk0)) {
+        if (all && launch_gg_classes(gs, n, G, zeros, wps, parts, s)) {
             CC_CHECK_LAUNCH();
             return CC_OK;
         }
@@ -1920,18 +1811,6 @@ int cc_conv2d_dgrad_group(int G, const long* gy, const long* w, const long* bias
         const float* pk = prepacked ? (const float*)prepacked[k] : nullptr;
         float* wk = ws ? ws + k * stride_f : nullptr;
         long off = 64;
-        int* tk = nullptr;
-        if (pk) {
-            long end = 64;
-            for (int py = 0; py < stride; py++)
-                for (int px = 0; px < stride; px++) {
-                    GG g;
-                    if (make_dgrad_class(g, py, px, nullptr, nullptr, nullptr, nullptr, B, K, OH, OW, 0, C, R, S, stride, pad, IH, IW, 0,
-                                         w_k_stride, w_c_stride, 0, 1.f, 0.f))
-                        end += (long)plan_conv(g).wp_floats;
-                }
-            tk = (int*)(const_cast<float*>(pk) + end);
-        }
         for (int py = 0; py < stride; py++) {
             for (int px = 0; px < stride; px++) {
                 GG g;
@@ -1941,7 +1820,7 @@ int cc_conv2d_dgrad_group(int G, const long* gy, const long* w, const long* bias
                     continue;
                 if (pk) {
                     const ConvPlan p = plan_conv(g);
-                    launch_gg(g, wk, s, pk + off, pk, tk);
+                    launch_gg(g, wk, s, pk + off, pk);
                     off += (long)p.wp_floats;
                 } else {
                     launch_gg(g, wk, s);

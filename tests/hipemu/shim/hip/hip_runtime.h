@@ -284,8 +284,6 @@ static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __A
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
-#define HIPEMU_SHIM 1
-#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 
 // ---- math / bit casts
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
