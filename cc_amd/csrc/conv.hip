@@ -694,10 +694,13 @@ inline ConvPlan plan_conv(const GG& g, int mult = 1) {
         p.tw16 = (a16 < a32 && !dbg_flag_early("CC_CONV_NO_TW16")) ? 1 : 0;
     }
     const int th = p.tw16 ? 8 : TH, tw = p.tw16 ? 16 : TW;
-    {   // few pixel tiles: halve the channel tile before resorting to split-K (no partial slabs, no epilogue launch)
+    {   // few pixel tiles: shrink the channel tile (more workgroups, every one over the whole reduction) before resorting to
+        // split-K (partial slabs + an epilogue launch); CC_CONV_BM_MINBLOCKS: block count below which the tile is halved
         const long tiles = (long)g.B * ((g.OWt + tw - 1) / tw) * ((g.OHt + th - 1) / th);
         const int thr = env_int_early("CC_CONV_BM64_BELOW", 0);
         if (p.bm == 128 && tiles * ((g.M + 127) / 128) < thr) p.bm = 64;
+        const int minb = env_int_early("CC_CONV_BM_MINBLOCKS", 0);
+        while (p.bm > 32 && tiles * ((g.M + p.bm - 1) / p.bm) < minb) p.bm /= 2;
     }
     const int ylast = g.dy0 + (g.Rt - 1) * g.dstep, xlast = g.dx0 + (g.St - 1) * g.dstep;
     p.ymin = g.dy0 < ylast ? g.dy0 : ylast;

@@ -147,9 +147,17 @@ class FlatAdam:
     def world():
         return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
+    @staticmethod
+    def comm_active():
+        """collectives are issued when there is more than one rank -- or when CC_FORCE_COMM=1 asks for them on a one-rank
+        process group (exercises the RCCL / two-graph path on a single GPU: tests, tools)"""
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size() > 1 or os.environ.get("CC_FORCE_COMM", "0") == "1"
+
     def all_reduce(self, lo=0, hi=None, async_op=False):
         """SUM-all-reduce flat_g[lo:hi] over the ranks (RCCL over xGMI; gloo in the CPU tests).  -> work handle or None."""
-        if self.world() > 1:
+        if self.comm_active():
             hi = self.flat_g.numel() if hi is None else hi
             if hi > lo:
                 return dist.all_reduce(self.flat_g[lo:hi], async_op=async_op)
@@ -191,7 +199,7 @@ class FlatAdam:
         self.lr, self.betas = g["lr"], tuple(g["betas"])
 
     def broadcast_from_rank0(self):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if self.comm_active():
             dist.broadcast(self.flat_p, 0)
 
 
@@ -211,7 +219,7 @@ class CCTrainer:
         # gradient segments of the flat bucket: [DispResNet6 | PoseNetB6] [MaskNet6 | Back2Future] (parameter order of
         # FlatAdam = train.py:305's chain)
         self.n_dp = sum(p.numel() for n in nets[:2] if n is not None for p in n.parameters() if p.requires_grad)
-        self.split_graphs = self.opt.world() > 1 if split_graphs is None else bool(split_graphs)
+        self.split_graphs = self.opt.comm_active() if split_graphs is None else bool(split_graphs)
         self.comm_ms = None
         self.static_batch = None
         self.losses = None
@@ -367,8 +375,8 @@ class CCTrainer:
                 self.graph_b.replay()
             losses = self.losses
         else:
-            losses = self._fwd_bwd(batch, between=reduce_dp if opt.world() > 1 else None)
-        if opt.world() > 1:
+            losses = self._fwd_bwd(batch, between=reduce_dp if opt.comm_active() else None)
+        if opt.comm_active():
             if not works:
                 works.append(opt.all_reduce(0, self.n_dp, async_op=True))
             works.append(opt.all_reduce(self.n_dp, None, async_op=True))      # mask + flow segment (70 MB): exposed

@@ -132,3 +132,67 @@ def test_training_step_reaches_no_vendor_conv_or_batchnorm_kernel():
            or n in ("aten::convolution", "aten::conv2d", "aten::miopen_convolution", "aten::native_batch_norm")]
     assert not bad, bad
     print("device kernels seen: %d distinct, e.g. %s" % (len(kernels), kernels[:6]))
+
+
+def test_two_graph_step_matches_single_graph():
+    """The data-parallel form of the step (two hipGraphs sharing a pool, the gradient all-reduce of the first segment issued
+    between the replays) on one GPU: same losses, gradients and parameters as the single-graph step."""
+    dev = torch.device("cuda")
+    bc = syn.sample(2, 128, 192, seed=1)
+    batch = (bc[0].to(dev), [r.to(dev) for r in bc[1]], bc[2].to(dev), bc[3].to(dev))
+    res = []
+    for split in (False, True):
+        nets = T.build_nets(dev, init=False)
+        for n in nets:
+            n.load_state_dict(syn.seeded_state_dict(n, 0))
+        tr = T.CCTrainer(nets, T.StepConfig(), use_graph=True, split_graphs=split)
+        l1 = {k: float(v) for k, v in tr.step(batch).items()}
+        g1 = tr.opt.flat_g.clone()
+        l2 = {k: float(v) for k, v in tr.step(batch).items()}
+        assert (tr.graph_b is not None) == split
+        res.append((l1, g1, l2, tr.opt.flat_p.clone()))
+    (a1, ga, a2, pa), (b1, gb, b2, pb) = res
+    for k in a1:
+        assert abs(a1[k] - b1[k]) <= 1e-6 * abs(a1[k]) + 1e-9, (k, a1[k], b1[k])
+        assert abs(a2[k] - b2[k]) <= 1e-5 * abs(a2[k]) + 1e-9, (k, a2[k], b2[k])
+    # feature-warp backward scatters with float atomics (like the reference's grid_sample): not bit-reproducible
+    assert float((ga - gb).norm() / ga.norm()) < 1e-4
+    assert float((pa - pb).abs().max()) <= 2.001e-4
+
+
+def test_step_with_rccl_process_group_of_one(monkeypatch):
+    """The multi-GPU code path on the one GPU a test box has: a 1-rank RCCL (backend 'nccl') process group with
+    CC_FORCE_COMM=1 -- parameter broadcast, the two hipGraphs with the asynchronous segment all-reduce between the replays,
+    the second all-reduce, Adam -- must reproduce the plain single-process step."""
+    import socket
+    import torch.distributed as dist
+    dev = torch.device("cuda")
+    bc = syn.sample(2, 128, 192, seed=1)
+    batch = (bc[0].to(dev), [r.to(dev) for r in bc[1]], bc[2].to(dev), bc[3].to(dev))
+
+    def run():
+        nets = T.build_nets(dev, init=False)
+        for n in nets:
+            n.load_state_dict(syn.seeded_state_dict(n, 0))
+        tr = T.CCTrainer(nets, T.StepConfig(), use_graph=True)
+        l1 = {k: float(v) for k, v in tr.step(batch).items()}
+        l2 = {k: float(v) for k, v in tr.step(batch).items()}
+        l3 = {k: float(v) for k, v in tr.step(batch).items()}
+        torch.cuda.synchronize()
+        return tr, l1, l2, l3
+    _, a1, a2, a3 = run()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(port))
+    monkeypatch.setenv("CC_FORCE_COMM", "1")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        tr, b1, b2, b3 = run()
+        assert tr.split_graphs and tr.graph_b is not None
+    finally:
+        dist.destroy_process_group()
+    for a, b in ((a1, b1), (a2, b2), (a3, b3)):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-5 * abs(a[k]) + 1e-9, (k, a[k], b[k])
