@@ -9,8 +9,10 @@ forward, 6-scale losses, backward, gradient all-reduce, Adam) on a synthetic per
 832x256 samples already resident in HBM.  value = N * 4 * K / time (whole-job images/sec, weak scaling).
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel family (fp32 MFMA implicit-GEMM convolutions): algorithmic FLOPs of every
-                launch of one instrumented step / their HIP-event durations, against the 157.3 TFLOP/s fp32 MFMA peak
+  roofline      the dominant DEVICE kernel (the fp32 MFMA implicit-GEMM convolution with the largest share of the step):
+                algorithmic FLOPs of its launches in one instrumented step / their durations -- HIP events recorded by the
+                library around the kernel launch itself (cc_timing_*) -- against the 157.3 TFLOP/s fp32 MFMA peak; traffic =
+                HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json)
   kernels       the same for each C-ABI entry point (conv: TFLOP/s; warp/SSIM: algorithmic GB/s vs 8 TB/s HBM)
   cpu_baseline  the oracle (CPU port of the reference path, oracle/step.py) timed on this box's host cores
                 (rank 0, N=1 only, bounded sample)
@@ -436,27 +438,43 @@ def main():
         kernels = ct.summary()
         groups = ct.kernel_groups()
         convs = {k: v for k, v in kernels.items() if "tflops" in v}
-        if groups:
-            # the dominant kernel = the conv kernel with the largest share of the step
-            kn, a = max(groups.items(), key=lambda kv: kv[1]["ms"])
+        # per-device-kernel durations: HIP events around the kernel launch itself, recorded inside the library (cc_timing_*),
+        # so that the roofline line names a kernel of the rocprofv3 summary and quotes ITS duration (not the C-ABI call's,
+        # which for split-K layers also contains the epilogue launch)
+        import ctypes
+        eng.call("cc_timing_enable", 1)
+        tr_e.step(batch)
+        buf = ctypes.create_string_buffer(1 << 16)
+        nchar = eng.fn["cc_timing_collect"](ctypes.addressof(buf), 1 << 16)
+        dev_k = {}
+        for ln in buf.raw[:nchar].decode().splitlines():
+            nm, n_, ms_, gf_ = ln.split("\t")
+            dev_k[nm] = {"launches": int(n_), "ms": float(ms_), "gflop": float(gf_)}
+        if dev_k:
+            # the dominant kernel = the device kernel with the largest share of the step
+            kn, a = max(dev_k.items(), key=lambda kv: kv[1]["ms"])
             ach = a["gflop"] / a["ms"] if a["ms"] > 0 else 0.0                       # GFLOP / ms = TFLOP/s
             tot_ms = sum(v["ms"] for v in convs.values())
             tot_fl = sum(v["tflops"] * v["ms"] for v in convs.values())
             fam = tot_fl / tot_ms if tot_ms > 0 else 0.0
             traffic, src = pmc_traffic(kn)
+            eager = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                         "tflops": round(v["gflop"] / v["ms"], 2) if v["ms"] > 0 else 0.0}
+                     for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:6]} if groups else None
             roof = {"bound": "mfma", "kernel": kn, "achieved": round(ach, 2), "peak": PEAK_MFMA_F32, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_MFMA_F32, 4), "traffic": traffic, "traffic_source": src,
                     "launches": a["launches"], "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2),
-                    # "+splitk": the bracketed C-ABI call is this kernel followed by one k_splitk_epilogue launch
-                    "kernels_per_call": 2 if kn.endswith("+splitk") else 1,
+                    "timing": "HIP events around the kernel launch on its stream (cc_timing_enable / cc_timing_collect), one "
+                              "eager step; all launches of this device kernel in the step (grouped, split-K and plain)",
                     "algorithmic_gflop_per_launch": round(a["gflop"] / a["launches"], 3),
-                    "algorithmic_bytes_per_launch": round(a["bytes"] / a["launches"]),
                     "ms_per_step": round(a["ms"], 3),
                     "conv_family": {"achieved": round(fam, 2), "frac": round(fam / PEAK_MFMA_F32, 4),
-                                    "launches": sum(v["calls"] for v in convs.values()), "ms_per_step": round(tot_ms, 3)},
+                                    "launches": sum(v["calls"] for v in convs.values()), "ms_per_step": round(tot_ms, 3),
+                                    "timing": "HIP events around each C-ABI call (kernel + its epilogue / reduction launches)"},
                     "by_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                       "tflops": round(v["gflop"] / v["ms"], 2) if v["ms"] > 0 else 0.0}
-                                  for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:8]}}
+                                  for k, v in sorted(dev_k.items(), key=lambda kv: -kv[1]["ms"])[:8]},
+                    "by_call_group": eager}
 
     if rank == 0:
         imgs = B * world * args.steps

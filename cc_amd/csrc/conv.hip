@@ -25,6 +25,29 @@
 #include "cc_common.h"
 #include "conv_internal.h"
 #include "../../include/ccengine.h"
+#include <vector>
+#include <string>
+
+// ---- per-kernel timing (measurement aid for bench.py's roofline line; off unless cc_timing_enable(1) was called on this
+// thread): the MAIN device kernel of every conv / weight-gradient call is bracketed with HIP events on its own stream, so the
+// reported duration is the kernel's (what rocprofv3 --kernel-trace shows), not the C-ABI call's.
+namespace cctiming {
+struct Rec { std::string name; double gflop; hipEvent_t e0, e1; };
+static thread_local std::vector<Rec>* recs = nullptr;
+struct Scope {
+    Rec* r = nullptr;
+    hipStream_t s;
+    Scope(const char* name, double gflop, hipStream_t st) : s(st) {
+        if (!recs) return;
+        recs->push_back(Rec{name, gflop, nullptr, nullptr});
+        r = &recs->back();
+        (void)hipEventCreate(&r->e0);
+        (void)hipEventCreate(&r->e1);
+        (void)hipEventRecord(r->e0, s);
+    }
+    ~Scope() { if (r) (void)hipEventRecord(r->e1, s); }
+};
+}  // namespace cctiming
 
 namespace {
 
@@ -1498,7 +1521,12 @@ inline void launch_gg(const GG& g, float* ws, hipStream_t s, const float* prepac
     }
     const CP c = make_cp(g, p, zeros, wp, part);
     dim3 grid((unsigned)(g.B * p.tiles_x * p.tiles_y), (unsigned)(p.Mpad / p.bm), (unsigned)p.nsplit);
-    dispatch_patch(p.bm, p.ck, p.tps, c, grid, p.smem, s);
+    {
+        char nm[96];
+        snprintf(nm, sizeof nm, "k_conv_patch<%d, %d, %d, %d>", p.bm, p.ck, p.tps, p.nsplit > 1 ? 1 : 0);
+        cctiming::Scope tsc(nm, 2e-9 * g.B * g.OHt * g.OWt * (double)g.M * g.Cin * g.Rt * g.St, s);
+        dispatch_patch(p.bm, p.ck, p.tps, c, grid, p.smem, s);
+    }
     if (p.nsplit > 1) {
         const long total = c.part_stride;
         hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)part,
@@ -1553,7 +1581,14 @@ inline bool launch_gg_classes(const GG* gs, int n, int mult, const float* const*
     if (dbg_flag_early("CC_CLASS_MERGE_TRACE"))
         fprintf(stderr, "[conv] %d problems in one launch: %d tiles, bm %d ck %d tps %d split %d\n", n, bx, ps[0].bm, ps[0].ck, tps, maxsplit);
     dim3 grid((unsigned)bx, (unsigned)(ps[0].Mpad / ps[0].bm), (unsigned)maxsplit);
-    dispatch_patch(ps[0].bm, ps[0].ck, tps, a, grid, smem, s);
+    {
+        char nm[96];
+        snprintf(nm, sizeof nm, "k_conv_patch_multi<%d, %d, %d>", ps[0].bm, ps[0].ck, tps);
+        double gf = 0;
+        for (int k = 0; k < n; k++) gf += 2e-9 * gs[k].B * gs[k].OHt * gs[k].OWt * (double)gs[k].M * gs[k].Cin * gs[k].Rt * gs[k].St;
+        cctiming::Scope tsc(nm, gf, s);
+        dispatch_patch(ps[0].bm, ps[0].ck, tps, a, grid, smem, s);
+    }
     if (nsplit_any) {
         const GG& g = gs[0];
         e.M = g.M; e.so = g.so; e.OH = g.OH; e.OW = g.OW; e.y_bs = g.y_bs; e.res_bs = g.res_bs;
@@ -1941,9 +1976,14 @@ int cc_conv2d_wgrad_group(int G, const long* a, const long* x, const long* gw, f
         const int BM = 32 * q.mt, BC = 32 * (4 / q.mt);
         dim3 grid((unsigned)(((M + BM - 1) / BM) * (q.Cp32 / BC)), (unsigned)G, (unsigned)q.nsplit);
         w.dbg = env_int("CC_W3_DBG", 0);
-        if (q.mt == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<4, 1>), grid, dim3(256), q.smem, s, w);
-        else if (q.mt == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<2, 2>), grid, dim3(256), q.smem, s, w);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<1, 4>), grid, dim3(256), q.smem, s, w);
+        {
+            char nm[64];
+            snprintf(nm, sizeof nm, "k_wgrad3x3<%d, %d>", q.mt, 4 / q.mt);
+            cctiming::Scope tsc(nm, 2e-9 * G * B * AH * AW * (double)M * Cin * 9, s);
+            if (q.mt == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<4, 1>), grid, dim3(256), q.smem, s, w);
+            else if (q.mt == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<2, 2>), grid, dim3(256), q.smem, s, w);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<1, 4>), grid, dim3(256), q.smem, s, w);
+        }
         const long tot = (long)9 * M * q.Cp32;
         hipLaunchKernelGGL(k_wgrad_patch_reduce, dim3((unsigned)((tot + 255) / 256), (unsigned)G), dim3(256), 0, s, rg,
                            q.nsplit, 9, M, Cin, q.Cp32, o_sm, o_sc, accumulate);
@@ -2009,9 +2049,14 @@ int cc_conv2d_wgrad_group(int G, const long* a, const long* x, const long* gw, f
     }
     g.pix_per_split = (int)pps;
     dim3 grid((unsigned)((Ntot + BN - 1) / BN), (unsigned)((M + bm - 1) / bm), (unsigned)(nsplit * G));
-    if (bm == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<128>), grid, dim3(256), 0, s, g);
-    else if (bm == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<64>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<32>), grid, dim3(256), 0, s, g);
+    {
+        char nm[64];
+        snprintf(nm, sizeof nm, "k_wgrad<%d>", bm);
+        cctiming::Scope tsc(nm, 2e-9 * G * B * AH * AW * (double)M * Cin * R * S, s);
+        if (bm == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<128>), grid, dim3(256), 0, s, g);
+        else if (bm == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<64>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<32>), grid, dim3(256), 0, s, g);
+    }
     if (!g.direct) {
         const long tot = (long)M * Ntot;
         hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((tot + 255) / 256), (unsigned)G), dim3(256), 0, s, rg,
@@ -2026,6 +2071,44 @@ int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B,
     const long ap = (long)a, xp = (long)x, gp = (long)gw;
     return cc_conv2d_wgrad_group(1, &ap, &xp, &gp, ws, B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, accumulate,
                                  stream);
+}
+
+/* ---- per-kernel timing (measurement aid): cc_timing_enable(1) starts recording on the calling thread, cc_timing_collect
+ * waits for the recorded kernels and writes one line per device kernel "name\tlaunches\ttotal_ms\ttotal_gflop\n" into the
+ * HOST buffer (returns the number of characters, stops recording). */
+int cc_timing_enable(int on) {
+    if (on && !cctiming::recs) cctiming::recs = new std::vector<cctiming::Rec>();
+    if (on) cctiming::recs->reserve(4096);
+    if (!on && cctiming::recs) {
+        for (auto& r : *cctiming::recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+        delete cctiming::recs;
+        cctiming::recs = nullptr;
+    }
+    return CC_OK;
+}
+
+int cc_timing_collect(void* out_host, int cap) {
+    char* out = (char*)out_host;
+    int len = 0;
+    if (!cctiming::recs || cap <= 0) return 0;
+    struct Agg { std::string name; int n; double ms, gf; };
+    std::vector<Agg> agg;
+    for (auto& r : *cctiming::recs) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(r.e1);
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        Agg* a = nullptr;
+        for (auto& x : agg) if (x.name == r.name) { a = &x; break; }
+        if (!a) { agg.push_back(Agg{r.name, 0, 0.0, 0.0}); a = &agg.back(); }
+        a->n++; a->ms += ms; a->gf += r.gflop;
+    }
+    for (auto& a : agg) {
+        const int k = snprintf(out + len, cap - len, "%s\t%d\t%.6f\t%.6f\n", a.name.c_str(), a.n, a.ms, a.gf);
+        if (k < 0 || k >= cap - len) break;
+        len += k;
+    }
+    cc_timing_enable(0);
+    return len;
 }
 
 /* ---- introspection (bench.py groups its per-call timings by the kernel a call dispatches to) */

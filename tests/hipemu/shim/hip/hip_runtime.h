@@ -46,6 +46,12 @@ typedef void* hipStream_t;
 typedef int hipError_t;
 enum { hipSuccess = 0 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
+typedef void* hipEvent_t;
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
