@@ -444,6 +444,7 @@ def main():
         import ctypes
         eng.call("cc_timing_enable", 1)
         tr_e.step(batch)
+        torch.cuda.synchronize()
         buf = ctypes.create_string_buffer(1 << 16)
         nchar = eng.fn["cc_timing_collect"](ctypes.addressof(buf), 1 << 16)
         dev_k = {}

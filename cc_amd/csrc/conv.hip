@@ -27,25 +27,31 @@
 #include "../../include/ccengine.h"
 #include <vector>
 #include <string>
+#include <mutex>
 
 // ---- per-kernel timing (measurement aid for bench.py's roofline line; off unless cc_timing_enable(1) was called on this
-// thread): the MAIN device kernel of every conv / weight-gradient call is bracketed with HIP events on its own stream, so the
+// process; autograd runs the backward pass on its own threads): the MAIN device kernel of every conv / weight-gradient call is bracketed with HIP events on its own stream, so the
 // reported duration is the kernel's (what rocprofv3 --kernel-trace shows), not the C-ABI call's.
 namespace cctiming {
 struct Rec { std::string name; double gflop; hipEvent_t e0, e1; };
-static thread_local std::vector<Rec>* recs = nullptr;
+static std::vector<Rec>* recs = nullptr;
+static std::mutex mtx;
 struct Scope {
-    Rec* r = nullptr;
+    hipEvent_t e1 = nullptr;
     hipStream_t s;
     Scope(const char* name, double gflop, hipStream_t st) : s(st) {
         if (!recs) return;
-        recs->push_back(Rec{name, gflop, nullptr, nullptr});
-        r = &recs->back();
-        (void)hipEventCreate(&r->e0);
-        (void)hipEventCreate(&r->e1);
-        (void)hipEventRecord(r->e0, s);
+        hipEvent_t e0 = nullptr;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        {
+            std::lock_guard<std::mutex> lk(mtx);
+            if (!recs) return;
+            recs->push_back(Rec{name, gflop, e0, e1});
+        }
+        (void)hipEventRecord(e0, s);
     }
-    ~Scope() { if (r) (void)hipEventRecord(r->e1, s); }
+    ~Scope() { if (e1) (void)hipEventRecord(e1, s); }
 };
 }  // namespace cctiming
 
@@ -2073,10 +2079,11 @@ int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B,
                                  stream);
 }
 
-/* ---- per-kernel timing (measurement aid): cc_timing_enable(1) starts recording on the calling thread, cc_timing_collect
+/* ---- per-kernel timing (measurement aid): cc_timing_enable(1) starts recording (process-wide), cc_timing_collect
  * waits for the recorded kernels and writes one line per device kernel "name\tlaunches\ttotal_ms\ttotal_gflop\n" into the
  * HOST buffer (returns the number of characters, stops recording). */
 int cc_timing_enable(int on) {
+    std::lock_guard<std::mutex> lk(cctiming::mtx);
     if (on && !cctiming::recs) cctiming::recs = new std::vector<cctiming::Rec>();
     if (on) cctiming::recs->reserve(4096);
     if (!on && cctiming::recs) {
@@ -2107,7 +2114,7 @@ int cc_timing_collect(void* out_host, int cap) {
         if (k < 0 || k >= cap - len) break;
         len += k;
     }
-    cc_timing_enable(0);
+    cc_timing_enable(0);       // (takes the lock itself)
     return len;
 }
 

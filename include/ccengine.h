@@ -243,7 +243,7 @@ int cc_conv2d_wgrad_group(int G, const long* a, const long* x, const long* gw, f
 int cc_act_bwd_bias_group(int G, const long* gy, const long* y, const long* geff, const long* gbias, float* ws, int B, int C, int H,
                           int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b, int accumulate_bias,
                           void* stream);
-/* per-kernel timing (measurement aid, per calling thread): between cc_timing_enable(1) and cc_timing_collect the MAIN device
+/* per-kernel timing (measurement aid, process-wide; the only state the library keeps): between cc_timing_enable(1) and cc_timing_collect the MAIN device
  * kernel of every conv / weight-gradient call is bracketed with HIP events on its stream; collect returns (HOST buffer) one line
  * per device kernel: "name\tlaunches\ttotal_ms\ttotal_gflop\n" and the number of characters written. */
 int cc_timing_enable(int on);
