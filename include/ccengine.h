@@ -348,6 +348,17 @@ int cc_upsample2x_fwd(const float* x, float* y, int B, int C, int H, int W, long
 int cc_upsample2x_bwd(const float* gy, float* gx, int B, int C, int H, int W, long gy_bs, long gx_bs, float scale, int accumulate,
                       void* stream);
 
+/* ---------------------------------------------------------------- validation side (train.py:588-777)
+ * The rigidity-mask composition of validate_flow_with_gt (train.py:673-687) in one pass; every output may be NULL:
+ *   rigidity [B,1,H,W] = (1 - (1-exp[:,1])*(1-exp[:,2]) > 0.5);  census [B,H,W] = (|cam-fwd|_u < thresh)*(|cam-fwd|_v < thresh);
+ *   combined [B,1,H,W] = 1 - (1-rigidity)*(1-census);  flow_non_rigid = (combined <= thresh)*flow_fwd;
+ *   flow_rigid = (combined > thresh)*flow_cam;  total_flow = flow_rigid + flow_non_rigid  (all [B,2,H,W]);
+ *   oob_rigid / oob_non_rigid [B,H,W] = flow2oob(flow_cam) / flow2oob(flow_fwd) (inverse_warp.py:222-238) as 0/1 floats.
+ * exp_mask [B,MC,H,W] with MC >= 3.  Per-sample semantics: the reference runs this with batch size 1 only (train.py:236). */
+int cc_rigidity_compose(const float* exp_mask, int MC, const float* flow_cam, const float* flow_fwd, float* rigidity,
+                        float* census, float* combined, float* flow_non_rigid, float* flow_rigid, float* total_flow,
+                        float* oob_rigid, float* oob_non_rigid, float thresh, int B, int H, int W, void* stream);
+
 /* ---------------------------------------------------------------- optimizer (train.py:307-310,568)
  * torch.optim.Adam(betas, eps, weight_decay=0) on the flat fp32 bucket; grads are multiplied by grad_scale first
  * (1/world_size after the RCCL all-reduce).  step_dev: device float, incremented by the call. */

@@ -332,6 +332,115 @@ def metrics_level():
     return g
 
 
+VB, VH, VW, VGH, VGW = 1, 64, 192, 90, 260      # validation case: batch 1 (train.py:236), ground truth larger than the net input
+RIGIDITY_NAMES = ("oob_rigid", "oob_non_rigid", "rigidity_mask", "rigidity_mask_census_soft", "rigidity_mask_census_u",
+                  "rigidity_mask_census_v", "rigidity_mask_census", "rigidity_mask_combined", "flow_fwd_non_rigid",
+                  "flow_fwd_rigid", "total_flow")
+
+
+def validate_args():
+    """The fields of train.py's global `args` that validate_* read (defaults of train.py:40-120 for the CC configuration)."""
+    import types
+    return types.SimpleNamespace(spatial_normalize=False, flownet="Back2Future", THRESH=0.01, DEBUG=False, log_terminal=False,
+                                 print_freq=10, sequence_length=5, rotation_mode="euler", padding_mode="zeros")
+
+
+def validate_inputs(n=2, seed=41):
+    """-> (val_flow_loader items, val_loader items): what datasets/validation_flow.py and validation_folders.py hand to
+    validate_flow_with_gt / validate_depth_with_gt (train.py:650, :600) -- seeded frames, KITTI-like sparse flow ground truth
+    (u, v, valid) and object map at their own resolution, depth ground truth with invalid pixels."""
+    flow_items, depth_items = [], []
+    r = np.random.RandomState(seed)
+    for i in range(n):
+        tgt, refs, K, Kinv = syn.sample(VB, VH, VW, seed=seed + i)
+        gt = np.concatenate([r.randn(VB, 2, VGH, VGW).astype(np.float32) * 4.0,
+                             (r.rand(VB, 1, VGH, VGW) > 0.4).astype(np.float32)], 1)
+        obj = (r.rand(VB, VGH, VGW) > 0.7).astype(np.float32)
+        flow_items.append((tgt, refs, K, Kinv, torch.from_numpy(gt), torch.from_numpy(obj)))
+        depth = (r.rand(VB, VH, VW).astype(np.float32) * 100.0 - 10.0)
+        depth_items.append((tgt, torch.from_numpy(depth)))
+    return flow_items, depth_items
+
+
+def validate_net_tweak(mask_net):
+    """The seeded MaskNet6 answers ~0.5 everywhere, i.e. 'rigid' for every pixel; shift its finest head so that the
+    composition of train.py:676 lands on both sides of 0.5 and the non-rigid branch of the loop carries pixels."""
+    with torch.no_grad():
+        mask_net.state_dict()["pred_mask1.bias"].fill_(-1.0)
+
+
+def rigidity_inputs(seed=43, B=1, H=40, W=56, thresh=0.5):
+    """Inputs of the rigidity-mask composition (train.py:673-687) that reach every branch: masks around 0.5, a third of the
+    pixels with |flow_cam - flow_fwd| below the threshold on both channels, flows large enough to leave the image."""
+    r = np.random.RandomState(seed)
+    mask = r.rand(B, 4, H, W).astype(np.float32)
+    cam = (r.randn(B, 2, H, W) * 12.0).astype(np.float32)
+    near = (r.rand(B, 1, H, W) < 0.5).astype(np.float32)
+    fwd = (cam + near * r.randn(B, 2, H, W) * thresh * 0.7 + (1 - near) * r.randn(B, 2, H, W) * 5.0).astype(np.float32)
+    t = torch.from_numpy
+    return dict(explainability_mask=t(mask), flow_cam=t(cam), flow_fwd=t(fwd), THRESH=thresh)
+
+
+def reference_train_functions():
+    """validate_depth_with_gt / validate_flow_with_gt / AverageMeter compiled from the UNMODIFIED source text of the reference's
+    train.py and logger.py (their module-level imports -- tensorboardX, blessings, progressbar, path -- do not exist here, so
+    the function nodes are lifted out of the parsed files and executed in a namespace holding the reference's own helper
+    functions), plus the rigidity-composition statements of train.py:673-687 as a standalone code object."""
+    import ast
+    import time
+    ref = ref_import.load(None)
+    ns = dict(torch=torch, np=np, time=time, Variable=torch.autograd.Variable,
+              spatial_normalize=ref.loss_functions.spatial_normalize, compute_errors=ref.loss_functions.compute_errors,
+              compute_all_epes=ref.loss_functions.compute_all_epes, flow_diff=ref.loss_functions.flow_diff,
+              pose2flow=ref.inverse_warp.pose2flow, flow2oob=ref.inverse_warp.flow2oob,
+              inverse_warp=ref.inverse_warp.inverse_warp, flow_warp=ref.inverse_warp.flow_warp)
+    tree = ast.parse(open(os.path.join(ref_import.REF_ROOT, "logger.py")).read())
+    keep = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "AverageMeter"]
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "reference/logger.py", "exec"), ns)
+    tree = ast.parse(open(os.path.join(ref_import.REF_ROOT, "train.py")).read())
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("validate_depth_with_gt", "validate_flow_with_gt")]
+    assert len(fns) == 2
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "reference/train.py", "exec"), ns)
+    vf = [n for n in fns if n.name == "validate_flow_with_gt"][0]
+    loop = [n for n in vf.body if isinstance(n, ast.For)][0]
+    stmts = [n for n in loop.body if isinstance(n, ast.Assign) and isinstance(n.targets[0], ast.Name)
+             and n.targets[0].id in RIGIDITY_NAMES]
+    assert [n.targets[0].id for n in stmts] == list(RIGIDITY_NAMES), [n.targets[0].id for n in stmts]
+    ns["_rigidity_code"] = compile(ast.Module(body=stmts, type_ignores=[]), "reference/train.py:673-687", "exec")
+    return ns
+
+
+def validate_level():
+    """validate_flow_with_gt / validate_depth_with_gt (train.py:588-777) and the rigidity composition, from the reference."""
+    import types
+    ns = reference_train_functions()
+    g = {}
+    ri = rigidity_inputs()
+    loc = dict(explainability_mask=ri["explainability_mask"], flow_cam=ri["flow_cam"], flow_fwd=ri["flow_fwd"],
+               args=types.SimpleNamespace(THRESH=ri["THRESH"]), flow2oob=ns["flow2oob"])
+    exec(ns["_rigidity_code"], loc)
+    for k in RIGIDITY_NAMES:
+        g["rigidity." + k] = npy(loc[k].float())
+    ref = ref_import.load(None)
+    nets = S.build_nets("ref", ref)
+    for n in nets:
+        n.load_state_dict(syn.seeded_state_dict(n, 0))
+    validate_net_tweak(nets[2])
+    flow_items, depth_items = validate_inputs()
+    ns["args"] = validate_args()
+    with torch.no_grad():
+        err, names = ns["validate_flow_with_gt"](flow_items, nets[0], nets[1], nets[2], nets[3], 0, None)
+        g["flow.errors"] = np.asarray([float(e) for e in err], dtype=np.float64)
+        g["flow.names"] = np.asarray(names)
+        err, names = ns["validate_depth_with_gt"](depth_items, nets[0], 0, None)
+        g["depth.errors"] = np.asarray([float(e) for e in err], dtype=np.float64)
+        g["depth.names"] = np.asarray(names)
+        ns["args"].spatial_normalize = True
+        err, _ = ns["validate_depth_with_gt"](depth_items, nets[0], 0, None)
+        g["depth.errors_spatial_normalize"] = np.asarray([float(e) for e in err], dtype=np.float64)
+    return g
+
+
 HEADLINE = (("c3_b4", True, 4, 256, 832),      # BASELINE.json configs[2]: the configuration the metric is quoted on
             ("c2_b4", False, 4, 256, 832),     # configs[1]
             ("c5_b2", True, 2, 512, 1664))     # configs[4] per-GPU shape
@@ -386,6 +495,10 @@ def main():
         print("wrote headline")
         return
     torch.set_num_threads(1)   # run-to-run bit reproducibility of the fixtures
+    if len(sys.argv) > 1 and sys.argv[1] == "validate":
+        np.savez_compressed(os.path.join(OUT, "validate.npz"), **validate_level())
+        print("wrote validate")
+        return
     np.savez_compressed(os.path.join(OUT, "metrics.npz"), **metrics_level())
     print("wrote metrics")
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":
