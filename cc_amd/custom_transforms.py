@@ -3,8 +3,9 @@
 Host side: the transform classes train.py:166-190 composes, same names, arguments, random-number draws (so the same seeds
 give the same augmentations) and intrinsics updates.  ``scipy.misc.imresize`` / ``imrotate`` -- removed from SciPy in 1.3
 and absent here -- are restated from SciPy 1.1's ``scipy/misc/pilutil.py`` (``toimage`` byte-scales float arrays to their
-own min..max before PIL's resize; bilinear resampling).  **Parity unpinned** for those two functions: the dependency the
-reference imports no longer exists, so there is nothing to run them against.
+own min..max before PIL's resize; bilinear resampling).  `imresize` is pinned by tests/test_transforms.py against Pillow and
+against an independent numpy restatement of Pillow's 8-bit resampler (oracle/pilutil.py, which also serves the reference's
+import when the fixture is generated); `imrotate` (RandomRotate, not in train.py:166-177's pipeline) stays **parity unpinned**.
 
 Device side: ``DeviceFrames`` fuses ArrayToTensor + Normalize (+ the mirror of RandomHorizontalFlip and the crop of
 RandomScaleCrop) for a whole batch of frames into one HIP launch (``cc_frames_to_tensor``) -- HWC uint8 / float32 frames go

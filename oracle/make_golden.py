@@ -257,13 +257,18 @@ def transform_inputs(seed=31, n=3, H=40, W=56):
 
 
 def load_reference_transforms():
-    """The unmodified custom_transforms.py; `scipy.misc.imresize/imrotate` (gone from SciPy) are provided by the
-    restatement in cc_amd/custom_transforms.py -- everything else in the fixture is the reference's own arithmetic."""
+    """The unmodified custom_transforms.py.  Its `from scipy.misc import imresize, imrotate` (gone from SciPy 1.3) is served by
+    oracle/pilutil.py -- a numpy restatement of SciPy 1.1's imresize over Pillow's 8-bit resampler, pinned to Pillow itself and
+    independent of cc_amd; everything else in the fixture is the reference's own arithmetic.  imrotate (RandomRotate, not in
+    the training pipeline of train.py:166-177) is not exercised by the fixture."""
     import importlib.util
     import types
-    from cc_amd import custom_transforms as mine
+    from oracle import pilutil
+
+    def _no_rotate(*a, **k):
+        raise NotImplementedError("imrotate is not part of the fixture")
     shim = types.ModuleType("scipy.misc")
-    shim.imresize, shim.imrotate = mine.imresize, mine.imrotate
+    shim.imresize, shim.imrotate = pilutil.imresize, _no_rotate
     import scipy
     sys.modules["scipy.misc"] = shim
     scipy.misc = shim

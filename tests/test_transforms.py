@@ -1,7 +1,8 @@
 """Input pipeline: cc_amd.custom_transforms against fixtures the unmodified reference
-custom_transforms.py produced (tests/golden/transforms.npz; its two removed SciPy imports are served by the restatement, so
-the fixture pins the reference's own arithmetic: RNG draw order, flip, crop, intrinsics updates, /255, normalise), and the
-fused device kernel against the host classes, bit for bit."""
+custom_transforms.py produced (tests/golden/transforms.npz; its removed `scipy.misc.imresize` import is served by
+oracle/pilutil.py -- a numpy restatement pinned to Pillow below and independent of cc_amd -- so the fixture pins the
+reference's own arithmetic: RNG draw order, flip, scale, crop, intrinsics updates, /255, normalise), and the fused device kernel
+against the host classes, bit for bit."""
 import os
 import random
 
@@ -16,6 +17,22 @@ from oracle.make_golden import run_train_transform, transform_inputs
 @pytest.fixture(scope="module")
 def gold(golden_dir):
     return np.load(os.path.join(golden_dir, "transforms.npz"))
+
+
+def test_oracle_imresize_is_pillow_bilinear():
+    """oracle/pilutil.py (SciPy 1.1 imresize = bytescale + Pillow 8-bit bilinear resample, restated in numpy) against Pillow
+    itself -- up- and down-scaling, both axes, float and uint8 input -- and against the product's imresize."""
+    from PIL import Image
+    from oracle import pilutil
+    r = np.random.RandomState(7)
+    for (H, W, h, w) in [(40, 56, 46, 64), (40, 56, 24, 32), (37, 53, 37, 80), (64, 64, 20, 100), (128, 416, 147, 478)]:
+        a = (r.rand(H, W, 3) * 300 - 20).astype(np.float32)                  # float input: byte-scaled to its own range first
+        ref = np.array(Image.fromarray(pilutil.bytescale(a), mode='RGB').resize((w, h), resample=Image.BILINEAR))
+        assert np.array_equal(pilutil.imresize(a, (h, w)), ref), (H, W, h, w)
+        assert np.array_equal(CT.imresize(a, (h, w)), ref), (H, W, h, w)
+        u8 = r.randint(0, 256, size=(H, W)).astype(np.uint8)
+        ref = np.array(Image.fromarray(u8, mode='L').resize((w, h), resample=Image.BILINEAR))
+        assert np.array_equal(pilutil.imresize(u8, (h, w)), ref) and np.array_equal(CT.imresize(u8, (h, w)), ref)
 
 
 def test_host_transforms_match_reference(gold):
