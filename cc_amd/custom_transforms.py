@@ -178,12 +178,15 @@ class DeviceFrames(object):
     def __init__(self, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), device="cuda"):
         self.mean, self.std, self.device = [float(m) for m in mean], [float(s) for s in std], torch.device(device)
 
-    def __call__(self, frames, out_hw=None, flips=None, offsets=None):
+    def _to_device(self, frames):
         if not torch.is_tensor(frames):
             frames = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(f) for f in frames])
                                                            if isinstance(frames, (list, tuple)) else frames))
         assert frames.dim() == 4 and frames.shape[3] == 3 and frames.dtype in (torch.uint8, torch.float32)
-        src = frames.to(self.device, non_blocking=True).contiguous()
+        return frames.to(self.device, non_blocking=True).contiguous()
+
+    def __call__(self, frames, out_hw=None, flips=None, offsets=None):
+        src = self._to_device(frames)
         N, H, W, _ = src.shape
         h, w = out_hw if out_hw is not None else (H, W)
         geo = np.zeros((N, 3), dtype=np.int32)
@@ -197,3 +200,109 @@ class DeviceFrames(object):
         engine().call("cc_frames_to_tensor", src, int(src.dtype == torch.uint8), dst, geo_d, N, H, W, h, w, self.mean[0],
                       self.mean[1], self.mean[2], self.std[0], self.std[1], self.std[2], STREAM)
         return dst
+
+    # ---- RandomScaleCrop's resize on the device
+    def resize_crop(self, frames, scaled_hw, out_hw, flips=None, offsets=None):
+        """RandomHorizontalFlip -> imresize to scaled_hw -> crop out_hw at offsets -> ArrayToTensor -> Normalize, all on the
+        device and bit-exact with the host classes.  scaled_hw: (sh, sw) or one pair per frame (the frames of one sample share
+        a draw, the samples of a batch do not).  -> fp32 [N,3,h,w]."""
+        src = self._to_device(frames)
+        N, H, W, _ = src.shape
+        h, w = out_hw
+        sizes = [tuple(scaled_hw)] * N if isinstance(scaled_hw[0], (int, np.integer)) else [tuple(s) for s in scaled_hw]
+        assert len(sizes) == N
+        tabs = {}
+        for sh, sw in sizes:
+            tabs.setdefault((H, sh), resample_table(H, sh))
+            tabs.setdefault((W, sw), resample_table(W, sw))
+        KT = max(t[1].shape[1] for t in tabs.values())
+        chunks, offs, pos = [], {}, 0
+        for key, (first, wts) in tabs.items():
+            pad = np.zeros((wts.shape[0], KT), dtype=np.int32)
+            pad[:, :wts.shape[1]] = wts
+            offs[key] = pos
+            chunks += [first.astype(np.int32), pad.reshape(-1)]
+            pos += first.size + pad.size
+        geo = np.zeros((N, 8), dtype=np.int32)
+        if flips is not None:
+            geo[:, 0] = np.asarray(flips, dtype=np.int32)
+        if offsets is not None:
+            geo[:, 1:3] = np.asarray(offsets, dtype=np.int32)
+        for n, (sh, sw) in enumerate(sizes):
+            geo[n, 3:7] = (sh, sw, offs[(W, sw)], offs[(H, sh)])
+            assert 0 <= geo[n, 1] and geo[n, 1] + h <= sh and 0 <= geo[n, 2] and geo[n, 2] + w <= sw, "crop window outside the scaled frame"
+        max_sw = max(sw for _, sw in sizes)
+        tmp_w = (max_sw + 3) // 4 * 4
+        E = engine()
+        ws = torch.empty(int(E.call("cc_frames_resize_ws_bytes", N, H, tmp_w)), dtype=torch.uint8, device=self.device)
+        geo_d = torch.from_numpy(geo).to(self.device)
+        tab_d = torch.from_numpy(np.concatenate(chunks)).to(self.device)
+        dst = torch.empty(N, 3, h, w, device=self.device, dtype=torch.float32)
+        E.call("cc_frames_resize_to_tensor", src, int(src.dtype == torch.uint8), dst, geo_d, tab_d, KT, ws, N, H, W, tmp_w, max_sw, h, w,
+               self.mean[0], self.mean[1], self.mean[2], self.std[0], self.std[1], self.std[2], STREAM)
+        return dst
+
+
+_TABLES = {}
+
+
+def resample_table(in_size, out_size):
+    """Pillow Resample.c precompute_coeffs + normalize_coeffs_8bpc for the bilinear filter: -> (first input index [out_size],
+    int32 weights [out_size, taps]) -- triangle filter of support max(scale, 1) around (i + 0.5) * scale, normalised in double,
+    quantised to 22-bit fixed point (PRECISION_BITS = 32 - 8 - 2)."""
+    key = (int(in_size), int(out_size))
+    if key not in _TABLES:
+        scale = float(in_size) / out_size
+        fscale = max(scale, 1.0)
+        support, ss = 1.0 * fscale, 1.0 / fscale
+        center = (np.arange(out_size, dtype=np.float64) + 0.5) * scale
+        first = np.maximum((center - support + 0.5).astype(np.int64), 0)             # C (int) cast: truncation
+        last = np.minimum((center + support + 0.5).astype(np.int64), in_size)
+        n = last - first
+        idx = np.arange(int(n.max()), dtype=np.float64)[None, :]
+        t = np.abs((idx + first[:, None] - center[:, None] + 0.5) * ss)
+        wts = np.where((t < 1.0) & (idx < n[:, None]), 1.0 - t, 0.0)
+        tot = np.cumsum(wts, axis=1)[:, -1:]                                          # sequential sum, as the C loop
+        wts = np.where(tot != 0.0, wts / np.where(tot != 0.0, tot, 1.0), wts)
+        q = np.trunc(np.where(wts < 0, -0.5 + wts * (1 << 22), 0.5 + wts * (1 << 22))).astype(np.int32)
+        _TABLES[key] = (first.astype(np.int32), q)
+    return _TABLES[key]
+
+
+class DeviceTrainTransform(object):
+    """train.py:166-177 `Compose([RandomHorizontalFlip(), RandomScaleCrop(), ArrayToTensor(), Normalize(mean, std)])` for a whole
+    batch of samples: the random draws and the intrinsics arithmetic happen on the host in the reference's order (Python
+    `random` for the flip, then `np.random` uniform(1, 1.1, 2) and the two randint of RandomScaleCrop -- the same seeds give
+    the same augmentations), the pixels never leave the device (`DeviceFrames.resize_crop`).
+    samples: list of (frames, intrinsics) with frames = list of [H,W,3] arrays, all samples of one size.
+    -> (fp32 [B, n_frames, 3, h, w] on the device, list of updated intrinsics)."""
+
+    def __init__(self, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), device="cuda", h=0, w=0):
+        self.frames = DeviceFrames(mean, std, device)
+        self.crop = RandomScaleCrop(h, w)
+
+    def __call__(self, samples):
+        flat, flips, offsets, sizes, Ks = [], [], [], [], []
+        out_hw = None
+        for frames, K in samples:
+            in_h, in_w, _ = frames[0].shape
+            K = np.copy(K)
+            flip = random.random() < 0.5                                              # RandomHorizontalFlip, :62
+            if flip:
+                K[0, 2] = in_w - K[0, 2]
+            sh, sw, xs, ys, oy, ox, oh, ow = self.crop.draw(in_h, in_w)               # RandomScaleCrop, :97-121
+            K[0] *= xs
+            K[1] *= ys
+            K[0, 2] -= ox
+            K[1, 2] -= oy
+            assert out_hw in (None, (oh, ow)), "DeviceTrainTransform: samples of one batch must share the output size"
+            out_hw = (oh, ow)
+            for f in frames:
+                flat.append(f)
+                flips.append(int(flip))
+                offsets.append((oy, ox))
+                sizes.append((sh, sw))
+            Ks.append(K)
+        out = self.frames.resize_crop(flat, sizes, out_hw, flips, offsets)
+        nf = len(samples[0][0])
+        return out.view(len(samples), nf, 3, out_hw[0], out_hw[1]), Ks

@@ -268,6 +268,16 @@ int cc_act_bwd_bias(const float* gy, const float* y_or_null, float* geff_or_null
  * geo: int32 [N,3] = (flip, off_y, off_x) per frame. */
 int cc_frames_to_tensor(const void* src, int src_is_u8, float* dst, const int* geo, int N, int H, int W, int h, int w, float mean0,
                         float mean1, float mean2, float std0, float std1, float std2, void* stream);
+/* ... with RandomScaleCrop's resize (custom_transforms.py:93-121: scipy.misc.imresize = byte-scale a float frame to its own
+ * min..max, then Pillow's 8-bit bilinear resampler) on the device as well, bit-exact with the host path: RandomHorizontalFlip ->
+ * resize to (sh_n, sw_n) -> crop h x w at (off_y_n, off_x_n) -> ArrayToTensor -> Normalize in 2 (uint8) / 4 (float32) launches.
+ * geo: int32 [N,8] = (flip, off_y, off_x, sh, sw, htab, vtab, 0); tab: int32 resampling tables, per distinct output size
+ * `first_input_index[size]` then `weights[size][KT]` (Pillow's 22-bit fixed-point coefficients, zero padded to KT taps);
+ * htab / vtab are offsets into tab.  ws: cc_frames_resize_ws_bytes(N, H, tmp_w) bytes with tmp_w >= max_sw = max_n sw_n. */
+size_t cc_frames_resize_ws_bytes(int N, int H, int tmp_w);
+int cc_frames_resize_to_tensor(const void* src, int src_is_u8, float* dst, const int* geo, const int* tab, int KT, void* ws, int N,
+                               int H, int W, int tmp_w, int max_sw, int h, int w, float mean0, float mean1, float mean2, float std0,
+                               float std1, float std2, void* stream);
 
 /* ---------------------------------------------------------------- BatchNorm2d, training mode
  * (models/DispResNet6.py:53-56: the Conv1x1 + BatchNorm2d shortcut of every ResNet stage; 13 per forward)

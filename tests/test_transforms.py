@@ -60,6 +60,57 @@ def _device_vs_host(dev):
             assert torch.equal(out[n], t[0]), n
 
 
+def _device_train_transform_vs_host(dev, sizes=((40, 56), (36, 52))):
+    """DeviceTrainTransform (flip -> Pillow-exact resize -> crop -> /255 -> normalise on the device) against the host classes
+    with the same seeds: pixels and intrinsics bit for bit, float32 frames (byte-scaled to their own range, the reference's
+    loader) and uint8 frames, several samples with different draws in one call."""
+    mean, std = (0.5, 0.45, 0.4), (0.5, 0.25, 0.2)
+    for (H, W) in sizes:
+        for as_u8 in (False, True):
+            samples = []
+            for k in range(3):
+                frames, K = transform_inputs(seed=50 + k, n=3, H=H, W=W)
+                if not as_u8:
+                    frames = [f * 0.8 + 10.0 for f in frames]            # min > 0, max < 255: bytescale stretches the contrast
+                else:
+                    frames = [f.astype(np.uint8) for f in frames]
+                samples.append((frames, K))
+            random.seed(11)
+            np.random.seed(11)
+            host = []
+            t = CT.Compose([CT.RandomHorizontalFlip(), CT.RandomScaleCrop(), CT.ArrayToTensor(), CT.Normalize(mean=mean, std=std)])
+            for frames, K in samples:
+                host.append(t([f.copy() for f in frames], np.copy(K)))
+            random.seed(11)
+            np.random.seed(11)
+            out, Ks = CT.DeviceTrainTransform(mean, std, device=dev)(samples)
+            assert out.shape == (3, 3, 3, H, W)
+            flipped = 0
+            for b, (imgs, K) in enumerate(host):
+                assert np.array_equal(np.asarray(K), np.asarray(Ks[b])), b
+                for i, im in enumerate(imgs):
+                    assert torch.equal(out[b, i].cpu(), im), (H, W, as_u8, b, i, float((out[b, i].cpu() - im).abs().max()))
+
+
+def test_resample_table_matches_oracle():
+    from oracle import pilutil
+    for (a, b) in [(40, 46), (56, 61), (375, 256), (1242, 832), (128, 140), (64, 20), (20, 64)]:
+        first, wts = CT.resample_table(a, b)
+        for i, (xmin, kk) in enumerate(pilutil._coefficients(a, b)):
+            assert first[i] == xmin and np.array_equal(wts[i, :len(kk)], kk) and not wts[i, len(kk):].any(), (a, b, i)
+
+
+def test_device_train_transform_emulated():
+    from hipemu.emu import emulated_engine
+    with emulated_engine():
+        _device_train_transform_vs_host("cpu")
+
+
+@pytest.mark.gpu
+def test_device_train_transform_gpu():
+    _device_train_transform_vs_host("cuda", sizes=((40, 56), (128, 416), (256, 832)))
+
+
 def test_device_frames_emulated():
     from hipemu.emu import emulated_engine
     with emulated_engine():
