@@ -1267,24 +1267,6 @@ __global__ void k_zero64(float* p) { p[threadIdx.x] = 0.f; }
 
 struct RG { const float* ws[MAXGRP]; float* gw[MAXGRP]; };
 
-// gw[m*o_sm + c*o_sc + t] = sum_z ws[z][t][m][c]      (blockIdx.y = problem of the group)
-__global__ __launch_bounds__(256) void k_wgrad_patch_reduce(RG rg, int nsplit,
-                                                            int T, int M, int Cin, int Cp32, long o_sm, long o_sc, int accum) {
-    const float* __restrict__ ws = rg.ws[blockIdx.y];
-    float* __restrict__ gw = rg.gw[blockIdx.y];
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;     // over [t][m][c]
-    const long tot = (long)T * M * Cp32;
-    if (e >= tot) return;
-    const int c = (int)(e % Cp32);
-    if (c >= Cin) return;
-    float s = 0.f;
-    for (int z = 0; z < nsplit; z++) s += ws[(long)z * tot + e];
-    const long r = e / Cp32;
-    const int m = (int)(r % M), t = (int)(r / M);
-    float* o = gw + (long)m * o_sm + (long)c * o_sc + t;
-    *o = accum ? (*o + s) : s;
-}
-
 struct WPlan {
     bool ok;
     int bmw, nt, TG, ngroups, Cp32, PH, PWr, PSc, npos, nbuf, tiles_x, tiles_y, ntiles, nsplit, tps;
@@ -1336,24 +1318,6 @@ inline WPlan plan_wgrad(int B, int M, int AH, int AW, int Cin, int R, int S, int
     p.nsplit = (p.ntiles + p.tps - 1) / p.tps;
     p.ws_floats = 64 + (size_t)p.nsplit * T * M * p.Cp32;
     return p;
-}
-
-// second stage: gw[m, (c,i,j)] = sum_split ws[split][m][(c,i,j)]      (blockIdx.y = problem of the group)
-__global__ __launch_bounds__(256) void k_wgrad_reduce(RG rg, int nsplit,
-                                                      int M, int Ntot, int RS, int St, long o_sm, long o_sc, int o_ri,
-                                                      int o_sj, int accum) {
-    const float* __restrict__ ws = rg.ws[blockIdx.y];
-    float* __restrict__ gw = rg.gw[blockIdx.y];
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    const long tot = (long)M * Ntot;
-    if (e >= tot) return;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; k++) s += ws[(long)k * tot + e];
-    const int m = (int)(e / Ntot), jn = (int)(e - (long)m * Ntot);
-    const int c = jn / RS, rem = jn - c * RS;
-    const int i = rem / St, j = rem - i * St;
-    float* o = gw + (long)m * o_sm + (long)c * o_sc + i * o_ri + j * o_sj;
-    *o = accum ? (*o + s) : s;
 }
 
 // ------------------------------------------------------------------ activation backward + bias gradient
@@ -1949,17 +1913,18 @@ static size_t wgrad_ws_bytes_base(int B, int M, int AH, int AW, int Cin, int R, 
  * ConvTranspose2d weight-gradient: a = input [B,Cin,IH,IW], x = dY, si = stride, o strides of [Cin,Cout,R,S].
  * Group form: G (<= 4) same-shaped problems in one launch (+ one reduction launch); a / x / gw: HOST arrays of device
  * addresses; ws: G consecutive areas of cc_conv2d_wgrad_ws_bytes() each. */
-int cc_conv2d_wgrad_group(int G, const long* a, const long* x, const long* gw, float* ws, int B, int M, int AH, int AW, long a_bs,
-                          int Cin, int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, int accumulate,
-                          void* stream) {
+static int wgrad_group_impl(int G, const long* a, const long* x, const long* gw, float* ws, int B, int M, int AH, int AW, long a_bs,
+                            int Cin, int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, int accumulate,
+                            void* stream, ccint::RedSink* sink) {
     if (G <= 0 || G > MAXGRP || B <= 0 || M <= 0 || Cin <= 0) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    long rd[MAXGRP][ccint::RD_LONGS];
     const size_t stride_f = cc_conv2d_wgrad_ws_bytes(B, M, AH, AW, Cin, R, S, si) / sizeof(float);
     {   // thin layers fill the chip on their own: one launch per problem
         bool thin = true;
         for (int k = 0; k < G && thin; k++)
             thin = ccint::wgrad_thin_launch((const float*)a[k], (const float*)x[k], (float*)gw[k], ws + k * stride_f, B, M, AH, AW, a_bs,
-                                            Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, accumulate, s);
+                                            Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, accumulate, s, sink);
         // eligibility depends on the geometry (and 16-byte alignment of the pointers): all problems or none, in practice
         if (thin) {
             CC_CHECK_LAUNCH();
@@ -1990,9 +1955,11 @@ int cc_conv2d_wgrad_group(int G, const long* a, const long* x, const long* gw, f
             else if (q.mt == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<2, 2>), grid, dim3(256), q.smem, s, w);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<1, 4>), grid, dim3(256), q.smem, s, w);
         }
-        const long tot = (long)9 * M * q.Cp32;
-        hipLaunchKernelGGL(k_wgrad_patch_reduce, dim3((unsigned)((tot + 255) / 256), (unsigned)G), dim3(256), 0, s, rg,
-                           q.nsplit, 9, M, Cin, q.Cp32, o_sm, o_sc, accumulate);
+        for (int k = 0; k < G; k++) {
+            const long d[ccint::RD_LONGS] = {1, (long)rg.ws[k], (long)rg.gw[k], q.nsplit, accumulate, o_sm, o_sc, 9, M, Cin, q.Cp32};
+            for (int i = 0; i < ccint::RD_LONGS; i++) rd[k][i] = d[i];
+        }
+        if (ccint::wgrad_reduce_emit(sink, &rd[0][0], G, s) != CC_OK) return CC_ERR_ARG;
         CC_CHECK_LAUNCH();
         return CC_OK;
     }
@@ -2020,11 +1987,8 @@ int cc_conv2d_wgrad_group(int G, const long* a, const long* x, const long* gw, f
                 else if (p.nt == 2) launch_wgrad_patch<32, 2>(w, grid, p.smem, s);
                 else launch_wgrad_patch<32, 1>(w, grid, p.smem, s);
             }
-            RG r1 = {};
-            r1.ws[0] = w.ws; r1.gw[0] = (float*)gw[k];
-            const long tot = (long)R * S * M * p.Cp32;
-            hipLaunchKernelGGL(k_wgrad_patch_reduce, dim3((unsigned)((tot + 255) / 256), 1), dim3(256), 0, s, r1,
-                               p.nsplit, R * S, M, Cin, p.Cp32, o_sm, o_sc, accumulate);
+            const long d[ccint::RD_LONGS] = {1, (long)w.ws, (long)gw[k], p.nsplit, accumulate, o_sm, o_sc, R * S, M, Cin, p.Cp32};
+            if (ccint::wgrad_reduce_emit(sink, d, 1, s) != CC_OK) return CC_ERR_ARG;
         }
         CC_CHECK_LAUNCH();
         return CC_OK;
@@ -2064,12 +2028,34 @@ int cc_conv2d_wgrad_group(int G, const long* a, const long* x, const long* gw, f
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<32>), grid, dim3(256), 0, s, g);
     }
     if (!g.direct) {
-        const long tot = (long)M * Ntot;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((tot + 255) / 256), (unsigned)G), dim3(256), 0, s, rg,
-                           (int)nsplit, M, (int)Ntot, R * S, S, o_sm, o_sc, S, 1, accumulate);
+        for (int k = 0; k < G; k++) {
+            const long d[ccint::RD_LONGS] = {0, (long)rg.ws[k], (long)rg.gw[k], nsplit, accumulate, o_sm, o_sc, M, Ntot, R * S, S, S, 1};
+            for (int i = 0; i < ccint::RD_LONGS; i++) rd[k][i] = d[i];
+        }
+        if (ccint::wgrad_reduce_emit(sink, &rd[0][0], G, s) != CC_OK) return CC_ERR_ARG;
     }
     CC_CHECK_LAUNCH();
     return CC_OK;
+}
+
+int cc_conv2d_wgrad_group(int G, const long* a, const long* x, const long* gw, float* ws, int B, int M, int AH, int AW, long a_bs,
+                          int Cin, int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, int accumulate,
+                          void* stream) {
+    return wgrad_group_impl(G, a, x, gw, ws, B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, accumulate, stream,
+                            nullptr);
+}
+
+/* ... with the reductions of the partial slabs left to the caller: their descriptors (16 longs each, at most G) are written to
+ * red_host[0 .. *nred_host) and ws must stay untouched until cc_wgrad_reduce_table has run on them. */
+int cc_conv2d_wgrad_group_defer(int G, const long* a, const long* x, const long* gw, float* ws, int B, int M, int AH, int AW,
+                                long a_bs, int Cin, int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc,
+                                int accumulate, long* red_host, int red_cap, int* nred_host, void* stream) {
+    if (!red_host || !nred_host || red_cap < G) return CC_ERR_ARG;
+    ccint::RedSink sink = {red_host, red_cap, 0};
+    const int r = wgrad_group_impl(G, a, x, gw, ws, B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, accumulate,
+                                   stream, &sink);
+    *nred_host = sink.n;
+    return r;
 }
 
 int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B, int M, int AH, int AW, long a_bs, int Cin,

@@ -196,43 +196,6 @@ __global__ __launch_bounds__(64 * THIN_NW) void k_wgrad_thin(WT g) {
     }
 }
 
-// gw[m*o_sm + c*o_sc + r*S + s] = sum_pb slab[combo][pb][t][m16][c16]   (fixed summation order)
-__global__ __launch_bounds__(1024) void k_wgrad_thin_reduce(const float* __restrict__ ws, float* __restrict__ gw, int npb, int TS,
-                                                            int S, int TR, int ngc, int ngt, int M, int Cin, int R, long o_sm,
-                                                            long o_sc, int accum) {
-    __shared__ float4 part[16][64];
-    const int combo = blockIdx.x / TS, t = blockIdx.x - combo * TS;
-    const int sub = threadIdx.x >> 6, q = threadIdx.x & 63;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int pb = sub; pb < npb; pb += 16) {
-        const float4 v = *(const float4*)(ws + (((long)combo * npb + pb) * TS + t) * 256 + 4 * q);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    part[sub][q] = s;
-    __syncthreads();
-    if (sub == 0) {
-        for (int z = 1; z < 16; z++) {
-            const float4 v = part[z][q];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-        int cb = combo;
-        const int tg = cb % ngt;
-        cb /= ngt;
-        const int cg = cb % ngc, mg = cb / ngc;
-        const int r = tg * TR + t / S, sc = t % S;
-        const int m = mg * 16 + (q >> 2), c0 = cg * 16 + (q & 3) * 4;
-        if (m < M && r < R) {
-            float* o = gw + (long)m * o_sm + (long)r * S + sc;
-            const float v[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-                if (c0 + e < Cin) {
-                    float* oe = o + (long)(c0 + e) * o_sc;
-                    *oe = accum ? (*oe + v[e]) : v[e];
-                }
-        }
-    }
-}
 
 int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
@@ -299,7 +262,8 @@ size_t wgrad_thin_ws_floats(int B, int M, int AH, int AW, int Cin, int R, int S,
 }
 
 bool wgrad_thin_launch(const float* a, const float* x, float* gw, float* ws, int B, int M, int AH, int AW, long a_bs, int Cin,
-                       int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, int accumulate, hipStream_t s) {
+                       int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, int accumulate, hipStream_t s,
+                       RedSink* sink) {
     const ThinPlan p = plan_thin(B, M, AH, AW, Cin, R, S, si);
     if (!p.ok || (IW & 3) || (a_bs & 3) || (x_bs & 3) || (((uintptr_t)a | (uintptr_t)x) & 15)) return false;
     if ((long)B * a_bs >= (1l << 31) || (long)B * x_bs >= (1l << 31)) return false;      // 32-bit offsets in the kernel
@@ -331,8 +295,8 @@ bool wgrad_thin_launch(const float* a, const float* x, float* gw, float* ws, int
         case K_1_2: launch_thin<1, 2, 0, 1>(g, grid, s); break;
         default: launch_thin<4, 2, 1, 4>(g, grid, s); break;
     }
-    hipLaunchKernelGGL(k_wgrad_thin_reduce, dim3((unsigned)(ncombo * p.TS)), dim3(1024), 0, s, (const float*)ws, gw, p.npb, p.TS, S,
-                       p.TR, p.ngc, p.ngt, M, Cin, R, o_sm, o_sc, accumulate);
+    const long rd[RD_LONGS] = {2, (long)ws, (long)gw, p.npb, accumulate, o_sm, o_sc, p.TS, S, p.TR, p.ngc, p.ngt, M, Cin, R, ncombo};
+    (void)wgrad_reduce_emit(sink, rd, 1, s);
     return true;
 }
 

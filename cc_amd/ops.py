@@ -132,18 +132,62 @@ class _WgradQueue:
         if not q:
             return
         B, M, AH, AW, Cin, IH, IW, R, S, si, pad, o_sm, o_sc = key
-        E = engine()
-        per = E.call("cc_conv2d_wgrad_ws_bytes", B, M, AH, AW, Cin, R, S, si)
-        a1, a2, a3 = _parr([t[0] for t in q]), _parr([t[1] for t in q]), _parr([t[2] for t in q])
-        E.call("cc_conv2d_wgrad_group", len(q), _addr(a1), _addr(a2), _addr(a3), _ws(per * len(q), q[0][0]), B, M, AH, AW, M * AH * AW,
-               Cin, IH, IW, Cin * IH * IW, R, S, si, pad, o_sm, o_sc, 1, STREAM)
+        _wgrad_group([t[0] for t in q], [t[1] for t in q], [t[2] for t in q], q[0][0], B, M, AH, AW, M * AH * AW, Cin, IH, IW,
+                     Cin * IH * IW, R, S, si, pad, o_sm, o_sc, 1)
 
     def flush(self):
         for key in list(self.pending):
             self._launch(key)
+        wgrad_reduces.flush()
+
+
+class _WgradReduces:
+    """Second stages (sums of the split-K partial slabs) of the weight-gradient launches of a backward stage, parked while the
+    trainer's queue is enabled and run as ONE cc_wgrad_reduce_table launch per 32 at the end of the stage: ~130 reductions of
+    8-15 us each per step become 5 launches that fill the chip.  The workspaces stay alive until then."""
+
+    def __init__(self):
+        self.desc = []
+        self.keep = []
+        self.targets = set()
+
+    def flush(self):
+        if self.desc:
+            import ctypes
+            arr = (ctypes.c_long * len(self.desc))(*self.desc)
+            engine().call("cc_wgrad_reduce_table", ctypes.addressof(arr), len(self.desc) // 16, STREAM)
+        self.desc, self.keep, self.targets = [], [], set()
 
 
 wgrad_queue = _WgradQueue()
+wgrad_reduces = _WgradReduces()
+_NO_DEFER = __import__("os").environ.get("CC_NO_WGRAD_DEFER", "0") == "1"       # A/B switch (tools/)
+
+
+def _wgrad_group(a_list, x_list, gw_list, ref, B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, accumulate):
+    """cc_conv2d_wgrad_group for G = len(a_list) <= 4 same-shaped problems.  Inside a trainer stage (queue enabled) and when the
+    results go straight into the optimizer's gradient bucket (accumulate), the reductions are parked (see _WgradReduces)."""
+    import ctypes
+    E = engine()
+    G = len(a_list)
+    per = E.call("cc_conv2d_wgrad_ws_bytes", B, M, AH, AW, Cin, R, S, si)
+    ws = _ws(per * G, ref)
+    a1, a2, a3 = _parr(a_list), _parr(x_list), _parr(gw_list)
+    if accumulate and wgrad_queue.enabled and not _NO_DEFER:
+        ptrs = [t.data_ptr() for t in gw_list]
+        if wgrad_reduces.targets.intersection(ptrs):      # a weight used twice in one stage: two parked `gw +=` would race
+            wgrad_reduces.flush()
+        wgrad_reduces.targets.update(ptrs)
+        red = (ctypes.c_long * (16 * G))()
+        nred = ctypes.c_int(0)
+        E.call("cc_conv2d_wgrad_group_defer", G, _addr(a1), _addr(a2), _addr(a3), ws, B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si,
+               pad, o_sm, o_sc, 1, ctypes.addressof(red), G, ctypes.addressof(nred), STREAM)
+        if nred.value:
+            wgrad_reduces.desc.extend(red[:16 * nred.value])
+            wgrad_reduces.keep.append((ws, gw_list))
+    else:
+        E.call("cc_conv2d_wgrad_group", G, _addr(a1), _addr(a2), _addr(a3), ws, B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad,
+               o_sm, o_sc, int(accumulate), STREAM)
 
 
 # ----------------------------------------------------------------------------- convolution
@@ -213,9 +257,8 @@ class _Conv2dFn(torch.autograd.Function):
                 wgrad_queue.push((B, Cout, OH, OW, Cin, IH, IW, R, S, stride, pad, Cin * R * S, R * S), gy, x, wsink)
             else:
                 gw = wsink if wsink is not None else torch.empty_like(w)
-                ws = _ws(E.call("cc_conv2d_wgrad_ws_bytes", B, Cout, OH, OW, Cin, R, S, stride), x)
-                E.call("cc_conv2d_wgrad", gy, x, gw, ws, B, Cout, OH, OW, Cout * OH * OW, Cin, IH, IW, Cin * IH * IW, R, S,
-                       stride, pad, Cin * R * S, R * S, int(wsink is not None), STREAM)
+                _wgrad_group([gy], [x], [gw], x, B, Cout, OH, OW, Cout * OH * OW, Cin, IH, IW, Cin * IH * IW, R, S, stride, pad,
+                             Cin * R * S, R * S, int(wsink is not None))
                 if wsink is not None:
                     gw = None
         gres = gy if (has_res and need[3]) else None
@@ -338,12 +381,10 @@ class _ConvGroupFn(torch.autograd.Function):
             wsinks = {k: _sink(ws[k]) for k in dw}
             all_wsink = all(v is not None for v in wsinks.values())
             gw = {k: (wsinks[k] if all_wsink else torch.empty_like(ws[k])) for k in dw}
-            per = E.call("cc_conv2d_wgrad_ws_bytes", B, Cout, OH, OW, Cin, R, S, stride)
             for c0 in range(0, len(dw), 4):
                 ch = dw[c0:c0 + 4]
-                a1, a2, a3 = _parr([gy[k] for k in ch]), _parr([xs[k] for k in ch]), _parr([gw[k] for k in ch])
-                E.call("cc_conv2d_wgrad_group", len(ch), _addr(a1), _addr(a2), _addr(a3), _ws(per * len(ch), xs[0]), B, Cout, OH, OW,
-                       Cout * OH * OW, Cin, IH, IW, Cin * IH * IW, R, S, stride, pad, Cin * R * S, R * S, int(all_wsink), STREAM)
+                _wgrad_group([gy[k] for k in ch], [xs[k] for k in ch], [gw[k] for k in ch], xs[0], B, Cout, OH, OW, Cout * OH * OW,
+                             Cin, IH, IW, Cin * IH * IW, R, S, stride, pad, Cin * R * S, R * S, int(all_wsink))
             if not all_wsink:
                 for k in dw:
                     gw_out[k] = gw[k]
@@ -425,9 +466,8 @@ class _ConvT2dFn(torch.autograd.Function):
         if need[1]:
             wsink = _sink(w)
             gw = wsink if wsink is not None else torch.empty_like(w)
-            ws = _ws(E.call("cc_conv2d_wgrad_ws_bytes", B, Cin, IH, IW, Cout, R, S, stride), x)
-            E.call("cc_conv2d_wgrad", x, gy, gw, ws, B, Cin, IH, IW, Cin * IH * IW, Cout, OH, OW, Cout * OH * OW, R, S,
-                   stride, pad, Cout * R * S, R * S, int(wsink is not None), STREAM)
+            _wgrad_group([x], [gy], [gw], x, B, Cin, IH, IW, Cin * IH * IW, Cout, OH, OW, Cout * OH * OW, R, S, stride, pad,
+                         Cout * R * S, R * S, int(wsink is not None))
             if wsink is not None:
                 gw = None
         return gx, gw, gbias, None, None, None, None, None
