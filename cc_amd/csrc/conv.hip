@@ -1915,7 +1915,7 @@ static size_t wgrad_ws_bytes_base(int B, int M, int AH, int AW, int Cin, int R, 
  * addresses; ws: G consecutive areas of cc_conv2d_wgrad_ws_bytes() each. */
 static int wgrad_group_impl(int G, const long* a, const long* x, const long* gw, float* ws, int B, int M, int AH, int AW, long a_bs,
                             int Cin, int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, int accumulate,
-                            void* stream, ccint::RedSink* sink) {
+                            void* stream, ccint::RedSink* sink, const float* zeros64 = nullptr) {
     if (G <= 0 || G > MAXGRP || B <= 0 || M <= 0 || Cin <= 0) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     long rd[MAXGRP][ccint::RD_LONGS];
@@ -1935,7 +1935,7 @@ static int wgrad_group_impl(int G, const long* a, const long* x, const long* gw,
     const W3Plan q = plan_w3(B, M, AH, AW, Cin, R, S, si, pad, IH, IW, G);
     if (q.ok) {
         W3 w = {};
-        w.zeros = ws;
+        w.zeros = zeros64 ? zeros64 : ws;
         for (int k = 0; k < G; k++) {
             w.ga[k] = (const float*)a[k]; w.gxp[k] = (const float*)x[k]; w.gws[k] = ws + k * stride_f + 64;
             rg.ws[k] = w.gws[k]; rg.gw[k] = (float*)gw[k];
@@ -1943,7 +1943,7 @@ static int wgrad_group_impl(int G, const long* a, const long* x, const long* gw,
         w.B = B; w.M = M; w.AH = AH; w.AW = AW; w.a_bs = a_bs; w.Cin = Cin; w.x_bs = x_bs;
         w.tiles_x = q.tiles_x; w.tiles_y = q.tiles_y; w.ntiles = q.ntiles; w.tiles_per_split = q.tps; w.nsplit = q.nsplit;
         w.Cpad = q.Cp32;
-        hipLaunchKernelGGL(k_zero64, dim3(1), dim3(64), 0, s, ws);
+        if (!zeros64) hipLaunchKernelGGL(k_zero64, dim3(1), dim3(64), 0, s, ws);
         const int BM = 32 * q.mt, BC = 32 * (4 / q.mt);
         dim3 grid((unsigned)(((M + BM - 1) / BM) * (q.Cp32 / BC)), (unsigned)G, (unsigned)q.nsplit);
         w.dbg = env_int("CC_W3_DBG", 0);
@@ -2046,14 +2046,16 @@ int cc_conv2d_wgrad_group(int G, const long* a, const long* x, const long* gw, f
 }
 
 /* ... with the reductions of the partial slabs left to the caller: their descriptors (16 longs each, at most G) are written to
- * red_host[0 .. *nred_host) and ws must stay untouched until cc_wgrad_reduce_table has run on them. */
+ * red_host[0 .. *nred_host) and ws must stay untouched until cc_wgrad_reduce_table has run on them.  zeros64_or_null: 64 zero
+ * floats that outlive the launch (the LDS-DMA source of halo pixels; without it a fill launch precedes the kernel). */
 int cc_conv2d_wgrad_group_defer(int G, const long* a, const long* x, const long* gw, float* ws, int B, int M, int AH, int AW,
                                 long a_bs, int Cin, int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc,
-                                int accumulate, long* red_host, int red_cap, int* nred_host, void* stream) {
+                                int accumulate, const float* zeros64_or_null, long* red_host, int red_cap, int* nred_host,
+                                void* stream) {
     if (!red_host || !nred_host || red_cap < G) return CC_ERR_ARG;
     ccint::RedSink sink = {red_host, red_cap, 0};
     const int r = wgrad_group_impl(G, a, x, gw, ws, B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, accumulate,
-                                   stream, &sink);
+                                   stream, &sink, zeros64_or_null);
     *nred_host = sink.n;
     return r;
 }

@@ -150,19 +150,8 @@ class _WgradReduces:
         self.desc = []
         self.keep = []
         self.targets = set()
-        self._side = None
-        self._side_used = False
-
-    def side_stream(self, device):
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=device)
-        self._side_used = True
-        return self._side
 
     def flush(self):
-        if self._side_used:
-            torch.cuda.current_stream().wait_stream(self._side)
-            self._side_used = False
         if self.desc:
             import ctypes
             arr = (ctypes.c_long * len(self.desc))(*self.desc)
@@ -172,8 +161,18 @@ class _WgradReduces:
 
 wgrad_queue = _WgradQueue()
 wgrad_reduces = _WgradReduces()
-_NO_DEFER = __import__("os").environ.get("CC_NO_WGRAD_DEFER", "0") == "1"       # A/B switches (tools/)
-_SIDE_STREAM = __import__("os").environ.get("CC_WGRAD_SIDE_STREAM", "0") == "1"
+_NO_DEFER = __import__("os").environ.get("CC_NO_WGRAD_DEFER", "0") == "1"       # A/B switch (tools/)
+
+
+_ZEROS64 = {}
+
+
+def _zeros64(ref):
+    """64 zero floats per device, never written: the halo source of the LDS-DMA weight-gradient kernels"""
+    z = _ZEROS64.get(ref.device)
+    if z is None:
+        z = _ZEROS64[ref.device] = torch.zeros(64, device=ref.device, dtype=torch.float32)
+    return z
 
 
 def _wgrad_group(a_list, x_list, gw_list, ref, B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, accumulate):
@@ -191,23 +190,11 @@ def _wgrad_group(a_list, x_list, gw_list, ref, B, M, AH, AW, a_bs, Cin, IH, IW, 
         wgrad_reduces.targets.update(ptrs)
         red = (ctypes.c_long * (16 * G))()
         nred = ctypes.c_int(0)
-        args = (G, _addr(a1), _addr(a2), _addr(a3), None, B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, 1,
-                ctypes.addressof(red), G, ctypes.addressof(nred), STREAM)
-        if _SIDE_STREAM and ref.is_cuda:
-            # the weight gradients of a stage depend on nothing downstream: launch them on a second stream so that they fill
-            # the CUs the latency-bound data-gradient chain leaves idle; joined again in _WgradReduces.flush()
-            side = wgrad_reduces.side_stream(ref.device)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                ws = _ws(per * G, ref)
-                E.call("cc_conv2d_wgrad_group_defer", *(args[:4] + (ws,) + args[5:]))
-            wgrad_reduces.keep.append((ws, gw_list, a_list, x_list))
-        else:
-            ws = _ws(per * G, ref)
-            E.call("cc_conv2d_wgrad_group_defer", *(args[:4] + (ws,) + args[5:]))
-            if nred.value:
-                wgrad_reduces.keep.append((ws, gw_list))
+        ws = _ws(per * G, ref)
+        E.call("cc_conv2d_wgrad_group_defer", G, _addr(a1), _addr(a2), _addr(a3), ws, B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si,
+               pad, o_sm, o_sc, 1, _zeros64(ref), ctypes.addressof(red), G, ctypes.addressof(nred), STREAM)
         if nred.value:
+            wgrad_reduces.keep.append((ws, gw_list))
             wgrad_reduces.desc.extend(red[:16 * nred.value])
     else:
         ws = _ws(per * G, ref)

@@ -243,10 +243,12 @@ int cc_conv2d_wgrad_group(int G, const long* a, const long* x, const long* gw, f
 /* The same launch with the reduction of its partial slabs left to the caller (the weight gradients are not needed before the
  * optimizer step): the reduction descriptors -- 16 longs each, at most G, none when the kernel wrote gw itself -- are written to
  * the HOST array red_host[0 .. *nred_host); ws must stay untouched until cc_wgrad_reduce_table has run on them.
+ * zeros64_or_null: 64 zero floats owned by the caller (source of halo pixels; saves a fill launch per call).
  * cc_wgrad_reduce_table: any number of parked reductions in one launch per 32 (fixed summation order, no atomics). */
 int cc_conv2d_wgrad_group_defer(int G, const long* a, const long* x, const long* gw, float* ws, int B, int M, int AH, int AW,
                                 long a_bs, int Cin, int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc,
-                                int accumulate, long* red_host, int red_cap, int* nred_host, void* stream);
+                                int accumulate, const float* zeros64_or_null, long* red_host, int red_cap, int* nred_host,
+                                void* stream);
 int cc_wgrad_reduce_table(const long* desc_host, int n, void* stream);
 int cc_act_bwd_bias_group(int G, const long* gy, const long* y, const long* geff, const long* gbias, float* ws, int B, int C, int H,
                           int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b, int accumulate_bias,
