@@ -40,6 +40,17 @@ def parse_header(path=HEADER):
     return out
 
 
+def image_dense(t):
+    """True for a 4-D NCHW tensor whose images are dense ([C,H,W] contiguous) but whose batch stride may be wider: a channel
+    slice of a concat buffer / of a concat gradient.  Entry points that take a batch stride (x_bs, gy_bs, a_bs ...) read such
+    views in place."""
+    if t.dim() != 4:
+        return False
+    B, C, H, W = t.shape
+    st = t.stride()
+    return st[3] == 1 and st[2] == W and st[1] == H * W and (B == 1 or st[0] >= C * H * W)
+
+
 class Engine:
     def __init__(self, path=LIB_PATH, require_device=True):
         if not os.path.isfile(path):
@@ -67,8 +78,9 @@ class Engine:
                                % (name, i, t.device))
         if t.dtype not in (torch.float32, torch.int32, torch.uint8, torch.int64):
             raise TypeError("%s arg %d: unsupported dtype %s" % (name, i, t.dtype))
-        if not t.is_contiguous():
-            raise ValueError("%s arg %d: tensor must be contiguous" % (name, i))
+        if not t.is_contiguous() and not image_dense(t):
+            raise ValueError("%s arg %d: tensor must be contiguous (or a per-image dense NCHW channel slice whose batch stride "
+                             "the call passes)" % (name, i))
         return t.data_ptr()
 
     def stream_ptr(self):

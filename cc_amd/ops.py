@@ -7,13 +7,26 @@ plumbing"): nearest upsampling + channel softmax of the (unused-by-training) occ
 import torch
 import torch.nn.functional as F
 
-from ._lib import engine, STREAM
+from ._lib import engine, image_dense, STREAM
 
 ACT = {None: 0, "relu": 1, "lrelu": 2, "sigmoid": 3}
 
 
 def _c(t):
     return t.contiguous().float()
+
+
+_NO_SLICE = __import__("os").environ.get("CC_NO_SLICE_GY", "0") == "1"       # A/B switch (tools/)
+
+
+def _slice_or_c(t):
+    """-> (tensor, batch stride in floats): a per-image dense channel slice (the narrow() views autograd hands to the producers
+    of a torch.cat) is read in place through the kernels' batch-stride arguments instead of being copied."""
+    if (t.dtype == torch.float32 and not t.is_contiguous() and image_dense(t) and t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0
+            and not _NO_SLICE):
+        return t, t.stride(0)
+    t = _c(t)
+    return t, t.shape[1] * t.shape[2] * t.shape[3]
 
 
 def _ws(nbytes, ref):
@@ -233,7 +246,8 @@ class _Conv2dFn(torch.autograd.Function):
         stride, pad, act, act_a, act_b, has_bias, has_res = ctx.cfg
         pre_act, pre_b = ctx.pre
         E = engine()
-        gy = _c(gy)
+        # a layer with an activation passes gy through cc_act_bwd_bias first: that call reads a concat-gradient slice in place
+        gy, gy_bs = _slice_or_c(gy) if act != 0 else (_c(gy), 0)
         B, Cin, IH, IW = x.shape
         Cout, _, R, S = w.shape
         OH, OW = gy.shape[2], gy.shape[3]
@@ -243,9 +257,10 @@ class _Conv2dFn(torch.autograd.Function):
             bsink = grad_sinks.get(ctx.bias_ptr) if grad_sinks else None
             gbias = bsink if bsink is not None else torch.empty(Cout, device=x.device, dtype=torch.float32)
         if act != 0 or gbias is not None:
-            geff = torch.empty_like(gy) if act != 0 else None
+            geff = torch.empty(gy.shape, device=gy.device, dtype=torch.float32) if act != 0 else None
             E.call("cc_act_bwd_bias", gy, y, geff, gbias, _ws(E.call("cc_act_bwd_ws_bytes", Cout), x), B, Cout, OH, OW,
-                   Cout * OH * OW, Cout * OH * OW, Cout * OH * OW, act, act_a, act_b, int(bsink is not None), STREAM)
+                   gy_bs if act != 0 else Cout * OH * OW, Cout * OH * OW, Cout * OH * OW, act, act_a, act_b, int(bsink is not None),
+                   STREAM)
             if geff is not None:
                 gy = geff
         if bsink is not None:
@@ -450,7 +465,7 @@ class _ConvT2dFn(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         stride, pad, act, has_bias = ctx.cfg
         E = engine()
-        gy = _c(gy)
+        gy, gy_bs = _slice_or_c(gy) if act != 0 else (_c(gy), 0)       # see _Conv2dFn.backward
         B, Cin, IH, IW = x.shape
         _, Cout, R, S = w.shape
         OH, OW = gy.shape[2], gy.shape[3]
@@ -460,9 +475,10 @@ class _ConvT2dFn(torch.autograd.Function):
             bsink = grad_sinks.get(ctx.bias_ptr) if grad_sinks else None
             gbias = bsink if bsink is not None else torch.empty(Cout, device=x.device, dtype=torch.float32)
         if act != 0 or gbias is not None:
-            geff = torch.empty_like(gy) if act != 0 else None
+            geff = torch.empty(gy.shape, device=gy.device, dtype=torch.float32) if act != 0 else None
             E.call("cc_act_bwd_bias", gy, y, geff, gbias, _ws(E.call("cc_act_bwd_ws_bytes", Cout), x), B, Cout, OH, OW,
-                   Cout * OH * OW, Cout * OH * OW, Cout * OH * OW, act, 1.0, ctx.act_b, int(bsink is not None), STREAM)
+                   gy_bs if act != 0 else Cout * OH * OW, Cout * OH * OW, Cout * OH * OW, act, 1.0, ctx.act_b,
+                   int(bsink is not None), STREAM)
             if geff is not None:
                 gy = geff
         if bsink is not None:
@@ -558,9 +574,9 @@ class _Up2xFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         B, C, H, W, scale = ctx.geom
-        gy = _c(gy)
+        gy, gy_bs = _slice_or_c(gy)
         gx = torch.empty(B, C, H, W, device=gy.device, dtype=torch.float32)
-        engine().call("cc_upsample2x_bwd", gy, gx, B, C, H, W, 4 * C * H * W, C * H * W, scale, 0, STREAM)
+        engine().call("cc_upsample2x_bwd", gy, gx, B, C, H, W, gy_bs, C * H * W, scale, 0, STREAM)
         return gx, None
 
 

@@ -606,3 +606,50 @@ def check_corr_patch(dev, cases=((2, 6, 9, 14, 5, 1), (1, 4, 12, 10, 7, 2), (1, 
         g1 = torch.autograd.grad(o, [ad, bd], go.to(dev))
         g0 = torch.autograd.grad(r, [ac, bc], go)
         assert max(rel(x, y) for x, y in zip(g1, g0)) < 5e-6, ("corr patch grads", (B, C, H, W, P, D))
+
+
+def check_concat_gradient_slices(dev, tol=2e-5):
+    """The producers of a torch.cat receive narrow() views of the concat gradient: conv / transposed conv (with activation) and
+    the x2 up-sampling read them in place through the kernels' batch-stride arguments (ops._slice_or_c) -- same gradients as
+    stock torch, and no contiguous copy of the slice is made."""
+    import torch.nn.functional as F
+    from cc_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 2, 8, 12
+    x1 = torch.randn(B, 8, H, W, generator=g).to(dev).requires_grad_(True)
+    x2 = torch.randn(B, 12, H // 2, W // 2, generator=g).to(dev).requires_grad_(True)
+    x3 = torch.randn(B, 4, H // 2, W // 2, generator=g).to(dev).requires_grad_(True)
+    w1 = (torch.randn(8, 8, 3, 3, generator=g) * 0.2).to(dev).requires_grad_(True)
+    b1 = torch.randn(8, generator=g).to(dev).requires_grad_(True)
+    w2 = (torch.randn(12, 8, 3, 3, generator=g) * 0.2).to(dev).requires_grad_(True)
+    wo = (torch.randn(5, 20, 3, 3, generator=g) * 0.2).to(dev).requires_grad_(True)
+    seen = []
+    orig = ops._slice_or_c
+
+    def spy(t):
+        r = orig(t)
+        seen.append(not r[0].is_contiguous())
+        return r
+    ops._slice_or_c = spy
+    try:
+        a = ops.conv2d(x1, w1, b1, 1, 1, act="relu")
+        b = ops.conv_transpose2d(x2, w2, None, 2, 1, 1, act="relu")
+        c = ops.upsample_bilinear2x(x3, 2.0)
+        y = ops.conv2d(torch.cat((a, b, c), 1), wo, None, 1, 1)
+        (y * y).sum().backward()
+    finally:
+        ops._slice_or_c = orig
+    got = [t.grad.clone() for t in (x1, x2, x3, w1, b1, w2, wo)]
+    for t in (x1, x2, x3, w1, b1, w2, wo):
+        t.grad = None
+    a = F.relu(F.conv2d(x1, w1, b1, 1, 1))
+    b = F.relu(F.conv_transpose2d(x2, w2, None, 2, 1, 1))
+    c = 2.0 * F.interpolate(x3, scale_factor=2, mode="bilinear", align_corners=False)
+    y = F.conv2d(torch.cat((a, b, c), 1), wo, None, 1, 1)
+    (y * y).sum().backward()
+    for n, u, t in zip(("x1", "x2", "x3", "w1", "b1", "w2", "wo"), got, (x1, x2, x3, w1, b1, w2, wo)):
+        err = float((u - t.grad).abs().max() / (t.grad.abs().max() + 1e-30))
+        assert err < tol, (n, err)
+    assert len(seen) == 3
+    if torch.device(dev).type == "cuda":
+        assert all(seen), seen          # every producer read its slice in place (CPU slices may miss the 16-byte alignment)

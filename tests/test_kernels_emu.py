@@ -73,5 +73,9 @@ def test_upsample2x():
     parity.check_upsample2x("cpu")
 
 
+def test_concat_gradient_slices():
+    parity.check_concat_gradient_slices("cpu")
+
+
 def test_conv_groups():
     parity.check_conv_groups("cpu")

@@ -93,6 +93,10 @@ def test_upsample2x():
     parity.check_upsample2x("cuda", cases=((4, 2, 64, 208, 20.0), (4, 1, 128, 416, 1.0)))
 
 
+def test_concat_gradient_slices():
+    parity.check_concat_gradient_slices("cuda")
+
+
 def test_conv_groups():
     parity.check_conv_groups("cuda")
     parity.check_conv_groups("cuda", cases=((4, 196, 16, 52, 128, 96, 1), (4, 64, 32, 104, 96, 32, 2)))
