@@ -5,6 +5,7 @@
 // backward stage at once (cc_wgrad_reduce_table): the same bytes in a grid that fills the chip.
 // Descriptor (RD_LONGS longs, host): kind, ws, gw, nsplit, accumulate, o_sm, o_sc, p0..p8
 //   kind 0 (k_wgrad):       gw[m*o_sm + c*o_sc + i*p4 + j*p5] (+)= sum_z ws[z][m][(c,i,j)]        p = M, Ntot, RS, St, o_ri, o_sj
+//                           (p6 is set at launch: dense destination + aligned slabs -> float4 path)
 //   kind 1 (k_wgrad3x3):    gw[m*o_sm + c*o_sc + t]           (+)= sum_z ws[z][t][m][c]            p = T, M, Cin, Cp32
 //   kind 2 (k_wgrad_thin):  gw[m*o_sm + c*o_sc + r*S + s]     (+)= sum_pb slab[combo][pb][t][m16][c16]
 //                                                                                  p = TS, S, TR, ngc, ngt, M, Cin, R, ncombo
@@ -38,8 +39,22 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_table(RT t) {
     const float* __restrict__ ws = d.ws;
     if (d.kind == 0) {
         const int M = d.p[0], Ntot = d.p[1], RS = d.p[2], St = d.p[3];
-        const long e = (long)bid * 256 + threadIdx.x;
         const long tot = (long)M * Ntot;
+        if (d.p[6]) {
+            // dense [M][C][R][S] destination (offset == e) and 16-byte aligned slabs: four elements per work-item
+            const long e = ((long)bid * 256 + threadIdx.x) * 4;
+            if (e >= tot) return;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int z = 0; z < d.nsplit; z++) {
+                const float4 v = *(const float4*)(ws + (long)z * tot + e);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            float4* o = (float4*)(d.gw + e);
+            if (d.accum) { const float4 g = *o; s.x = g.x + s.x; s.y = g.y + s.y; s.z = g.z + s.z; s.w = g.w + s.w; }
+            *o = s;
+            return;
+        }
+        const long e = (long)bid * 256 + threadIdx.x;
         if (e >= tot) return;
         float s = 0.f;
         for (int z = 0; z < d.nsplit; z++) s += ws[(long)z * tot + e];
@@ -48,17 +63,21 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_table(RT t) {
         const int i = rem / St, j = rem - i * St;
         put(d.gw + (long)m * d.o_sm + (long)c * d.o_sc + i * d.p[4] + j * d.p[5], s, d.accum);
     } else if (d.kind == 1) {
+        // one work-item per (m, c): its T taps are T coalesced slab reads and ONE run of T consecutive floats in gw (a work-item
+        // per slab element writes every 36-byte run from 9 different workgroups)
         const int T = d.p[0], M = d.p[1], Cin = d.p[2], Cp32 = d.p[3];
-        const long e = (long)bid * 256 + threadIdx.x;     // over [t][m][c]
-        const long tot = (long)T * M * Cp32;
-        if (e >= tot) return;
-        const int c = (int)(e % Cp32);
+        const long mc = (long)bid * 256 + threadIdx.x;     // over [m][c]
+        const long per = (long)M * Cp32;
+        if (mc >= per) return;
+        const int c = (int)(mc % Cp32), m = (int)(mc / Cp32);
         if (c >= Cin) return;
-        float s = 0.f;
-        for (int z = 0; z < d.nsplit; z++) s += ws[(long)z * tot + e];
-        const long r = e / Cp32;
-        const int m = (int)(r % M), tt = (int)(r / M);
-        put(d.gw + (long)m * d.o_sm + (long)c * d.o_sc + tt, s, d.accum);
+        const long tot = (long)T * per;
+        float* o = d.gw + (long)m * d.o_sm + (long)c * d.o_sc;
+        for (int tt = 0; tt < T; tt++) {
+            float s = 0.f;
+            for (int z = 0; z < d.nsplit; z++) s += ws[(long)z * tot + (long)tt * per + mc];
+            put(o + tt, s, d.accum);
+        }
     } else {
         // one workgroup = a quarter (16 float4) of one [m16][c16] slab position; 16 sub-groups stride over the npb slabs, then
         // sub-group 0 adds the 16 partial sums in order
@@ -98,8 +117,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_table(RT t) {
 
 long blocks_of(const long* h) {
     switch ((int)h[0]) {
-        case 0: return (h[7] * h[8] + 255) / 256;
-        case 1: return (h[7] * h[8] * h[10] + 255) / 256;
+        case 0: return h[13] ? (h[7] * h[8] / 4 + 255) / 256 : (h[7] * h[8] + 255) / 256;
+        case 1: return (h[8] * h[10] + 255) / 256;
         case 2: return h[15] * h[7] * 4;
         default: return -1;
     }
@@ -120,7 +139,15 @@ int wgrad_reduce_launch(const long* desc, int n, hipStream_t s) {
             d.kind = (int)h[0]; d.ws = (const float*)h[1]; d.gw = (float*)h[2]; d.nsplit = (int)h[3]; d.accum = (int)h[4];
             d.o_sm = h[5]; d.o_sc = h[6];
             for (int i = 0; i < 9; i++) d.p[i] = (int)h[7 + i];
-            const long nb = blocks_of(h);
+            long hv[RD_LONGS];
+            for (int i = 0; i < RD_LONGS; i++) hv[i] = h[i];
+            if (d.kind == 0) {      // p[6]: identity destination mapping, float4-able
+                const long tot = h[7] * h[8];
+                hv[13] = (d.o_sm == h[8] && d.o_sc == h[9] && h[11] == h[10] && h[12] == 1 && tot % 4 == 0 &&
+                          ((uintptr_t)d.ws % 16 == 0) && ((uintptr_t)d.gw % 16 == 0)) ? 1 : 0;
+                d.p[6] = (int)hv[13];
+            }
+            const long nb = blocks_of(hv);
             if (nb <= 0 || !d.ws || !d.gw || d.nsplit <= 0 || blk + nb >= (1l << 31)) return CC_ERR_ARG;
             blk += nb;
             d.blk_end = (int)blk;
