@@ -31,9 +31,22 @@ def load_pretrained(net, path, map_location=None):
 
 
 def resume(save_path, disp_net, pose_net, mask_net, flow_net, map_location=None):
-    """train.py:286-295 (the reference restores the four networks, not the optimizer).  -> epoch of the checkpoint."""
+    """train.py:286-295: restore the four networks from ``*_checkpoint.pth.tar``.  -> epoch of the checkpoint.
+    Call it BEFORE building the optimizer / CCTrainer (as train.py does), then `resume_optimizer`."""
     epoch = None
     for prefix, net in zip(FILE_PREFIXES[:4], (disp_net, pose_net, mask_net, flow_net)):
         if net is not None:
             epoch = load_pretrained(net, os.path.join(str(save_path), '{}_checkpoint.pth.tar'.format(prefix)), map_location)
     return epoch
+
+
+def resume_optimizer(save_path, optimizer, map_location=None):
+    """train.py:311-314: ``if (save_path/'optimizer_checkpoint.pth.tar').exists(): optimizer.load_state_dict(...)`` -- Adam
+    moments and step count continue where the checkpoint left them.  optimizer: ``CCTrainer.opt`` (FlatAdam), a CCTrainer, or
+    a ``torch.optim.Adam`` over the same parameter chain.  -> True when a checkpoint was loaded."""
+    path = os.path.join(str(save_path), 'optimizer_checkpoint.pth.tar')
+    if not os.path.exists(path):
+        return False
+    opt = getattr(optimizer, "opt", optimizer)
+    opt.load_state_dict(torch.load(path, map_location=map_location)['state_dict'])
+    return True
