@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 for V in default "$@" default; do
   if [ "$V" = default ]; then E=""; else E="$V"; fi
-  F=$(echo "$V" | tr ' =' '__')
+  F=$(echo "$V" | tr ' =/' '___')
   ( env $E timeout 300 python bench.py --no-cpu-baseline --no-kernel-timing --steps 30 ) > gpurun_out/bench_${TAG}_$F.log 2> gpurun_out/bench_${TAG}_$F.err
   echo "$V: $(grep timed gpurun_out/bench_${TAG}_$F.err)"
 done
