@@ -367,6 +367,13 @@ CONV_CASES = [  # B, Cin, H, W, Cout, k, stride, pad, act, bias, residual
     (1, 6, 21, 75, 8, 3, 2, 1, "relu", True, False),
     (2, 64, 5, 40, 64, 3, 1, 1, "relu", False, True),
     (1, 40, 6, 32, 96, 3, 1, 1, "lrelu", True, False),
+    # few-channel 3x3 layers on larger maps (prediction heads: <= 4 outputs; their data-gradients: <= 4 reduction channels; a
+    # 3-channel input layer)
+    (1, 20, 32, 72, 4, 3, 1, 1, "sigmoid", True, False),
+    (2, 9, 33, 70, 1, 3, 1, 1, "sigmoid", True, False),
+    (1, 16, 40, 64, 2, 3, 1, 1, None, True, False),
+    (1, 3, 32, 72, 16, 3, 1, 1, "relu", True, False),
+    (2, 2, 35, 66, 5, 3, 1, 1, "lrelu", False, False),
 ]
 # few channels x many pixels (wgrad_thin.hip; the pixel threshold is lowered for the small test maps)
 CONV_CASES_THIN = [
