@@ -62,6 +62,20 @@ int cc_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
     return CC_OK;
 }
 
+/* The same update on a sub-range of the bucket (the caller passes the range's base pointers); tick = 0 leaves the step counter as
+ * it is: the second and later segments of one optimizer step.  Lets the update of a segment whose gradients have arrived run
+ * while the all-reduce of the next segment is still in flight. */
+int cc_adam_step_segment(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* step_dev, long n, float lr,
+                         float beta1, float beta2, float eps, float grad_scale, int tick, void* stream) {
+    if (n <= 0) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (tick) hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, s, step_dev);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, n,
+                       lr, beta1, beta2, eps, (const float*)step_dev, grad_scale);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
 int cc_fill(float* p, long n, float value, void* stream) {
     if (n <= 0) return CC_ERR_ARG;
     hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, p, n, value);

@@ -170,6 +170,14 @@ class FlatAdam:
         engine().call("cc_adam_step", self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.step_dev, self.n,
                       float(self.lr), float(self.betas[0]), float(self.betas[1]), 1e-8, float(grad_scale), STREAM)
 
+    def step_segment(self, lo, hi, tick, grad_scale=1.0):
+        """The update of elements [lo, hi) of the bucket (lo % 4 == 0); tick: advance the step counter (first segment only)."""
+        hi = self.n if hi is None else hi
+        assert lo % 4 == 0 and 0 <= lo < hi <= self.n
+        engine().call("cc_adam_step_segment", self.flat_p[lo:hi], self.flat_g[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                      self.step_dev, hi - lo, float(self.lr), float(self.betas[0]), float(self.betas[1]), 1e-8, float(grad_scale),
+                      int(tick), STREAM)
+
     def state_dict(self):
         """The layout of ``torch.optim.Adam.state_dict()`` (what train.py:408-410 stores in optimizer_checkpoint.pth.tar):
         per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` cut out of the flat buckets, one param group."""
@@ -380,6 +388,14 @@ class CCTrainer:
             if not works:
                 works.append(opt.all_reduce(0, self.n_dp, async_op=True))
             works.append(opt.all_reduce(self.n_dp, None, async_op=True))      # mask + flow segment (70 MB): exposed
+            cut = self.n_dp // 4 * 4            # float4 update: cut at a 16-byte boundary (the <= 3 elements left go second)
+            if 0 < cut < opt.n and len(works) == 2 and all(w is not None for w in works):
+                # the big segment's update runs while the small segment is still being exchanged
+                works[0].wait()
+                opt.step_segment(0, cut, True, opt.grad_scale())
+                works[1].wait()
+                opt.step_segment(cut, None, False, opt.grad_scale())
+                return losses
             for w in works:
                 if w is not None:
                     w.wait()

@@ -384,6 +384,10 @@ int cc_rigidity_compose(const float* exp_mask, int MC, const float* flow_cam, co
  * (1/world_size after the RCCL all-reduce).  step_dev: device float, incremented by the call. */
 int cc_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* step_dev, long n, float lr,
                  float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* ... on a sub-range of the bucket (base pointers of the range; tick = 0: do not advance the step counter -- the second and
+ * later segments of one optimizer step), so that a segment can be updated while the next one's all-reduce is in flight. */
+int cc_adam_step_segment(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* step_dev, long n, float lr,
+                         float beta1, float beta2, float eps, float grad_scale, int tick, void* stream);
 int cc_fill(float* p, long n, float value, void* stream);
 
 #ifdef __cplusplus
