@@ -7,8 +7,8 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer to contiguous fp32 NCHW data owned by the caller
- *     (torch tensors); nothing is allocated or freed inside, there is no global state, all entry
- *     points are thread-safe and capturable into a hipGraph;
+ *     (torch tensors); nothing is allocated or freed inside and no state is kept between calls (the one exception is the
+ *     measurement aid cc_timing_*, off by default), all entry points are thread-safe and capturable into a hipGraph;
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
  *   - return value: 0 = launched; CC_ERR_ARG (-1) bad argument; CC_ERR_LAUNCH (-2) launch failed;
  *   - P is the 3x4 projection K.[R|t] (inverse_warp.py:214,278), Kinv the 3x3 inverse
