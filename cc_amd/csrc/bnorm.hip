@@ -178,10 +178,18 @@ __global__ __launch_bounds__(256) void k_bn_small_fwd(const float* __restrict__ 
     float s[2] = {0.f, 0.f};
     for (int n = 0; n < B; n++) {
         const float* __restrict__ xp = x + (long)n * bs + (long)c * HW;
-        for (int e = threadIdx.x; e < HW; e += 256) {
-            const float d = xp[e] - k;
-            s[0] += d;
-            s[1] += d * d;
+        // four loads in flight per work item, accumulated in element order (the plain loop is one load latency per element)
+        for (int e0 = threadIdx.x; e0 < HW; e0 += 1024) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = (e0 + 256 * u < HW) ? xp[e0 + 256 * u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (e0 + 256 * u < HW) {
+                    const float d = v[u] - k;
+                    s[0] += d;
+                    s[1] += d * d;
+                }
         }
     }
     cc::block_sum_256<2>(s, red);
@@ -208,7 +216,14 @@ __global__ __launch_bounds__(256) void k_bn_small_fwd(const float* __restrict__ 
     for (int n = 0; n < B; n++) {
         const float* __restrict__ xp = x + (long)n * bs + (long)c * HW;
         float* __restrict__ yp = y + (long)n * bs + (long)c * HW;
-        for (int e = threadIdx.x; e < HW; e += 256) yp[e] = fmaf(xp[e], sc, sh);
+        for (int e0 = threadIdx.x; e0 < HW; e0 += 1024) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = (e0 + 256 * u < HW) ? xp[e0 + 256 * u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (e0 + 256 * u < HW) yp[e0 + 256 * u] = fmaf(v[u], sc, sh);
+        }
     }
 }
 
@@ -226,10 +241,20 @@ __global__ __launch_bounds__(256) void k_bn_small_bwd(const float* __restrict__ 
     for (int n = 0; n < B; n++) {
         const float* __restrict__ xp = x + (long)n * bs + (long)c * HW;
         const float* __restrict__ gp = gy + (long)n * bs + (long)c * HW;
-        for (int e = threadIdx.x; e < HW; e += 256) {
-            const float g = gp[e];
-            s[0] += g;
-            s[1] += g * (xp[e] - m);
+        for (int e0 = threadIdx.x; e0 < HW; e0 += 1024) {          // four (gy, x) pairs in flight, accumulated in element order
+            float g[4], v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool in = e0 + 256 * u < HW;
+                g[u] = in ? gp[e0 + 256 * u] : 0.f;
+                v[u] = in ? xp[e0 + 256 * u] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (e0 + 256 * u < HW) {
+                    s[0] += g[u];
+                    s[1] += g[u] * (v[u] - m);
+                }
         }
     }
     cc::block_sum_256<2>(s, red);
@@ -249,7 +274,18 @@ __global__ __launch_bounds__(256) void k_bn_small_bwd(const float* __restrict__ 
         const float* __restrict__ xp = x + (long)n * bs + (long)c * HW;
         const float* __restrict__ gp = gy + (long)n * bs + (long)c * HW;
         float* __restrict__ op = gx + (long)n * bs + (long)c * HW;
-        for (int e = threadIdx.x; e < HW; e += 256) op[e] = c1 * (gp[e] - c2 - (xp[e] - m) * c3);
+        for (int e0 = threadIdx.x; e0 < HW; e0 += 1024) {
+            float g[4], v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool in = e0 + 256 * u < HW;
+                g[u] = in ? gp[e0 + 256 * u] : 0.f;
+                v[u] = in ? xp[e0 + 256 * u] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (e0 + 256 * u < HW) op[e0 + 256 * u] = c1 * (g[u] - c2 - (v[u] - m) * c3);
+        }
     }
 }
 

@@ -322,17 +322,30 @@ __device__ __forceinline__ void repack_body(const long* __restrict__ d, float* t
     const int m0 = (bid % nmt) * 64, c0 = (bid / nmt) * CT;
     const int CTT = CT * T, n = 64 * CTT;
     const bool m_slow = w_sm > w_sc;
-    for (int e = threadIdx.x; e < n; e += 256) {
-        int m_, c_, t;
-        if (m_slow) { m_ = e / CTT; const int r = e - m_ * CTT; c_ = r / T; t = r - c_ * T; }
-        else { c_ = e / (64 * T); const int r = e - c_ * 64 * T; m_ = r / T; t = r - m_ * T; }
-        const int m = m0 + m_, c = c0 + c_;
-        float v = 0.f;
-        if (m < M && c < Cin) {
-            const int i = t / St, j = t - i * St;
-            v = w[w0 + (long)m * w_sm + (long)c * w_sc + i * w_ri + j * w_sj];
+    // eight loads in flight per work item (one load, wait, LDS store per iteration leaves the kernel at 1.6 TB/s: latency-bound)
+    for (int e0 = threadIdx.x; e0 < n; e0 += 8 * 256) {
+        float v[8];
+        int li[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = e0 + u * 256;
+            v[u] = 0.f;
+            li[u] = -1;
+            if (e < n) {
+                int m_, c_, t;
+                if (m_slow) { m_ = e / CTT; const int r = e - m_ * CTT; c_ = r / T; t = r - c_ * T; }
+                else { c_ = e / (64 * T); const int r = e - c_ * 64 * T; m_ = r / T; t = r - m_ * T; }
+                const int m = m0 + m_, c = c0 + c_;
+                li[u] = (t * CT + c_) * 65 + m_;
+                if (m < M && c < Cin) {
+                    const int i = t / St, j = t - i * St;
+                    v[u] = w[w0 + (long)m * w_sm + (long)c * w_sc + i * w_ri + j * w_sj];
+                }
+            }
         }
-        tile[(t * CT + c_) * 65 + m_] = v;
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (li[u] >= 0) tile[li[u]] = v[u];
     }
     __syncthreads();
     for (int e = threadIdx.x; e < n; e += 256) {
@@ -650,8 +663,19 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
                                                          int act, float act_a, float act_b, int res_mul) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
+    // eight partial loads in flight, added in split order (a one-by-one loop is a chain of nsplit dependent HBM/L2 latencies and
+    // this kernel is nothing else)
     float v = 0.f;
-    for (int k = 0; k < nsplit; k++) v += part[(long)k * part_stride + e];
+    {
+        for (int k = 0; k < nsplit; k += 8) {
+            float p8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) p8[u] = (k + u < nsplit) ? part[(long)(k + u) * part_stride + e] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (k + u < nsplit) v += p8[u];
+        }
+    }
     const int HWt = OHt * OWt;
     const long per = (long)M * HWt;
     const int n = (int)(e / per);
@@ -683,7 +707,16 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_multi(EPM a) {
     const long e = (long)((int)blockIdx.x - first) * 256 + threadIdx.x;
     if (e >= c.total) return;
     float v = 0.f;
-    for (int z = 0; z < c.nsplit; z++) v += c.part[(long)z * c.part_stride + e];
+    {
+        for (int z = 0; z < c.nsplit; z += 8) {      // see k_splitk_epilogue
+            float p8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) p8[u] = (z + u < c.nsplit) ? c.part[(long)(z + u) * c.part_stride + e] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (z + u < c.nsplit) v += p8[u];
+        }
+    }
     const int HWt = c.OHt * c.OWt;
     const long per = (long)a.M * HWt;
     const int n = (int)(e / per);
@@ -1350,18 +1383,31 @@ __global__ __launch_bounds__(256) void k_act_bwd(AB t, int HW, long gy_bs, long 
         const float* __restrict__ yp = (act != ACT_NONE) ? y + (long)n * y_bs + (long)m * HW : nullptr;
         float* __restrict__ ep = geff ? geff + (long)n * ge_bs + (long)m * HW : nullptr;
         if (VEC4) {
-            const int nq = HW >> 2;
-            for (int q = blockIdx.x * 256 + threadIdx.x; q < nq; q += cpp * 256) {
-                float4 g = ((const float4*)gp)[q];
-                if (act != ACT_NONE) {
-                    const float4 v = ((const float4*)yp)[q];
-                    g.x = act_grad(g.x, v.x, act, act_a, act_b);
-                    g.y = act_grad(g.y, v.y, act, act_a, act_b);
-                    g.z = act_grad(g.z, v.z, act, act_a, act_b);
-                    g.w = act_grad(g.w, v.w, act, act_a, act_b);
+            // four iterations' loads (up to 8 x 16 bytes) in flight per work item; same element order as a one-by-one loop
+            const int nq = HW >> 2, stp = cpp * 256;
+            for (int q0 = blockIdx.x * 256 + threadIdx.x; q0 < nq; q0 += 4 * stp) {
+                float4 gg[4], vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int q = q0 + u * stp;
+                    gg[u] = (q < nq) ? ((const float4*)gp)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    vv[u] = (q < nq && act != ACT_NONE) ? ((const float4*)yp)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                if (ep) ((float4*)ep)[q] = g;
-                s[0] += (g.x + g.y) + (g.z + g.w);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int q = q0 + u * stp;
+                    if (q < nq) {
+                        float4 g = gg[u];
+                        if (act != ACT_NONE) {
+                            g.x = act_grad(g.x, vv[u].x, act, act_a, act_b);
+                            g.y = act_grad(g.y, vv[u].y, act, act_a, act_b);
+                            g.z = act_grad(g.z, vv[u].z, act, act_a, act_b);
+                            g.w = act_grad(g.w, vv[u].w, act, act_a, act_b);
+                        }
+                        if (ep) ((float4*)ep)[q] = g;
+                        s[0] += (g.x + g.y) + (g.z + g.w);
+                    }
+                }
             }
         } else {
             for (int e = blockIdx.x * 256 + threadIdx.x; e < HW; e += cpp * 256) {
@@ -2168,9 +2214,9 @@ size_t cc_act_bwd_ws_bytes(int C) { return (size_t)C * 64 * sizeof(float); }
 /* geff = gy * act'(y) (geff may alias gy or be null), gbias[c] = sum_{n,p} geff (gbias may be null).
  * Group form: G (<= 4) same-shaped problems per launch; gy / y / geff / gbias: HOST arrays of device addresses (0 = null,
  * uniformly over the group); ws: G areas of cc_act_bwd_ws_bytes(C) each. */
-int cc_act_bwd_bias_group(int G, const long* gy, const long* y, const long* geff, const long* gbias, float* ws, int B, int C, int H,
-                          int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b, int accumulate_bias,
-                          void* stream) {
+static int act_bwd_bias_impl(int G, const long* gy, const long* y, const long* geff, const long* gbias, float* ws, int B, int C, int H,
+                             int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b, int accumulate_bias,
+                             void* stream, ccint::RedSink* sink) {
     if (G <= 0 || G > MAXGRP || B <= 0 || C <= 0) return CC_ERR_ARG;
     const bool has_y = y && y[0], has_ge = geff && geff[0], has_gb = gbias && gbias[0];
     if (act != ACT_NONE && !has_y) return CC_ERR_ARG;
@@ -2207,10 +2253,39 @@ int cc_act_bwd_bias_group(int G, const long* gy, const long* y, const long* geff
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_act_bwd<false>), grid, dim3(256), 0, s, t, HW, gy_bs, y_bs, geff_bs, act, act_a, act_b,
                            nb, accumulate_bias);
-    if (has_gb && !single)
-        hipLaunchKernelGGL(k_bias_reduce, dim3(C, G), dim3(64), 0, s, r, nchunk, accumulate_bias);
+    if (has_gb && !single) {
+        if (sink) {      // second stage parked: kind 4 of the reduce table (same per-channel summation as k_bias_reduce)
+            for (int k = 0; k < G; k++) {
+                const long d[ccint::RD_LONGS] = {4, (long)r.partial[k], (long)r.gbias[k], nchunk, accumulate_bias, 0, 0, C};
+                if (ccint::wgrad_reduce_emit(sink, d, 1, s) != CC_OK) return CC_ERR_ARG;
+            }
+        } else {
+            hipLaunchKernelGGL(k_bias_reduce, dim3(C, G), dim3(64), 0, s, r, nchunk, accumulate_bias);
+        }
+    }
     CC_CHECK_LAUNCH();
     return CC_OK;
+}
+
+int cc_act_bwd_bias_group(int G, const long* gy, const long* y, const long* geff, const long* gbias, float* ws, int B, int C, int H,
+                          int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b, int accumulate_bias,
+                          void* stream) {
+    return act_bwd_bias_impl(G, gy, y, geff, gbias, ws, B, C, H, W, gy_bs, y_bs, geff_bs, act, act_a, act_b, accumulate_bias, stream,
+                             nullptr);
+}
+
+/* ... with the second stage of the bias gradient (sum of the per-chunk partials in ws) left to the caller: descriptors for
+ * cc_wgrad_reduce_table (16 longs each, at most G, none when the kernel wrote gbias itself) go to red_host[0 .. *nred_host);
+ * ws must stay untouched until that call. */
+int cc_act_bwd_bias_group_defer(int G, const long* gy, const long* y, const long* geff, const long* gbias, float* ws, int B, int C,
+                                int H, int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b,
+                                int accumulate_bias, long* red_host, int red_cap, int* nred_host, void* stream) {
+    if (!red_host || !nred_host || red_cap < G) return CC_ERR_ARG;
+    ccint::RedSink sink = {red_host, red_cap, 0};
+    const int rc = act_bwd_bias_impl(G, gy, y, geff, gbias, ws, B, C, H, W, gy_bs, y_bs, geff_bs, act, act_a, act_b, accumulate_bias,
+                                     stream, &sink);
+    *nred_host = sink.n;
+    return rc;
 }
 
 int cc_act_bwd_bias(const float* gy, const float* y_or_null, float* geff_or_null, float* gbias_or_null, float* ws, int B,

@@ -9,6 +9,7 @@
 //   kind 1 (k_wgrad3x3):    gw[m*o_sm + c*o_sc + t]           (+)= sum_z ws[z][t][m][c]            p = T, M, Cin, Cp32
 //   kind 2 (k_wgrad_thin):  gw[m*o_sm + c*o_sc + r*S + s]     (+)= sum_pb slab[combo][pb][t][m16][c16]
 //                                                                                  p = TS, S, TR, ngc, ngt, M, Cin, R, ncombo
+//   kind 4 (bias gradient, second stage of k_act_bwd): gw[m] (+)= sum_k ws[m*nsplit + k]                           p = C
 #include "cc_common.h"
 #include "conv_internal.h"
 #include "../../include/ccengine.h"
@@ -44,10 +45,16 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_table(RT t) {
             // dense [M][C][R][S] destination (offset == e) and 16-byte aligned slabs: four elements per work-item
             const long e = ((long)bid * 256 + threadIdx.x) * 4;
             if (e >= tot) return;
+            // eight slab loads in flight, added in slab order (the launch is as long as its longest dependent chain)
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int z = 0; z < d.nsplit; z++) {
-                const float4 v = *(const float4*)(ws + (long)z * tot + e);
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            for (int z = 0; z < d.nsplit; z += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    v[u] = (z + u < d.nsplit) ? *(const float4*)(ws + (long)(z + u) * tot + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (z + u < d.nsplit) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
             }
             float4* o = (float4*)(d.gw + e);
             if (d.accum) { const float4 g = *o; s.x = g.x + s.x; s.y = g.y + s.y; s.z = g.z + s.z; s.w = g.w + s.w; }
@@ -57,7 +64,14 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_table(RT t) {
         const long e = (long)bid * 256 + threadIdx.x;
         if (e >= tot) return;
         float s = 0.f;
-        for (int z = 0; z < d.nsplit; z++) s += ws[(long)z * tot + e];
+        for (int z = 0; z < d.nsplit; z += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = (z + u < d.nsplit) ? ws[(long)(z + u) * tot + e] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (z + u < d.nsplit) s += v[u];
+        }
         const int m = (int)(e / Ntot), jn = (int)(e - (long)m * Ntot);
         const int c = jn / RS, rem = jn - c * RS;
         const int i = rem / St, j = rem - i * St;
@@ -73,10 +87,42 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_table(RT t) {
         if (c >= Cin) return;
         const long tot = (long)T * per;
         float* o = d.gw + (long)m * d.o_sm + (long)c * d.o_sc;
-        for (int tt = 0; tt < T; tt++) {
+        if (T == 9) {
+            // the nine taps side by side: nine independent loads per slab instead of nine dependent passes over the slabs
+            float s9[9];
+#pragma unroll
+            for (int tt = 0; tt < 9; tt++) s9[tt] = 0.f;
+            int z = 0;
+            for (; z + 2 <= d.nsplit; z += 2) {
+                const float* wz = ws + (long)z * tot + mc;
+                float v0[9], v1[9];
+#pragma unroll
+                for (int tt = 0; tt < 9; tt++) { v0[tt] = wz[(long)tt * per]; v1[tt] = wz[tot + (long)tt * per]; }
+#pragma unroll
+                for (int tt = 0; tt < 9; tt++) { s9[tt] += v0[tt]; s9[tt] += v1[tt]; }
+            }
+            for (; z < d.nsplit; z++) {
+                const float* wz = ws + (long)z * tot + mc;
+#pragma unroll
+                for (int tt = 0; tt < 9; tt++) s9[tt] += wz[(long)tt * per];
+            }
+#pragma unroll
+            for (int tt = 0; tt < 9; tt++) put(o + tt, s9[tt], d.accum);
+        } else {
+            for (int tt = 0; tt < T; tt++) {
+                float s = 0.f;
+                for (int z = 0; z < d.nsplit; z++) s += ws[(long)z * tot + (long)tt * per + mc];
+                put(o + tt, s, d.accum);
+            }
+        }
+    } else if (d.kind == 4) {
+        // four channels per workgroup, one wave each: the summation of k_bias_reduce
+        const int m = bid * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (m < d.p[0]) {
             float s = 0.f;
-            for (int z = 0; z < d.nsplit; z++) s += ws[(long)z * tot + (long)tt * per + mc];
-            put(o + tt, s, d.accum);
+            for (int k = lane; k < d.nsplit; k += 64) s += ws[(long)m * d.nsplit + k];
+            s = cc::wave_sum(s);
+            if (lane == 0) put(d.gw + m, s, d.accum);
         }
     } else {
         // one workgroup = a quarter (16 float4) of one [m16][c16] slab position; 16 sub-groups stride over the npb slabs, then
@@ -87,7 +133,15 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_table(RT t) {
         const int combo = ct / TS, tt = ct - combo * TS;
         const int sub = threadIdx.x >> 4, q = quarter * 16 + (threadIdx.x & 15);
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int pb = sub; pb < npb; pb += 16) {
+        int pb = sub;
+        for (; pb + 112 < npb; pb += 128) {        // eight slab loads in flight, added in slab order
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = *(const float4*)(ws + (((long)combo * npb + pb + 16 * u) * TS + tt) * 256 + 4 * q);
+#pragma unroll
+            for (int u = 0; u < 8; u++) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; pb < npb; pb += 16) {
             const float4 v = *(const float4*)(ws + (((long)combo * npb + pb) * TS + tt) * 256 + 4 * q);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
@@ -120,6 +174,7 @@ long blocks_of(const long* h) {
         case 0: return h[13] ? (h[7] * h[8] / 4 + 255) / 256 : (h[7] * h[8] + 255) / 256;
         case 1: return (h[8] * h[10] + 255) / 256;
         case 2: return h[15] * h[7] * 4;
+        case 4: return (h[7] + 3) / 4;
         default: return -1;
     }
 }

@@ -177,6 +177,33 @@ wgrad_reduces = _WgradReduces()
 _NO_DEFER = __import__("os").environ.get("CC_NO_WGRAD_DEFER", "0") == "1"       # A/B switch (tools/)
 
 
+def _act_bwd_bias(gys, ys, geffs, gbs, ref, B, C, H, W, gy_bs, act, act_a, act_b, accumulate):
+    """cc_act_bwd_bias_group for G = len(gys) <= 4 same-shaped problems (lists may hold None uniformly).  Inside a trainer stage
+    the second stage of bias gradients that accumulate into the optimizer's bucket is parked with the weight-gradient
+    reductions (one table launch per stage instead of one k_bias_reduce per call)."""
+    import ctypes
+    E = engine()
+    G = len(gys)
+    a1, a2, a3, a4 = _parr(gys), _parr(ys), _parr(geffs), _parr(gbs)
+    has_y, has_ge, has_gb = ys[0] is not None, geffs[0] is not None, gbs[0] is not None
+    ws = _ws(E.call("cc_act_bwd_ws_bytes", C) * G, ref)
+    args = (G, _addr(a1), _addr(a2) if has_y else 0, _addr(a3) if has_ge else 0, _addr(a4) if has_gb else 0, ws, B, C, H, W,
+            gy_bs, C * H * W, C * H * W, act, act_a, act_b, int(accumulate))
+    if has_gb and accumulate and wgrad_queue.enabled and not _NO_DEFER:
+        ptrs = [t.data_ptr() for t in gbs]
+        if wgrad_reduces.targets.intersection(ptrs):
+            wgrad_reduces.flush()
+        wgrad_reduces.targets.update(ptrs)
+        red = (ctypes.c_long * (16 * G))()
+        nred = ctypes.c_int(0)
+        E.call("cc_act_bwd_bias_group_defer", *args, ctypes.addressof(red), G, ctypes.addressof(nred), STREAM)
+        if nred.value:
+            wgrad_reduces.keep.append((ws, gbs))
+            wgrad_reduces.desc.extend(red[:16 * nred.value])
+    else:
+        E.call("cc_act_bwd_bias_group", *args, STREAM)
+
+
 _ZEROS64 = {}
 
 
@@ -258,9 +285,8 @@ class _Conv2dFn(torch.autograd.Function):
             gbias = bsink if bsink is not None else torch.empty(Cout, device=x.device, dtype=torch.float32)
         if act != 0 or gbias is not None:
             geff = torch.empty(gy.shape, device=gy.device, dtype=torch.float32) if act != 0 else None
-            E.call("cc_act_bwd_bias", gy, y, geff, gbias, _ws(E.call("cc_act_bwd_ws_bytes", Cout), x), B, Cout, OH, OW,
-                   gy_bs if act != 0 else Cout * OH * OW, Cout * OH * OW, Cout * OH * OW, act, act_a, act_b, int(bsink is not None),
-                   STREAM)
+            _act_bwd_bias([gy], [y if act != 0 else None], [geff], [gbias], x, B, Cout, OH, OW,
+                          gy_bs if act != 0 else Cout * OH * OW, act, act_a, act_b, bsink is not None)
             if geff is not None:
                 gy = geff
         if bsink is not None:
@@ -372,14 +398,9 @@ class _ConvGroupFn(torch.autograd.Function):
             with_b = len(gb) == len(idx)
             for c0 in range(0, len(idx), 4):
                 ch = idx[c0:c0 + 4]
-                a1 = _parr([gy[k] for k in ch])
-                a2 = _parr([ys[k] if do_act else None for k in ch])
-                a3 = _parr([geff.get(k) for k in ch])
-                a4 = _parr([gb.get(k) if with_b else None for k in ch])
-                wsb = _ws(E.call("cc_act_bwd_ws_bytes", Cout) * len(ch), xs[0])
-                E.call("cc_act_bwd_bias_group", len(ch), _addr(a1), _addr(a2) if do_act else 0, _addr(a3) if do_act else 0,
-                       _addr(a4) if with_b else 0, wsb, B, Cout, OH, OW, Cout * OH * OW, Cout * OH * OW, Cout * OH * OW,
-                       act if do_act else 0, act_a, act_b, int(all_sink), STREAM)
+                _act_bwd_bias([gy[k] for k in ch], [ys[k] if do_act else None for k in ch], [geff.get(k) for k in ch],
+                              [gb.get(k) if with_b else None for k in ch], xs[0], B, Cout, OH, OW, Cout * OH * OW,
+                              act if do_act else 0, act_a, act_b, all_sink)
             if not with_b and gb:          # mixed case: the remaining bias gradients one by one
                 for k in gb:
                     E.call("cc_act_bwd_bias", geff.get(k, gy[k]), None, None, gb[k], _ws(E.call("cc_act_bwd_ws_bytes", Cout), xs[0]),
@@ -476,9 +497,8 @@ class _ConvT2dFn(torch.autograd.Function):
             gbias = bsink if bsink is not None else torch.empty(Cout, device=x.device, dtype=torch.float32)
         if act != 0 or gbias is not None:
             geff = torch.empty(gy.shape, device=gy.device, dtype=torch.float32) if act != 0 else None
-            E.call("cc_act_bwd_bias", gy, y, geff, gbias, _ws(E.call("cc_act_bwd_ws_bytes", Cout), x), B, Cout, OH, OW,
-                   gy_bs if act != 0 else Cout * OH * OW, Cout * OH * OW, Cout * OH * OW, act, 1.0, ctx.act_b,
-                   int(bsink is not None), STREAM)
+            _act_bwd_bias([gy], [y if act != 0 else None], [geff], [gbias], x, B, Cout, OH, OW,
+                          gy_bs if act != 0 else Cout * OH * OW, act, 1.0, ctx.act_b, bsink is not None)
             if geff is not None:
                 gy = geff
         if bsink is not None:

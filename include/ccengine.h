@@ -268,6 +268,10 @@ int cc_conv2d_wgrad_kernel(int B, int M, int AH, int AW, int Cin, int IH, int IW
                            void* name_out_host, int cap);
 size_t cc_act_bwd_ws_bytes(int C);
 /* geff = gy * act'(y);  gbias[c] (+)= sum geff  (either output may be null; geff may alias gy) */
+/* Group form with the second stage of the bias gradient parked (see cc_conv2d_wgrad_group_defer / cc_wgrad_reduce_table). */
+int cc_act_bwd_bias_group_defer(int G, const long* gy, const long* y, const long* geff, const long* gbias, float* ws, int B, int C,
+                                int H, int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b,
+                                int accumulate_bias, long* red_host, int red_cap, int* nred_host, void* stream);
 int cc_act_bwd_bias(const float* gy, const float* y_or_null, float* geff_or_null, float* gbias_or_null, float* ws, int B,
                     int C, int H, int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b,
                     int accumulate_bias, void* stream);
