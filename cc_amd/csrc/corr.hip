@@ -63,13 +63,22 @@ __global__ __launch_bounds__(256) void k_corr_bwd_f1(const float* __restrict__ g
     for (int dy = 0; dy < PATCH; dy++) {
         const int yy = y + dy - R;
         if (yy < 0 || yy >= H) continue;
+        // the nine taps of the row are loaded before they are used (a load inside each skipped-or-not iteration is a chain of up
+        // to 81 latencies per work item); taps outside the row contribute fmaf(g, 0, acc) == acc
+        float gv[PATCH], sv[PATCH];
 #pragma unroll
         for (int dx = 0; dx < PATCH; dx++) {
             const int xx = x + dx - R;
-            if (xx < 0 || xx >= W) continue;
             const int d = dy * PATCH + dx;
             const int ch = chan_of_disp ? chan_of_disp[d] : d;
-            acc = fmaf(g[(size_t)ch * HW], src[yy * W + xx], acc);
+            const bool in = (xx >= 0) && (xx < W);
+            gv[dx] = in ? g[(size_t)ch * HW] : 0.f;
+            sv[dx] = in ? src[yy * W + xx] : 0.f;
+        }
+#pragma unroll
+        for (int dx = 0; dx < PATCH; dx++) {
+            const int xx = x + dx - R;
+            if (xx >= 0 && xx < W) acc = fmaf(gv[dx], sv[dx], acc);
         }
     }
     const size_t o = ((size_t)b * C + c) * HW + p;
@@ -92,14 +101,21 @@ __global__ __launch_bounds__(256) void k_corr_bwd_f2(const float* __restrict__ g
     for (int dy = 0; dy < PATCH; dy++) {
         const int ys = y - dy + R;
         if (ys < 0 || ys >= H) continue;
+        float gv[PATCH], sv[PATCH];              // see k_corr_bwd_f1
 #pragma unroll
         for (int dx = 0; dx < PATCH; dx++) {
             const int xs = x - dx + R;
-            if (xs < 0 || xs >= W) continue;
             const int d = dy * PATCH + dx;
             const int ch = chan_of_disp ? chan_of_disp[d] : d;
+            const bool in = (xs >= 0) && (xs < W);
             const int q = ys * W + xs;
-            acc = fmaf(g[(size_t)ch * HW + q], src[q], acc);
+            gv[dx] = in ? g[(size_t)ch * HW + q] : 0.f;
+            sv[dx] = in ? src[q] : 0.f;
+        }
+#pragma unroll
+        for (int dx = 0; dx < PATCH; dx++) {
+            const int xs = x - dx + R;
+            if (xs >= 0 && xs < W) acc = fmaf(gv[dx], sv[dx], acc);
         }
     }
     g2[((size_t)b * C + c) * HW + p] = acc / (float)C;
@@ -169,7 +185,25 @@ __global__ __launch_bounds__(256) void k_corr_fwd4(const float* __restrict__ f1,
     if (yy >= 0 && yy < H) {
         const float* a = f1 + (size_t)b * C * HW + p;
         const float* bb = f2 + (size_t)b * C * HW + yy * W;
-        for (int c = 0; c < C; c++) {
+        // two channels' operands (8 x 16 bytes) in flight per step, consumed in channel order: the small pyramid levels run
+        // 1-2 waves per SIMD and a one-channel loop is then a chain of C load latencies
+        int c = 0;
+        for (; c + 2 <= C; c += 2) {
+            const float4 av0 = *(const float4*)(a + (size_t)c * HW), av1 = *(const float4*)(a + (size_t)(c + 1) * HW);
+            float v0[12], v1[12];
+            load12(bb + (size_t)c * HW, x, W, v0);
+            load12(bb + (size_t)(c + 1) * HW, x, W, v1);
+            const float a0[4] = {av0.x, av0.y, av0.z, av0.w}, a1[4] = {av1.x, av1.y, av1.z, av1.w};
+#pragma unroll
+            for (int j = 0; j < PATCH; j++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc[j][k] = fmaf(a0[k], v0[k + j], acc[j][k]);     // x+k + j-4 -> v[k+j]
+#pragma unroll
+            for (int j = 0; j < PATCH; j++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc[j][k] = fmaf(a1[k], v1[k + j], acc[j][k]);
+        }
+        for (; c < C; c++) {
             const float4 av = *(const float4*)(a + (size_t)c * HW);
             const float a4[4] = {av.x, av.y, av.z, av.w};
             float v[12];
@@ -177,7 +211,7 @@ __global__ __launch_bounds__(256) void k_corr_fwd4(const float* __restrict__ f1,
 #pragma unroll
             for (int j = 0; j < PATCH; j++)
 #pragma unroll
-                for (int k = 0; k < 4; k++) acc[j][k] = fmaf(a4[k], v[k + j], acc[j][k]);      // x+k + j-4 -> v[k+j]
+                for (int k = 0; k < 4; k++) acc[j][k] = fmaf(a4[k], v[k + j], acc[j][k]);
         }
     }
     const float inv = 1.f / (float)C;

@@ -124,7 +124,14 @@ __global__ __launch_bounds__(256) void k_reduce_add(const float* __restrict__ pa
                                                     float* __restrict__ accum) {
     __shared__ float red[4];
     float v[1] = {0.f};
-    for (int i = threadIdx.x; i < n; i += 256) v[0] += partials[i];
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 256) {        // eight loads in flight, added in index order
+        float p8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) p8[u] = (i0 + 256 * u < n) ? partials[i0 + 256 * u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i0 + 256 * u < n) v[0] += p8[u];
+    }
     cc::block_sum_256<1>(v, red);
     if (threadIdx.x == 0) accum[0] += coef * v[0];
 }

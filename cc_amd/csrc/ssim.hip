@@ -347,14 +347,24 @@ __device__ __forceinline__ void ssim_adjoint_body(const float* __restrict__ adjA
     for (int c = 0; c < 3; c++) {
         const size_t plane = ((size_t)b * 3 + c) * HW;
         if (c > 0) __syncthreads();
-        for (int i = tid; i < TIN * TIN; i += 256) {
-            const int r = i / TIN, col = i - r * TIN;
-            const int yy = oy0 - HALO + r, xx = ox0 - HALO + col;
-            const bool in = (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
-            const size_t o = plane + (size_t)yy * W + xx;
-            tin[0][i] = in ? adjA[o] : 0.f;
-            tin[1][i] = in ? adjB[o] : 0.f;
-            tin[2][i] = in ? adjC[o] : 0.f;
+        for (int i0 = tid; i0 < TIN * TIN; i0 += 4 * 256) {        // 12 loads in flight per work item, then the LDS stores
+            float va[4], vb[4], vc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + 256 * u;
+                const int r = i / TIN, col = i - r * TIN;
+                const int yy = oy0 - HALO + r, xx = ox0 - HALO + col;
+                const bool in = (i < TIN * TIN) && (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
+                const size_t o = plane + (size_t)yy * W + xx;
+                va[u] = in ? adjA[o] : 0.f;
+                vb[u] = in ? adjB[o] : 0.f;
+                vc[u] = in ? adjC[o] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + 256 * u;
+                if (i < TIN * TIN) { tin[0][i] = va[u]; tin[1][i] = vb[u]; tin[2][i] = vc[u]; }
+            }
         }
         __syncthreads();
         for (int it = tid; it < TIN * (TS / 4); it += 256) {

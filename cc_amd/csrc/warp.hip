@@ -74,6 +74,23 @@ __device__ __forceinline__ float blend(const Bilinear& t, float nw, float ne, fl
     return fmaf(se, t.n * t.w, fmaf(sw, t.n * t.e, fmaf(ne, t.s * t.w, nw * (t.s * t.e))));
 }
 
+// out_c = bilinear sample of plane c for c in [0, C): up to four channels' taps in flight (one channel per iteration is a chain of
+// C load latencies; the stores do not wait)
+__device__ __forceinline__ void sample_channels(const float* __restrict__ src, float* __restrict__ dst, int C, int HW, int W,
+                                                const Bilinear& t) {
+    for (int c0 = 0; c0 < C; c0 += 4) {
+        float nw[4], ne[4], sw[4], se[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            nw[u] = ne[u] = sw[u] = se[u] = 0.f;
+            if (c0 + u < C) gather4(src + (size_t)(c0 + u) * HW, W, t, nw[u], ne[u], sw[u], se[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (c0 + u < C) dst[(size_t)(c0 + u) * HW] = blend(t, nw[u], ne[u], sw[u], se[u]);
+    }
+}
+
 struct Rigid {
     float ray[3], cam[3], p0, p1, p2, Z, xn, yn;
     bool xo, yo;   // coordinate rewritten to 2 (zeros mode): no gradient
@@ -139,11 +156,7 @@ __global__ __launch_bounds__(256) void k_inverse_warp_fwd(const float* __restric
     bilinear_setup<AC, BORDER>(r.xn, r.yn, W, H, t);
     const float* src = img + (size_t)b * C * HW;
     float* dst = out + (size_t)b * C * HW + p;
-    for (int c = 0; c < C; c++) {
-        float nw, ne, sw, se;
-        gather4(src + (size_t)c * HW, W, t, nw, ne, sw, se);
-        dst[(size_t)c * HW] = blend(t, nw, ne, sw, se);
-    }
+    sample_channels(src, dst, C, HW, W, t);
 }
 
 // d(sum_c gout_c * sample_c)/d(ix, iy) (ATen grid_sampler_2d_backward, bilinear)
@@ -151,19 +164,31 @@ __device__ __forceinline__ void sample_grad(const float* __restrict__ src, const
                                             int W, const Bilinear& t, float* __restrict__ gimg, float& gix, float& giy) {
     gix = 0.f;
     giy = 0.f;
-    for (int c = 0; c < C; c++) {
-        float nw, ne, sw, se;
-        gather4(src + (size_t)c * HW, W, t, nw, ne, sw, se);
-        const float g = gout[(size_t)c * HW];
-        gix += ((ne - nw) * t.s + (se - sw) * t.n) * g;
-        giy += ((sw - nw) * t.e + (se - ne) * t.w) * g;
-        if (gimg) {
-            float* gp = gimg + (size_t)c * HW + t.y0 * W + t.x0;
-            if (t.vy0 && t.vx0) atomicAdd(gp, g * (t.s * t.e));
-            if (t.vy0 && t.vx1) atomicAdd(gp + 1, g * (t.s * t.w));
-            if (t.vy1 && t.vx0) atomicAdd(gp + W, g * (t.n * t.e));
-            if (t.vy1 && t.vx1) atomicAdd(gp + W + 1, g * (t.n * t.w));
+    // up to four channels' loads (4 taps + the output gradient each) in flight, consumed in channel order: with one channel per
+    // iteration the loop is a chain of C load latencies (the image warps have C = 3, the feature warps 16-128 per wave)
+    for (int c0 = 0; c0 < C; c0 += 4) {
+        float nw[4], ne[4], sw[4], se[4], g[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            nw[u] = ne[u] = sw[u] = se[u] = g[u] = 0.f;
+            if (c0 + u < C) {
+                gather4(src + (size_t)(c0 + u) * HW, W, t, nw[u], ne[u], sw[u], se[u]);
+                g[u] = gout[(size_t)(c0 + u) * HW];
+            }
         }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (c0 + u < C) {
+                gix += ((ne[u] - nw[u]) * t.s + (se[u] - sw[u]) * t.n) * g[u];
+                giy += ((sw[u] - nw[u]) * t.e + (se[u] - ne[u]) * t.w) * g[u];
+                if (gimg) {
+                    float* gp = gimg + (size_t)(c0 + u) * HW + t.y0 * W + t.x0;
+                    if (t.vy0 && t.vx0) atomicAdd(gp, g[u] * (t.s * t.e));
+                    if (t.vy0 && t.vx1) atomicAdd(gp + 1, g[u] * (t.s * t.w));
+                    if (t.vy1 && t.vx0) atomicAdd(gp + W, g[u] * (t.n * t.e));
+                    if (t.vy1 && t.vx1) atomicAdd(gp + W + 1, g[u] * (t.n * t.w));
+                }
+            }
     }
 }
 
@@ -298,11 +323,7 @@ __global__ __launch_bounds__(256) void k_flow_warp_fwd(const float* __restrict__
     // gridDim.z > 1: channel groups (many-channel feature maps on small pyramid levels need more than HW work-items)
     const int cper = (C + (int)gridDim.z - 1) / (int)gridDim.z;
     const int c0 = (int)blockIdx.z * cper, c1 = (c0 + cper < C) ? c0 + cper : C;
-    for (int c = c0; c < c1; c++) {
-        float nw, ne, sw, se;
-        gather4(src + (size_t)c * HW, W, t, nw, ne, sw, se);
-        dst[(size_t)c * HW] = blend(t, nw, ne, sw, se);
-    }
+    if (c0 < c1) sample_channels(src + (size_t)c0 * HW, dst + (size_t)c0 * HW, c1 - c0, HW, W, t);
 }
 
 template <bool AC, bool BORDER, bool FEATURE>
@@ -424,11 +445,7 @@ __global__ __launch_bounds__(256) void k_inverse_warp_fwd_jobs(JobTab t, int C) 
     bilinear_setup<AC, BORDER>(r.xn, r.yn, W, H, bl);
     const float* src = img + (size_t)b * C * HW;
     float* dst = out + (size_t)b * C * HW + p;
-    for (int c = 0; c < C; c++) {
-        float nw, ne, sw, se;
-        gather4(src + (size_t)c * HW, W, bl, nw, ne, sw, se);
-        dst[(size_t)c * HW] = blend(bl, nw, ne, sw, se);
-    }
+    sample_channels(src, dst, C, HW, W, bl);
 }
 
 // rigid bwd slots: 0 gout, 1 img, 2 depth, 3 P, 4 Kinv, 5 gdepth [B,H,W], 6 gP partials [B][nb][12]
@@ -488,11 +505,7 @@ __global__ __launch_bounds__(256) void k_flow_warp_fwd_jobs(JobTab t, int C) {
     bilinear_setup<AC, BORDER>(xn, yn, W, H, bl);
     const float* src = img + (size_t)b * C * HW;
     float* dst = out + (size_t)b * C * HW + p;
-    for (int c = 0; c < C; c++) {
-        float nw, ne, sw, se;
-        gather4(src + (size_t)c * HW, W, bl, nw, ne, sw, se);
-        dst[(size_t)c * HW] = blend(bl, nw, ne, sw, se);
-    }
+    sample_channels(src, dst, C, HW, W, bl);
 }
 
 template <bool AC, bool BORDER>
