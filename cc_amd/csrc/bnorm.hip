@@ -29,17 +29,29 @@ __global__ __launch_bounds__(256) void k_bn_stats(const float* __restrict__ x, c
     const float k = BWD ? mean[c] : x[(long)c * HW];            // forward: shift by the channel's first value
     float s[2] = {0.f, 0.f};
     if (VEC4) {
-        const int nq = HW >> 2;
-        for (int q = blockIdx.x * 256 + threadIdx.x; q < nq; q += cpp * 256) {
-            const float4 v = ((const float4*)xp)[q];
-            const float d[4] = {v.x - k, v.y - k, v.z - k, v.w - k};
-            if (BWD) {
-                const float4 g = ((const float4*)gp)[q];
-                s[0] += (g.x + g.y) + (g.z + g.w);
-                s[1] += (g.x * d[0] + g.y * d[1]) + (g.z * d[2] + g.w * d[3]);
-            } else {
-                s[0] += (d[0] + d[1]) + (d[2] + d[3]);
-                s[1] += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        // four iterations' loads in flight per work item, accumulated in element order
+        const int nq = HW >> 2, stp = cpp * 256;
+        for (int q0 = blockIdx.x * 256 + threadIdx.x; q0 < nq; q0 += 4 * stp) {
+            float4 vv[4], gg[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int q = q0 + u * stp;
+                vv[u] = (q < nq) ? ((const float4*)xp)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+                gg[u] = (BWD && q < nq) ? ((const float4*)gp)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (q0 + u * stp >= nq) continue;
+                const float4 v = vv[u];
+                const float d[4] = {v.x - k, v.y - k, v.z - k, v.w - k};
+                if (BWD) {
+                    const float4 g = gg[u];
+                    s[0] += (g.x + g.y) + (g.z + g.w);
+                    s[1] += (g.x * d[0] + g.y * d[1]) + (g.z * d[2] + g.w * d[3]);
+                } else {
+                    s[0] += (d[0] + d[1]) + (d[2] + d[3]);
+                    s[1] += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+                }
             }
         }
     } else {
