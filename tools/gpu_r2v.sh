@@ -8,4 +8,4 @@ for i in 1 2; do
 ( timeout 300 python bench.py --no-cpu-baseline --no-kernel-timing --steps 30 ) > gpurun_out/bench_${TAG}_$i.log 2> gpurun_out/bench_${TAG}_$i.err
 echo "run $i: $(grep timed gpurun_out/bench_${TAG}_$i.err)"
 done
-bash tools/gpu_prof.sh $TAG > gpurun_out/prof_$TAG.out 2>&1; grep -E "k_act_bwd|k_bias_reduce|reduce_table|one replayed" gpurun_out/step_trace_$TAG.txt
+bash tools/gpu_prof.sh $TAG > gpurun_out/prof_$TAG.out 2>&1; grep -E "k_conv_patch|k_wgrad<|one replayed" gpurun_out/step_trace_$TAG.txt
