@@ -24,5 +24,6 @@ with open(sys.argv[1]) as f:
 names = sorted({c for v in tot.values() for c in v})
 print("kernel".ljust(46), "n".rjust(4), " ".join(c.replace("SQ_", "")[:14].rjust(15) for c in names))
 rows = sorted(tot.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", kv[1].get("SQ_BUSY_CYCLES", 0)))
-for k, v in rows[:28]:
+import os
+for k, v in rows[:int(os.environ.get('PMC_ROWS', '28'))]:
     print(k[:46].ljust(46), str(cnt[k]).rjust(4), " ".join(("%.4g" % v.get(c, 0)).rjust(15) for c in names))
