@@ -660,3 +660,33 @@ def check_concat_gradient_slices(dev, tol=2e-5):
     assert len(seen) == 3
     if torch.device(dev).type == "cuda":
         assert all(seen), seen          # every producer read its slice in place (CPU slices may miss the 16-byte alignment)
+
+
+def check_adam(dev, n=10007, steps=3):
+    """cc_adam_step against torch.optim.Adam (betas (0.9, 0.999), eps 1e-8, no weight decay: train.py:307-310) over several steps
+    with a gradient scale, and cc_adam_step_segment: the update of [0, cut) with the tick followed by [cut, n) without it is bit
+    for bit the one-launch update (the data-parallel step updates the big gradient segment while the small one is still being
+    exchanged)."""
+    from cc_amd._lib import engine, STREAM
+    E = engine()
+    g = torch.Generator().manual_seed(9)
+    p0 = torch.randn(n, generator=g)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=2e-4, betas=(0.9, 0.999), eps=1e-8)
+    mk = lambda: [t.to(dev) for t in (p0.clone(), torch.zeros(n), torch.zeros(n), torch.zeros(1))]
+    pa, ma, va, sa = mk()       # one launch
+    pb, mb, vb, sb = mk()       # two segments
+    cut = (n // 3) // 4 * 4
+    scale = 0.5
+    for _ in range(steps):
+        grad = torch.randn(n, generator=g)
+        ref_p.grad = (grad * scale).clone()
+        opt.step()
+        gd = grad.to(dev)
+        E.call("cc_adam_step", pa, gd, ma, va, sa, n, 2e-4, 0.9, 0.999, 1e-8, scale, STREAM)
+        E.call("cc_adam_step_segment", pb[:cut], gd[:cut], mb[:cut], vb[:cut], sb, cut, 2e-4, 0.9, 0.999, 1e-8, scale, 1, STREAM)
+        E.call("cc_adam_step_segment", pb[cut:], gd[cut:], mb[cut:], vb[cut:], sb, n - cut, 2e-4, 0.9, 0.999, 1e-8, scale, 0, STREAM)
+    assert float(sa) == steps and float(sb) == steps
+    assert torch.equal(pa.cpu(), pb.cpu()) and torch.equal(ma.cpu(), mb.cpu()) and torch.equal(va.cpu(), vb.cpu())
+    err = float((pa.cpu() - ref_p.detach()).abs().max())
+    assert err <= 1e-6, err          # a few ulp (different but equivalent operation order: lr / bc1 folded into the step size)

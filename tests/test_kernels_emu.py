@@ -77,5 +77,9 @@ def test_concat_gradient_slices():
     parity.check_concat_gradient_slices("cpu")
 
 
+def test_adam_and_segments():
+    parity.check_adam("cpu")
+
+
 def test_conv_groups():
     parity.check_conv_groups("cpu")

@@ -97,6 +97,10 @@ def test_concat_gradient_slices():
     parity.check_concat_gradient_slices("cuda")
 
 
+def test_adam_and_segments():
+    parity.check_adam("cuda")
+
+
 def test_conv_groups():
     parity.check_conv_groups("cuda")
     parity.check_conv_groups("cuda", cases=((4, 196, 16, 52, 128, 96, 1), (4, 64, 32, 104, 96, 32, 2)))
