@@ -22,6 +22,7 @@
 // deterministic second-stage reduction (no atomics).
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "cc_common.h"
 #include "conv_internal.h"
 #include "../../include/ccengine.h"
@@ -80,6 +81,7 @@ struct GG {
     int OHt, OWt, so, oy0, ox0, OH, OW; long y_bs, res_bs;
     int act; float act_a, act_b;
     int res_mul;
+    const float* add; long add_bs;      // res_mul mode only: tensor of y's shape added before act'(res) is applied (may alias y)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float a, float b) {
@@ -100,8 +102,11 @@ __device__ __forceinline__ float act_grad(float g, float v, int act, float act_a
 // epilogue tail shared by every conv kernel: res_mul == 0: act(v + res);  res_mul == 1 (data-gradient calls): the gradient
 // w.r.t. the PRE-activation of the layer that produced this conv's input, v * act'(r), r = that layer's output (= this
 // conv's input, same shape as the gradient) -- the producer's separate activation-backward pass disappears
-__device__ __forceinline__ float conv_tail(float v, bool has_res, float r, int res_mul, int act, float a, float b) {
-    if (has_res && res_mul) return act_grad(v, r, act, a, b);
+// (round 3) ... and with `add`: (v + add) * act'(r) -- the other gradient contributions of a fan-out tensor (a residual
+// shortcut, a skip connection, what earlier data-gradients left in the same buffer: add may alias the output) are summed
+// here instead of by separate accumulation launches
+__device__ __forceinline__ float conv_tail(float v, bool has_res, float r, int res_mul, int act, float a, float b, float addv = 0.f) {
+    if (has_res && res_mul) return act_grad(v + addv, r, act, a, b);
     if (has_res) v += r;
     return apply_act(v, act, a, b);
 }
@@ -235,6 +240,7 @@ __global__ __launch_bounds__(256) void k_gather_gemm(GG g) {
         const long pix = (long)(g.oy0 + g.so * ty) * g.OW + (g.ox0 + g.so * tx);
         float* yb = g.y + (long)n * g.y_bs + pix;
         const float* rbp = g.res ? g.res + (long)n * g.res_bs + pix : nullptr;
+        const float* abp = g.add ? g.add + (long)n * g.add_bs + pix : nullptr;
 #pragma unroll
         for (int a = 0; a < TM; a++) {
 #pragma unroll
@@ -243,7 +249,8 @@ __global__ __launch_bounds__(256) void k_gather_gemm(GG g) {
                 if (m < g.M) {
                     float v = acc[a][b][r];
                     if (g.bias) v += g.bias[m];
-                    yb[(long)m * y_cs] = conv_tail(v, rbp != nullptr, rbp ? rbp[(long)m * y_cs] : 0.f, g.res_mul, g.act, g.act_a, g.act_b);
+                    yb[(long)m * y_cs] = conv_tail(v, rbp != nullptr, rbp ? rbp[(long)m * y_cs] : 0.f, g.res_mul, g.act, g.act_a, g.act_b,
+                                                   abp ? abp[(long)m * y_cs] : 0.f);
                 }
             }
         }
@@ -279,6 +286,7 @@ struct CP {
     int nsplit, cps; long part_stride;
     int act; float act_a, act_b;
     int res_mul;
+    const float* add; long add_bs;
 };
 
 // wp[(t*Cpad + c)*Mpad + m] = w[w0 + m*w_sm + c*w_sc + i*w_ri + j*w_sj]  (0 beyond Cin / M), t = i*St + j
@@ -577,7 +585,8 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
                     if (g.bias) v += g.bias[m];
                     const long o = (long)n * g.y_bs + pix + (long)m * y_cs;
                     const bool hr = g.res != nullptr;
-                    g.y[o] = conv_tail(v, hr, hr ? g.res[(long)n * g.res_bs + pix + (long)m * y_cs] : 0.f, g.res_mul, g.act, g.act_a, g.act_b);
+                    g.y[o] = conv_tail(v, hr, hr ? g.res[(long)n * g.res_bs + pix + (long)m * y_cs] : 0.f, g.res_mul, g.act, g.act_a, g.act_b,
+                                       g.add ? g.add[(long)n * g.add_bs + pix + (long)m * y_cs] : 0.f);
                 }
             }
         }
@@ -604,6 +613,7 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
         } else {
             float* yb = g.y + (long)n * g.y_bs + pix;
             const float* rbp = g.res ? g.res + (long)n * g.res_bs + pix : nullptr;
+            const float* abp = g.add ? g.add + (long)n * g.add_bs + pix : nullptr;
 #pragma unroll
             for (int a = 0; a < TM; a++)
 #pragma unroll
@@ -612,7 +622,8 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
                     if (m < g.M) {
                         float v = acc[a][b][r];
                         if (g.bias) v += g.bias[m];
-                        yb[(long)m * y_cs] = conv_tail(v, rbp != nullptr, rbp ? rbp[(long)m * y_cs] : 0.f, g.res_mul, g.act, g.act_a, g.act_b);
+                        yb[(long)m * y_cs] = conv_tail(v, rbp != nullptr, rbp ? rbp[(long)m * y_cs] : 0.f, g.res_mul, g.act, g.act_a, g.act_b,
+                                                       abp ? abp[(long)m * y_cs] : 0.f);
                     }
                 }
         }
@@ -651,7 +662,7 @@ __global__ __launch_bounds__(256, CC_PATCH_LB) void k_conv_patch_multi(CPM a) {
     for (int q = 0; q < MAXCLS - 1; q++)
         if (q + 1 < a.n && (int)blockIdx.x >= a.bx_end[q]) { k = q + 1; first = a.bx_end[q]; }
     const CP& g = a.c[k];
-    if ((int)blockIdx.z >= g.nsplit) return;
+    if ((int)blockIdx.z >= g.nsplit || (int)blockIdx.y * BM >= g.Mpad) return;       // grid.y / grid.z are the launch's maxima
     conv_patch_body<BM, CK, TPS, 2>(g, (int)blockIdx.x - first);
 }
 
@@ -660,7 +671,8 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
                                                          const float* __restrict__ bias, const float* __restrict__ res,
                                                          float* __restrict__ y, int M, int OHt, int OWt, int so, int oy0,
                                                          int ox0, int OH, int OW, long y_bs, long res_bs, long total,
-                                                         int act, float act_a, float act_b, int res_mul) {
+                                                         int act, float act_a, float act_b, int res_mul,
+                                                         const float* add, long add_bs) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     // eight partial loads in flight, added in split order (a one-by-one loop is a chain of nsplit dependent HBM/L2 latencies and
@@ -685,17 +697,23 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
     const int ty = t / OWt, tx = t - ty * OWt;
     const long o = (long)m * OH * OW + (long)(oy0 + so * ty) * OW + (ox0 + so * tx);
     if (bias) v += bias[m];
-    y[(long)n * y_bs + o] = conv_tail(v, res != nullptr, res ? res[(long)n * res_bs + o] : 0.f, res_mul, act, act_a, act_b);
+    y[(long)n * y_bs + o] = conv_tail(v, res != nullptr, res ? res[(long)n * res_bs + o] : 0.f, res_mul, act, act_a, act_b,
+                                      add ? add[(long)n * add_bs + o] : 0.f);
 }
 
-struct EPC { const float* part; const float* bias; const float* res; float* y; int nsplit; long part_stride; int OHt, OWt, oy0, ox0; long total; };
+// every class carries its own geometry and epilogue (round 3: the problems of one launch may come from different layers of
+// different networks -- cc_conv2d_list)
+struct EPC {
+    const float* part; const float* bias; const float* res; const float* add; float* y;
+    int nsplit; long part_stride; int OHt, OWt, oy0, ox0; long total;
+    int M, so, OH, OW; long y_bs, res_bs, add_bs;
+    int act; float act_a, act_b;
+    int res_mul;
+};
 struct EPM {
     EPC c[MAXCLS];
     int n;
     int bx_end[MAXCLS];
-    int M, so, OH, OW; long y_bs, res_bs;
-    int act; float act_a, act_b;
-    int res_mul;
 };
 
 __global__ __launch_bounds__(256) void k_splitk_epilogue_multi(EPM a) {
@@ -718,15 +736,16 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_multi(EPM a) {
         }
     }
     const int HWt = c.OHt * c.OWt;
-    const long per = (long)a.M * HWt;
+    const long per = (long)c.M * HWt;
     const int n = (int)(e / per);
     const long r = e - (long)n * per;
     const int m = (int)(r / HWt);
     const int t = (int)(r - (long)m * HWt);
     const int ty = t / c.OWt, tx = t - ty * c.OWt;
-    const long o = (long)m * a.OH * a.OW + (long)(c.oy0 + a.so * ty) * a.OW + (c.ox0 + a.so * tx);
+    const long o = (long)m * c.OH * c.OW + (long)(c.oy0 + c.so * ty) * c.OW + (c.ox0 + c.so * tx);
     if (c.bias) v += c.bias[m];
-    c.y[(long)n * a.y_bs + o] = conv_tail(v, c.res != nullptr, c.res ? c.res[(long)n * a.res_bs + o] : 0.f, a.res_mul, a.act, a.act_a, a.act_b);
+    c.y[(long)n * c.y_bs + o] = conv_tail(v, c.res != nullptr, c.res ? c.res[(long)n * c.res_bs + o] : 0.f, c.res_mul, c.act, c.act_a, c.act_b,
+                                          c.add ? c.add[(long)n * c.add_bs + o] : 0.f);
 }
 
 static int dbg_flag_early(const char* name) {
@@ -1516,6 +1535,7 @@ inline CP make_cp(const GG& g, const ConvPlan& p, const float* zeros, const floa
     c.tiles_x = p.tiles_x; c.tiles_y = p.tiles_y;
     c.nsplit = p.nsplit; c.cps = p.cps; c.part_stride = (long)g.B * g.M * g.OHt * g.OWt;
     c.act = g.act; c.act_a = g.act_a; c.act_b = g.act_b; c.res_mul = g.res_mul;
+    c.add = g.add; c.add_bs = g.add_bs;
     return c;
 }
 
@@ -1547,75 +1567,79 @@ inline void launch_gg(const GG& g, float* ws, hipStream_t s, const float* prepac
         const long total = c.part_stride;
         hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)part,
                            p.nsplit, c.part_stride, g.bias, g.res, g.y, g.M, g.OHt, g.OWt, g.so, g.oy0, g.ox0, g.OH, g.OW,
-                           g.y_bs, g.res_bs, total, g.act, g.act_a, g.act_b, g.res_mul);
+                           g.y_bs, g.res_bs, total, g.act, g.act_a, g.act_b, g.res_mul, g.add, g.add_bs);
     }
 }
 
-// n problems (parity classes of one stride-2 data-gradient and / or the same-shaped convolutions of parallel branches) in
-// ONE conv launch (+ ONE split-K epilogue launch).  Needs prepacked weight images and every problem on the patch kernel with
-// the same tile configuration.  zeros[k] / wps[k] / parts[k]: the 64-float zero block, weight image and partial-slab area of
-// problem k.  -> false: caller launches them one by one.
-inline bool launch_gg_classes(const GG* gs, int n, int mult, const float* const* zeros, const float* const* wps,
-                              float* const* parts, hipStream_t s) {
-    if (n < 2 || n > MAXCLS || dbg_flag_early("CC_NO_CLASS_MERGE")) return false;
-    ConvPlan ps[MAXCLS];
+// n problems in ONE conv launch (+ ONE split-K epilogue launch): the parity classes of a stride-2 data-gradient, the
+// same-shaped convolutions of parallel branches, and (round 3, cc_conv2d_list) independent layers of DIFFERENT networks --
+// every class carries its own geometry, channel count and epilogue; what the classes of a launch share is the tile
+// configuration (BM, CK) of the kernel instance.  Needs prepacked weight images.  zeros / wp / part: the 64-float zero block,
+// weight image and partial-slab area of the class.
+struct ClsIn { GG g; ConvPlan p; const float* zeros; const float* wp; float* part; };
+
+inline size_t smem_cls(const ConvPlan& p, int tps) { return (size_t)(2 * tps * p.ck * p.bm + 2 * p.ck * p.PS) * sizeof(float); }
+
+inline bool launch_classes(const ClsIn* cs, int n, hipStream_t s, bool idle_taps = false) {
+    if (n < 1 || n > MAXCLS) return false;
     size_t smem = 0;
-    int tps = 3, maxsplit = 1;
+    int tps = 3, maxsplit = 1, maxy = 1;
     for (int k = 0; k < n; k++) {
-        ps[k] = plan_conv(gs[k], mult);
-        if (!ps[k].use_patch || ps[k].bm != ps[0].bm || ps[k].ck != ps[0].ck || !wps[k]) return false;
-        if (gs[k].res != nullptr && !gs[k].res_mul) return false;
-        if (gs[k].M != gs[0].M || gs[k].so != gs[0].so || gs[k].OH != gs[0].OH || gs[k].OW != gs[0].OW || gs[k].y_bs != gs[0].y_bs ||
-            gs[k].res_bs != gs[0].res_bs || gs[k].act != gs[0].act || gs[k].res_mul != gs[0].res_mul)
-            return false;
-        if (ps[k].tps != 3) tps = 1;
-        if (ps[k].nsplit > maxsplit) maxsplit = ps[k].nsplit;
+        const ConvPlan& p = cs[k].p;
+        if (!p.use_patch || p.bm != cs[0].p.bm || p.ck != cs[0].p.ck || !cs[k].wp) return false;
+        // three taps per stage launch-wide unless a class's patch does not leave room (a class with fewer taps idles the slots)
+        if (p.tps != 3 && !(idle_taps && cs[k].g.Rt * cs[k].g.St < 3 && smem_cls(p, 3) <= 80 * 1024)) tps = 1;
+        if (p.nsplit > maxsplit) maxsplit = p.nsplit;
+        if (p.Mpad / p.bm > maxy) maxy = p.Mpad / p.bm;
     }
-    CPM a = {};        // ~3 KB + ~1 KB of host stack, passed to the launches by value
+    CPM a = {};        // ~3 KB + ~1.5 KB of host stack, passed to the launches by value
     EPM e = {};
     a.n = n; e.n = n;
     int bx = 0, ebx = 0, nsplit_any = 0;
+    double gf = 0;
     for (int k = 0; k < n; k++) {
-        const GG& g = gs[k];
-        const ConvPlan& p = ps[k];
-        // LDS: A buffers follow the launch-wide TPS, the patch buffers this class's PS
-        const size_t sm = (size_t)(2 * tps * p.ck * p.bm + 2 * p.ck * p.PS) * sizeof(float);
+        const GG& g = cs[k].g;
+        const ConvPlan& p = cs[k].p;
+        const size_t sm = smem_cls(p, tps);          // A buffers follow the launch-wide TPS, the patch buffers this class's PS
         if (sm > smem) smem = sm;
-        a.c[k] = make_cp(g, p, zeros[k], wps[k], parts[k]);
+        a.c[k] = make_cp(g, p, cs[k].zeros, cs[k].wp, cs[k].part);
         bx += g.B * p.tiles_x * p.tiles_y;
         a.bx_end[k] = bx;
         EPC& c = e.c[k];
-        c.part = parts[k]; c.bias = g.bias; c.res = g.res; c.y = g.y;
+        c.part = cs[k].part; c.bias = g.bias; c.res = g.res; c.add = g.add; c.y = g.y;
         c.nsplit = p.nsplit; c.part_stride = a.c[k].part_stride;
         c.OHt = g.OHt; c.OWt = g.OWt; c.oy0 = g.oy0; c.ox0 = g.ox0;
         c.total = (p.nsplit > 1) ? a.c[k].part_stride : 0;
+        c.M = g.M; c.so = g.so; c.OH = g.OH; c.OW = g.OW; c.y_bs = g.y_bs; c.res_bs = g.res_bs; c.add_bs = g.add_bs;
+        c.act = g.act; c.act_a = g.act_a; c.act_b = g.act_b; c.res_mul = g.res_mul;
         ebx += (int)((c.total + 255) / 256);
         e.bx_end[k] = ebx;
         if (p.nsplit > 1) nsplit_any = 1;
+        gf += 2e-9 * g.B * g.OHt * g.OWt * (double)g.M * g.Cin * g.Rt * g.St;
     }
     if (smem > 80 * 1024) return false;
-    if (dbg_flag_early("CC_CLASS_MERGE_TRACE"))
-        fprintf(stderr, "[conv] %d problems in one launch: %d tiles, bm %d ck %d tps %d split %d\n", n, bx, ps[0].bm, ps[0].ck, tps, maxsplit);
-    dim3 grid((unsigned)bx, (unsigned)(ps[0].Mpad / ps[0].bm), (unsigned)maxsplit);
+    dim3 grid((unsigned)bx, (unsigned)maxy, (unsigned)maxsplit);
     {
         char nm[96];
-        snprintf(nm, sizeof nm, "k_conv_patch_multi<%d, %d, %d>", ps[0].bm, ps[0].ck, tps);
-        double gf = 0;
-        for (int k = 0; k < n; k++) gf += 2e-9 * gs[k].B * gs[k].OHt * gs[k].OWt * (double)gs[k].M * gs[k].Cin * gs[k].Rt * gs[k].St;
+        snprintf(nm, sizeof nm, "k_conv_patch_multi<%d, %d, %d>", cs[0].p.bm, cs[0].p.ck, tps);
         cctiming::Scope tsc(nm, gf, s);
-        dispatch_patch(ps[0].bm, ps[0].ck, tps, a, grid, smem, s);
+        dispatch_patch(cs[0].p.bm, cs[0].p.ck, tps, a, grid, smem, s);
     }
-    if (nsplit_any) {
-        const GG& g = gs[0];
-        e.M = g.M; e.so = g.so; e.OH = g.OH; e.OW = g.OW; e.y_bs = g.y_bs; e.res_bs = g.res_bs;
-        e.act = g.act; e.act_a = g.act_a; e.act_b = g.act_b; e.res_mul = g.res_mul;
-        if (dbg_flag_early("CC_CLASS_MERGE_TRACE"))
-            for (int k = 0; k < n; k++)
-                fprintf(stderr, "[conv]   epi class %d: part %p y %p nsplit %d total %ld bx_end %d\n", k, (const void*)e.c[k].part,
-                        (void*)e.c[k].y, e.c[k].nsplit, e.c[k].total, e.bx_end[k]);
-        hipLaunchKernelGGL(k_splitk_epilogue_multi, dim3((unsigned)ebx), dim3(256), 0, s, e);
-    }
+    if (nsplit_any) hipLaunchKernelGGL(k_splitk_epilogue_multi, dim3((unsigned)ebx), dim3(256), 0, s, e);
     return true;
+}
+
+// the G (x parity classes) same-shaped problems of the *_group entry points: split-K planned for the whole launch (mult)
+inline bool launch_gg_classes(const GG* gs, int n, int mult, const float* const* zeros, const float* const* wps,
+                              float* const* parts, hipStream_t s) {
+    if (n < 2 || n > MAXCLS || dbg_flag_early("CC_NO_CLASS_MERGE")) return false;
+    ClsIn cs[MAXCLS];
+    for (int k = 0; k < n; k++) {
+        cs[k].g = gs[k];
+        cs[k].p = plan_conv(gs[k], mult);
+        cs[k].zeros = zeros[k]; cs[k].wp = wps[k]; cs[k].part = parts[k];
+    }
+    return launch_classes(cs, n, s);
 }
 
 }  // namespace
@@ -1893,6 +1917,141 @@ int cc_conv2d_dgrad(const float* gy, const float* w, const float* bias_or_null, 
     const long gyp = (long)gy, wp = (long)w, bp = (long)bias_or_null, gxp = (long)gx, pk = (long)prepacked_or_null;
     return cc_conv2d_dgrad_group(1, &gyp, &wp, &bp, &gxp, nullptr, ws, &pk, B, K, OH, OW, gy_bs, C, R, S, stride, pad, IH, IW, gx_bs,
                                  0, w_k_stride, w_c_stride, act, act_a, act_b, stream);
+}
+
+/* ---- heterogeneous launch lists (round 3) ------------------------------------------------------------------------------
+ * n independent convolution problems -- layers of different networks, or a layer's forward next to another layer's
+ * data-gradient -- in as few launches as their tile configurations allow: problems whose kernel instance (BM, CK) agrees
+ * share ONE k_conv_patch_multi launch (+ one split-K epilogue launch), <= 12 classes per launch; split-K is planned for
+ * the launch as a whole (the chip is filled by all of its problems together).  desc_host: n records of CC_CL_LONGS longs:
+ *   0 kind (0: conv2d forward arithmetic, 1: transposed arithmetic = data-gradient / ConvTranspose2d forward)
+ *   1 x (kind 1: gy)  2 w  3 bias  4 res (kind 0: added before act; kind 1: `mul`, see cc_conv2d_dgrad_group)  5 y (gx)
+ *   6 prepacked weight image (required)  7 add (kind 1 with mul: (sum + add) * act'(mul); may alias y)
+ *   8 B  9 Cin (K)  10 IH (OH)  11 IW (OW)  12 x_bs  13 Cout (C)  14 R  15 S  16 stride  17 pad  18 OH (IH)  19 OW (IW)
+ *   20 y_bs  21 res_bs  22 add_bs  23 act  24 act_a (float bits)  25 act_b (float bits)  26 w_k_stride  27 w_c_stride
+ * ws: cc_conv2d_list_ws_bytes() bytes (partial slabs of every class). */
+constexpr int CL_LONGS = 32;
+struct ListCls { ClsIn c; int prob; };
+
+static float bits_to_float(long v) { unsigned u = (unsigned)v; float f; memcpy(&f, &u, 4); return f; }
+
+// -> classes of all problems in order (plans: no split yet), or -1 on a malformed record
+static int list_classes(int n, const long* d, std::vector<ListCls>& out) {
+    for (int i = 0; i < n; i++) {
+        const long* r = d + (long)i * CL_LONGS;
+        const float act_a = bits_to_float(r[24]), act_b = bits_to_float(r[25]);
+        const int B = (int)r[8], Ci = (int)r[9], H0 = (int)r[10], W0 = (int)r[11], Co = (int)r[13], R = (int)r[14], S = (int)r[15];
+        const int stride = (int)r[16], pad = (int)r[17], H1 = (int)r[18], W1 = (int)r[19];
+        if (B <= 0 || Ci <= 0 || Co <= 0 || R <= 0 || S <= 0 || stride <= 0 || !r[6]) return -1;
+        const float* pk = (const float*)r[6];
+        if (r[0] == 0) {
+            ListCls lc = {};
+            lc.c.g = make_fwd((const float*)r[1], (const float*)r[2], (const float*)r[3], (const float*)r[4], (float*)r[5], B, Ci, H0, W0,
+                              r[12], Co, R, S, stride, pad, H1, W1, r[20], r[21], (int)r[23], act_a, act_b);
+            lc.c.p = plan_conv(lc.c.g);
+            lc.c.zeros = pk; lc.c.wp = pk + 64; lc.prob = i;
+            out.push_back(lc);
+        } else {
+            long off = 64;
+            for (int py = 0; py < stride; py++)
+                for (int px = 0; px < stride; px++) {
+                    ListCls lc = {};
+                    if (!make_dgrad_class(lc.c.g, py, px, (const float*)r[1], (const float*)r[2], (const float*)r[3], (float*)r[5], B, Ci, H0,
+                                          W0, r[12], Co, R, S, stride, pad, H1, W1, r[20], r[26], r[27], (int)r[23], act_a, act_b,
+                                          (const float*)r[4], r[21]))
+                        continue;
+                    lc.c.g.add = (const float*)r[7]; lc.c.g.add_bs = r[22];
+                    if (lc.c.g.add && !lc.c.g.res_mul) return -1;          // raw accumulation is res (kind 0 form) or add WITH mul
+                    lc.c.p = plan_conv(lc.c.g);
+                    lc.c.zeros = pk; lc.c.wp = pk + off; lc.prob = i;
+                    off += (long)lc.c.p.wp_floats;
+                    out.push_back(lc);
+                }
+        }
+    }
+    return (int)out.size();
+}
+
+// split-K of the classes of ONE launch: fill the chip with all of them together, then cut classes whose workgroups would run
+// much longer than the launch as a whole (a 512-channel layer on an 8x26 map next to a 128-channel one on 64x208)
+static void list_plan_splits(ListCls** cls, int n, int target) {
+    long fill = 0;
+    double work = 0;
+    for (int k = 0; k < n; k++) {
+        const ConvPlan& p = cls[k]->c.p;
+        const GG& g = cls[k]->c.g;
+        const long blocks = (long)g.B * p.tiles_x * p.tiles_y * (p.Mpad / p.bm);
+        fill += blocks;
+        work += (double)blocks * (p.Cpad / p.ck) * ((g.Rt * g.St + 2) / 3);
+    }
+    const long slots = fill < 256 ? 256 : (fill > 1024 ? 1024 : fill);
+    const double t_ideal = work / (double)slots;            // stages per workgroup slot if the launch were perfectly balanced
+    for (int k = 0; k < n; k++) {
+        ConvPlan& p = cls[k]->c.p;
+        const GG& g = cls[k]->c.g;
+        const int nchunk = p.Cpad / p.ck;
+        long want = 1;
+        if (fill < 256 && nchunk >= 4) want = (target + fill - 1) / fill;
+        else if (nchunk >= 8) {
+            const double len = (double)nchunk * ((g.Rt * g.St + 2) / 3);
+            const double cap = t_ideal > 24 ? t_ideal : 24;
+            if (len > 2 * cap) want = (long)(len / cap + 0.999);
+        }
+        if (want > nchunk / 2) want = nchunk / 2;
+        if (want > 32) want = 32;
+        p.nsplit = 1; p.cps = nchunk;
+        if (want >= 2) {
+            p.cps = (int)((nchunk + want - 1) / want);
+            p.nsplit = (nchunk + p.cps - 1) / p.cps;
+        }
+        p.part_floats = p.nsplit > 1 ? (size_t)p.nsplit * g.B * g.M * g.OHt * g.OWt : 0;
+    }
+}
+
+// groups the classes into launches (same (bm, ck), <= MAXCLS, list order kept inside a launch), plans the splits, assigns the
+// partial-slab areas; launches when s_or_null is a stream (ws != nullptr).  -> floats of workspace needed / used, -1: error
+static long list_run(int n, const long* d, float* ws, int target, bool launch, hipStream_t s) {
+    std::vector<ListCls> all;
+    if (list_classes(n, d, all) < 0) return -1;
+    std::vector<char> done(all.size(), 0);
+    long off = 64;
+    for (size_t i = 0; i < all.size(); i++) {
+        if (done[i]) continue;
+        if (!all[i].c.p.use_patch) {
+            done[i] = 1;
+            if (launch) launch_gg_flat(all[i].c.g, s);
+            continue;
+        }
+        ListCls* grp[MAXCLS];
+        int m = 0;
+        for (size_t j = i; j < all.size() && m < MAXCLS; j++)
+            if (!done[j] && all[j].c.p.use_patch && all[j].c.p.bm == all[i].c.p.bm && all[j].c.p.ck == all[i].c.p.ck) {
+                grp[m++] = &all[j];
+                done[j] = 1;
+            }
+        list_plan_splits(grp, m, target);
+        ClsIn cs[MAXCLS];
+        for (int k = 0; k < m; k++) {
+            grp[k]->c.part = ws ? ws + off : nullptr;
+            off += (long)grp[k]->c.p.part_floats;
+            cs[k] = grp[k]->c;
+        }
+        if (launch && !launch_classes(cs, m, s, true)) return -1;
+    }
+    return off;
+}
+
+size_t cc_conv2d_list_ws_bytes(int n, const long* desc_host, int split_target) {
+    if (n <= 0 || !desc_host) return 0;
+    const long f = list_run(n, desc_host, nullptr, split_target > 0 ? split_target : 512, false, nullptr);
+    return f < 0 ? 0 : (size_t)f * sizeof(float);
+}
+
+int cc_conv2d_list(int n, const long* desc_host, float* ws, int split_target, void* stream) {
+    if (n <= 0 || !desc_host || !ws) return CC_ERR_ARG;
+    if (list_run(n, desc_host, ws, split_target > 0 ? split_target : 512, true, (hipStream_t)stream) < 0) return CC_ERR_ARG;
+    CC_CHECK_LAUNCH();
+    return CC_OK;
 }
 
 struct W3Plan { bool ok; int mt, nbuf, tiles_x, tiles_y, ntiles, nsplit, tps, Cp32; size_t smem, ws_floats; };

@@ -77,6 +77,16 @@ class PackRegistry:
         self.entries[key] = {"buf": buf, "descs": descs, "epoch": -1, "w": w}
         self.dirty = True
 
+    def ensure(self, kind, w, geom):
+        """-> the image buffer of (kind, w, geom), registered on the spot when unknown (launch plans hold its address);
+        its CONTENT is valid after the next prepack_all().  None: this geometry does not run on the patch kernel."""
+        key = (kind, w.data_ptr(), geom)
+        ent = self.entries.get(key)
+        if ent is None:
+            self._register(key, kind, w, geom)
+            ent = self.entries[key]
+        return ent["buf"] if ent else None
+
     def prepack_all(self):
         """Start of a trainer step: refresh every registered image (the weights changed in Adam) and open registration."""
         live = [e for e in self.entries.values() if e]

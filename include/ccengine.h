@@ -253,6 +253,20 @@ int cc_wgrad_reduce_table(const long* desc_host, int n, void* stream);
 int cc_act_bwd_bias_group(int G, const long* gy, const long* y, const long* geff, const long* gbias, float* ws, int B, int C, int H,
                           int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b, int accumulate_bias,
                           void* stream);
+/* ---- launch lists (round 3): n INDEPENDENT convolution problems of different shapes -- layers of different networks
+ * (train.py:454-463 runs DispResNet6, PoseNetB6, MaskNet6 and Back2Future one after the other although they share nothing but
+ * their input), or a layer's forward next to another's data-gradient -- in as few launches as their tile configurations
+ * allow: problems whose kernel instance agrees share ONE launch (+ one split-K epilogue launch), split-K is planned for the
+ * launch as a whole.  desc_host: n records of 32 longs (HOST memory):
+ *   0 kind (0: conv2d forward arithmetic as cc_conv2d_fwd, 1: transposed arithmetic as cc_conv2d_dgrad_group)
+ *   1 x (kind 1: gy)  2 w  3 bias  4 res (kind 0: added before act; kind 1: `mul`)  5 y (kind 1: gx)
+ *   6 prepacked weight image (required, from cc_repack_table)  7 add (kind 1 with mul: gx = (sum + add) * act'(mul): the other
+ *     gradient contributions of a fan-out tensor summed in the epilogue; may alias gx)
+ *   8 B  9 Cin (K)  10 IH (OH)  11 IW (OW)  12 x_bs  13 Cout (C)  14 R  15 S  16 stride  17 pad  18 OH (IH)  19 OW (IW)
+ *   20 y_bs  21 res_bs  22 add_bs  23 act  24 act_a (float bits)  25 act_b (float bits)  26 w_k_stride  27 w_c_stride
+ * ws: cc_conv2d_list_ws_bytes() bytes.  split_target: workgroups a launch should at least have (0 -> 512). */
+size_t cc_conv2d_list_ws_bytes(int n, const long* desc_host, int split_target);
+int cc_conv2d_list(int n, const long* desc_host, float* ws, int split_target, void* stream);
 /* per-kernel timing (measurement aid, process-wide; the only state the library keeps): between cc_timing_enable(1) and cc_timing_collect the MAIN device
  * kernel of every conv / weight-gradient call is bracketed with HIP events on its stream; collect returns (HOST buffer) one line
  * per device kernel: "name\tlaunches\ttotal_ms\ttotal_gflop\n" and the number of characters written. */

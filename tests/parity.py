@@ -527,6 +527,46 @@ def check_conv_groups(dev, tol=2e-5, prepack=True, cases=((2, 6, 9, 14, 20, 12, 
     ops.packs.reset()
 
 
+def check_conv_list(dev, tol=2e-5):
+    """cc_conv2d_list: four problems of different shapes and kinds in one call -- a residual + ReLU forward (130 channels),
+    a plain forward on another map size, a stride-2 data-gradient with the fused (sum + add) * relu'(mul) epilogue and a
+    stride-1 data-gradient accumulating in place under LeakyReLU' -- against torch's convolutions."""
+    import torch.nn.functional as F
+    from cc_amd import ops, launchlist as LL
+    g = torch.Generator().manual_seed(5)
+
+    def rn(*s):
+        return torch.randn(*s, generator=g)
+    ops.packs.reset()
+    xa, wa, ba, ra = rn(2, 24, 5, 8), rn(130, 24, 3, 3) * 0.2, rn(130), rn(2, 130, 5, 8)
+    xb, wb = rn(1, 70, 9, 14), rn(128, 70, 3, 3) * 0.1
+    wc, gyc, mulc, addc = rn(136, 40, 3, 3) * 0.1, rn(2, 136, 5, 6), torch.relu(rn(2, 40, 10, 12)), rn(2, 40, 10, 12)
+    wd, gyd, muld, gxd0 = rn(72, 33, 3, 3) * 0.1, rn(2, 72, 6, 7), rn(2, 33, 6, 7), rn(2, 33, 6, 7)
+    # a 160-channel wide buffer whose channels 20..59 receive problem C's result (batch-strided output)
+    wide = torch.zeros(2, 160, 10, 12)
+    d = [t.clone().to(dev) for t in (xa, wa, ba, ra, xb, wb, wc, gyc, mulc, addc, wd, gyd, muld, gxd0, wide)]
+    xa_, wa_, ba_, ra_, xb_, wb_, wc_, gyc_, mulc_, addc_, wd_, gyd_, muld_, gxd_, wide_ = d
+    ya_ = torch.empty(2, 130, 5, 8, device=dev)
+    yb_ = torch.empty(1, 128, 9, 14, device=dev)
+    gxc_ = wide_[:, 20:60]
+    recs = [LL.conv_record(xa_, wa_, ba_, ra_, ya_, 1, 1, 1),
+            LL.conv_record(xb_, wb_, None, None, yb_, 1, 1, 0),
+            LL.tconv_record(gyc_, wc_, None, gxc_, 2, 1, 40 * 9, 9, 3, 3, act=1, mul=mulc_, add=addc_),
+            LL.tconv_record(gyd_, wd_, None, gxd_, 1, 1, 33 * 9, 9, 3, 3, act=2, mul=muld_, add=gxd_)]
+    ll = LL.LaunchList(recs, dev)
+    ops.packs.prepack_all()
+    ll.run()
+    ops.packs.invalidate()
+    ref = [F.relu(F.conv2d(xa, wa, ba, 1, 1) + ra), F.conv2d(xb, wb, None, 1, 1),
+           (F.conv_transpose2d(gyc, wc, None, 2, 1, 1) + addc) * (mulc > 0).float()]
+    rd = F.conv_transpose2d(gyd, wd, None, 1, 1) + gxd0
+    ref.append(torch.where(muld > 0, rd, 0.2 * rd))
+    errs = [rel(a, b) for a, b in zip((ya_, yb_, gxc_, gxd_), ref)]
+    assert max(errs) < tol, errs
+    assert float(wide_[:, :20].abs().max()) == 0 and float(wide_[:, 60:].abs().max()) == 0      # the slice's neighbours untouched
+    ops.packs.reset()
+
+
 def check_corr(dev, cases=((2, 8, 6, 12), (1, 5, 7, 13), (2, 12, 5, 8), (1, 33, 9, 20))):
     """9x9 cost volume (Back2Future): plain `correlate` and the fused pair with the idx_fwd / idx_bwd channel
     permutations, forward and all gradients, vs the oracle; W % 4 == 0 runs the register-blocked kernels, other widths

@@ -83,3 +83,7 @@ def test_adam_and_segments():
 
 def test_conv_groups():
     parity.check_conv_groups("cpu")
+
+
+def test_conv_launch_list():
+    parity.check_conv_list("cpu")

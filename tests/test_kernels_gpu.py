@@ -104,3 +104,7 @@ def test_adam_and_segments():
 def test_conv_groups():
     parity.check_conv_groups("cuda")
     parity.check_conv_groups("cuda", cases=((4, 196, 16, 52, 128, 96, 1), (4, 64, 32, 104, 96, 32, 2)))
+
+
+def test_conv_launch_list():
+    parity.check_conv_list("cuda")
