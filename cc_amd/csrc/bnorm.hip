@@ -301,6 +301,17 @@ __global__ __launch_bounds__(256) void k_bn_small_bwd(const float* __restrict__ 
     }
 }
 
+// eval mode: scale_c = w_c / sqrt(running_var_c + eps), shift_c = b_c - running_mean_c * scale_c
+__global__ __launch_bounds__(256) void k_bn_eval_coef(const float* __restrict__ weight, const float* __restrict__ bias,
+                                                      const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                                      float* __restrict__ scale_shift, int C, float eps, int grad_only) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float sc = (weight ? weight[c] : 1.f) / sqrtf(rvar[c] + eps);
+    scale_shift[c] = sc;
+    scale_shift[C + c] = grad_only ? 0.f : ((bias ? bias[c] : 0.f) - rmean[c] * sc);
+}
+
 inline int bn_cpp(int B, int HW) {
     int cpp = (HW + 8191) / 8192;
     const int cap = BN_MAXCHUNK / B > 0 ? BN_MAXCHUNK / B : 1;
@@ -372,6 +383,29 @@ int cc_bn_train_bwd(const float* gy, const float* x, const float* weight_or_null
                        gweight_or_null, gbias_or_null, coef, C, (float)((long)B * HW), accumulate_wb);
     if (v4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_bwd_apply<true>), g, dim3(256), 0, s, gy, x, save_mean, (const float*)coef, gx, C, HW, bs);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_bwd_apply<false>), g, dim3(256), 0, s, gy, x, save_mean, (const float*)coef, gx, C, HW, bs);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+/* nn.BatchNorm2d forward in eval mode: the affine map of the running statistics, y = (x - running_mean_c) / sqrt(running_var_c
+ * + eps) * w_c + b_c (DispResNet6's shortcut BatchNorms inside the validation loops, train.py:588-777).  grad_only != 0: the
+ * input gradient of that map instead, y = x * w_c / sqrt(running_var_c + eps) (x = upstream gradient).  ws: 2*C floats. */
+int cc_bn_eval_fwd(const float* x, const float* weight_or_null, const float* bias_or_null, const float* running_mean,
+                   const float* running_var, float* y, float* ws, int B, int C, int H, int W, float eps, int grad_only,
+                   void* stream) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !running_mean || !running_var) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int HW = H * W;
+    hipLaunchKernelGGL(k_bn_eval_coef, dim3((C + 255) / 256), dim3(256), 0, s, weight_or_null, bias_or_null, running_mean,
+                       running_var, ws, C, eps, grad_only);
+    int cpp = (HW + 8191) / 8192;
+    if (cpp < 1) cpp = 1;
+    if (cpp > 64) cpp = 64;
+    const bool v4 = (HW % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
+    dim3 g(cpp, C, B);
+    const long bs = (long)C * HW;
+    if (v4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_apply<true>), g, dim3(256), 0, s, x, y, (const float*)ws, C, HW, bs);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_apply<false>), g, dim3(256), 0, s, x, y, (const float*)ws, C, HW, bs);
     CC_CHECK_LAUNCH();
     return CC_OK;
 }

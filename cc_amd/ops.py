@@ -579,15 +579,50 @@ class _BNTrainFn(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None
 
 
+class _BNEvalFn(torch.autograd.Function):
+    """nn.BatchNorm2d in eval mode (running statistics) on csrc/bnorm.hip; differentiable w.r.t. its input."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps):
+        x = _c(x)
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        engine().call("cc_bn_eval_fwd", x, weight, bias, running_mean, running_var, y, _ws(8 * C, x), B, C, H, W, float(eps), 0,
+                      STREAM)
+        ctx.save_for_backward(weight, running_mean, running_var)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        weight, running_mean, running_var = ctx.saved_tensors
+        gy = _c(gy)
+        B, C, H, W = gy.shape
+        gx = torch.empty_like(gy)
+        engine().call("cc_bn_eval_fwd", gy, weight, None, running_mean, running_var, gx, _ws(8 * C, gy), B, C, H, W, ctx.eps, 1,
+                      STREAM)
+        return gx, None, None, None, None, None
+
+
 def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps):
-    """nn.BatchNorm2d.forward.  Training mode always runs on csrc/bnorm.hip (three launches for >= 16 k values per channel,
-    one workgroup-per-channel launch below); eval mode is the affine map of the running statistics (stock torch)."""
+    """nn.BatchNorm2d.forward on csrc/bnorm.hip.  Training mode: three launches for >= 16 k values per channel, one
+    workgroup-per-channel launch below.  Eval mode: the affine map of the running statistics (cc_bn_eval_fwd).  Outside the
+    reference's use of the layer (4-d input, fixed momentum, tracked statistics, eval-mode parameter gradients) it raises."""
+    if x.dim() != 4:
+        raise NotImplementedError("ccengine BatchNorm: 4-d NCHW input (the reference's nn.BatchNorm2d use)")
     if not training:
-        return F.batch_norm(x, running_mean, running_var, weight, bias, False, 0.0, eps)
+        if running_mean is None or running_var is None:
+            raise NotImplementedError("ccengine BatchNorm: eval mode needs tracked running statistics")
+        if torch.is_grad_enabled() and ((weight is not None and weight.requires_grad) or (bias is not None and bias.requires_grad)):
+            raise NotImplementedError("ccengine BatchNorm: parameter gradients in eval mode (freeze the affine parameters, as "
+                                      "train.py's --fix-* flags do, or train in train() mode)")
+        return _BNEvalFn.apply(x, weight, bias, running_mean, running_var, eps)
+    if momentum is None:
+        raise NotImplementedError("ccengine BatchNorm: a fixed momentum (the reference's nn.BatchNorm2d use)")
+    if x.shape[0] * x.shape[2] * x.shape[3] == 1:
+        raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (list(x.shape),))
     if num_batches_tracked is not None:
         num_batches_tracked.add_(1)
-    if x.dim() != 4 or momentum is None:
-        raise NotImplementedError("ccengine BatchNorm: 4-d input and a fixed momentum (the reference's nn.BatchNorm2d use)")
     return _BNTrainFn.apply(x, weight, bias, running_mean, running_var, momentum, eps)
 
 

@@ -319,6 +319,11 @@ int cc_bn_train_fwd(const float* x, const float* weight_or_null, const float* bi
 int cc_bn_train_bwd(const float* gy, const float* x, const float* weight_or_null, const float* save_mean,
                     const float* save_invstd, float* gx, float* gweight_or_null, float* gbias_or_null, float* ws, int B, int C,
                     int H, int W, int accumulate_wb, void* stream);
+/* eval mode (running statistics): y = (x - running_mean_c) / sqrt(running_var_c + eps) * w_c + b_c; grad_only != 0: the input
+ * gradient of that map, y = x * w_c / sqrt(running_var_c + eps).  ws: 2*C floats. */
+int cc_bn_eval_fwd(const float* x, const float* weight_or_null, const float* bias_or_null, const float* running_mean,
+                   const float* running_var, float* y, float* ws, int B, int C, int H, int W, float eps, int grad_only,
+                   void* stream);
 
 /* ---------------------------------------------------------------- job-table forms of the loss path
  * loss_functions.py runs every photometric / consensus term once per (pyramid scale, reference frame): `for scale ... for ref`

@@ -2,6 +2,7 @@
 inputs.  `dev` is "cuda" for the real library (-m gpu) or "cpu" for the x86 emulation build of the same
 kernel sources (tests/hipemu).  Tolerances are the ones SURVEY.md section 8c / BASELINE.json state."""
 import numpy as np
+import pytest
 import torch
 
 from cc_amd import synthetic as syn, inverse_warp as IW, loss_functions as LF, ssim as SS
@@ -636,6 +637,17 @@ def check_batch_norm(dev, cases=((2, 5, 7, 12), (3, 16, 9, 13), (2, 8, 32, 64), 
         g0 = torch.autograd.grad(r, [xc, wc, bc], go)
         errs = [rel(a, b) for a, b in zip(g1, g0)]
         assert max(errs) < 1e-5, ("bn grads", (B, C, H, W), errs)
+        # eval mode (running statistics; the validation loops): output and input gradient, statistics untouched
+        rm1, rv1 = rmd.clone(), rvd.clone()
+        ye = ops.batch_norm(xd, wd.detach(), bd.detach(), rmd, rvd, None, False, 0.1, 1e-5)
+        re = F.batch_norm(xc, rmc, rvc, wc.detach(), bc.detach(), False, 0.1, 1e-5)
+        assert rel(ye, re) < 2e-6, ("bn eval out", (B, C, H, W), rel(ye, re))
+        assert torch.equal(rm1, rmd) and torch.equal(rv1, rvd)
+        ge1, = torch.autograd.grad(ye, [xd], go.to(dev))
+        ge0, = torch.autograd.grad(re, [xc], go)
+        assert rel(ge1, ge0) < 2e-6, ("bn eval grad", (B, C, H, W), rel(ge1, ge0))
+    with pytest.raises(ValueError):          # torch's own check: one value per channel cannot be normalised
+        ops.batch_norm(torch.zeros(1, 3, 1, 1, device=dev), None, None, None, None, None, True, 0.1, 1e-5)
 
 
 def check_corr_patch(dev, cases=((2, 6, 9, 14, 5, 1), (1, 4, 12, 10, 7, 2), (1, 3, 6, 7, 21, 2))):

@@ -1,0 +1,97 @@
+"""Product-side parity of call patterns the step tests do not reach:
+  * BASELINE.json configs[0] -- DispNetS + PoseExpNet(output_exp=False), one scale, a bare ``None`` explainability mask,
+    ``wssim=0`` and ``smooth_loss`` (the train.py-style call of oracle/make_golden.py `step_level`, golden keys c1.*);
+  * ``rotation_mode='quat'`` of inverse_warp (inverse_warp.py:122-143,250-283) against the reference's own output.
+Emulator build on CPU (-m "not gpu") and the gfx950 library (-m gpu)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cc_amd import models, synthetic as syn
+from cc_amd import loss_functions as LF
+from cc_amd import inverse_warp as IW
+from oracle.make_golden import FB, FH, FW, SB, SH, SW, pyramid_inputs
+
+
+def _config1(dev, golden_dir):
+    g = dict(np.load(os.path.join(golden_dir, "step_acF.npz")))
+    tgt, refs, K, Kinv = syn.sample(SB, SH, SW, seed=1)
+    dn, pn = models.DispNetS(), models.PoseExpNet(nb_ref_imgs=4, output_exp=False)
+    for n in (dn, pn):
+        n.load_state_dict(syn.seeded_state_dict(n, 0))
+        n.to(dev).train()
+    tgt, refs, K, Kinv = tgt.to(dev), [r.to(dev) for r in refs], K.to(dev), Kinv.to(dev)
+    disp = dn(tgt)
+    exp, pose = pn(tgt, refs)                         # Q12: PoseExpNet returns (masks, pose); four None masks without output_exp
+    assert exp == [None] * 4                          # PoseExpNet.py:84-91
+    depth = 1 / disp[0]
+    l1 = LF.photometric_reconstruction_loss(tgt, refs, K, Kinv, depth, None, pose, wssim=0)
+    l3 = LF.smooth_loss(depth)
+    LF.check_finite()
+    rep = {}
+    for name, got, key in (("loss_1", l1, "c1.loss_1"), ("loss_3", l3, "c1.loss_3")):
+        want = float(g[key])
+        rep[name] = abs(float(got.detach()) - want) / abs(want)
+        assert rep[name] <= 1e-4, (name, float(got.detach()), want)
+    ref_pose = torch.from_numpy(g["c1.pose"])
+    rep["pose"] = float((pose.detach().cpu() - ref_pose).abs().max() / ref_pose.abs().max())
+    assert rep["pose"] <= 1e-4, rep
+    # the gradient reaches both networks through the one-scale, mask-free loss
+    (l1 + 0.1 * l3).backward()
+    for n in (dn, pn):
+        sq = sum(float(p.grad.double().pow(2).sum()) for p in n.parameters() if p.grad is not None)
+        assert np.isfinite(sq) and sq > 0
+    return rep
+
+
+def test_config1_on_the_engine_emulated(golden_dir):
+    from hipemu.emu import emulated_engine
+    with emulated_engine():
+        print(_config1("cpu", golden_dir))
+
+
+@pytest.mark.gpu
+def test_config1_on_the_engine_gpu(golden_dir):
+    print(_config1("cuda", golden_dir))
+
+
+def _quat(dev, golden_dir, tag, ac):
+    g = dict(np.load(os.path.join(golden_dir, "functions_%s.npz" % tag)))
+    tgt, refs, K, Kinv = syn.sample(FB, FH, FW, seed=1)
+    pyr = pyramid_inputs(FB, FH, FW)
+    pose = syn.kernel_inputs(FB, 8, 8, seed=2)["pose"] * 3.0
+    d0 = pyr[0]["depth"][:, 0]
+    from cc_amd import config
+    old = config.align_corners
+    config.align_corners = ac
+    try:
+        mat = IW.pose_vec2mat((pose[:, 0] * 10).to(dev), "quat")
+        assert float((mat.cpu() - torch.from_numpy(g["pose_mat_quat"])).abs().max()) <= 2e-6
+        d = d0.to(dev).requires_grad_(True)
+        p = pose[:, 0].to(dev).requires_grad_(True)
+        out = IW.inverse_warp(refs[0].to(dev), d, p, K.to(dev), Kinv.to(dev), "quat")
+        ref = torch.from_numpy(g["inverse_warp_quat"])
+        diff = (out.detach().cpu() - ref).abs()
+        # same bar as the euler warp tests: a tap may flip where a coordinate sits within an ulp of an integer
+        frac = float((diff > 1e-5).float().mean())
+        assert frac <= 2e-3, frac
+        out.sum().backward()                     # the fused backward accepts the quaternion pose path
+        assert torch.isfinite(d.grad).all() and torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0
+    finally:
+        config.align_corners = old
+    return frac
+
+
+@pytest.mark.parametrize("tag,ac", [("acF", False), ("acT", True)])
+def test_inverse_warp_quat_emulated(golden_dir, tag, ac):
+    from hipemu.emu import emulated_engine
+    with emulated_engine():
+        print("quat out-of-tolerance fraction", _quat("cpu", golden_dir, tag, ac))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,ac", [("acF", False), ("acT", True)])
+def test_inverse_warp_quat_gpu(golden_dir, tag, ac):
+    print("quat out-of-tolerance fraction", _quat("cuda", golden_dir, tag, ac))
