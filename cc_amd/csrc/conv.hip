@@ -1844,10 +1844,10 @@ size_t cc_conv2d_dgrad_group_ws_bytes(int G, int B, int K, int OH, int OW, int C
     return (size_t)G * best * sizeof(float);
 }
 
-int cc_conv2d_dgrad_group(int G, const long* gy, const long* w, const long* bias, const long* gx, const long* mul, float* ws,
-                          const long* prepacked, int B, int K, int OH, int OW, long gy_bs, int C, int R, int S, int stride,
-                          int pad, int IH, int IW, long gx_bs, long mul_bs, long w_k_stride, long w_c_stride, int act, float act_a,
-                          float act_b, void* stream) {
+static int dgrad_group_impl(int G, const long* gy, const long* w, const long* bias, const long* gx, const long* mul,
+                            const long* add, float* ws, const long* prepacked, int B, int K, int OH, int OW, long gy_bs, int C,
+                            int R, int S, int stride, int pad, int IH, int IW, long gx_bs, long mul_bs, long add_bs,
+                            long w_k_stride, long w_c_stride, int act, float act_a, float act_b, void* stream) {
     if (G <= 0 || G > MAXCLS || B <= 0 || K <= 0 || C <= 0 || stride <= 0) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const size_t stride_f = cc_conv2d_dgrad_group_ws_bytes(G, B, K, OH, OW, C, R, S, stride, pad, IH, IW) / sizeof(float) / G;
@@ -1871,6 +1871,10 @@ int cc_conv2d_dgrad_group(int G, const long* gy, const long* w, const long* bias
                                           bias ? (const float*)bias[k] : nullptr, (float*)gx[k], B, K, OH, OW, gy_bs, C, R, S,
                                           stride, pad, IH, IW, gx_bs, w_k_stride, w_c_stride, act, act_a, act_b,
                                           mul ? (const float*)mul[k] : nullptr, mul_bs)) { all = false; break; }
+                    if (add && add[k]) {
+                        if (mul && mul[k]) { gs[n].add = (const float*)add[k]; gs[n].add_bs = add_bs; }
+                        else { gs[n].res = (const float*)add[k]; gs[n].res_bs = add_bs; gs[n].res_mul = 0; }      // gx = act(sum + add)
+                    }
                     const ConvPlan p = plan_conv(gs[n], G);
                     zeros[n] = pk;
                     wps[n] = pk + off;
@@ -1896,6 +1900,10 @@ int cc_conv2d_dgrad_group(int G, const long* gy, const long* w, const long* bias
                                       (float*)gx[k], B, K, OH, OW, gy_bs, C, R, S, stride, pad, IH, IW, gx_bs, w_k_stride,
                                       w_c_stride, act, act_a, act_b, mul ? (const float*)mul[k] : nullptr, mul_bs))
                     continue;
+                if (add && add[k]) {
+                    if (mul && mul[k]) { g.add = (const float*)add[k]; g.add_bs = add_bs; }
+                    else { g.res = (const float*)add[k]; g.res_bs = add_bs; g.res_mul = 0; }
+                }
                 if (pk) {
                     const ConvPlan p = plan_conv(g);
                     launch_gg(g, wk, s, pk + off, pk);
@@ -1908,6 +1916,24 @@ int cc_conv2d_dgrad_group(int G, const long* gy, const long* w, const long* bias
     }
     CC_CHECK_LAUNCH();
     return CC_OK;
+}
+
+int cc_conv2d_dgrad_group(int G, const long* gy, const long* w, const long* bias, const long* gx, const long* mul, float* ws,
+                          const long* prepacked, int B, int K, int OH, int OW, long gy_bs, int C, int R, int S, int stride,
+                          int pad, int IH, int IW, long gx_bs, long mul_bs, long w_k_stride, long w_c_stride, int act, float act_a,
+                          float act_b, void* stream) {
+    return dgrad_group_impl(G, gy, w, bias, gx, mul, nullptr, ws, prepacked, B, K, OH, OW, gy_bs, C, R, S, stride, pad, IH, IW, gx_bs,
+                            mul_bs, 0, w_k_stride, w_c_stride, act, act_a, act_b, stream);
+}
+
+/* ... with `add`: gx = (sum + add) * act'(mul), or act(sum + add) without mul (act 0: plain accumulation) -- the other gradient contributions of a fan-out tensor (a residual
+ * shortcut's gradient, what earlier data-gradients left in gx: add may alias gx) are summed in the epilogue. */
+int cc_conv2d_dgrad_group_add(int G, const long* gy, const long* w, const long* gx, const long* mul, const long* add, float* ws,
+                              const long* prepacked, int B, int K, int OH, int OW, long gy_bs, int C, int R, int S, int stride,
+                              int pad, int IH, int IW, long gx_bs, long mul_bs, long add_bs, long w_k_stride, long w_c_stride,
+                              int act, float act_a, float act_b, void* stream) {
+    return dgrad_group_impl(G, gy, w, nullptr, gx, mul, add, ws, prepacked, B, K, OH, OW, gy_bs, C, R, S, stride, pad, IH, IW, gx_bs,
+                            mul_bs, add_bs, w_k_stride, w_c_stride, act, act_a, act_b, stream);
 }
 
 int cc_conv2d_dgrad(const float* gy, const float* w, const float* bias_or_null, float* gx, float* ws,

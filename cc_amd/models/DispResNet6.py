@@ -4,7 +4,8 @@ import torch.nn as nn
 
 from .. import nn as L
 from .. import ops
-from ._blocks import xavier_zero_bias, crop_like, make_layer, conv_call
+from ..tape import run_network
+from ._blocks import xavier_zero_bias, make_layer, basic_block
 
 _ENC = [32, 64, 128, 256, 512, 512, 512]
 _DEC = [512, 512, 256, 128, 64, 32, 16]
@@ -34,25 +35,45 @@ class DispResNet6(nn.Module):
     def init_weights(self):
         xavier_zero_bias(self)
 
-    def _disp(self, lvl, feat):
-        head = getattr(self, "predict_disp%d" % lvl)[0]
-        return ops.conv2d(feat, head.weight, head.bias, 1, 1, "sigmoid", None, float(self.alpha), float(self.beta))
-
-    def forward(self, x):
-        c = [x, conv_call(self.conv1[2], conv_call(self.conv1[0], x, defer=True), pre_act="relu")]
+    def _body(self, tape, x):
+        """The forward pass on the tape: every decoder concatenation (upconv, skip[, disp_up]) is one buffer whose slices the
+        up-convolution, the encoder stage and the disparity up-sampling write directly."""
+        B, _, H, W = x.t.shape
+        hw = [(H, W)]
+        for _ in range(7):
+            hw.append(((hw[-1][0] - 1) // 2 + 1, (hw[-1][1] - 1) // 2 + 1))          # k7/s2/p3 and k3/s2/p1 alike
+        cats = {}
+        for j, lvl in enumerate(range(7, 0, -1)):
+            chans = [_DEC[j]] + ([_ENC[lvl - 2]] if lvl > 1 else []) + ([1] if lvl <= 3 else [])
+            cats[lvl] = tape.concat(B, chans, hw[lvl - 1][0], hw[lvl - 1][1], x.t)
+        c1a = tape.conv(x, self.conv1[0].weight, self.conv1[0].bias, 2, 3, "relu")
+        c = [x, tape.conv(c1a, self.conv1[2].weight, self.conv1[2].bias, 1, 3, "relu", out=cats[2].slot(1))]
         for i in range(2, 8):
-            c.append(getattr(self, "conv%d" % i)(c[-1]))
+            stage = getattr(self, "conv%d" % i)
+            y = basic_block(tape, stage[0], c[-1])
+            c.append(basic_block(tape, stage[1], y, out=cats[i + 1].slot(1) if i < 7 else None))
         out, disps, prev = c[7], {}, None
         for lvl in range(7, 0, -1):
-            skip = c[lvl - 1]
-            up = crop_like(getattr(self, "upconv%d" % lvl)(out), skip)
-            parts = [up] if lvl == 1 else [up, skip]                      # concat order (upconv, skip[, disp_up])
+            cb = cats[lvl]
+            Hs, Ws = hw[lvl - 1]
+            up_m = getattr(self, "upconv%d" % lvl)[0]
+            fits = (2 * out.t.shape[2], 2 * out.t.shape[3]) == (Hs, Ws)
+            up = tape.conv_transpose(out, up_m.weight, up_m.bias, 2, 1, 1, "relu", out=cb.slot(0) if fits else None)
+            cb.put(0, tape.crop(up, Hs, Ws))
+            if lvl > 1:
+                cb.put(1, c[lvl - 1])
             if lvl <= 3:
-                parts.append(crop_like(ops.upsample_bilinear2x(prev), skip))
-            out = getattr(self, "iconv%d" % lvl)(torch.cat(parts, 1))
+                k = 2 if lvl > 1 else 1
+                fits = (2 * prev.t.shape[2], 2 * prev.t.shape[3]) == (Hs, Ws)
+                du = tape.upsample2x(prev, 1.0, out=cb.slot(k) if fits else None)
+                cb.put(k, tape.crop(du, Hs, Ws))
+            out = basic_block(tape, getattr(self, "iconv%d" % lvl)[0], cb.done())
             if lvl <= 6:
-                prev = self._disp(lvl, out)
+                head = getattr(self, "predict_disp%d" % lvl)[0]
+                prev = tape.conv(out, head.weight, head.bias, 1, 1, "sigmoid", float(self.alpha), float(self.beta))
                 disps[lvl] = prev
-        if self.training:
-            return tuple(disps[l] for l in range(1, 7))
-        return disps[1]
+        return [disps[l] for l in range(1, 7)] if self.training else [disps[1]]
+
+    def forward(self, x):
+        outs = run_network(self._body, [x], list(self.parameters()))
+        return tuple(outs) if self.training else outs[0]

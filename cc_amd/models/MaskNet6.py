@@ -4,6 +4,7 @@ import torch.nn as nn
 
 from .. import nn as L
 from .. import ops
+from ..tape import run_network
 from ._blocks import xavier_zero_bias, seq_conv_act
 from .PoseNetB6 import PLANES, KS
 
@@ -40,20 +41,50 @@ class MaskNet6(nn.Module):
             nn.init.xavier_uniform_(m.weight.data)
             m.bias.data.zero_()
 
+    def _body(self, tape, x):
+        """Encoder outputs and deconvolution outputs are written straight into the (out_upconv, out_conv) concatenation
+        buffers of the decoder (MaskNet6.py:98-118); each prediction head is recorded before the concatenation that also
+        consumes its input, so that the head's data-gradient is the last contribution and applies relu'."""
+        B, _, H, W = x.t.shape
+        hw = [(H, W)]
+        for i in range(6):
+            k, p = KS[i], (KS[i] - 1) // 2
+            hw.append(((hw[-1][0] + 2 * p - k) // 2 + 1, (hw[-1][1] + 2 * p - k) // 2 + 1))
+        cats = {}
+        if self.output_exp:
+            for j, lvl in enumerate(range(5, 0, -1)):                     # input of deconv{lvl}: (u_{lvl+1}, c[lvl-1])
+                cats[lvl] = tape.concat(B, [_UP[j], PLANES[lvl - 1]], hw[lvl][0], hw[lvl][1], x.t)
+        c = []
+        for i in range(6):
+            m = getattr(self, "conv%d" % (i + 1))[0]
+            x = tape.conv(x, m.weight, m.bias, 2, m.padding[0], "relu", out=cats[i + 1].slot(1) if (i + 1) in cats else None)
+            c.append(x)
+        masks = {}
+        if self.output_exp:
+            u = None
+            for lvl in range(6, 0, -1):
+                d = getattr(self, "deconv%d" % lvl)[0]
+                if lvl == 6:
+                    src = c[5]
+                else:
+                    cb = cats[lvl]
+                    cb.put(0, u)
+                    cb.put(1, c[lvl - 1])
+                    src = cb.done()
+                nxt = cats.get(lvl - 1)
+                OH, OW = 2 * src.t.shape[2], 2 * src.t.shape[3]
+                fits = nxt is not None and tuple(nxt.slot(0).shape[2:]) == (OH, OW)
+                u = tape.conv_transpose(src, d.weight, d.bias, 2, 1, 0, "relu", out=nxt.slot(0) if fits else None)
+                pm = getattr(self, "pred_mask%d" % lvl)
+                masks[lvl] = tape.conv(u, pm.weight, pm.bias, 1, 1, "sigmoid")
+        if not self.output_exp:
+            return []
+        return [masks[l] for l in range(1, 7)] if self.training else [masks[1]]
+
     def forward(self, target_image, ref_imgs):
         assert len(ref_imgs) == self.nb_ref_imgs
         x = torch.cat([target_image] + list(ref_imgs), 1)
-        c = []
-        for i in range(6):
-            x = getattr(self, "conv%d" % (i + 1))(x)
-            c.append(x)
-        masks = {l: None for l in range(1, 7)}
-        if self.output_exp:
-            u = self.deconv6(c[5])
-            masks[6] = self.pred_mask6(u)
-            for lvl in range(5, 0, -1):
-                u = getattr(self, "deconv%d" % lvl)(torch.cat((u, c[lvl - 1]), 1))     # (out_upconv, out_conv)
-                masks[lvl] = getattr(self, "pred_mask%d" % lvl)(u)
-        if self.training:
-            return tuple(masks[l] for l in range(1, 7))
-        return masks[1]
+        if not self.output_exp:
+            return tuple([None] * 6) if self.training else None
+        outs = run_network(self._body, [x], list(self.parameters()))
+        return tuple(outs) if self.training else outs[0]

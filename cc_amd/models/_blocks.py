@@ -50,6 +50,18 @@ class BasicBlock(nn.Module):
         return ops.conv2d(y, self.conv2.weight, None, 1, 1, "relu", residual=r, pre_act="relu")
 
 
+def basic_block(tape, blk, x, out=None):
+    """BasicBlock on the tape (cc_amd/tape.py).  conv1 is recorded as the FIRST consumer of x: its data-gradient is then the
+    last contribution to x's gradient and carries the shortcut's gradient and relu'(x) in its epilogue."""
+    y = tape.conv(x, blk.conv1.weight, None, blk.stride, 1, "relu")
+    if blk.downsample is None:
+        r = x
+    else:
+        ds = blk.downsample
+        r = tape.batch_norm(tape.conv(x, ds[0].weight, None, ds[0].stride[0], 0, None), ds[1])
+    return tape.conv(y, blk.conv2.weight, None, 1, 1, "relu", residual=r, out=out)
+
+
 def make_layer(cin, cout, blocks, stride):
     """models/DispResNet6.py:45-60: the first block gets a 1x1(stride)+BatchNorm shortcut when shapes change."""
     ds = None

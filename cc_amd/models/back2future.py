@@ -5,9 +5,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import config
 from .. import nn as L
 from .. import ops
 from ..inverse_warp import feature_warp
+from ..tape import run_network
 
 
 def conv_feat_block(nIn, nOut):
@@ -80,74 +82,98 @@ class Model(nn.Module):
         """back2future.py:287-321 (flow_scale: the constant the reference multiplies into the flow before the call)."""
         return feature_warp(x, flo, flow_scale=flow_scale)
 
-    def _decoders(self, decs, ins):
+    def _decoders(self, tape, decs, ins):
         """The 6-layer decoder stacks of one pyramid level (decoder_fwd / decoder_bwd [/ decoder_occ]) layer by layer as
-        grouped launches: same-shaped layers of the parallel stacks share one kernel launch per pass; LeakyReLU backward of
-        layers 0-4 is applied by the next layer's data-gradient epilogue (ops.conv2d_group defer / pre_act)."""
+        grouped launches: same-shaped layers of the parallel stacks share one kernel launch per pass; the LeakyReLU backward
+        of layers 0-4 is applied by the next layer's data-gradient epilogue (cc_amd/tape.py)."""
         xs = list(ins)
         for i in range(6):
             convs = [d[2 * i] for d in decs]
             act = "lrelu" if i < 5 else None
-            kw = dict(defer=i < 5, pre_act="lrelu" if i > 0 else None)
             # the first layer of decoder_occ6 has its own input width (354 vs 162 channels): group by shape
             shapes = sorted({tuple(c.weight.shape) for c in convs})
             ys = [None] * len(decs)
             for shp in shapes:
                 idx = [k for k, c in enumerate(convs) if tuple(c.weight.shape) == shp]
-                out = ops.conv2d_group([xs[k] for k in idx], [convs[k].weight for k in idx], [convs[k].bias for k in idx],
-                                       1, 1, act, **kw)
+                out = tape.conv_group([xs[k] for k in idx], [convs[k].weight for k in idx], [convs[k].bias for k in idx], 1, 1, act)
                 for k, y in zip(idx, out):
                     ys[k] = y
             xs = ys
         return xs
 
-    def forward(self, im_tar, im_refs):
-        n = self.normalize([im_tar] + list(im_refs))
+    def _body(self, tape, n0, n1, n2):
+        """Forward pass on the tape.  Inputs: the normalised target, I-, I+ frames."""
+        ac = config.align_corners
         feats = {}
-        xs = [n[0], n[2], n[1]]                                    # a = target, b = I+, c = I-  (back2future.py:159,166)
+        xs = [n0, n2, n1]                                          # a = target, b = I+, c = I-  (back2future.py:159,166)
         for lvl in range(1, 7):
             blocks = [getattr(self, "conv%d%s" % (lvl, s)) for s in "abc"]
-            ys = ops.conv2d_group(xs, [b[0].weight for b in blocks], [b[0].bias for b in blocks], 2, 1, "lrelu", defer=True)
-            xs = ops.conv2d_group(ys, [b[2].weight for b in blocks], [b[2].bias for b in blocks], 1, 1, "lrelu",
-                                  pre_act="lrelu")
+            ys = tape.conv_group(xs, [b[0].weight for b in blocks], [b[0].bias for b in blocks], 2, 1, "lrelu")
+            xs = tape.conv_group(ys, [b[2].weight for b in blocks], [b[2].bias for b in blocks], 1, 1, "lrelu")
             for s, x in zip("abc", xs):
                 feats[(lvl, s)] = x
-        flow_f, flow_b, up_f, up_b, occ = {}, {}, {}, {}, {}
+        flow_f, flow_b, up_f, up_b, occ_raw = {}, {}, {}, {}, {}
         bw, cw = feats[(6, "b")], feats[(6, "c")]
-        up = ops.upsample_bilinear2x
+        inv_b, inv_c = ops._inv_perm(self.idx_fwd, n0.t.device), ops._inv_perm(self.idx_bwd, n0.t.device)
         for lvl in range(6, 1, -1):
             a = feats[(lvl, "a")]
-            corr = ops.correlation_pair(a, bw, cw, self.idx_fwd, self.idx_bwd)
+            B, C, H, W = a.t.shape
             if lvl == 6:
+                cb_o = tape.concat(B, [162, C], H, W, a.t) if not self.elide_occ else None
+                corr = tape.corr_pair(a, bw, cw, inv_b, inv_c, out=cb_o.slot(0) if cb_o is not None else None)
                 in_f = in_b = corr
-                in_o = torch.cat((corr, a), 1)
+                if cb_o is not None:
+                    cb_o.put(0, corr)
+                    cb_o.put(1, a)
+                    in_o = cb_o.done()
             else:
-                in_f = torch.cat((corr, a, up_f[lvl + 1]), 1)
-                in_b = torch.cat((corr, a, up_b[lvl + 1]), 1)
+                cb_f = tape.concat(B, [162, C, 2], H, W, a.t)
+                cb_b = tape.concat(B, [162, C, 2], H, W, a.t)
+                corr = tape.corr_pair(a, bw, cw, inv_b, inv_c, out=cb_f.slot(0))
+                cb_f.put(0, corr)
+                cb_f.put(1, a)
+                cb_f.put(2, up_f[lvl + 1])
+                cb_b.buf[:, :162 + C].copy_(cb_f.buf[:, :162 + C])        # (corr, a) once more for the backward-flow decoder
+                cb_b.parts[0], cb_b.parts[1] = corr, a
+                cb_b.put(2, up_b[lvl + 1])
+                in_f, in_b = cb_f.done(), cb_b.done()
                 in_o = in_f
             decs = [getattr(self, "decoder_fwd%d" % lvl), getattr(self, "decoder_bwd%d" % lvl)]
             ins = [in_f, in_b]
             if not self.elide_occ:
                 decs.append(getattr(self, "decoder_occ%d" % lvl))
                 ins.append(in_o)
-            outs = self._decoders(decs, ins)
+            outs = self._decoders(tape, decs, ins)
             flow_f[lvl], flow_b[lvl] = outs[0], outs[1]
-            up_f[lvl] = up(flow_f[lvl])
-            up_b[lvl] = up(flow_b[lvl])
+            up_f[lvl] = tape.upsample2x(flow_f[lvl])
+            up_b[lvl] = tape.upsample2x(flow_b[lvl])
             if not self.elide_occ:
-                occ[lvl] = torch.softmax(outs[2], dim=1)
+                occ_raw[lvl] = outs[2]
             if lvl > 2:
                 s = self.WARP_SCALE[lvl]
-                bw = self.warp(feats[(lvl - 1, "b")], up_f[lvl], s)
-                cw = self.warp(feats[(lvl - 1, "c")], up_f[lvl], -s)       # the FORWARD flow for both (Q9)
-        ff = [up(up_f[l], self.FULL_SCALE[l]) for l in range(2, 7)]         # scale fused into the up-sampling launch
-        fb = [up(up_b[l], -self.FULL_SCALE[l]) for l in range(2, 7)]
-        oc = None if self.elide_occ else [F.interpolate(occ[l], scale_factor=4) for l in range(2, 7)]
+                bw = tape.feature_warp(feats[(lvl - 1, "b")], up_f[lvl], s, ac)
+                cw = tape.feature_warp(feats[(lvl - 1, "c")], up_f[lvl], -s, ac)       # the FORWARD flow for both (Q9)
+        ff = [tape.upsample2x(up_f[l], self.FULL_SCALE[l]) for l in range(2, 7)]        # scale fused into the up-sampling launch
+        fb = [tape.upsample2x(up_b[l], -self.FULL_SCALE[l]) for l in range(2, 7)]
+        if self.training and self.nlevels == 6:
+            ff += tape.torch_fn([up_f[6]], lambda t: (0.625 * t,))
+            fb += tape.torch_fn([up_b[6]], lambda t: (-0.625 * t,))
+        if not self.training:
+            ff, fb = ff[:1], fb[:1]
+        self._n_flow = len(ff)
+        return ff + fb + [occ_raw[l] for l in sorted(occ_raw)]
+
+    def forward(self, im_tar, im_refs):
+        n = self.normalize([im_tar] + list(im_refs))
+        outs = list(run_network(self._body, n, list(self.parameters())))
+        k = self._n_flow
+        ff, fb, raw = outs[:k], outs[k:2 * k], outs[2 * k:]
+        oc = None
+        if raw:                       # occlusion maps: softmax + nearest up-sampling (stock torch; train.py:463 discards them)
+            occ = dict(zip(range(2, 7), (torch.softmax(t, dim=1) for t in raw)))
+            oc = [F.interpolate(occ[l], scale_factor=4) for l in range(2, 7)]
+            if self.training and self.nlevels == 6:
+                oc.append(F.interpolate(occ[6], scale_factor=2))
         if self.training:
-            if self.nlevels == 6:
-                ff.append(0.625 * up_f[6])
-                fb.append(-0.625 * up_b[6])
-                if oc is not None:
-                    oc.append(F.interpolate(occ[6], scale_factor=2))
             return ff, fb, oc
         return ff[0], fb[0], (None if oc is None else oc[0])

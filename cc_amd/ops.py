@@ -146,6 +146,9 @@ class _WgradQueue:
 
     def push(self, key, a, x, gw):
         q = self.pending.setdefault(key, [])
+        if any(t[2].data_ptr() == gw.data_ptr() for t in q):      # a weight used twice: two `gw +=` of ONE launch would race
+            self._launch(key)
+            q = self.pending.setdefault(key, [])
         q.append((a, x, gw))
         if len(q) >= self.GROUP:
             self._launch(key)
@@ -154,9 +157,9 @@ class _WgradQueue:
         q = self.pending.pop(key, None)
         if not q:
             return
-        B, M, AH, AW, Cin, IH, IW, R, S, si, pad, o_sm, o_sc = key
-        _wgrad_group([t[0] for t in q], [t[1] for t in q], [t[2] for t in q], q[0][0], B, M, AH, AW, M * AH * AW, Cin, IH, IW,
-                     Cin * IH * IW, R, S, si, pad, o_sm, o_sc, 1)
+        B, M, AH, AW, Cin, IH, IW, R, S, si, pad, o_sm, o_sc, a_bs, x_bs = key
+        _wgrad_group([t[0] for t in q], [t[1] for t in q], [t[2] for t in q], q[0][0], B, M, AH, AW, a_bs, Cin, IH, IW,
+                     x_bs, R, S, si, pad, o_sm, o_sc, 1)
 
     def flush(self):
         for key in list(self.pending):
@@ -317,7 +320,8 @@ class _Conv2dFn(torch.autograd.Function):
         if need[1]:
             wsink = _sink(w)
             if wsink is not None and wgrad_queue.enabled:
-                wgrad_queue.push((B, Cout, OH, OW, Cin, IH, IW, R, S, stride, pad, Cin * R * S, R * S), gy, x, wsink)
+                wgrad_queue.push((B, Cout, OH, OW, Cin, IH, IW, R, S, stride, pad, Cin * R * S, R * S, Cout * OH * OW, Cin * IH * IW),
+                                 gy, x, wsink)
             else:
                 gw = wsink if wsink is not None else torch.empty_like(w)
                 _wgrad_group([gy], [x], [gw], x, B, Cout, OH, OW, Cout * OH * OW, Cin, IH, IW, Cin * IH * IW, R, S, stride, pad,

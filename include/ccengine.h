@@ -237,6 +237,13 @@ int cc_conv2d_dgrad_group(int G, const long* gy, const long* w, const long* bias
                           const long* prepacked, int B, int K, int OH, int OW, long gy_bs, int C, int R, int S, int stride,
                           int pad, int IH, int IW, long gx_bs, long mul_bs, long w_k_stride, long w_c_stride, int act, float act_a,
                           float act_b, void* stream);
+/* ... with `add` (HOST array like mul): gx = (sum + add) * act'(mul), or act(sum + add) without mul (act 0: plain accumulation) -- the other gradient contributions of a fan-out
+ * tensor (the gradient a residual shortcut carries, what earlier data-gradients left in gx: add may alias gx) are summed in the
+ * epilogue instead of by accumulation launches (models/DispResNet6.py:31-43: out = relu(conv2(relu(conv1(x))) + x)). */
+int cc_conv2d_dgrad_group_add(int G, const long* gy, const long* w, const long* gx, const long* mul, const long* add, float* ws,
+                              const long* prepacked, int B, int K, int OH, int OW, long gy_bs, int C, int R, int S, int stride,
+                              int pad, int IH, int IW, long gx_bs, long mul_bs, long add_bs, long w_k_stride, long w_c_stride,
+                              int act, float act_a, float act_b, void* stream);
 int cc_conv2d_wgrad_group(int G, const long* a, const long* x, const long* gw, float* ws, int B, int M, int AH, int AW, long a_bs,
                           int Cin, int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, int accumulate,
                           void* stream);
