@@ -418,12 +418,30 @@ def main():
             if i < 2:
                 first_losses.append({k: float(v) for k, v in losses.items()})
             log("warm-up step %d done at %.1f s" % (i, time.perf_counter() - t_w))
+    comm_cal = tr.calibrate_comm() if world > 1 else None            # each segment's all-reduce alone (outside the timed region)
     sync()
+    # per-step device time stamps: an event after every step on the compute stream (no host synchronisation inside the region)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         losses = tr.step(batch)
+        marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+
+    def pct(q):
+        return round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 3)
+    step_ms = {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": round(per_step[0], 3), "max": round(per_step[-1], 3),
+               "source": "HIP events after every step on the compute stream; `ms_per_step` is the wall-clock mean of the region"}
+    comm = tr.comm_stats() if world > 1 else None
+    rank_losses = None
+    if world > 1:
+        lt = torch.tensor([float(losses["loss"])], device=dev, dtype=torch.float64)
+        allv = [torch.zeros_like(lt) for _ in range(world)]
+        dist.all_gather(allv, lt)
+        rank_losses = [round(float(v.item()), 6) for v in allv]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -493,8 +511,10 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "height": H, "width": W, "scales": 6,
                        "frames": 5, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph,
                        "trained_nets": "disp+pose (mask, flow frozen: README --fix-masknet --fix-flownet)" if args.freeze else "all",
-                       "loss": round(loss_val, 6), "rccl_ranks": world,
+                       "loss": round(loss_val, 6), "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                       "rank_losses": rank_losses,
                        "dead_occlusion_decoders_elided": bool(args.elide_occ)},
+            "step_ms": step_ms, "comm": comm,
             "roofline": roof, "kernels": kernels,
         }
         if want_cpu:

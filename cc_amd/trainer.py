@@ -227,8 +227,12 @@ class CCTrainer:
         # gradient segments of the flat bucket: [DispResNet6 | PoseNetB6] [MaskNet6 | Back2Future] (parameter order of
         # FlatAdam = train.py:305's chain)
         self.n_dp = sum(p.numel() for n in nets[:2] if n is not None for p in n.parameters() if p.requires_grad)
-        self.split_graphs = self.opt.comm_active() if split_graphs is None else bool(split_graphs)
-        self.comm_ms = None
+        # two stages / two graphs only when both gradient segments exist (with MaskNet6 + Back2Future frozen -- README's
+        # --fix-masknet --fix-flownet -- stage B is empty: one graph, one all-reduce)
+        two_segments = 0 < self.n_dp < self.opt.n
+        self.split_graphs = (self.opt.comm_active() and two_segments) if split_graphs is None else bool(split_graphs)
+        self.comm_events = []            # per step: (before wait 0, after wait 0, before wait 1, after wait 1) on the compute stream
+        self.comm_standalone_ms = None   # calibrate_comm(): each segment's all-reduce alone, nothing to hide under
         self.static_batch = None
         self.losses = None
         self.nan_flags = []
@@ -365,6 +369,52 @@ class CCTrainer:
         utils.save_checkpoint(save_path, sd[0], sd[1], sd[2], sd[3], {"epoch": epoch + 1, "state_dict": self.opt.state_dict()},
                               is_best)
 
+    def segments(self):
+        """[(lo, hi)] of the flat gradient bucket as exchanged: [DispResNet6 | PoseNetB6] [MaskNet6 | Back2Future]"""
+        n = self.opt.flat_g.numel()
+        return [(0, self.n_dp), (self.n_dp, n)] if 0 < self.n_dp < self.opt.n else [(0, n)]
+
+    def calibrate_comm(self, reps=3):
+        """Each gradient segment's all-reduce ALONE on an idle device (median of `reps`, host-synchronised): the yardstick
+        the exposed times of comm_stats() are read against.  Outside any timed region; needs an initialised process group."""
+        if not self.opt.comm_active():
+            return None
+        out = []
+        for lo, hi in self.segments():
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                w = dist.all_reduce(self.opt.flat_g[lo:hi], async_op=True)
+                w.wait()
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            out.append(sorted(ts)[len(ts) // 2])
+        self.comm_standalone_ms = out
+        return out
+
+    def comm_stats(self):
+        """Exposed communication of the recent steps (call after a device synchronise): median stream time the compute stream
+        spent waiting for each segment's all-reduce; `overlapped` = the standalone duration (calibrate_comm) minus that."""
+        if not self.comm_events:
+            return None
+        segs = self.segments()
+        per = []
+        for ev in self.comm_events:
+            per.append([ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(len(ev) // 2)])
+        med = [sorted(col)[len(col) // 2] for col in zip(*per)]
+        r = {"segments_mb": [round(4e-6 * (hi - lo), 1) for lo, hi in segs], "exposed_ms": [round(v, 3) for v in med],
+             "exposed_ms_total": round(sum(med), 3), "steps_sampled": len(per),
+             "design": "two all-reduces per step (the [DispResNet6|PoseNetB6] segment is issued after backward stage A and runs "
+                       "under stage B; the [MaskNet6|Back2Future] segment after stage B) in place of north_star's single "
+                       "all-reduce; one all-reduce when only one segment is trainable"}
+        if self.comm_standalone_ms and len(self.comm_standalone_ms) == len(med):
+            r["standalone_ms"] = [round(v, 3) for v in self.comm_standalone_ms]
+            r["overlapped_ms"] = round(sum(max(0.0, a - b) for a, b in zip(self.comm_standalone_ms, med)), 3)
+        return r
+
     def step(self, batch):
         """train.py:445-568 for one mini-batch: returns the (device) loss tensors of this step."""
         opt = self.opt
@@ -389,15 +439,32 @@ class CCTrainer:
                 works.append(opt.all_reduce(0, self.n_dp, async_op=True))
             works.append(opt.all_reduce(self.n_dp, None, async_op=True))      # mask + flow segment (70 MB): exposed
             cut = self.n_dp // 4 * 4            # float4 update: cut at a 16-byte boundary (the <= 3 elements left go second)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if losses["loss"].is_cuda else None
             if 0 < cut < opt.n and len(works) == 2 and all(w is not None for w in works):
-                # the big segment's update runs while the small segment is still being exchanged
+                # the big segment's update runs while the small segment is still being exchanged.  work.wait() makes the
+                # compute stream wait for the collective: the stream time between the events around it is the EXPOSED part
+                # of that collective (what backward stage B / the first Adam segment did not hide)
+                if ev:
+                    ev[0].record()
                 works[0].wait()
+                if ev:
+                    ev[1].record()
                 opt.step_segment(0, cut, True, opt.grad_scale())
+                if ev:
+                    ev[2].record()
                 works[1].wait()
+                if ev:
+                    ev[3].record()
+                    self.comm_events = (self.comm_events + [ev])[-64:]
                 opt.step_segment(cut, None, False, opt.grad_scale())
                 return losses
+            if ev:
+                ev[0].record()
             for w in works:
                 if w is not None:
                     w.wait()
+            if ev:
+                ev[1].record()
+                self.comm_events = (self.comm_events + [ev[:2]])[-64:]
         opt.step(opt.grad_scale())                                          # :568
         return losses

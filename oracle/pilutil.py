@@ -79,3 +79,69 @@ def imresize(arr, size, interp='bilinear'):
     img = _pass(img, w, 1)         # ImagingResample: horizontal pass first
     img = _pass(img, h, 0)
     return img[:, :, 0] if two_d else img
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# scipy.misc.imrotate (custom_transforms.py:5,84: RandomRotate, composed first in train.py:178-184's pipeline)
+#   * SciPy 1.1 pilutil.imrotate = toimage(arr) (byte-scale as above) -> Image.rotate(angle, resample=BILINEAR) -> array;
+#   * Pillow Image.rotate (expand=False, centre = (w/2, h/2)): the inverse affine map
+#         [ cos(-a)  sin(-a) | cx - (cos(-a)*cx + sin(-a)*cy) ]      cos / sin rounded to 15 decimals
+#         [-sin(-a)  cos(-a) | cy - (-sin(-a)*cx + cos(-a)*cy) ]
+#   * Pillow src/libImaging/Geometry.c ImagingGenericTransform + affine_transform + bilinear_filter32RGB, all in double:
+#     source position of output pixel (x, y) = M . (x + 0.5, y + 0.5); outside [0, w) x [0, h) -> 0 (black); else shift by
+#     -0.5, floor, blend the 2x2 neighbourhood (indices clamped to the image, the lower row replaced by the upper one beyond the
+#     last row) as v = a + (b - a) * d horizontally then vertically, truncate to uint8.
+# Pinned bit for bit against Pillow itself by tests/test_transforms.py::test_oracle_imrotate_is_pillow_bilinear.
+def rotate_matrix(w, h, angle):
+    """the six coefficients Image.rotate hands to the affine transform (Python floats = C doubles)"""
+    import math
+    angle = angle % 360.0
+    a = -math.radians(angle)
+    m = [round(math.cos(a), 15), round(math.sin(a), 15), 0.0, round(-math.sin(a), 15), round(math.cos(a), 15), 0.0]
+    cx, cy = w / 2, h / 2
+    m[2] = m[0] * -cx + m[1] * -cy + m[2]
+    m[5] = m[3] * -cx + m[4] * -cy + m[5]
+    m[2] += cx
+    m[5] += cy
+    return m
+
+
+def affine_bilinear(img, m):
+    """Pillow's affine transform with the bilinear filter on a uint8 [H,W,C] (or [H,W]) image, output size = input size"""
+    two_d = img.ndim == 2
+    if two_d:
+        img = img[:, :, None]
+    H, W, C = img.shape
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float64) + 0.5, np.arange(W, dtype=np.float64) + 0.5, indexing="ij")
+    xin = m[0] * xs + m[1] * ys + m[2]
+    yin = m[3] * xs + m[4] * ys + m[5]
+    inside = ~((xin < 0.0) | (xin >= W) | (yin < 0.0) | (yin >= H))
+    xin = xin - 0.5
+    yin = yin - 0.5
+    x = np.floor(xin).astype(np.int64)          # FLOOR(v): floor for negatives, truncation otherwise = floor
+    y = np.floor(yin).astype(np.int64)
+    dx = (xin - x)[:, :, None]
+    dy = (yin - y)[:, :, None]
+    x0, x1 = np.clip(x, 0, W - 1), np.clip(x + 1, 0, W - 1)
+    yc = np.clip(y, 0, H - 1)
+    src = img.astype(np.float64)
+    a, b = src[yc, x0], src[yc, x1]
+    v1 = a + (b - a) * dx
+    y1ok = ((y + 1 >= 0) & (y + 1 < H))[:, :, None]
+    y1 = np.clip(y + 1, 0, H - 1)
+    a2, b2 = src[y1, x0], src[y1, x1]
+    v2 = np.where(y1ok, a2 + (b2 - a2) * dx, v1)
+    v = v1 + (v2 - v1) * dy
+    out = np.where(inside[:, :, None], v, 0.0).astype(np.uint8)          # (UINT8) v: truncation
+    return out[:, :, 0] if two_d else out
+
+
+def imrotate(arr, angle, interp='bilinear'):
+    """scipy.misc.imrotate(arr, angle) for HxW or HxWx3 arrays, bilinear only (what custom_transforms.py uses)."""
+    assert interp == 'bilinear'
+    img = bytescale(arr)
+    a = angle % 360.0
+    if a == 0:
+        return img.copy()
+    assert a not in (90.0, 180.0, 270.0), "quarter turns take Pillow's transpose fast paths (RandomRotate draws from (0, 10))"
+    return affine_bilinear(img, rotate_matrix(img.shape[1], img.shape[0], angle))

@@ -74,9 +74,12 @@ def _quat(dev, golden_dir, tag, ac):
         out = IW.inverse_warp(refs[0].to(dev), d, p, K.to(dev), Kinv.to(dev), "quat")
         ref = torch.from_numpy(g["inverse_warp_quat"])
         diff = (out.detach().cpu() - ref).abs()
-        # same bar as the euler warp tests: a tap may flip where a coordinate sits within an ulp of an integer
-        frac = float((diff > 1e-5).float().mean())
-        assert frac <= 2e-3, frac
+        # the quaternion -> matrix algebra runs as stock torch on the device (inverse_warp.py:122-143 is off the training path):
+        # P differs from the host's in the last ulp, i.e. ~1e-4 px at coordinates of a few hundred pixels -> the same absolute
+        # bar as tests/test_kernels_gpu.py::test_warps_full_size; beyond it only tap flips (coordinate within an ulp of an integer)
+        atol = 1e-5 if dev == "cpu" else 3e-4
+        frac = float((diff > atol).float().mean())
+        assert frac <= 2e-3, (frac, float(diff.max()))
         out.sum().backward()                     # the fused backward accepts the quaternion pose path
         assert torch.isfinite(d.grad).all() and torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0
     finally:
