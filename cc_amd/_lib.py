@@ -76,7 +76,7 @@ class Engine:
         if self.require_device and not t.is_cuda:
             raise RuntimeError("%s arg %d: tensor is on %s; the ccengine kernels need a HIP device (no CPU path)"
                                % (name, i, t.device))
-        if t.dtype not in (torch.float32, torch.int32, torch.uint8, torch.int64):
+        if t.dtype not in (torch.float32, torch.int32, torch.uint8, torch.int64, torch.float64):
             raise TypeError("%s arg %d: unsupported dtype %s" % (name, i, t.dtype))
         if not t.is_contiguous() and not image_dense(t):
             raise ValueError("%s arg %d: tensor must be contiguous (or a per-image dense NCHW channel slice whose batch stride "

@@ -156,6 +156,68 @@ __global__ __launch_bounds__(256) void k_frames_resize_v(const unsigned char* __
     for (int c = 0; c < 3; c++) d[(size_t)c * h * w] = ((float)clip8(acc[c] >> PREC) / 255.0f - mean[c]) / stdv[c];
 }
 
+// ---- RandomRotate on the device (custom_transforms.py:75-86, composed first in train.py:178-184): scipy.misc.imrotate =
+// byte-scale of the float frame to its own min..max, then Pillow's Image.rotate(angle, BILINEAR, expand=False) =
+// ImagingGenericTransform + affine_transform + bilinear_filter32RGB (Geometry.c), all in double: the source position of output
+// pixel (x, y) is M . (x + 0.5, y + 0.5) (M: six doubles built on the host exactly as Image.rotate builds them); outside
+// [0, W) x [0, H) -> 0; else shift by -0.5, floor, blend the clamped 2x2 neighbourhood as a + (b - a) * d (the lower row
+// replaced by the upper one beyond the last row), truncate to uint8.  rot per frame: (apply, a0 .. a5, -) doubles; apply == 0:
+// the frame is only byte-scaled (what the resize that follows would do first).  Output: uint8 [N,H,W,3].
+template <typename T>
+__global__ __launch_bounds__(256) void k_frames_rotate(const T* __restrict__ src, const float* __restrict__ minmax,
+                                                       unsigned char* __restrict__ dst, const double* __restrict__ rot, int H, int W) {
+    const int n = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= H * W) return;
+    const int y = p / W, x = p - y * W;
+    float cmin = 0.f, scale = 1.f;
+    if constexpr (sizeof(T) == 4) {
+        cmin = minmax[2 * n];
+        float cs = minmax[2 * n + 1] - cmin;
+        if (cs == 0.f) cs = 1.f;
+        scale = 255.0f / cs;
+    }
+    const T* img = src + (size_t)n * H * W * 3;
+    unsigned char* d = dst + ((size_t)n * H * W + p) * 3;
+    auto tap = [&](int yy, int xx, int c) -> double {
+        const T v = img[((size_t)yy * W + xx) * 3 + c];
+        if constexpr (sizeof(T) == 4) return (double)bytescale((float)v, cmin, scale);
+        else return (double)v;
+    };
+    const double* r = rot + 8 * n;
+    if (r[0] == 0.0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) d[c] = (unsigned char)(int)tap(y, x, c);
+        return;
+    }
+    const double xs = (double)x + 0.5, ys = (double)y + 0.5;
+    double xin = r[1] * xs + r[2] * ys + r[3];
+    double yin = r[4] * xs + r[5] * ys + r[6];
+    if (xin < 0.0 || xin >= (double)W || yin < 0.0 || yin >= (double)H) {
+        d[0] = d[1] = d[2] = 0;
+        return;
+    }
+    xin -= 0.5;
+    yin -= 0.5;
+    const int xi = (int)floor(xin), yi = (int)floor(yin);
+    const double dx = xin - (double)xi, dy = yin - (double)yi;
+    const int x0 = xi < 0 ? 0 : (xi < W ? xi : W - 1);
+    const int x1 = xi + 1 < 0 ? 0 : (xi + 1 < W ? xi + 1 : W - 1);
+    const int y0 = yi < 0 ? 0 : (yi < H ? yi : H - 1);
+    const bool low = (yi + 1 >= 0) && (yi + 1 < H);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double a = tap(y0, x0, c), b = tap(y0, x1, c);
+        double v1 = a + (b - a) * dx, v2 = v1;
+        if (low) {
+            const double a2 = tap(yi + 1, x0, c), b2 = tap(yi + 1, x1, c);
+            v2 = a2 + (b2 - a2) * dx;
+        }
+        v1 = v1 + (v2 - v1) * dy;
+        d[c] = (unsigned char)(int)v1;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -204,6 +266,30 @@ int cc_frames_resize_to_tensor(const void* src, int src_is_u8, float* dst, const
     }
     hipLaunchKernelGGL(k_frames_resize_v, dim3((unsigned)((h * w + 255) / 256), (unsigned)N), dim3(256), 0, s,
                        (const unsigned char*)tmp, dst, geo, tab, H, tmp_w, KT, h, w, mean0, mean1, mean2, std0, std1, std2);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+size_t cc_frames_rotate_ws_bytes(int N) { return (size_t)N * (MMB * 2 + 2) * sizeof(float); }
+
+/* RandomRotate (custom_transforms.py:75-86) for N frames: dst_u8 [N,H,W,3] = Pillow-exact bilinear rotation of the byte-scaled
+ * frames.  rot: double [N,8] = (apply, a0..a5, 0) per frame, a* = the affine coefficients Image.rotate computes (host side:
+ * cc_amd/custom_transforms.py rotate_matrix); apply == 0: byte-scale only.  ws: cc_frames_rotate_ws_bytes(N). */
+int cc_frames_rotate(const void* src, int src_is_u8, void* dst_u8, const double* rot, void* ws, int N, int H, int W, void* stream) {
+    if (!src || !dst_u8 || !rot || !ws || N <= 0 || H <= 0 || W <= 0) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    float* mmws = (float*)ws;
+    float* minmax = mmws + (size_t)N * MMB * 2;
+    dim3 g((unsigned)((H * W + 255) / 256), (unsigned)N);
+    if (!src_is_u8) {
+        hipLaunchKernelGGL(k_frames_minmax_partial, dim3(MMB, (unsigned)N), dim3(256), 0, s, (const float*)src, mmws, (long)H * W * 3);
+        hipLaunchKernelGGL(k_frames_minmax_final, dim3((unsigned)N), dim3(MMB), 0, s, (const float*)mmws, minmax);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frames_rotate<float>), g, dim3(256), 0, s, (const float*)src, (const float*)minmax,
+                           (unsigned char*)dst_u8, rot, H, W);
+    } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frames_rotate<unsigned char>), g, dim3(256), 0, s, (const unsigned char*)src,
+                           (const float*)minmax, (unsigned char*)dst_u8, rot, H, W);
+    }
     CC_CHECK_LAUNCH();
     return CC_OK;
 }

@@ -3,9 +3,11 @@
 Host side: the transform classes train.py:166-190 composes, same names, arguments, random-number draws (so the same seeds
 give the same augmentations) and intrinsics updates.  ``scipy.misc.imresize`` / ``imrotate`` -- removed from SciPy in 1.3
 and absent here -- are restated from SciPy 1.1's ``scipy/misc/pilutil.py`` (``toimage`` byte-scales float arrays to their
-own min..max before PIL's resize; bilinear resampling).  `imresize` is pinned by tests/test_transforms.py against Pillow and
-against an independent numpy restatement of Pillow's 8-bit resampler (oracle/pilutil.py, which also serves the reference's
-import when the fixture is generated); `imrotate` (RandomRotate, not in train.py:166-177's pipeline) stays **parity unpinned**.
+own min..max before PIL's resize / rotate; bilinear resampling).  Both are pinned by tests/test_transforms.py against Pillow
+and against independent numpy restatements of Pillow's 8-bit resampler and of its affine-bilinear transform (oracle/pilutil.py,
+which also serves the reference's imports when the fixture is generated).  `RandomRotate` is the FIRST transform of the
+pipeline train.py:178-184 composes when the flow network is trained (the all-trainable configuration the metric is quoted on);
+train.py:171-176 (--fix-flownet) leaves it out.
 
 Device side: ``DeviceFrames`` fuses ArrayToTensor + Normalize (+ the mirror of RandomHorizontalFlip and the crop of
 RandomScaleCrop) for a whole batch of frames into one HIP launch (``cc_frames_to_tensor``) -- HWC uint8 / float32 frames go
@@ -18,7 +20,7 @@ import torch
 from ._lib import engine, STREAM
 
 
-# ----------------------------------------------------------------------------- scipy.misc restatements (parity unpinned)
+# ----------------------------------------------------------------------------- scipy.misc restatements (pinned: tests/test_transforms.py)
 def _bytescale(data, cmin=None, cmax=None, high=255, low=0):
     """scipy 1.1 misc/pilutil.py bytescale."""
     if data.dtype == np.uint8:
@@ -63,6 +65,20 @@ def imrotate(arr, angle, interp='bilinear'):
     from PIL import Image
     func = {'nearest': Image.NEAREST, 'bilinear': Image.BILINEAR, 'bicubic': Image.BICUBIC}
     return np.array(_toimage(arr).rotate(angle, resample=func[interp]))
+
+
+def rotate_matrix(w, h, angle):
+    """The six affine coefficients PIL.Image.rotate(angle, expand=False) hands to its transform (inverse map, centre (w/2, h/2),
+    cos / sin rounded to 15 decimals) -- the arithmetic of Pillow's Image.py, in Python floats = C doubles."""
+    import math
+    a = -math.radians(angle % 360.0)
+    m = [round(math.cos(a), 15), round(math.sin(a), 15), 0.0, round(-math.sin(a), 15), round(math.cos(a), 15), 0.0]
+    cx, cy = w / 2, h / 2
+    m[2] = m[0] * -cx + m[1] * -cy + m[2]
+    m[5] = m[3] * -cx + m[4] * -cy + m[5]
+    m[2] += cx
+    m[5] += cy
+    return m
 
 
 # ----------------------------------------------------------------------------- host transforms (custom_transforms.py)
@@ -121,11 +137,20 @@ class RandomHorizontalFlip(object):
 
 
 class RandomRotate(object):
-    def __call__(self, images, intrinsics):
+    """custom_transforms.py:75-86: with probability 1/2 rotate every frame of the sample by one angle from U(0, 10) degrees."""
+
+    @staticmethod
+    def draw():
+        """the random decisions of __call__ in its order -> angle in degrees, or None (no rotation)"""
         if np.random.random() > 0.5:
+            return None
+        return np.random.uniform(0, 10)
+
+    def __call__(self, images, intrinsics):
+        rot = self.draw()
+        if rot is None:
             return images, intrinsics
         assert intrinsics is not None
-        rot = np.random.uniform(0, 10)
         return [imrotate(im, rot) for im in images], intrinsics
 
 
@@ -201,6 +226,25 @@ class DeviceFrames(object):
                       self.mean[1], self.mean[2], self.std[0], self.std[1], self.std[2], STREAM)
         return dst
 
+    # ---- RandomRotate on the device
+    def rotate(self, frames, angles):
+        """scipy.misc.imrotate of every frame (angles[n] in degrees, None = not rotated: byte-scaled only, which is what the
+        resize that follows does first) -> uint8 [N,H,W,3] on the device, bit-exact with the host classes."""
+        src = self._to_device(frames)
+        N, H, W, _ = src.shape
+        assert len(angles) == N
+        rot = np.zeros((N, 8), dtype=np.float64)
+        for n, a in enumerate(angles):
+            if a is not None and (a % 360.0) != 0:
+                assert (a % 360.0) not in (90.0, 180.0, 270.0), "quarter turns: Pillow transposes instead of resampling"
+                rot[n, 0] = 1.0
+                rot[n, 1:7] = rotate_matrix(W, H, a)
+        E = engine()
+        ws = torch.empty(int(E.call("cc_frames_rotate_ws_bytes", N)), dtype=torch.uint8, device=self.device)
+        dst = torch.empty(N, H, W, 3, dtype=torch.uint8, device=self.device)
+        E.call("cc_frames_rotate", src, int(src.dtype == torch.uint8), dst, torch.from_numpy(rot).to(self.device), ws, N, H, W, STREAM)
+        return dst
+
     # ---- RandomScaleCrop's resize on the device
     def resize_crop(self, frames, scaled_hw, out_hw, flips=None, offsets=None):
         """RandomHorizontalFlip -> imresize to scaled_hw -> crop out_hw at offsets -> ArrayToTensor -> Normalize, all on the
@@ -270,23 +314,26 @@ def resample_table(in_size, out_size):
 
 
 class DeviceTrainTransform(object):
-    """train.py:166-177 `Compose([RandomHorizontalFlip(), RandomScaleCrop(), ArrayToTensor(), Normalize(mean, std)])` for a whole
-    batch of samples: the random draws and the intrinsics arithmetic happen on the host in the reference's order (Python
+    """train.py:171-176 `Compose([RandomHorizontalFlip(), RandomScaleCrop(), ArrayToTensor(), Normalize(mean, std)])`, or with
+    rotate=True train.py:178-184's pipeline (RandomRotate first: `cc_frames_rotate`), for a whole batch of samples: the random draws and the intrinsics arithmetic happen on the host in the reference's order (Python
     `random` for the flip, then `np.random` uniform(1, 1.1, 2) and the two randint of RandomScaleCrop -- the same seeds give
     the same augmentations), the pixels never leave the device (`DeviceFrames.resize_crop`).
     samples: list of (frames, intrinsics) with frames = list of [H,W,3] arrays, all samples of one size.
     -> (fp32 [B, n_frames, 3, h, w] on the device, list of updated intrinsics)."""
 
-    def __init__(self, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), device="cuda", h=0, w=0):
+    def __init__(self, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), device="cuda", h=0, w=0, rotate=False):
         self.frames = DeviceFrames(mean, std, device)
         self.crop = RandomScaleCrop(h, w)
+        self.rotate = rotate          # True: train.py:178-184 (RandomRotate first: the pipeline when the flow network is trained)
 
     def __call__(self, samples):
-        flat, flips, offsets, sizes, Ks = [], [], [], [], []
+        flat, flips, offsets, sizes, Ks, angles = [], [], [], [], [], []
         out_hw = None
         for frames, K in samples:
             in_h, in_w, _ = frames[0].shape
             K = np.copy(K)
+            rot = RandomRotate.draw() if self.rotate else None                        # RandomRotate, :78-82 (intrinsics unchanged)
+            angles += [rot] * len(frames)
             flip = random.random() < 0.5                                              # RandomHorizontalFlip, :62
             if flip:
                 K[0, 2] = in_w - K[0, 2]
@@ -303,6 +350,8 @@ class DeviceTrainTransform(object):
                 offsets.append((oy, ox))
                 sizes.append((sh, sw))
             Ks.append(K)
+        if self.rotate:
+            flat = self.frames.rotate(flat, angles)           # uint8 frames on the device; flip / resize / crop follow there
         out = self.frames.resize_crop(flat, sizes, out_hw, flips, offsets)
         nf = len(samples[0][0])
         return out.view(len(samples), nf, 3, out_hw[0], out_hw[1]), Ks

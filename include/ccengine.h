@@ -313,6 +313,12 @@ size_t cc_frames_resize_ws_bytes(int N, int H, int tmp_w);
 int cc_frames_resize_to_tensor(const void* src, int src_is_u8, float* dst, const int* geo, const int* tab, int KT, void* ws, int N,
                                int H, int W, int tmp_w, int max_sw, int h, int w, float mean0, float mean1, float mean2, float std0,
                                float std1, float std2, void* stream);
+/* RandomRotate (custom_transforms.py:75-86; first transform of train.py:178-184's pipeline) on the device: scipy.misc.imrotate =
+ * byte-scale + Pillow Image.rotate(angle, BILINEAR) restated in double (Geometry.c affine transform + bilinear_filter32RGB),
+ * bit-exact with the host path.  dst_u8: uint8 [N,H,W,3]; rot: double [N,8] = (apply, a0..a5, 0), the coefficients Image.rotate
+ * builds (apply == 0: byte-scale only, the first thing the resize that follows would do).  ws: cc_frames_rotate_ws_bytes(N). */
+size_t cc_frames_rotate_ws_bytes(int N);
+int cc_frames_rotate(const void* src, int src_is_u8, void* dst_u8, const double* rot, void* ws, int N, int H, int W, void* stream);
 
 /* ---------------------------------------------------------------- BatchNorm2d, training mode
  * (models/DispResNet6.py:53-56: the Conv1x1 + BatchNorm2d shortcut of every ResNet stage; 13 per forward)

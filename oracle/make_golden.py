@@ -259,16 +259,15 @@ def transform_inputs(seed=31, n=3, H=40, W=56):
 def load_reference_transforms():
     """The unmodified custom_transforms.py.  Its `from scipy.misc import imresize, imrotate` (gone from SciPy 1.3) is served by
     oracle/pilutil.py -- a numpy restatement of SciPy 1.1's imresize over Pillow's 8-bit resampler, pinned to Pillow itself and
-    independent of cc_amd; everything else in the fixture is the reference's own arithmetic.  imrotate (RandomRotate, not in
-    the training pipeline of train.py:166-177) is not exercised by the fixture."""
+    independent of cc_amd; everything else in the fixture is the reference's own arithmetic.  `imrotate` (RandomRotate, the first
+    transform of train.py:178-184's pipeline) is served the same way: oracle/pilutil.imrotate restates SciPy 1.1's imrotate over
+    Pillow's affine-bilinear transform and is pinned bit for bit against Pillow (tests/test_transforms.py)."""
     import importlib.util
     import types
     from oracle import pilutil
 
-    def _no_rotate(*a, **k):
-        raise NotImplementedError("imrotate is not part of the fixture")
     shim = types.ModuleType("scipy.misc")
-    shim.imresize, shim.imrotate = pilutil.imresize, _no_rotate
+    shim.imresize, shim.imrotate = pilutil.imresize, pilutil.imrotate
     import scipy
     sys.modules["scipy.misc"] = shim
     scipy.misc = shim
@@ -290,9 +289,31 @@ def run_train_transform(ct, seed):
     return imgs, Kout
 
 
+def run_train_transform_rotate(ct, seed):
+    """train.py:178-184: the pipeline with RandomRotate first (the flow network is trained), seeded like run_train_transform."""
+    import random
+    frames, K = transform_inputs()
+    random.seed(seed)
+    np.random.seed(seed)
+    t = ct.Compose([ct.RandomRotate(), ct.RandomHorizontalFlip(), ct.RandomScaleCrop(), ct.ArrayToTensor(),
+                    ct.Normalize(mean=[0.5, 0.5, 0.5], std=[0.5, 0.5, 0.5])])
+    imgs, Kout = t([f.copy() for f in frames], np.copy(K))
+    return imgs, Kout
+
+
+ROT_SEEDS = (0, 1, 2, 3, 4, 5)
+
+
 def transforms_level():
     ct = load_reference_transforms()
     g = {}
+    for seed in ROT_SEEDS:
+        imgs, Kout = run_train_transform_rotate(ct, seed)
+        g["rot.seed%d.K" % seed] = np.asarray(Kout, dtype=np.float32)
+        for i, im in enumerate(imgs):
+            g["rot.seed%d.img%d" % (seed, i)] = npy(im)
+    frames, _ = transform_inputs()
+    g["rot.direct"] = np.asarray(ct.imrotate(frames[0], 7.25))                   # the reference module's own imported name
     for seed in (0, 1, 2, 3):
         imgs, Kout = run_train_transform(ct, seed)
         g["seed%d.K" % seed] = np.asarray(Kout, dtype=np.float32)
