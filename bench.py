@@ -182,6 +182,8 @@ class CallTimer:
             real = name
             if name == "cc_conv2d_wgrad_group_defer":      # same launch, its reduction parked (cc_wgrad_reduce_table)
                 name = "cc_conv2d_wgrad_group"
+            if name == "cc_conv2d_dgrad_group_add":        # same launch, further gradient contributions summed in its epilogue
+                name = "cc_conv2d_dgrad_group"
             if name in WORK:
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
@@ -464,13 +466,24 @@ def main():
         # so that the roofline line names a kernel of the rocprofv3 summary and quotes ITS duration (not the C-ABI call's,
         # which for split-K layers also contains the epilogue launch)
         import ctypes
-        eng.call("cc_timing_enable", 1)
-        tr_e.step(batch)
-        torch.cuda.synchronize()
-        buf = ctypes.create_string_buffer(1 << 16)
-        nchar = eng.fn["cc_timing_collect"](ctypes.addressof(buf), 1 << 16)
+        from cc_amd import build as _build
+        dev_lines = []
+        try:
+            tools_lib = _build.TOOLS_OUT if os.path.isfile(_build.TOOLS_OUT) else _build.build_tools()
+            # the timing registry lives in the TOOLS build of the library only (same sources, -DCC_TOOLS); the product library that
+            # ran the timed region above keeps no state
+            with _lib.use_library(tools_lib) as teng:
+                assert teng.fn["cc_is_tools_build"]() == 1
+                teng.call("cc_timing_enable", 1)
+                tr_e.step(batch)
+                torch.cuda.synchronize()
+                buf = ctypes.create_string_buffer(1 << 16)
+                nchar = teng.fn["cc_timing_collect"](ctypes.addressof(buf), 1 << 16)
+                dev_lines = buf.raw[:nchar].decode().splitlines()
+        except (RuntimeError, OSError, AssertionError) as e:
+            log("tools build unavailable (%r): no per-device-kernel timing" % (e,))
         dev_k = {}
-        for ln in buf.raw[:nchar].decode().splitlines():
+        for ln in dev_lines:
             nm, n_, ms_, gf_ = ln.split("\t")
             dev_k[nm] = {"launches": int(n_), "ms": float(ms_), "gflop": float(gf_)}
         if dev_k:

@@ -118,6 +118,25 @@ def engine():
     return _engine
 
 
+class use_library(object):
+    """Context manager: run the enclosed calls on another build of the library (the tools build with its switches and timing
+    registry -- cc_amd/build.py build_tools() -- for bench.py's instrumented step and the A/B scripts).  Not used by the product."""
+
+    def __init__(self, path):
+        self.e = Engine(path)
+
+    def __enter__(self):
+        global _engine
+        self.prev = _engine
+        _engine = self.e
+        return self.e
+
+    def __exit__(self, *a):
+        global _engine
+        _engine = self.prev
+        return False
+
+
 def _set_engine_for_tests(e):
     """Test hook (tests/hipemu): inject an Engine bound to the x86 emulation build of the SAME kernel
     sources.  Never called by the package itself."""

@@ -42,8 +42,24 @@ def source_hash():
     return int(h.hexdigest()[:8], 16)
 
 
-def build(verbose=False, force=False):
+TOOLS_OUT = os.path.join(os.path.dirname(HERE), "tools", "_bin", "libccengine_tools.so")
+
+
+def build_tools(verbose=False, force=False):
+    """The same sources with -DCC_TOOLS: kernel-selection switches (environment variables) and the per-kernel timing registry
+    compiled in -> tools/_bin/libccengine_tools.so.  Loaded by bench.py for its instrumented eager step and by the A/B scripts
+    under tools/ (CC_LIB_PATH); never by the product path."""
+    return build(verbose, force, out=TOOLS_OUT, obj=os.path.join(CSRC, "_obj_tools"), extra=["-DCC_TOOLS"])
+
+
+def build(verbose=False, force=False, out=None, obj=None, extra=()):
+    OUT_, OBJ_ = out or OUT, obj or OBJ
+    return _build(verbose, force, OUT_, OBJ_, list(extra))
+
+
+def _build(verbose, force, OUT, OBJ, extra):
     os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
     headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h"))
     jobs = []
     objs = []
@@ -55,7 +71,7 @@ def build(verbose=False, force=False):
         objs.append(obj)
         is_ver = os.path.basename(src) == "version.hip"
         if force or _stale(obj, [src] + headers) or (is_ver and hash_changed):
-            jobs.append([HIPCC] + FLAGS + (["-DCC_SRC_HASH=%du" % sh] if is_ver else []) + ["-c", src, "-o", obj])
+            jobs.append([HIPCC] + FLAGS + extra + (["-DCC_SRC_HASH=%du" % sh] if is_ver else []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -76,3 +92,5 @@ def build(verbose=False, force=False):
 
 if __name__ == "__main__":
     print(build(verbose=True, force="--force" in sys.argv))
+    if "--tools" in sys.argv:
+        print(build_tools(verbose=True, force="--force" in sys.argv))

@@ -25,6 +25,7 @@
 #include <string.h>
 #include "cc_common.h"
 #include "conv_internal.h"
+#include "cc_tools.h"
 #include "../../include/ccengine.h"
 #include <vector>
 #include <string>
@@ -34,6 +35,7 @@
 // process; autograd runs the backward pass on its own threads): the MAIN device kernel of every conv / weight-gradient call is bracketed with HIP events on its own stream, so the
 // reported duration is the kernel's (what rocprofv3 --kernel-trace shows), not the C-ABI call's.
 namespace cctiming {
+#ifdef CC_TOOLS
 struct Rec { std::string name; double gflop; hipEvent_t e0, e1; };
 static std::vector<Rec>* recs = nullptr;
 static std::mutex mtx;
@@ -54,6 +56,9 @@ struct Scope {
     }
     ~Scope() { if (e1) (void)hipEventRecord(e1, s); }
 };
+#else
+struct Scope { Scope(const char*, double, hipStream_t) {} };      // product build: no registry, no events
+#endif
 }  // namespace cctiming
 
 namespace {
@@ -64,7 +69,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // BM = 16 (layers with <= 16 output channels: the full-resolution ends of the nets, prediction heads, their data-gradients):
 // v_mfma_f32_16x16x4_f32 tiles, so that no MFMA row is spent on channels that do not exist (a 32-row tile wastes half)
 inline int pick_bm_fwd(int M) {
-    static const int no16 = []() { const char* v = getenv("CC_CONV_NO_BM16"); return (v && v[0] == '1') ? 1 : 0; }();
+    static const int no16 = cctools::env_flag("CC_CONV_NO_BM16");
     return M > 64 ? 128 : (M > 32 ? 64 : ((M > 16 || no16) ? 32 : 16));
 }
 
@@ -748,10 +753,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_multi(EPM a) {
                                           c.add ? c.add[(long)n * c.add_bs + o] : 0.f);
 }
 
-static int dbg_flag_early(const char* name) {
-    const char* v = getenv(name);
-    return (v && v[0] == '1') ? 1 : 0;
-}
+static int dbg_flag_early(const char* name) { return cctools::env_flag(name); }
 
 struct ConvPlan {
     bool use_patch;
@@ -760,10 +762,7 @@ struct ConvPlan {
     size_t smem, wp_floats, part_floats;
 };
 
-static int env_int_early(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
+static int env_int_early(const char* name, int dflt) { return cctools::env_int(name, dflt); }
 
 // mult: number of same-shaped problems that share the launch (split-K only has to fill what they leave empty)
 inline ConvPlan plan_conv(const GG& g, int mult = 1) {
@@ -1330,10 +1329,7 @@ inline void launch_wgrad_patch(const WP& w, dim3 grid, size_t smem, hipStream_t 
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad_patch<BMW, NT>), grid, dim3(WG_THREADS), smem, s, w);
 }
 
-static int dbg_flag(const char* name) {
-    const char* v = getenv(name);
-    return (v && v[0] == '1') ? 1 : 0;
-}
+static int dbg_flag(const char* name) { return cctools::env_flag(name); }
 
 inline WPlan plan_wgrad(int B, int M, int AH, int AW, int Cin, int R, int S, int si) {
     WPlan p = {};
@@ -2082,10 +2078,7 @@ int cc_conv2d_list(int n, const long* desc_host, float* ws, int split_target, vo
 
 struct W3Plan { bool ok; int mt, nbuf, tiles_x, tiles_y, ntiles, nsplit, tps, Cp32; size_t smem, ws_floats; };
 
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
+static int env_int(const char* name, int dflt) { return cctools::env_int(name, dflt); }
 
 inline W3Plan plan_w3(int B, int M, int AH, int AW, int Cin, int R, int S, int si, int pad, int IH, int IW, int G = 1) {
     W3Plan p = {};
@@ -2204,7 +2197,7 @@ static int wgrad_group_impl(int G, const long* a, const long* x, const long* gw,
             w.R = R; w.S = S; w.si = si; w.pad = pad; w.PH = p.PH; w.PWr = p.PWr; w.PSc = p.PSc; w.npos = p.npos;
             w.tiles_x = p.tiles_x; w.tiles_y = p.tiles_y; w.ntiles = p.ntiles; w.tiles_per_split = p.tps; w.nsplit = p.nsplit;
             w.TG = p.TG; w.ngroups = p.ngroups; w.Cp32 = p.Cp32; w.nbuf = p.nbuf;
-            { const char* v = getenv("CC_WGRAD_DBG"); w.dbg = v ? atoi(v) : 0; }
+            w.dbg = cctools::env_int("CC_WGRAD_DBG", 0);
             hipLaunchKernelGGL(k_zero64, dim3(1), dim3(64), 0, s, wsk);      // the LDS-DMA halo source (a kernel, not a memset node)
             dim3 grid((unsigned)(((M + p.bmw - 1) / p.bmw) * (p.Cp32 / 32) * p.ngroups), 1, (unsigned)p.nsplit);
             if (p.bmw == 64) {
@@ -2301,6 +2294,7 @@ int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B,
 /* ---- per-kernel timing (measurement aid): cc_timing_enable(1) starts recording (process-wide), cc_timing_collect
  * waits for the recorded kernels and writes one line per device kernel "name\tlaunches\ttotal_ms\ttotal_gflop\n" into the
  * HOST buffer (returns the number of characters, stops recording). */
+#ifdef CC_TOOLS
 int cc_timing_enable(int on) {
     std::lock_guard<std::mutex> lk(cctiming::mtx);
     if (on && !cctiming::recs) cctiming::recs = new std::vector<cctiming::Rec>();
@@ -2335,6 +2329,20 @@ int cc_timing_collect(void* out_host, int cap) {
     }
     cc_timing_enable(0);       // (takes the lock itself)
     return len;
+}
+#else
+/* product build: no timing registry (the library keeps no state); the tools build records */
+int cc_timing_enable(int on) { return on ? CC_ERR_ARG : CC_OK; }
+int cc_timing_collect(void* out_host, int cap) { (void)out_host; (void)cap; return 0; }
+#endif
+
+/* 1 for the tools build (switches + timing compiled in), 0 for the product library */
+int cc_is_tools_build(void) {
+#ifdef CC_TOOLS
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 /* ---- introspection (bench.py groups its per-call timings by the kernel a call dispatches to) */

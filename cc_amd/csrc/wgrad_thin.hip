@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include "cc_common.h"
 #include "conv_internal.h"
+#include "cc_tools.h"
 
 namespace {
 
@@ -197,10 +198,7 @@ __global__ __launch_bounds__(64 * THIN_NW) void k_wgrad_thin(WT g) {
 }
 
 
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
+int env_int(const char* name, int dflt) { return cctools::env_int(name, dflt); }
 
 struct ThinPlan {
     bool ok;

@@ -274,9 +274,14 @@ int cc_act_bwd_bias_group(int G, const long* gy, const long* y, const long* geff
  * ws: cc_conv2d_list_ws_bytes() bytes.  split_target: workgroups a launch should at least have (0 -> 512). */
 size_t cc_conv2d_list_ws_bytes(int n, const long* desc_host, int split_target);
 int cc_conv2d_list(int n, const long* desc_host, float* ws, int split_target, void* stream);
-/* per-kernel timing (measurement aid, process-wide; the only state the library keeps): between cc_timing_enable(1) and cc_timing_collect the MAIN device
- * kernel of every conv / weight-gradient call is bracketed with HIP events on its stream; collect returns (HOST buffer) one line
- * per device kernel: "name\tlaunches\ttotal_ms\ttotal_gflop\n" and the number of characters written. */
+/* per-kernel timing (measurement aid) -- TOOLS BUILD ONLY (tools/_bin/libccengine_tools.so, cc_amd/build.py build_tools(): the
+ * same sources with -DCC_TOOLS; cc_is_tools_build() tells which one is loaded).  The product library reads no environment
+ * variable and keeps no state: there cc_timing_enable(1) returns CC_ERR_ARG and cc_timing_collect 0.  In the tools build,
+ * between cc_timing_enable(1) and cc_timing_collect the MAIN device kernel of every conv / weight-gradient call is bracketed
+ * with HIP events on its stream; collect returns (HOST buffer) one line per device kernel:
+ * "name\tlaunches\ttotal_ms\ttotal_gflop\n" and the number of characters written.  The kernel-selection switches listed in
+ * tools/README.md (CC_CONV_*, CC_WGRAD_*, ...) exist in the tools build only as well. */
+int cc_is_tools_build(void);
 int cc_timing_enable(int on);
 int cc_timing_collect(void* out_host, int cap);
 /* introspection: the name of the device kernel the corresponding entry point dispatches to for this geometry (as it

@@ -13,7 +13,7 @@ BUILD = os.path.join(HERE, "_build")
 OUT = os.path.join(BUILD, "libccengine_emu.so")
 CXX = "/opt/rocm/lib/llvm/bin/clang++"
 FLAGS = ["-x", "c++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fopenmp", "-mfma", "-mavx2",
-         "-Wno-unknown-attributes", "-Wno-unused-value",
+         "-Wno-unknown-attributes", "-Wno-unused-value", "-DCC_TOOLS",      # tools switches: tests steer kernel selection with them
          "-I", os.path.join(HERE, "shim"), "-I", os.path.join(ROOT, "include")]
 
 

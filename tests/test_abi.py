@@ -47,3 +47,18 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_product_library_reads_no_environment_and_keeps_no_timing_state():
+    """the product library is stateless -- kernel-selection switches and the per-kernel timing registry exist in
+    the tools build only (tools/_bin/libccengine_tools.so, -DCC_TOOLS)."""
+    import subprocess
+    lib = build.build()
+    syms = subprocess.run(["nm", "-D", lib], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms
+    dll = ctypes.CDLL(lib)
+    assert dll.cc_is_tools_build() == 0
+    assert dll.cc_timing_enable(1) != 0 and dll.cc_timing_collect(None, 0) == 0
+    tools = build.build_tools()
+    assert "getenv" in subprocess.run(["nm", "-D", tools], capture_output=True, text=True, check=True).stdout
+    assert ctypes.CDLL(tools).cc_is_tools_build() == 1

@@ -64,9 +64,15 @@ def test_convs_prepacked_weight_images():
 
 
 def test_convs_thin_wgrad(monkeypatch):
+    # the kernel-selection switches exist in the tools build only (cc_amd/build.py build_tools): small maps are steered through
+    # wgrad_thin.hip there; the product library's own thresholds are covered by test_convs_full_size_thin_layers below
+    from cc_amd import _lib, build
     monkeypatch.setenv("CC_WGRAD_THIN_MINPIX", "0")
     monkeypatch.setenv("CC_WGRAD_THIN_UPB", "8")
-    parity.check_convs("cuda", cases=parity.CONV_CASES_THIN)
+    with _lib.use_library(build.build_tools()) as e:
+        assert e.fn["cc_is_tools_build"]() == 1
+        parity.check_convs("cuda", cases=parity.CONV_CASES_THIN)
+    assert _lib.engine().fn["cc_is_tools_build"]() == 0
 
 
 def test_convs_full_size_thin_layers():

@@ -3,6 +3,8 @@
 TAG=$1; shift
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+# the kernel-selection switches exist in the tools build of the library only (cc_amd/build.py build_tools)
+export CC_LIB_PATH=${CC_LIB_PATH:-$PWD/tools/_bin/libccengine_tools.so}
 for V in default "$@" default; do
   if [ "$V" = default ]; then E=""; else E="$V"; fi
   F=$(echo "$V" | tr ' =/' '___')
