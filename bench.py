@@ -305,16 +305,31 @@ def cpu_model():
 
 
 def cpu_baseline(batch_cpu, init_sd, args):
-    """The oracle (CPU port of the reference step, pinned bit-exact to the reference by tests/golden) on this box's host
-    cores -- reported beside the metric, never the target.  It starts from the SAME initial weights as the GPU run, so its
-    first two steps double as the bench-time parity gate.  -> (baseline dict, [losses per step])"""
+    """The reference's own modules (oracle/_ref/ccref.zip: the unmodified files of SURVEY.md 8a packed by `make -C oracle` in the
+    build container, loaded through oracle/ref_import.py's two shims) -- or, where that archive is missing, the oracle (the CPU
+    port pinned bit-exact to the reference by tests/golden) -- on this box's host cores.  Reported beside the metric, never
+    the target.  It starts from the SAME initial weights as the GPU run, so its first two steps double as the bench-time
+    parity gate.  -> (baseline dict, [losses per step])"""
     from oracle import step as S
+    from oracle import ref_import
     n = args.cpu_threads if args.cpu_threads > 0 else min(usable_cpus(), 64)
     torch.set_num_threads(n)
-    nets = S.build_nets("oracle", flow=(args.config == "c3"), mask=(args.config == "c3"))
+    impl, kind = None, "port"
+    if ref_import.reference_available():
+        try:
+            impl = ref_import.load()
+            kind = "reference"
+        except Exception as e:                                   # noqa: BLE001 -- any import problem: fall back to the port
+            log("reference modules unusable (%r): timing the CPU port instead" % (e,))
+            impl = None
+    if impl is not None:
+        nets = S.build_nets("ref", impl, flow=(args.config == "c3"), mask=(args.config == "c3"))
+    else:
+        nets = S.build_nets("oracle", flow=(args.config == "c3"), mask=(args.config == "c3"))
     for m, sd in zip(nets, init_sd):
         if m is not None:
             m.load_state_dict(sd)
+            m.train()
     if args.freeze:
         for m in nets[2:]:
             if m is not None:
@@ -325,16 +340,19 @@ def cpu_baseline(batch_cpu, init_sd, args):
     losses, times = [], []
     for i in range(1 + args.cpu_steps):
         t0 = time.time()
-        losses.append(S.cc_step(nets, opt, batch_cpu, cfg))
+        losses.append(S.cc_step(nets, opt, batch_cpu, cfg, impl))
         times.append(time.time() - t0)
         log("cpu baseline step %d: %.1f s (%d threads)" % (i, times[-1], n))
     timed = sorted(times[1:])
     dt = timed[len(timed) // 2] if timed else times[0]
-    return {"value": round(batch_cpu[0].shape[0] / dt, 4), "unit": "images/s", "cores": n, "kind": "port",
+    what = ("the reference's own inverse_warp / loss_functions / ssim / models files (oracle/_ref/ccref.zip, unmodified; two "
+            "import shims: the absent spatial_correlation_sampler CUDA extension restated in torch, .cuda() a no-op) driven by "
+            "oracle/step.py's mirror of train.py:445-568" if kind == "reference" else
+            "oracle/step.py (the CPU port of train.py:445-568, pinned to the reference by tests/golden)")
+    return {"value": round(batch_cpu[0].shape[0] / dt, 4), "unit": "images/s", "cores": n, "kind": kind,
             "cpu": cpu_model(), "host_threads": os.cpu_count(), "usable_threads": usable_cpus(),
-            "sample": "median of %d full CC steps (fwd+bwd+Adam) after 1 warm-up, B=%d %dx%d, oracle/step.py (the CPU port "
-                      "of train.py:445-568, pinned to the reference by tests/golden), torch %s, %d threads"
-                      % (len(timed), batch_cpu[0].shape[0], batch_cpu[0].shape[3], batch_cpu[0].shape[2],
+            "sample": "median of %d full CC steps (fwd+bwd+Adam) after 1 warm-up, B=%d %dx%d, %s, torch %s, %d threads"
+                      % (len(timed), batch_cpu[0].shape[0], batch_cpu[0].shape[3], batch_cpu[0].shape[2], what,
                          torch.__version__, n),
             "s_per_step": round(dt, 3), "s_per_step_all": [round(t, 3) for t in times]}, losses
 

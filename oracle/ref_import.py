@@ -1,9 +1,11 @@
 """TEST INFRASTRUCTURE ONLY -- loader for the *unmodified* reference modules.
 
-Only usable where ``/root/reference`` exists (the build container).  It is used
-by ``oracle/make_golden.py`` to generate the fixtures under ``tests/golden/``
-and by ``tests/test_oracle_vs_reference.py`` (skipped when the reference tree is
-absent, i.e. on the GPU box).  Nothing in ``cc_amd/`` may import this file.
+Usable where ``/root/reference`` exists (the build container) or where the
+archive ``oracle/_ref/ccref.zip`` has been built from it (``make -C oracle``:
+the nine unmodified files of SURVEY.md 8a, git-ignored, shipped to the GPU box
+like a built library).  It is used by ``oracle/make_golden.py`` to generate the
+fixtures under ``tests/golden/`` and by ``bench.py``'s ``cpu_baseline`` child
+(kind "reference").  Nothing in ``cc_amd/`` may import this file.
 
 Two shims are needed to run the reference on CPU:
 
@@ -26,10 +28,30 @@ import warnings
 import torch
 
 REF_ROOT = os.environ.get("CC_REFERENCE_ROOT", "/root/reference")
+REF_ZIP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "ccref.zip")
+
+
+def _unpack_archive():
+    """The reference tree is absent (GPU box) but oracle/_ref/ccref.zip travelled: unpack it to a temporary directory."""
+    global REF_ROOT
+    import atexit
+    import shutil
+    import tempfile
+    import zipfile
+    d = tempfile.mkdtemp(prefix="ccref_")
+    atexit.register(shutil.rmtree, d, ignore_errors=True)
+    with zipfile.ZipFile(REF_ZIP) as z:
+        z.extractall(d)
+    REF_ROOT = d
 
 
 def reference_available():
-    return os.path.isfile(os.path.join(REF_ROOT, "inverse_warp.py"))
+    if os.path.isfile(os.path.join(REF_ROOT, "inverse_warp.py")):
+        return True
+    if os.path.isfile(REF_ZIP):
+        _unpack_archive()
+        return os.path.isfile(os.path.join(REF_ROOT, "inverse_warp.py"))
+    return False
 
 
 def _corr_sample(input1, input2, kernel_size=1, patch_size=1, stride=1,
