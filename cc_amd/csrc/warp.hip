@@ -160,8 +160,16 @@ __global__ __launch_bounds__(256) void k_inverse_warp_fwd(const float* __restric
 }
 
 // d(sum_c gout_c * sample_c)/d(ix, iy) (ATen grid_sampler_2d_backward, bilinear)
+// fx != nullptr: the scatter goes to a 64-bit FIXED-POINT image (contribution * fx_scale rounded to an integer, fx_scale a power
+// of two): integer addition is associative, so the sums -- unlike float atomics -- do not depend on the order in which the
+// atomics land (config.deterministic, cc_feature_warp_bwd_det)
+__device__ __forceinline__ void fx_add(unsigned long long* p, float v, float fx_scale) {
+    atomicAdd(p, (unsigned long long)__float2ll_rn(v * fx_scale));
+}
+
 __device__ __forceinline__ void sample_grad(const float* __restrict__ src, const float* __restrict__ gout, int C, int HW,
-                                            int W, const Bilinear& t, float* __restrict__ gimg, float& gix, float& giy) {
+                                            int W, const Bilinear& t, float* __restrict__ gimg, float& gix, float& giy,
+                                            unsigned long long* __restrict__ fx = nullptr, float fx_scale = 0.f) {
     gix = 0.f;
     giy = 0.f;
     // up to four channels' loads (4 taps + the output gradient each) in flight, consumed in channel order: with one channel per
@@ -181,7 +189,13 @@ __device__ __forceinline__ void sample_grad(const float* __restrict__ src, const
             if (c0 + u < C) {
                 gix += ((ne[u] - nw[u]) * t.s + (se[u] - sw[u]) * t.n) * g[u];
                 giy += ((sw[u] - nw[u]) * t.e + (se[u] - ne[u]) * t.w) * g[u];
-                if (gimg) {
+                if (fx) {
+                    unsigned long long* gp = fx + (size_t)(c0 + u) * HW + t.y0 * W + t.x0;
+                    if (t.vy0 && t.vx0) fx_add(gp, g[u] * (t.s * t.e), fx_scale);
+                    if (t.vy0 && t.vx1) fx_add(gp + 1, g[u] * (t.s * t.w), fx_scale);
+                    if (t.vy1 && t.vx0) fx_add(gp + W, g[u] * (t.n * t.e), fx_scale);
+                    if (t.vy1 && t.vx1) fx_add(gp + W + 1, g[u] * (t.n * t.w), fx_scale);
+                } else if (gimg) {
                     float* gp = gimg + (size_t)(c0 + u) * HW + t.y0 * W + t.x0;
                     if (t.vy0 && t.vx0) atomicAdd(gp, g[u] * (t.s * t.e));
                     if (t.vy0 && t.vx1) atomicAdd(gp + 1, g[u] * (t.s * t.w));
@@ -355,8 +369,17 @@ __global__ __launch_bounds__(256) void k_flow_warp_bwd(const float* __restrict__
 template <bool AC>
 __global__ __launch_bounds__(256) void k_feature_warp_bwd4(const float* __restrict__ gout, const float* __restrict__ img,
                                                            const float* __restrict__ flow, float* __restrict__ gflow,
-                                                           float* __restrict__ gimg, int C, int H, int W, float fs) {
+                                                           float* __restrict__ gimg, int C, int H, int W, float fs,
+                                                           unsigned long long* __restrict__ fx = nullptr,
+                                                           const unsigned* __restrict__ fx_max = nullptr) {
     __shared__ float part[4][64][2];
+    // deterministic form: scale = 2^(46 - exponent of max |gout|): the largest contribution uses <= 47 bits, 2^16 of them fit
+    float fx_scale = 0.f;
+    if (fx) {
+        int e = 0;
+        (void)frexpf(__uint_as_float(*fx_max), &e);
+        fx_scale = ldexpf(1.0f, 46 - e);
+    }
     const int b = blockIdx.y, HW = H * W;
     const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
     const int p = blockIdx.x * 64 + lane;
@@ -374,7 +397,8 @@ __global__ __launch_bounds__(256) void k_feature_warp_bwd4(const float* __restri
         gmy = t.gmy;
         if (c0 < c1)
             sample_grad(img + ((size_t)b * C + c0) * HW, gout + ((size_t)b * C + c0) * HW + p, c1 - c0, HW, W, t,
-                        gimg ? gimg + ((size_t)b * C + c0) * HW : nullptr, gix, giy);
+                        gimg ? gimg + ((size_t)b * C + c0) * HW : nullptr, gix, giy,
+                        fx ? fx + ((size_t)b * C + c0) * HW : nullptr, fx_scale);
     }
     part[cg][lane][0] = gix;
     part[cg][lane][1] = giy;
@@ -629,6 +653,43 @@ __global__ __launch_bounds__(256) void k_cam2pixel(const float* __restrict__ cam
 
 inline dim3 pix_grid(int B, int H, int W) { return dim3((unsigned)((H * W + 255) / 256), (unsigned)B); }
 
+// ---- fixed-point scatter support (cc_feature_warp_bwd_det)
+__global__ __launch_bounds__(256) void k_fx_zero(unsigned long long* __restrict__ p, long n) {
+    for (long i = (long)blockIdx.x * 1024 + threadIdx.x; i < n && i < (long)(blockIdx.x + 1) * 1024; i += 256) p[i] = 0ull;
+}
+
+// max |x| as the bit pattern of a non-negative float: unsigned atomicMax is order-independent
+__global__ __launch_bounds__(256) void k_fx_absmax(const float* __restrict__ x, unsigned* __restrict__ out, long n) {
+    __shared__ unsigned red[256];
+    unsigned m = 0u;
+    const long base = (long)blockIdx.x * 4096;
+    for (int k = 0; k < 16; k++) {
+        const long i = base + k * 256 + threadIdx.x;
+        if (i < n) {
+            const unsigned b = __float_as_uint(fabsf(x[i]));
+            if (b < 0x7f800000u && b > m) m = b;             // finite values only
+        }
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st && red[threadIdx.x + st] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && red[0]) atomicMax(out, red[0]);
+}
+
+__global__ __launch_bounds__(256) void k_fx_to_float(const unsigned long long* __restrict__ fx, const unsigned* __restrict__ mx,
+                                                     float* __restrict__ out, long n, int accumulate) {
+    int e = 0;
+    (void)frexpf(__uint_as_float(*mx), &e);
+    const float inv = ldexpf(1.0f, e - 46);
+    for (long i = (long)blockIdx.x * 1024 + threadIdx.x; i < n && i < (long)(blockIdx.x + 1) * 1024; i += 256) {
+        const float v = (float)(long long)fx[i] * inv;
+        out[i] = accumulate ? out[i] + v : v;
+    }
+}
+
 }  // namespace
 
 #define CC_DISPATCH_AC_PAD(KERN, ac, border, ...)                                                            \
@@ -772,6 +833,30 @@ int cc_feature_warp_bwd(const float* gout, const float* feat, const float* flow,
     }
     if (align_corners) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<true, true, true>), g, dim3(256), 0, s, gout, feat, flow, gflow_or_null, gfeat_or_null, C, H, W, flow_scale);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_flow_warp_bwd<false, true, true>), g, dim3(256), 0, s, gout, feat, flow, gflow_or_null, gfeat_or_null, C, H, W, flow_scale);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+/* The same backward with a run-to-run REPRODUCIBLE feature gradient: contributions are accumulated as 64-bit fixed-point integers
+ * (integer atomics are order-independent), scaled by a power of two taken from max |gout|, then converted:
+ *   gfeat (+)= fixed / scale.   ws: cc_feature_warp_bwd_det_ws_bytes(B, C, H, W).  Four launches instead of one + the caller's
+ * zero fill.  (The reference's grid_sample backward scatters with float atomics and is not reproducible either.) */
+size_t cc_feature_warp_bwd_det_ws_bytes(int B, int C, int H, int W) { return ((size_t)B * C * H * W + 2) * sizeof(unsigned long long); }
+
+int cc_feature_warp_bwd_det(const float* gout, const float* feat, const float* flow, float* gflow_or_null, float* gfeat,
+                            void* ws, int B, int C, int H, int W, int align_corners, float flow_scale, int accumulate,
+                            void* stream) {
+    if (B <= 0 || C <= 0 || H < 1 || W < 1 || !gfeat || !ws) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)B * C * H * W;
+    unsigned long long* fx = (unsigned long long*)ws + 2;
+    unsigned* mx = (unsigned*)ws;
+    hipLaunchKernelGGL(k_fx_zero, dim3((unsigned)((n + 2 + 1023) / 1024)), dim3(256), 0, s, (unsigned long long*)ws, n + 2);
+    hipLaunchKernelGGL(k_fx_absmax, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, s, gout, mx, n);
+    dim3 g4((unsigned)((H * W + 63) / 64), (unsigned)B);
+    if (align_corners) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feature_warp_bwd4<true>), g4, dim3(256), 0, s, gout, feat, flow, gflow_or_null, (float*)nullptr, C, H, W, flow_scale, fx, (const unsigned*)mx);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feature_warp_bwd4<false>), g4, dim3(256), 0, s, gout, feat, flow, gflow_or_null, (float*)nullptr, C, H, W, flow_scale, fx, (const unsigned*)mx);
+    hipLaunchKernelGGL(k_fx_to_float, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, (const unsigned long long*)fx, (const unsigned*)mx, gfeat, n, accumulate);
     CC_CHECK_LAUNCH();
     return CC_OK;
 }

@@ -20,7 +20,7 @@ import ctypes
 
 import torch
 
-from . import ops
+from . import config, ops
 from ._lib import engine, STREAM
 
 ACT = ops.ACT
@@ -560,6 +560,12 @@ class Tape:
                 # the feature gradient is a scatter (atomicAdd): straight into x's accumulated gradient when there is one
                 if x.needs:
                     def write(gx, acc):
+                        if config.deterministic and C >= 16:
+                            ws = torch.empty(int(E.call("cc_feature_warp_bwd_det_ws_bytes", B, C, H, W)), dtype=torch.uint8,
+                                             device=gx.device)
+                            E.call("cc_feature_warp_bwd_det", g, xt, ft, gflow, gx, ws, B, C, H, W, int(align_corners),
+                                   float(flow_scale), int(acc), STREAM)
+                            return
                         if not acc:
                             gx.zero_()
                         E.call("cc_feature_warp_bwd", g, xt, ft, gflow, gx, B, C, H, W, int(align_corners), float(flow_scale), STREAM)

@@ -72,6 +72,14 @@ int cc_feature_warp_fwd(const float* feat, const float* flow, float* out, int B,
                         int align_corners, float flow_scale, void* stream);
 int cc_feature_warp_bwd(const float* gout, const float* feat, const float* flow, float* gflow_or_null,
                         float* gfeat_or_null, int B, int C, int H, int W, int align_corners, float flow_scale, void* stream);
+/* The same backward with a run-to-run REPRODUCIBLE feature gradient (cc_amd.config.deterministic): the scatter accumulates
+ * 64-bit fixed-point integers (integer atomics are order-independent; scale = a power of two from max |gout|) and converts at
+ * the end: gfeat = (accumulate ? gfeat : 0) + sum.  ws: cc_feature_warp_bwd_det_ws_bytes().  The reference's grid_sample
+ * backward (models/back2future.py:287-321) scatters with float atomics on CUDA and is not reproducible either. */
+size_t cc_feature_warp_bwd_det_ws_bytes(int B, int C, int H, int W);
+int cc_feature_warp_bwd_det(const float* gout, const float* feat, const float* flow, float* gflow_or_null, float* gfeat,
+                            void* ws, int B, int C, int H, int W, int align_corners, float flow_scale, int accumulate,
+                            void* stream);
 
 /* inverse_warp.py:82-119,146-162,214,278 (+ loss_functions.py:91): P[n] = K_s[n] . [Rx.Ry.Rz | t] for pose[n] =
  * (tx,ty,tz,rx,ry,rz) at pose + n*pose_stride, K_s = K with rows 0,1 divided by k_div (the pyramid downscale).

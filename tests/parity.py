@@ -568,6 +568,37 @@ def check_conv_list(dev, tol=2e-5):
     ops.packs.reset()
 
 
+def check_feature_warp_deterministic(dev, cases=((2, 32, 16, 24), (1, 96, 12, 20), (2, 128, 8, 13))):
+    """cc_feature_warp_bwd_det (config.deterministic: the feature-gradient scatter as 64-bit fixed-point integer atomics) against
+    the float-atomic kernel: same gradient to 1e-6 of its magnitude, accumulation onto an existing gradient, and two runs of
+    the deterministic form bit for bit (flows of several pixels, many targets landing on the same source pixel: border
+    clamping)."""
+    from cc_amd._lib import engine, STREAM
+    E = engine()
+    g = torch.Generator().manual_seed(17)
+    for (B, C, H, W) in cases:
+        feat = torch.randn(B, C, H, W, generator=g).to(dev)
+        flow = (torch.randn(B, 2, H, W, generator=g) * 6.0).to(dev)          # many samples beyond the border (clamped)
+        gout = (torch.randn(B, C, H, W, generator=g) * 1e-4).to(dev)
+        base = torch.randn(B, C, H, W, generator=g).to(dev) * 1e-4
+        ref = torch.zeros_like(feat)
+        gflow0 = torch.empty_like(flow)
+        E.call("cc_feature_warp_bwd", gout, feat, flow, gflow0, ref, B, C, H, W, 0, 0.625, STREAM)
+        outs = []
+        for rep in range(2):
+            ws = torch.empty(int(E.call("cc_feature_warp_bwd_det_ws_bytes", B, C, H, W)), dtype=torch.uint8, device=dev)
+            got, gflow1 = torch.empty_like(feat), torch.empty_like(flow)
+            E.call("cc_feature_warp_bwd_det", gout, feat, flow, gflow1, got, ws, B, C, H, W, 0, 0.625, 0, STREAM)
+            outs.append(got)
+            assert torch.equal(gflow0, gflow1)
+        assert torch.equal(outs[0], outs[1])
+        assert rel(outs[0], ref) < 1e-6, ((B, C, H, W), rel(outs[0], ref))
+        acc = base.clone()
+        ws = torch.empty(int(E.call("cc_feature_warp_bwd_det_ws_bytes", B, C, H, W)), dtype=torch.uint8, device=dev)
+        E.call("cc_feature_warp_bwd_det", gout, feat, flow, None, acc, ws, B, C, H, W, 0, 0.625, 1, STREAM)
+        assert rel(acc, base + ref) < 1e-6
+
+
 def check_corr(dev, cases=((2, 8, 6, 12), (1, 5, 7, 13), (2, 12, 5, 8), (1, 33, 9, 20))):
     """9x9 cost volume (Back2Future): plain `correlate` and the fused pair with the idx_fwd / idx_bwd channel
     permutations, forward and all gradients, vs the oracle; W % 4 == 0 runs the register-blocked kernels, other widths

@@ -87,3 +87,7 @@ def test_conv_groups():
 
 def test_conv_launch_list():
     parity.check_conv_list("cpu")
+
+
+def test_feature_warp_deterministic_scatter():
+    parity.check_feature_warp_deterministic("cpu")

@@ -114,3 +114,8 @@ def test_conv_groups():
 
 def test_conv_launch_list():
     parity.check_conv_list("cuda")
+
+
+def test_feature_warp_deterministic_scatter():
+    parity.check_feature_warp_deterministic("cuda")
+    parity.check_feature_warp_deterministic("cuda", cases=((4, 32, 64, 208), (4, 128, 8, 26)))

@@ -134,9 +134,13 @@ def test_training_step_reaches_no_vendor_conv_or_batchnorm_kernel():
     print("device kernels seen: %d distinct, e.g. %s" % (len(kernels), kernels[:6]))
 
 
-def test_two_graph_step_matches_single_graph():
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_two_graph_step_matches_single_graph(deterministic, monkeypatch):
     """The data-parallel form of the step (two hipGraphs sharing a pool, the gradient all-reduce of the first segment issued
-    between the replays) on one GPU: same losses, gradients and parameters as the single-graph step."""
+    between the replays) on one GPU: same losses, gradients and parameters as the single-graph step -- bit for bit with
+    config.deterministic (the feature-warp scatter as integer atomics), to 1e-4 of the gradient norm with float atomics."""
+    from cc_amd import config
+    monkeypatch.setattr(config, "deterministic", deterministic)
     dev = torch.device("cuda")
     bc = syn.sample(2, 128, 192, seed=1)
     batch = (bc[0].to(dev), [r.to(dev) for r in bc[1]], bc[2].to(dev), bc[3].to(dev))
@@ -155,9 +159,35 @@ def test_two_graph_step_matches_single_graph():
     for k in a1:
         assert abs(a1[k] - b1[k]) <= 1e-6 * abs(a1[k]) + 1e-9, (k, a1[k], b1[k])
         assert abs(a2[k] - b2[k]) <= 1e-5 * abs(a2[k]) + 1e-9, (k, a2[k], b2[k])
+    if deterministic:
+        assert a1 == b1 and a2 == b2 and torch.equal(ga, gb) and torch.equal(pa, pb)
+        return
     # feature-warp backward scatters with float atomics (like the reference's grid_sample): not bit-reproducible
     assert float((ga - gb).norm() / ga.norm()) < 1e-4
     assert float((pa - pb).abs().max()) <= 2.001e-4
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_step_is_bit_reproducible_in_deterministic_mode(use_graph, monkeypatch):
+    """SURVEY.md section 5 (deterministic reductions + reproducibility test): with config.deterministic two independent runs
+    of three training steps from the same weights and data produce identical losses, gradients and parameters -- every
+    reduction of the step has a fixed order, the one scatter accumulates integers."""
+    from cc_amd import config
+    monkeypatch.setattr(config, "deterministic", True)
+    dev = torch.device("cuda")
+    bc = syn.sample(2, 128, 192, seed=1)
+    batch = (bc[0].to(dev), [r.to(dev) for r in bc[1]], bc[2].to(dev), bc[3].to(dev))
+    runs = []
+    for _ in range(2):
+        nets = T.build_nets(dev, init=False)
+        for n in nets:
+            n.load_state_dict(syn.seeded_state_dict(n, 0))
+        tr = T.CCTrainer(nets, T.StepConfig(), use_graph=use_graph)
+        ls = [{k: float(v) for k, v in tr.step(batch).items()} for _ in range(3)]
+        runs.append((ls, tr.opt.flat_g.clone(), tr.opt.flat_p.clone()))
+    (la, ga, pa), (lb, gb, pb) = runs
+    assert la == lb, (la, lb)
+    assert torch.equal(ga, gb) and torch.equal(pa, pb)
 
 
 def test_step_with_rccl_process_group_of_one(monkeypatch):
