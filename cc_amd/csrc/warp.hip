@@ -651,6 +651,95 @@ __global__ __launch_bounds__(256) void k_cam2pixel(const float* __restrict__ cam
     out[((size_t)b * HW + p) * 2 + 1] = yn;
 }
 
+// backward of the two stand-alone halves (validation-side API of inverse_warp.py:31-79; the training step uses the fused warp).
+// pixel2cam: cam_i = ray_i * d, ray = Kinv . (x, y, 1):  gdepth = sum_i g_i ray_i;  gKinv[i][j] = sum_p g_i d (x, y, 1)_j
+// (per-block partials in 12-float records, reduced by k_reduce_gP: slots 0..8 = gKinv row-major).
+__global__ __launch_bounds__(256) void k_pixel2cam_bwd(const float* __restrict__ g, const float* __restrict__ depth,
+                                                       const float* __restrict__ Kinv, float* __restrict__ gdepth,
+                                                       float* __restrict__ part, int H, int W) {
+    __shared__ float red[4 * 12];
+    const int b = blockIdx.y, HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) acc[i] = 0.f;
+    if (p < HW) {
+        const int y = p / W, x = p - y * W;
+        const float* Ki = Kinv + 9 * b;
+        const float d = depth[(size_t)b * HW + p];
+        const float pix[3] = {(float)x, (float)y, 1.0f};
+        float gd = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float gi = g[((size_t)b * 3 + i) * HW + p];
+            const float ray = fmaf(Ki[3 * i + 2], 1.0f, fmaf(Ki[3 * i + 1], (float)y, Ki[3 * i] * (float)x));
+            gd += gi * ray;
+#pragma unroll
+            for (int j = 0; j < 3; j++) acc[3 * i + j] = gi * d * pix[j];
+        }
+        if (gdepth) gdepth[(size_t)b * HW + p] = gd;
+    }
+    cc::block_sum_256<12>(acc, red);
+    if (threadIdx.x == 0) {
+        float* o = part + ((size_t)b * gridDim.x + blockIdx.x) * 12;
+#pragma unroll
+        for (int i = 0; i < 12; i++) o[i] = acc[i];
+    }
+}
+
+// cam2pixel: q = rot . cam + tr, Z = max(q2, 1e-3), (xn, yn) = 2 (q0, q1) / Z / (W-1, H-1) - 1; rewritten OOB coordinates and a
+// clamped Z carry no gradient (Q10).  gcam = rot^T gq (gq itself without rot); gP[i][0..2] = sum_p gq_i cam, gP[i][3] = sum_p gq_i.
+__global__ __launch_bounds__(256) void k_cam2pixel_bwd(const float* __restrict__ ggrid, const float* __restrict__ cam,
+                                                       const float* __restrict__ P, float* __restrict__ gcam,
+                                                       float* __restrict__ part, int H, int W, int has_rot, int has_tr, int rewrite) {
+    __shared__ float red[4 * 12];
+    const int b = blockIdx.y, HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) acc[i] = 0.f;
+    if (p < HW) {
+        const float c[3] = {cam[((size_t)b * 3 + 0) * HW + p], cam[((size_t)b * 3 + 1) * HW + p], cam[((size_t)b * 3 + 2) * HW + p]};
+        const float* Pb = P + 12 * b;
+        float q[3] = {c[0], c[1], c[2]};
+        if (has_rot) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) q[i] = fmaf(Pb[4 * i + 2], c[2], fmaf(Pb[4 * i + 1], c[1], Pb[4 * i] * c[0]));
+        }
+        if (has_tr) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) q[i] = q[i] + Pb[4 * i + 3];
+        }
+        const float Z = fmaxf(q[2], 1e-3f);
+        const float xn = (2.0f * (q[0] / Z)) / (float)(W - 1) - 1.0f;
+        const float yn = (2.0f * (q[1] / Z)) / (float)(H - 1) - 1.0f;
+        float gxn = ggrid[((size_t)b * HW + p) * 2], gyn = ggrid[((size_t)b * HW + p) * 2 + 1];
+        if (rewrite && (xn > 1.f || xn < -1.f)) gxn = 0.f;
+        if (rewrite && (yn > 1.f || yn < -1.f)) gyn = 0.f;
+        const float gu = gxn * (2.0f / (float)(W - 1)), gv = gyn * (2.0f / (float)(H - 1));
+        const float iz = 1.0f / Z;
+        float gq[3] = {gu * iz, gv * iz, 0.f};
+        if (!(q[2] < 1e-3f)) gq[2] = -(gu * q[0] + gv * q[1]) * iz * iz;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            float gc = has_rot ? (gq[0] * Pb[j] + gq[1] * Pb[4 + j] + gq[2] * Pb[8 + j]) : gq[j];
+            if (gcam) gcam[((size_t)b * 3 + j) * HW + p] = gc;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) acc[4 * i + j] = gq[i] * c[j];
+            acc[4 * i + 3] = gq[i];
+        }
+    }
+    cc::block_sum_256<12>(acc, red);
+    if (threadIdx.x == 0) {
+        float* o = part + ((size_t)b * gridDim.x + blockIdx.x) * 12;
+#pragma unroll
+        for (int i = 0; i < 12; i++) o[i] = acc[i];
+    }
+}
+
 inline dim3 pix_grid(int B, int H, int W) { return dim3((unsigned)((H * W + 255) / 256), (unsigned)B); }
 
 // ---- fixed-point scatter support (cc_feature_warp_bwd_det)
@@ -717,6 +806,31 @@ int cc_cam2pixel(const float* cam, const float* P, float* grid, int B, int H, in
     if (B <= 0 || H < 2 || W < 2) return CC_ERR_ARG;
     hipLaunchKernelGGL(k_cam2pixel, pix_grid(B, H, W), dim3(256), 0, (hipStream_t)stream, cam, P, grid, H, W, has_rot, has_tr,
                        rewrite_oob);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+/* backward of cc_pixel2cam: g [B,3,H,W] -> gdepth [B,H,W] (or null), gKinv12 [B,12] (slots 0..8 = d/dKinv row-major, 9..11 zero).
+ * ws_partials: cc_warp_partials_bytes(B, H, W). */
+int cc_pixel2cam_bwd(const float* g, const float* depth, const float* Kinv, float* gdepth_or_null, float* gKinv12, float* ws_partials,
+                     int B, int H, int W, void* stream) {
+    if (B <= 0 || H < 1 || W < 1 || !g || !gKinv12 || !ws_partials) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 gr = pix_grid(B, H, W);
+    hipLaunchKernelGGL(k_pixel2cam_bwd, gr, dim3(256), 0, s, g, depth, Kinv, gdepth_or_null, ws_partials, H, W);
+    hipLaunchKernelGGL(k_reduce_gP, dim3(B), dim3(64), 0, s, (const float*)ws_partials, gKinv12, (int)gr.x, 0);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+/* backward of cc_cam2pixel: ggrid [B,H,W,2] -> gcam [B,3,H,W] (or null), gP [B,12] rows (d/drot | d/dtr). */
+int cc_cam2pixel_bwd(const float* ggrid, const float* cam, const float* P, float* gcam_or_null, float* gP, float* ws_partials, int B,
+                     int H, int W, int has_rot, int has_tr, int rewrite_oob, void* stream) {
+    if (B <= 0 || H < 2 || W < 2 || !ggrid || !gP || !ws_partials) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 gr = pix_grid(B, H, W);
+    hipLaunchKernelGGL(k_cam2pixel_bwd, gr, dim3(256), 0, s, ggrid, cam, P, gcam_or_null, ws_partials, H, W, has_rot, has_tr, rewrite_oob);
+    hipLaunchKernelGGL(k_reduce_gP, dim3(B), dim3(64), 0, s, (const float*)ws_partials, gP, (int)gr.x, 0);
     CC_CHECK_LAUNCH();
     return CC_OK;
 }

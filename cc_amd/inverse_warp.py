@@ -30,29 +30,6 @@ def check_sizes(input, input_name, expected):
 
 
 # ------------------------------------------------------------------ pixel2cam / cam2pixel (stand-alone halves of the fused warp)
-def _pixel2cam_torch(depth, intrinsics_inv):
-    b, h, w = depth.size()
-    i = torch.arange(0, h, device=depth.device, dtype=depth.dtype).view(1, h, 1).expand(1, h, w)
-    j = torch.arange(0, w, device=depth.device, dtype=depth.dtype).view(1, 1, w).expand(1, h, w)
-    pix = torch.stack((j, i, torch.ones_like(i)), dim=1).expand(b, 3, h, w).contiguous().view(b, 3, -1)
-    return intrinsics_inv.bmm(pix).view(b, 3, h, w) * depth.unsqueeze(1)
-
-
-def _cam2pixel_torch(cam_coords, proj_c2p_rot, proj_c2p_tr, padding_mode):
-    b, _, h, w = cam_coords.size()
-    flat = cam_coords.reshape(b, 3, -1)
-    pc = proj_c2p_rot.bmm(flat) if proj_c2p_rot is not None else flat
-    if proj_c2p_tr is not None:
-        pc = pc + proj_c2p_tr
-    X, Y, Z = pc[:, 0], pc[:, 1], pc[:, 2].clamp(min=1e-3)
-    Xn = 2 * (X / Z) / (w - 1) - 1
-    Yn = 2 * (Y / Z) / (h - 1) - 1
-    if padding_mode == 'zeros':
-        Xn = torch.where(((Xn > 1) | (Xn < -1)).detach(), torch.full_like(Xn, 2), Xn)
-        Yn = torch.where(((Yn > 1) | (Yn < -1)).detach(), torch.full_like(Yn, 2), Yn)
-    return torch.stack([Xn, Yn], dim=2).view(b, h, w, 2)
-
-
 class _Pixel2CamFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, depth, Kinv):
@@ -64,12 +41,15 @@ class _Pixel2CamFn(torch.autograd.Function):
         return cam
 
     @staticmethod
-    def backward(ctx, g):        # off the training path: differentiate the reference's own formula
+    def backward(ctx, g):
         d, Ki = ctx.saved_tensors
-        with torch.enable_grad():
-            dd, kk = d.detach().requires_grad_(True), Ki.detach().requires_grad_(True)
-            gd, gk = torch.autograd.grad(_pixel2cam_torch(dd, kk), [dd, kk], g)
-        return gd, gk
+        B, H, W = d.shape
+        E = engine()
+        gd = torch.empty_like(d) if ctx.needs_input_grad[0] else None
+        gk = torch.empty(B, 12, device=d.device, dtype=torch.float32)
+        ws = torch.empty(int(E.call("cc_warp_partials_bytes", B, H, W)) // 4, device=d.device, dtype=torch.float32)
+        E.call("cc_pixel2cam_bwd", _f32c(g), d, Ki, gd, gk, ws, B, H, W, STREAM)
+        return gd, (gk[:, :9].reshape(B, 3, 3) if ctx.needs_input_grad[1] else None)
 
 
 class _Cam2PixelFn(torch.autograd.Function):
@@ -82,23 +62,29 @@ class _Cam2PixelFn(torch.autograd.Function):
             P[:, :, :3] = rot
         if tr is not None:
             P[:, :, 3:] = tr
+        P = P.reshape(B, 12)
         grid = torch.empty(B, H, W, 2, device=c.device, dtype=torch.float32)
-        engine().call("cc_cam2pixel", c, P.reshape(B, 12), grid, B, H, W, int(rot is not None), int(tr is not None),
+        engine().call("cc_cam2pixel", c, P, grid, B, H, W, int(rot is not None), int(tr is not None),
                       1 if mode == 'zeros' else 0, STREAM)
-        ctx.save_for_backward(c, rot, tr)
-        ctx.mode = mode
+        ctx.save_for_backward(c, P)
+        ctx.cfg = (rot is not None, tr is not None, mode)
         return grid
 
     @staticmethod
     def backward(ctx, g):
-        c, rot, tr = ctx.saved_tensors
-        with torch.enable_grad():
-            ins = [t.detach().requires_grad_(True) if t is not None else None for t in (c, rot, tr)]
-            out = _cam2pixel_torch(ins[0], ins[1], ins[2], ctx.mode)
-            live = [t for t in ins if t is not None]
-            gs = list(torch.autograd.grad(out, live, g, allow_unused=True))
-        res = [gs.pop(0) if t is not None else None for t in ins]
-        return res[0], res[1], res[2], None
+        c, P = ctx.saved_tensors
+        has_rot, has_tr, mode = ctx.cfg
+        B, _, H, W = c.shape
+        E = engine()
+        gcam = torch.empty_like(c) if ctx.needs_input_grad[0] else None
+        gP = torch.empty(B, 12, device=c.device, dtype=torch.float32)
+        ws = torch.empty(int(E.call("cc_warp_partials_bytes", B, H, W)) // 4, device=c.device, dtype=torch.float32)
+        E.call("cc_cam2pixel_bwd", _f32c(g), c, P, gcam, gP, ws, B, H, W, int(has_rot), int(has_tr), 1 if mode == 'zeros' else 0,
+               STREAM)
+        gP = gP.reshape(B, 3, 4)
+        grot = gP[:, :, :3].contiguous() if (has_rot and ctx.needs_input_grad[1]) else None
+        gtr = gP[:, :, 3:].contiguous() if (has_tr and ctx.needs_input_grad[2]) else None
+        return gcam, grot, gtr, None
 
 
 def pixel2cam(depth, intrinsics_inv):

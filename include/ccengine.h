@@ -35,6 +35,13 @@ size_t cc_version(void);
 int cc_pixel2cam(const float* depth, const float* Kinv, float* cam, int B, int H, int W, void* stream);
 int cc_cam2pixel(const float* cam, const float* P, float* grid, int B, int H, int W, int has_rot, int has_tr, int rewrite_oob,
                  void* stream);
+/* their backward passes (inverse_warp.py:31-79 under autograd): per-pixel adjoints + a deterministic two-stage reduction of the
+ * matrix gradients.  gKinv12 [B,12]: slots 0..8 = d/dKinv row-major; gP [B,12]: rows (d/drot | d/dtr); rewritten out-of-range
+ * coordinates and a clamped Z carry no gradient.  ws_partials: cc_warp_partials_bytes(B, H, W). */
+int cc_pixel2cam_bwd(const float* g, const float* depth, const float* Kinv, float* gdepth_or_null, float* gKinv12, float* ws_partials,
+                     int B, int H, int W, void* stream);
+int cc_cam2pixel_bwd(const float* ggrid, const float* cam, const float* P, float* gcam_or_null, float* gP, float* ws_partials, int B,
+                     int H, int W, int has_rot, int has_tr, int rewrite_oob, void* stream);
 
 /* scratch for the per-workgroup partial sums of dL/dP: B * ceil(H*W/256) * 12 floats */
 size_t cc_warp_partials_bytes(int B, int H, int W);

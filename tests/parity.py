@@ -599,6 +599,38 @@ def check_feature_warp_deterministic(dev, cases=((2, 32, 16, 24), (1, 96, 12, 20
         assert rel(acc, base + ref) < 1e-6
 
 
+def check_pixel2cam_cam2pixel_grads(dev, B=2, H=20, W=28):
+    """The stand-alone pixel2cam / cam2pixel (inverse_warp.py:31-79) under autograd: outputs and ALL gradients (depth, K^-1,
+    camera points, rotation, translation; 'zeros' rewrite and the no-rotation / no-translation switches) of the HIP kernels
+    against the oracle's restatement of the reference formulas."""
+    g = torch.Generator().manual_seed(4)
+    depth = torch.rand(B, H, W, generator=g) * 5 + 0.5
+    _, _, K, Kinv = syn.sample(B, H, W, seed=1)
+    pose = torch.randn(B, 6, generator=g) * 0.05
+    P = G.projection(pose, K)
+    for mode, use_rot, use_tr in (("zeros", True, True), ("border", True, True), ("zeros", False, True), ("zeros", True, False)):
+        outs = []
+        for side in ("dev", "cpu"):
+            d_ = depth.clone().to(dev if side == "dev" else "cpu").requires_grad_(True)
+            ki = Kinv.clone().to(d_.device).requires_grad_(True)
+            rot = P[:, :, :3].clone().contiguous().to(d_.device).requires_grad_(True) if use_rot else None
+            tr = P[:, :, 3:].clone().contiguous().to(d_.device).requires_grad_(True) if use_tr else None
+            if side == "dev":
+                cam = IW.pixel2cam(d_, ki)
+                grid = IW.cam2pixel(cam, rot, tr, mode)
+            else:
+                cam = G.pixel2cam(d_, ki)
+                grid = G.cam2pixel(cam, rot, tr, mode)
+            wgt = torch.randn(grid.shape, generator=torch.Generator().manual_seed(9)).to(grid.device)
+            wrt = [t for t in (d_, ki, rot, tr) if t is not None]
+            gs = torch.autograd.grad((grid * wgt).sum() + (cam * cam).sum() * 1e-3, wrt)
+            outs.append((cam.detach().cpu(), grid.detach().cpu(), [x.cpu() for x in gs]))
+        (c1, g1, gr1), (c0, g0, gr0) = outs
+        assert rel(c1, c0) < 1e-6 and frac_bad(g1, g0, 1e-5, 1e-5) < 1e-3
+        for a, b in zip(gr1, gr0):
+            assert rel(a, b) < 2e-4, (mode, use_rot, use_tr, rel(a, b))
+
+
 def check_corr(dev, cases=((2, 8, 6, 12), (1, 5, 7, 13), (2, 12, 5, 8), (1, 33, 9, 20))):
     """9x9 cost volume (Back2Future): plain `correlate` and the fused pair with the idx_fwd / idx_bwd channel
     permutations, forward and all gradients, vs the oracle; W % 4 == 0 runs the register-blocked kernels, other widths

@@ -91,3 +91,7 @@ def test_conv_launch_list():
 
 def test_feature_warp_deterministic_scatter():
     parity.check_feature_warp_deterministic("cpu")
+
+
+def test_pixel2cam_cam2pixel_gradients():
+    parity.check_pixel2cam_cam2pixel_grads("cpu")

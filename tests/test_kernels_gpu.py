@@ -119,3 +119,8 @@ def test_conv_launch_list():
 def test_feature_warp_deterministic_scatter():
     parity.check_feature_warp_deterministic("cuda")
     parity.check_feature_warp_deterministic("cuda", cases=((4, 32, 64, 208), (4, 128, 8, 26)))
+
+
+def test_pixel2cam_cam2pixel_gradients():
+    parity.check_pixel2cam_cam2pixel_grads("cuda")
+    parity.check_pixel2cam_cam2pixel_grads("cuda", B=2, H=128, W=416)
