@@ -62,11 +62,15 @@ class Engine:
         self.lib = ctypes.CDLL(path)
         self.sigs = parse_header()
         self.fn = {}
-        for name, (ret, types, _) in self.sigs.items():
+        self.strided_ok = {}
+        for name, (ret, types, names) in self.sigs.items():
             f = getattr(self.lib, name)      # AttributeError if the library lacks a declared symbol
             f.restype = ret
             f.argtypes = types
             self.fn[name] = f
+            # per-image dense channel slices (wider batch stride) are accepted only by entry points that TAKE batch strides /
+            # channel totals; everywhere else a non-contiguous tensor is an error, not a silently mis-strided read
+            self.strided_ok[name] = any(n.endswith("_bs") or "bstride" in n or n.endswith("channels_total") for n in names)
 
     def _ptr(self, t, name, i):
         if t is None:
@@ -78,9 +82,9 @@ class Engine:
                                % (name, i, t.device))
         if t.dtype not in (torch.float32, torch.int32, torch.uint8, torch.int64, torch.float64):
             raise TypeError("%s arg %d: unsupported dtype %s" % (name, i, t.dtype))
-        if not t.is_contiguous() and not image_dense(t):
-            raise ValueError("%s arg %d: tensor must be contiguous (or a per-image dense NCHW channel slice whose batch stride "
-                             "the call passes)" % (name, i))
+        if not t.is_contiguous() and not (self.strided_ok.get(name, False) and image_dense(t)):
+            raise ValueError("%s arg %d: tensor must be contiguous (per-image dense NCHW channel slices only where the entry "
+                             "point takes their batch stride)" % (name, i))
         return t.data_ptr()
 
     def stream_ptr(self):

@@ -825,6 +825,33 @@ inline ConvPlan plan_conv(const GG& g, int mult = 1) {
             p.nsplit = (nchunk + p.cps - 1) / p.cps;
         }
     }
+    // Wave quantisation (round 3): a launch of 257..~1000 workgroups runs as ceil(blocks / 256) "rounds" on the 256 CUs -- the
+    // MFMA pipes of a CU are saturated by one workgroup, so k co-resident workgroups take k times as long -- e.g. the 336
+    // workgroups of Back2Future's level-3 decoder groups (32x104 maps, G = 3) cost two rounds for 1.3 rounds of work.  A modest
+    // split-K re-balances them when the reduction is long enough to pay for the partial slabs.  Cost model (microseconds):
+    //   T(ns) = ceil(blocks * ns / 256) * (stages / ns) * t_stage(BM) + 2.5  [+ 2 * ns * out_bytes / 3 TB/s + 5 when ns > 1]
+    // calibrated on the split-K launches of the step (512->512 on 8x26: model 59 us, measured 63).
+    if (blocks >= 256 && nchunk >= 8 && cctools::env_int("CC_CONV_BALANCE", 1)) {
+        const int T = g.Rt * g.St;
+        const double mfma_cyc = (p.bm == 128 ? 3072.0 : p.bm == 64 ? 1536.0 : p.bm == 32 ? 768.0 : 384.0) * (p.tps == 3 ? 1.0 : 1.0 / 3.0);
+        const double t_stage = mfma_cyc / 2100.0;
+        const double stages = (double)nchunk * ((T + p.tps - 1) / p.tps);
+        const double out_bytes = 4.0 * g.B * g.M * g.OHt * g.OWt * (mult > 1 ? mult : 1);
+        auto cost = [&](int ns) {
+            const double k = (double)((blocks * ns + 255) / 256);
+            double t = k * (stages / ns) * t_stage + 2.5;
+            if (ns > 1) t += 2.0 * ns * out_bytes / 3.0e6 + 5.0;
+            return t;
+        };
+        int best = 1;
+        const int cap = nchunk / 4 < 8 ? nchunk / 4 : 8;
+        for (int ns = 2; ns <= cap; ns++)
+            if (cost(ns) < cost(best)) best = ns;
+        if (best > 1 && cost(best) < 0.01 * cctools::env_int("CC_CONV_BALANCE_PCT", 97) * cost(1)) {
+            p.cps = (nchunk + best - 1) / best;
+            p.nsplit = (nchunk + p.cps - 1) / p.cps;
+        }
+    }
     p.part_floats = p.nsplit > 1 ? (size_t)p.nsplit * g.B * g.M * g.OHt * g.OWt : 0;
     return p;
 }
@@ -1579,10 +1606,15 @@ inline size_t smem_cls(const ConvPlan& p, int tps) { return (size_t)(2 * tps * p
 inline bool launch_classes(const ClsIn* cs, int n, hipStream_t s, bool idle_taps = false) {
     if (n < 1 || n > MAXCLS) return false;
     size_t smem = 0;
-    int tps = 3, maxsplit = 1, maxy = 1;
+    int tps = 3, maxsplit = 1, maxy = 1, ref = -1;
+    if (cctools::env_int("CC_CONV_IDLE_TAPS", 1)) idle_taps = true;
     for (int k = 0; k < n; k++) {
         const ConvPlan& p = cs[k].p;
-        if (!p.use_patch || p.bm != cs[0].p.bm || p.ck != cs[0].p.ck || !cs[k].wp) return false;
+        // a class no tap reaches (the odd output parities of a 1x1 stride-2 data-gradient: DispResNet6's shortcut convolutions):
+        // its result is the epilogue of zero -- it takes no workgroup of the conv launch, only a slot of the epilogue launch
+        if (cs[k].g.Cin == 0) continue;
+        if (ref < 0) ref = k;
+        if (!p.use_patch || p.bm != cs[ref].p.bm || p.ck != cs[ref].p.ck || !cs[k].wp) return false;
         // three taps per stage launch-wide unless a class's patch does not leave room (a class with fewer taps idles the slots)
         if (p.tps != 3 && !(idle_taps && cs[k].g.Rt * cs[k].g.St < 3 && smem_cls(p, 3) <= 80 * 1024)) tps = 1;
         if (p.nsplit > maxsplit) maxsplit = p.nsplit;
@@ -1590,38 +1622,43 @@ inline bool launch_classes(const ClsIn* cs, int n, hipStream_t s, bool idle_taps
     }
     CPM a = {};        // ~3 KB + ~1.5 KB of host stack, passed to the launches by value
     EPM e = {};
-    a.n = n; e.n = n;
-    int bx = 0, ebx = 0, nsplit_any = 0;
+    e.n = n;
+    int bx = 0, ebx = 0, epi_any = 0, nc = 0;
     double gf = 0;
     for (int k = 0; k < n; k++) {
         const GG& g = cs[k].g;
         const ConvPlan& p = cs[k].p;
-        const size_t sm = smem_cls(p, tps);          // A buffers follow the launch-wide TPS, the patch buffers this class's PS
-        if (sm > smem) smem = sm;
-        a.c[k] = make_cp(g, p, cs[k].zeros, cs[k].wp, cs[k].part);
-        bx += g.B * p.tiles_x * p.tiles_y;
-        a.bx_end[k] = bx;
+        const bool empty = g.Cin == 0;
         EPC& c = e.c[k];
-        c.part = cs[k].part; c.bias = g.bias; c.res = g.res; c.add = g.add; c.y = g.y;
-        c.nsplit = p.nsplit; c.part_stride = a.c[k].part_stride;
+        c.part = empty ? nullptr : cs[k].part; c.bias = g.bias; c.res = g.res; c.add = g.add; c.y = g.y;
+        c.part_stride = (long)g.B * g.M * g.OHt * g.OWt;
+        c.nsplit = empty ? 0 : p.nsplit;
         c.OHt = g.OHt; c.OWt = g.OWt; c.oy0 = g.oy0; c.ox0 = g.ox0;
-        c.total = (p.nsplit > 1) ? a.c[k].part_stride : 0;
+        c.total = (empty || p.nsplit > 1) ? c.part_stride : 0;
         c.M = g.M; c.so = g.so; c.OH = g.OH; c.OW = g.OW; c.y_bs = g.y_bs; c.res_bs = g.res_bs; c.add_bs = g.add_bs;
         c.act = g.act; c.act_a = g.act_a; c.act_b = g.act_b; c.res_mul = g.res_mul;
         ebx += (int)((c.total + 255) / 256);
         e.bx_end[k] = ebx;
-        if (p.nsplit > 1) nsplit_any = 1;
+        if (c.total) epi_any = 1;
+        if (empty) continue;
+        const size_t sm = smem_cls(p, tps);          // A buffers follow the launch-wide TPS, the patch buffers this class's PS
+        if (sm > smem) smem = sm;
+        a.c[nc] = make_cp(g, p, cs[k].zeros, cs[k].wp, cs[k].part);
+        bx += g.B * p.tiles_x * p.tiles_y;
+        a.bx_end[nc] = bx;
+        nc++;
         gf += 2e-9 * g.B * g.OHt * g.OWt * (double)g.M * g.Cin * g.Rt * g.St;
     }
+    a.n = nc;
     if (smem > 80 * 1024) return false;
-    dim3 grid((unsigned)bx, (unsigned)maxy, (unsigned)maxsplit);
-    {
+    if (nc > 0) {
+        dim3 grid((unsigned)bx, (unsigned)maxy, (unsigned)maxsplit);
         char nm[96];
-        snprintf(nm, sizeof nm, "k_conv_patch_multi<%d, %d, %d>", cs[0].p.bm, cs[0].p.ck, tps);
+        snprintf(nm, sizeof nm, "k_conv_patch_multi<%d, %d, %d>", cs[ref].p.bm, cs[ref].p.ck, tps);
         cctiming::Scope tsc(nm, gf, s);
-        dispatch_patch(cs[0].p.bm, cs[0].p.ck, tps, a, grid, smem, s);
+        dispatch_patch(cs[ref].p.bm, cs[ref].p.ck, tps, a, grid, smem, s);
     }
-    if (nsplit_any) hipLaunchKernelGGL(k_splitk_epilogue_multi, dim3((unsigned)ebx), dim3(256), 0, s, e);
+    if (epi_any) hipLaunchKernelGGL(k_splitk_epilogue_multi, dim3((unsigned)ebx), dim3(256), 0, s, e);
     return true;
 }
 
@@ -1783,6 +1820,7 @@ size_t cc_conv2d_dgrad_pack_floats(int B, int K, int OH, int OW, int C, int R, i
             if (!make_dgrad_class(g, py, px, nullptr, nullptr, nullptr, nullptr, B, K, OH, OW, 0, C, R, S, stride, pad, IH, IW, 0,
                                   w_k_stride, w_c_stride, 0, 1.f, 0.f))
                 continue;
+            if (g.Cin == 0) continue;                    // no tap reaches this parity class (1x1 stride 2): epilogue only, no image
             const ConvPlan p = plan_conv(g);
             if (!p.use_patch) return 0;
             tot += p.wp_floats;
@@ -1800,6 +1838,7 @@ int cc_conv2d_dgrad_pack_desc(int B, int K, int OH, int OW, int C, int R, int S,
             if (!make_dgrad_class(g, py, px, nullptr, nullptr, nullptr, nullptr, B, K, OH, OW, 0, C, R, S, stride, pad, IH, IW, 0,
                                   w_k_stride, w_c_stride, 0, 1.f, 0.f))
                 continue;
+            if (g.Cin == 0) continue;
             const ConvPlan p = plan_conv(g);
             if (!p.use_patch) return 0;
             fill_desc(g, p, src_ptr, pack_base_ptr + off * (long)sizeof(float), desc_out_host + 16 * n);
@@ -1900,7 +1939,12 @@ static int dgrad_group_impl(int G, const long* gy, const long* w, const long* bi
                     if (mul && mul[k]) { g.add = (const float*)add[k]; g.add_bs = add_bs; }
                     else { g.res = (const float*)add[k]; g.res_bs = add_bs; g.res_mul = 0; }
                 }
-                if (pk) {
+                if (g.Cin == 0) {                       // result = epilogue of zero
+                    const long total = (long)g.B * g.M * g.OHt * g.OWt;
+                    hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)nullptr,
+                                       0, total, g.bias, g.res, g.y, g.M, g.OHt, g.OWt, g.so, g.oy0, g.ox0, g.OH, g.OW, g.y_bs, g.res_bs,
+                                       total, g.act, g.act_a, g.act_b, g.res_mul, g.add, g.add_bs);
+                } else if (pk) {
                     const ConvPlan p = plan_conv(g);
                     launch_gg(g, wk, s, pk + off, pk);
                     off += (long)p.wp_floats;

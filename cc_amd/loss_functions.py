@@ -105,13 +105,15 @@ def _off(t, nfloats):
 MAX_JOBS = 24
 
 _nan_flags = []
+_sticky_nan = {}          # device -> 1-element flag: OR of the flags that left the bounded list unchecked
 
 
 def check_finite(persistent=()):
     """Deferred form of the reference's ``assert((loss == loss).item() == 1)`` (one host sync).  `persistent`: flag
     tensors that a captured hipGraph step rewrites at every replay (CCTrainer keeps them; they are never dropped)."""
-    flags = list(_nan_flags) + list(persistent)
+    flags = list(_nan_flags) + list(persistent) + list(_sticky_nan.values())
     del _nan_flags[:]
+    _sticky_nan.clear()
     bad = bool(torch.stack([f.reshape(()) for f in flags]).ne(0).any().item()) if flags else False
     assert not bad, "NaN encountered in a photometric loss term"
 
@@ -128,8 +130,16 @@ def _register_nan_flag(flag):
         assert flag.item() == 0, "NaN encountered in a photometric loss term"
     else:
         _nan_flags.append(flag)
-        if len(_nan_flags) > 64:
-            del _nan_flags[:-64]
+        if len(_nan_flags) > 96 and not (flag.is_cuda and torch.cuda.is_current_stream_capturing()):
+            # a caller that checks rarely (or never): the oldest flags are OR-ed into one sticky flag per device instead of
+            # being dropped, so that an early NaN still fails the next check_finite()
+            old, keep = _nan_flags[:-64], _nan_flags[-64:]
+            del _nan_flags[:]
+            _nan_flags.extend(keep)
+            for dev in {f.device for f in old}:
+                m = torch.stack([f.reshape(()) for f in old if f.device == dev]).ne(0).any().to(torch.float32).reshape(1)
+                prev = _sticky_nan.get(dev)
+                _sticky_nan[dev] = m if prev is None else torch.maximum(prev, m)
 
 
 class _PyramidCache:

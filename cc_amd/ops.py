@@ -238,6 +238,10 @@ def _wgrad_group(a_list, x_list, gw_list, ref, B, M, AH, AW, a_bs, Cin, IH, IW, 
     a1, a2, a3 = _parr(a_list), _parr(x_list), _parr(gw_list)
     if accumulate and wgrad_queue.enabled and not _NO_DEFER:
         ptrs = [t.data_ptr() for t in gw_list]
+        if len(set(ptrs)) != len(ptrs):                    # one weight twice in ONE launch: its two `gw +=` would race -> one by one
+            for a, x, gw in zip(a_list, x_list, gw_list):
+                _wgrad_group([a], [x], [gw], ref, B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, accumulate)
+            return
         if wgrad_reduces.targets.intersection(ptrs):      # a weight used twice in one stage: two parked `gw +=` would race
             wgrad_reduces.flush()
         wgrad_reduces.targets.update(ptrs)

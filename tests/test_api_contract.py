@@ -130,3 +130,29 @@ def test_checkpoint_wire_format(tmp_path):
     assert float(tr3.opt.step_dev) == 1.0
     os.remove(os.path.join(tmp_path, "optimizer_checkpoint.pth.tar"))
     assert utils.resume_optimizer(tmp_path, tr3) is False
+
+
+def test_nan_flags_are_never_dropped_unchecked():
+    """a caller that checks rarely still sees an early NaN -- flags leaving the bounded list are OR-ed into a sticky
+    flag instead of being deleted (the reference asserts on every term, loss_functions.py:60,105,115)."""
+    from cc_amd import loss_functions as LF
+    LF._nan_flags.clear()
+    LF._sticky_nan.clear()
+    LF._register_nan_flag(torch.ones(1))
+    for _ in range(300):
+        LF._register_nan_flag(torch.zeros(1))
+    assert len(LF._nan_flags) <= 97
+    with pytest.raises(AssertionError):
+        LF.check_finite()
+    LF.check_finite()                      # the failed check consumed the flags
+
+
+def test_engine_rejects_strided_views_where_no_batch_stride_is_passed():
+    """channel slices are read in place only by entry points that take a batch stride."""
+    from cc_amd import _lib
+    e = _lib.Engine(require_device=False)
+    wide = torch.zeros(2, 8, 4, 6)
+    sl = wide[:, 2:5]
+    assert e._ptr(sl, "cc_conv2d_fwd", 0) == sl.data_ptr()
+    with pytest.raises(ValueError):
+        e._ptr(sl, "cc_ssim_fwd", 0)
