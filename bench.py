@@ -36,8 +36,8 @@ PEAK_HBM = 8000.0       # GB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="per-GPU mini-batch")
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=832)
