@@ -397,6 +397,13 @@ __global__ __launch_bounds__(256) void k_repack_table(const long* __restrict__ d
 // 32 MFMAs (2 k cycles) and the LDS-read latency + barrier skew at every stage boundary costs ~10-15 %; TPS = 3 (a whole
 // tap row of a 3x3) amortises it 3x for 32 KB more LDS (still two workgroups per CU).
 // SPLIT: 0 = whole reduction in this workgroup (fused epilogue), 1 = split-K partial slabs, 2 = decided per class at run time
+#if defined(CC_ABLATE_DMA) || defined(CC_ABLATE_LDS) || defined(CC_ABLATE_BARRIER) || defined(CC_ABLATE_MFMA)
+// ablation builds compute garbage: keep it finite and tiny so that the rest of the step runs at its normal speed
+__device__ __forceinline__ float abl_fix(float v) { return (v == v && fabsf(v) < 1e30f) ? 1e-6f * fminf(fmaxf(v, -1.f), 1.f) : 0.f; }
+#else
+__device__ __forceinline__ float abl_fix(float v) { return v; }
+#endif
+
 template <int BM, int CK, int TPS, int SPLIT>
 __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
     constexpr int WM = (BM >= 64) ? BM / 2 : 32;
@@ -510,9 +517,11 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
             int ti = 0, tj = 0;
             for (int tap0 = 0; tap0 < T; tap0 += TPS, s++) {
                 // prefetch the next stage's operands (other buffers; their last readers passed the previous barrier)
+#ifndef CC_ABLATE_DMA          // ablation builds (tools/ablate_conv.sh): timing only, results are garbage
                 if (tap0 + TPS < T) load_A(chunk, tap0 + TPS, (s + 1) & 1);
                 else if (chunk + 1 < c_end) load_A(chunk + 1, 0, (s + 1) & 1);
                 if (tap0 == 0 && chunk + 1 < c_end) load_patch(chunk + 1, (chunk + 1) & 1);
+#endif
 #pragma unroll
                 for (int tt = 0; tt < TPS; tt++) {
                     if (tap0 + tt < T) {
@@ -547,10 +556,17 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
                         float af[CK / 2][TM], bf[CK / 2][TN];
 #pragma unroll
                         for (int ks = 0; ks < CK / 2; ks++) {
+#ifdef CC_ABLATE_LDS
+#pragma unroll
+                            for (int a = 0; a < TM; a++) af[ks][a] = 1e-3f * (float)((lane & 7) + a);
+#pragma unroll
+                            for (int b = 0; b < TN; b++) bf[ks][b] = 1e-3f * (float)((lane & 3) + b);
+#else
 #pragma unroll
                             for (int a = 0; a < TM; a++) af[ks][a] = Al[(2 * ks) * BM + a * 32];
 #pragma unroll
                             for (int b = 0; b < TN; b++) bf[ks][b] = Pl[(2 * ks) * g.PS + (g.si * rowstep * b) * g.PWr];
+#endif
                         }
 #pragma unroll
                         for (int ks = 0; ks < CK / 2; ks++) {
@@ -558,13 +574,19 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
                             for (int a = 0; a < TM; a++)
 #pragma unroll
                                 for (int b = 0; b < TN; b++)
+#ifdef CC_ABLATE_MFMA      // one VALU multiply-add instead of the 64-cycle matrix instruction: what the step costs WITHOUT the matrix work
+                                    acc[a][b][0] = fmaf(af[ks][a], bf[ks][b], acc[a][b][0]);
+#else
                                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks][a], bf[ks][b], acc[a][b], 0, 0, 0);
+#endif
                         }
                         if (++tj == g.St) { tj = 0; ti++; }
                     }
                 }
                 CC_WAIT_VMCNT0();
+#ifndef CC_ABLATE_BARRIER
                 __syncthreads();
+#endif
             }
         }
     }
@@ -584,9 +606,9 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
                 const int m = m0 + 4 * (lane >> 4) + r;
                 if (m >= g.M) continue;
                 if (SPLIT == 1 || (SPLIT == 2 && g.nsplit > 1)) {
-                    g.part[(long)blockIdx.z * g.part_stride + ((long)n * g.M + m) * HWt + (long)ty * g.OWt + tx] = acc16[h][r];
+                    g.part[(long)blockIdx.z * g.part_stride + ((long)n * g.M + m) * HWt + (long)ty * g.OWt + tx] = abl_fix(acc16[h][r]);
                 } else {
-                    float v = acc16[h][r];
+                    float v = abl_fix(acc16[h][r]);
                     if (g.bias) v += g.bias[m];
                     const long o = (long)n * g.y_bs + pix + (long)m * y_cs;
                     const bool hr = g.res != nullptr;
@@ -613,7 +635,7 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int m = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    if (m < g.M) pb[(long)m * HWt] = acc[a][b][r];
+                    if (m < g.M) pb[(long)m * HWt] = abl_fix(acc[a][b][r]);
                 }
         } else {
             float* yb = g.y + (long)n * g.y_bs + pix;
@@ -625,7 +647,7 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
                 for (int r = 0; r < 16; r++) {
                     const int m = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                     if (m < g.M) {
-                        float v = acc[a][b][r];
+                        float v = abl_fix(acc[a][b][r]);
                         if (g.bias) v += g.bias[m];
                         yb[(long)m * y_cs] = conv_tail(v, rbp != nullptr, rbp ? rbp[(long)m * y_cs] : 0.f, g.res_mul, g.act, g.act_a, g.act_b,
                                                        abp ? abp[(long)m * y_cs] : 0.f);
