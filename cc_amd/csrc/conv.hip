@@ -22,6 +22,7 @@
 // deterministic second-stage reduction (no atomics).
 #include <stdio.h>
 #include <stdlib.h>
+#include <stddef.h>
 #include <string.h>
 #include "cc_common.h"
 #include "conv_internal.h"
@@ -292,6 +293,7 @@ struct CP {
     int act; float act_a, act_b;
     int res_mul;
     const float* add; long add_bs;
+    int vec4;              // fused epilogue may use 16-byte accesses: unit lattice stride, rows 16-byte aligned in y / res / add
 };
 
 // wp[(t*Cpad + c)*Mpad + m] = w[w0 + m*w_sm + c*w_sc + i*w_ri + j*w_sj]  (0 beyond Cin / M), t = i*St + j
@@ -606,7 +608,8 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
                 const int m = m0 + 4 * (lane >> 4) + r;
                 if (m >= g.M) continue;
                 if (SPLIT == 1 || (SPLIT == 2 && g.nsplit > 1)) {
-                    g.part[(long)blockIdx.z * g.part_stride + ((long)n * g.M + m) * HWt + (long)ty * g.OWt + tx] = abl_fix(acc16[h][r]);
+                    const int Wp16 = g.tiles_x * (g.tw16 ? 16 : TW), Hp16 = g.tiles_y * (g.tw16 ? 8 : TH);      // padded slab rows
+                    g.part[(long)blockIdx.z * g.part_stride + (((long)n * g.M + m) * Hp16 + ty) * Wp16 + tx] = abl_fix(acc16[h][r]);
                 } else {
                     float v = abl_fix(acc16[h][r]);
                     if (g.bias) v += g.bias[m];
@@ -619,41 +622,101 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
         }
         return;
     }
-    // ---- epilogue: D col = lane&31 -> tx, row -> channel
-    const int tx = tx0 + lc;
+    // ---- epilogue (round 3): 16-byte stores.  The MFMA result has one PIXEL per lane and 16 channel rows per register set: storing
+    // it as it lies costs 16 scalar stores per 32x32 tile (64 per wave).  Each tile goes through a wave-private 4 KB LDS block
+    // (free after the main loop's last barrier) and comes back as float4 = 4 consecutive pixels of one channel row: 4 dwordx4
+    // stores per tile; residual / add / mul operands are read as float4 the same way (same-box A/B: -0.22 ms/step).
+    //   write: lane (pixel c = lane & 31, half lk) -> T[row][c], row = (r & 3) + 8 * (r >> 2) + 4 * lk   (32 consecutive floats per
+    //          32-lane group: conflict-free);  read k = 0..3: lane -> row 8k + (lane >> 3), columns 4 * (lane & 7) .. +3.
+    // Partial slabs (split-K) are padded to whole tiles, [split][n][m][tiles_y * th][tiles_x * tw]: every 16-byte store is aligned and
+    // in bounds without a guard.
+    float* Tt = smem + wid * 1024;
+    const int c4 = (lane & 7) * 4, rsub = lane >> 3;
+    const int lr4 = g.tw16 ? (c4 >> 4) : 0, lc4 = g.tw16 ? (c4 & 15) : c4;
+    const int tx = tx0 + lc4;
+    const int Wp = g.tiles_x * (g.tw16 ? 16 : TW), Hp = g.tiles_y * (g.tw16 ? 8 : TH);
+    const bool split = (SPLIT == 1 || (SPLIT == 2 && g.nsplit > 1));
+    const bool vec = g.vec4 != 0;       // 16-byte path of the fused epilogue (decided on the host, make_cp)
+    // One 32x32 accumulator tile at a time, called with literal (a, b): a loop over acc[a][b] that the compiler does not fully unroll
+    // sends the accumulators to scratch memory -- in the MAIN loop as well.  Split and fused forms are separate code paths behind one
+    // uniform branch, so that neither keeps the other's operands alive (the multi-problem kernel is at the SGPR limit).
+    auto stage = [&](const f32x16& A) {
 #pragma unroll
-    for (int b = 0; b < TN; b++) {
-        const int ty = ty0 + rowstep * (row0 + b) + lr;
-        if (ty >= g.OHt || tx >= g.OWt) continue;
-        const long pix = (long)(g.oy0 + g.so * ty) * g.OW + (g.ox0 + g.so * tx);
-        if (SPLIT == 1 || (SPLIT == 2 && g.nsplit > 1)) {
-            // partial slabs are dense over the LATTICE: [split][n][m][ty*OWt + tx]
-            const int HWt = g.OHt * g.OWt;
-            float* pb = g.part + (long)blockIdx.z * g.part_stride + ((long)n * g.M) * HWt + (long)ty * g.OWt + tx;
+        for (int r = 0; r < 16; r++) Tt[((r & 3) + 8 * (r >> 2) + 4 * lk) * 32 + l31] = abl_fix(A[r]);
+        __builtin_amdgcn_wave_barrier();
+    };
+    if (split) {
+        auto tile = [&](const f32x16& A, const int a, const int b) {
+            stage(A);
+            const int ty = ty0 + rowstep * (row0 + b) + lr4;
+            float* pb = g.part + (long)blockIdx.z * g.part_stride + (((long)n * g.M + (m0 + wm * WM + a * 32 + rsub)) * Hp + ty) * Wp + tx;
+            const long mstep = (long)8 * Hp * Wp;
 #pragma unroll
-            for (int a = 0; a < TM; a++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int m = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    if (m < g.M) pb[(long)m * HWt] = abl_fix(acc[a][b][r]);
+            for (int k = 0; k < 4; k++) {
+                const float4 v = *reinterpret_cast<const float4*>(&Tt[(8 * k + rsub) * 32 + c4]);
+                if (m0 + wm * WM + a * 32 + 8 * k + rsub < g.M) {
+                    *reinterpret_cast<float4*>(pb + k * mstep) = v;
+#ifdef CC_ABLATE_STORE
+                    *reinterpret_cast<volatile float4*>(pb + k * mstep) = v;
+#endif
                 }
-        } else {
-            float* yb = g.y + (long)n * g.y_bs + pix;
-            const float* rbp = g.res ? g.res + (long)n * g.res_bs + pix : nullptr;
-            const float* abp = g.add ? g.add + (long)n * g.add_bs + pix : nullptr;
-#pragma unroll
-            for (int a = 0; a < TM; a++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int m = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    if (m < g.M) {
-                        float v = abl_fix(acc[a][b][r]);
-                        if (g.bias) v += g.bias[m];
-                        yb[(long)m * y_cs] = conv_tail(v, rbp != nullptr, rbp ? rbp[(long)m * y_cs] : 0.f, g.res_mul, g.act, g.act_a, g.act_b,
-                                                       abp ? abp[(long)m * y_cs] : 0.f);
-                    }
-                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        tile(acc[0][0], 0, 0);
+        if constexpr (TN > 1) tile(acc[0][1], 0, 1);
+        if constexpr (TM > 1) {
+            tile(acc[1][0], 1, 0);
+            if constexpr (TN > 1) tile(acc[1][1], 1, 1);
         }
+        return;
+    }
+    const bool hr = g.res != nullptr, ha = g.add != nullptr;
+    auto tile = [&](const f32x16& A, const int a, const int b) {
+        stage(A);
+        const int ty = ty0 + rowstep * (row0 + b) + lr4;
+        const bool inside = ty < g.OHt && tx < g.OWt;
+        const long pix = (long)(g.oy0 + g.so * ty) * g.OW + (g.ox0 + g.so * tx);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float4 v = *reinterpret_cast<const float4*>(&Tt[(8 * k + rsub) * 32 + c4]);
+            const int m = m0 + wm * WM + a * 32 + 8 * k + rsub;
+            if (m < g.M && inside) {
+                const long o = (long)m * y_cs + pix;
+                const float bias = g.bias ? g.bias[m] : 0.f;
+                const float v0 = v.x + bias, v1 = v.y + bias, v2 = v.z + bias, v3 = v.w + bias;
+                if (vec && tx + 3 < g.OWt) {
+                    float4 rr = make_float4(0.f, 0.f, 0.f, 0.f), aa = rr;
+                    if (hr) rr = *reinterpret_cast<const float4*>(g.res + (long)n * g.res_bs + o);
+                    if (ha) aa = *reinterpret_cast<const float4*>(g.add + (long)n * g.add_bs + o);
+                    float4 out;
+                    out.x = conv_tail(v0, hr, rr.x, g.res_mul, g.act, g.act_a, g.act_b, aa.x);
+                    out.y = conv_tail(v1, hr, rr.y, g.res_mul, g.act, g.act_a, g.act_b, aa.y);
+                    out.z = conv_tail(v2, hr, rr.z, g.res_mul, g.act, g.act_a, g.act_b, aa.z);
+                    out.w = conv_tail(v3, hr, rr.w, g.res_mul, g.act, g.act_a, g.act_b, aa.w);
+                    *reinterpret_cast<float4*>(g.y + (long)n * g.y_bs + o) = out;
+#ifdef CC_ABLATE_STORE
+                    *reinterpret_cast<volatile float4*>(g.y + (long)n * g.y_bs + o) = out;
+#endif
+                } else {
+                    const long st = g.so;
+                    float* yo = g.y + (long)n * g.y_bs + o;
+                    const float* ro = hr ? g.res + (long)n * g.res_bs + o : nullptr;
+                    const float* ao = ha ? g.add + (long)n * g.add_bs + o : nullptr;
+                    yo[0] = conv_tail(v0, hr, hr ? ro[0] : 0.f, g.res_mul, g.act, g.act_a, g.act_b, ao ? ao[0] : 0.f);
+                    if (tx + 1 < g.OWt) yo[st] = conv_tail(v1, hr, hr ? ro[st] : 0.f, g.res_mul, g.act, g.act_a, g.act_b, ao ? ao[st] : 0.f);
+                    if (tx + 2 < g.OWt) yo[2 * st] = conv_tail(v2, hr, hr ? ro[2 * st] : 0.f, g.res_mul, g.act, g.act_a, g.act_b, ao ? ao[2 * st] : 0.f);
+                    if (tx + 3 < g.OWt) yo[3 * st] = conv_tail(v3, hr, hr ? ro[3 * st] : 0.f, g.res_mul, g.act, g.act_a, g.act_b, ao ? ao[3 * st] : 0.f);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    tile(acc[0][0], 0, 0);
+    if constexpr (TN > 1) tile(acc[0][1], 0, 1);
+    if constexpr (TM > 1) {
+        tile(acc[1][0], 1, 0);
+        if constexpr (TN > 1) tile(acc[1][1], 1, 1);
     }
 }
 
@@ -688,7 +751,14 @@ __global__ __launch_bounds__(256, CC_PATCH_LB) void k_conv_patch_multi(CPM a) {
 #pragma unroll
     for (int q = 0; q < MAXCLS - 1; q++)
         if (q + 1 < a.n && (int)blockIdx.x >= a.bx_end[q]) { k = q + 1; first = a.bx_end[q]; }
+    // the class descriptor is read straight from the kernel-argument segment (scalar loads at a run-time offset): indexing the
+    // by-value argument `a.c[k]` makes the compiler copy descriptors to scratch memory once the body is large
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CC_HIPEMU)
+    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    const CP& g = *(reinterpret_cast<const CP*>(ka + offsetof(CPM, c)) + k);
+#else
     const CP& g = a.c[k];
+#endif
     if ((int)blockIdx.z >= g.nsplit || (int)blockIdx.y * BM >= g.Mpad) return;       // grid.y / grid.z are the launch's maxima
     conv_patch_body<BM, CK, TPS, 2>(g, (int)blockIdx.x - first);
 }
@@ -699,22 +769,9 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
                                                          float* __restrict__ y, int M, int OHt, int OWt, int so, int oy0,
                                                          int ox0, int OH, int OW, long y_bs, long res_bs, long total,
                                                          int act, float act_a, float act_b, int res_mul,
-                                                         const float* add, long add_bs) {
+                                                         const float* add, long add_bs, int Hp, int Wp) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
-    // eight partial loads in flight, added in split order (a one-by-one loop is a chain of nsplit dependent HBM/L2 latencies and
-    // this kernel is nothing else)
-    float v = 0.f;
-    {
-        for (int k = 0; k < nsplit; k += 8) {
-            float p8[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) p8[u] = (k + u < nsplit) ? part[(long)(k + u) * part_stride + e] : 0.f;
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (k + u < nsplit) v += p8[u];
-        }
-    }
     const int HWt = OHt * OWt;
     const long per = (long)M * HWt;
     const int n = (int)(e / per);
@@ -722,6 +779,21 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
     const int m = (int)(r / HWt);
     const int t = (int)(r - (long)m * HWt);
     const int ty = t / OWt, tx = t - ty * OWt;
+    // the slabs are padded to whole tiles: [split][n][m][Hp][Wp]
+    const long po = (((long)n * M + m) * Hp + ty) * Wp + tx;
+    // eight partial loads in flight, added in split order (a one-by-one loop is a chain of nsplit dependent HBM/L2 latencies and
+    // this kernel is nothing else)
+    float v = 0.f;
+    {
+        for (int k = 0; k < nsplit; k += 8) {
+            float p8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) p8[u] = (k + u < nsplit) ? part[(long)(k + u) * part_stride + po] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (k + u < nsplit) v += p8[u];
+        }
+    }
     const long o = (long)m * OH * OW + (long)(oy0 + so * ty) * OW + (ox0 + so * tx);
     if (bias) v += bias[m];
     y[(long)n * y_bs + o] = conv_tail(v, res != nullptr, res ? res[(long)n * res_bs + o] : 0.f, res_mul, act, act_a, act_b,
@@ -733,6 +805,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
 struct EPC {
     const float* part; const float* bias; const float* res; const float* add; float* y;
     int nsplit; long part_stride; int OHt, OWt, oy0, ox0; long total;
+    int Hp, Wp;                      // padded slab rows / pitch (whole tiles)
     int M, so, OH, OW; long y_bs, res_bs, add_bs;
     int act; float act_a, act_b;
     int res_mul;
@@ -751,17 +824,6 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_multi(EPM a) {
     const EPC& c = a.c[k];
     const long e = (long)((int)blockIdx.x - first) * 256 + threadIdx.x;
     if (e >= c.total) return;
-    float v = 0.f;
-    {
-        for (int z = 0; z < c.nsplit; z += 8) {      // see k_splitk_epilogue
-            float p8[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) p8[u] = (z + u < c.nsplit) ? c.part[(long)(z + u) * c.part_stride + e] : 0.f;
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (z + u < c.nsplit) v += p8[u];
-        }
-    }
     const int HWt = c.OHt * c.OWt;
     const long per = (long)c.M * HWt;
     const int n = (int)(e / per);
@@ -769,6 +831,18 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue_multi(EPM a) {
     const int m = (int)(r / HWt);
     const int t = (int)(r - (long)m * HWt);
     const int ty = t / c.OWt, tx = t - ty * c.OWt;
+    const long po = (((long)n * c.M + m) * c.Hp + ty) * c.Wp + tx;
+    float v = 0.f;
+    {
+        for (int z = 0; z < c.nsplit; z += 8) {      // see k_splitk_epilogue
+            float p8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) p8[u] = (z + u < c.nsplit) ? c.part[(long)(z + u) * c.part_stride + po] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (z + u < c.nsplit) v += p8[u];
+        }
+    }
     const long o = (long)m * c.OH * c.OW + (long)(c.oy0 + c.so * ty) * c.OW + (c.ox0 + c.so * tx);
     if (c.bias) v += c.bias[m];
     c.y[(long)n * c.y_bs + o] = conv_tail(v, c.res != nullptr, c.res ? c.res[(long)n * c.res_bs + o] : 0.f, c.res_mul, c.act, c.act_a, c.act_b,
@@ -828,6 +902,7 @@ inline ConvPlan plan_conv(const GG& g, int mult = 1) {
     // three taps per pipeline stage when the extra weight buffers still leave two workgroups per CU (2 x 80 KB)
     p.tps = (g.Rt * g.St >= 3 && smem_of(p.ck, 3) <= 80 * 1024 && !dbg_flag_early("CC_CONV_TPS1")) ? 3 : 1;
     p.smem = smem_of(p.ck, p.tps);
+    if (p.bm >= 32 && p.smem < 16384) p.smem = 16384;        // the epilogue transposes one 32x32 tile per wave through LDS
     p.use_patch = (p.smem <= 150 * 1024) && g.Cin > 0;
     p.Mpad = ((g.M + p.bm - 1) / p.bm) * p.bm;
     p.Cpad = ((g.Cin + p.ck - 1) / p.ck) * p.ck;
@@ -874,7 +949,8 @@ inline ConvPlan plan_conv(const GG& g, int mult = 1) {
             p.nsplit = (nchunk + p.cps - 1) / p.cps;
         }
     }
-    p.part_floats = p.nsplit > 1 ? (size_t)p.nsplit * g.B * g.M * g.OHt * g.OWt : 0;
+    // partial slabs are padded to whole tiles (16-byte stores without guards): [split][n][m][tiles_y * th][tiles_x * tw]
+    p.part_floats = p.nsplit > 1 ? (size_t)p.nsplit * g.B * g.M * (p.tiles_y * th) * (p.tiles_x * tw) : 0;
     return p;
 }
 
@@ -1578,9 +1654,13 @@ inline CP make_cp(const GG& g, const ConvPlan& p, const float* zeros, const floa
     c.OHt = g.OHt; c.OWt = g.OWt; c.so = g.so; c.oy0 = g.oy0; c.ox0 = g.ox0; c.OH = g.OH; c.OW = g.OW;
     c.y_bs = g.y_bs; c.res_bs = g.res_bs;
     c.tiles_x = p.tiles_x; c.tiles_y = p.tiles_y;
-    c.nsplit = p.nsplit; c.cps = p.cps; c.part_stride = (long)g.B * g.M * g.OHt * g.OWt;
+    c.nsplit = p.nsplit; c.cps = p.cps;
+    c.part_stride = (long)g.B * g.M * (p.tiles_y * (p.tw16 ? 8 : TH)) * (p.tiles_x * (p.tw16 ? 16 : TW));      // padded slabs
     c.act = g.act; c.act_a = g.act_a; c.act_b = g.act_b; c.res_mul = g.res_mul;
     c.add = g.add; c.add_bs = g.add_bs;
+    c.vec4 = (g.so == 1) && ((g.OW & 3) == 0) && ((g.ox0 & 3) == 0) && ((((uintptr_t)g.y) & 15) == 0) && ((g.y_bs & 3) == 0) &&
+             (!g.res || ((((uintptr_t)g.res) & 15) == 0 && (g.res_bs & 3) == 0)) &&
+             (!g.add || ((((uintptr_t)g.add) & 15) == 0 && (g.add_bs & 3) == 0));
     return c;
 }
 
@@ -1609,10 +1689,11 @@ inline void launch_gg(const GG& g, float* ws, hipStream_t s, const float* prepac
         dispatch_patch(p.bm, p.ck, p.tps, c, grid, p.smem, s);
     }
     if (p.nsplit > 1) {
-        const long total = c.part_stride;
+        const long total = (long)g.B * g.M * g.OHt * g.OWt;
         hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)part,
                            p.nsplit, c.part_stride, g.bias, g.res, g.y, g.M, g.OHt, g.OWt, g.so, g.oy0, g.ox0, g.OH, g.OW,
-                           g.y_bs, g.res_bs, total, g.act, g.act_a, g.act_b, g.res_mul, g.add, g.add_bs);
+                           g.y_bs, g.res_bs, total, g.act, g.act_a, g.act_b, g.res_mul, g.add, g.add_bs,
+                           p.tiles_y * (p.tw16 ? 8 : TH), p.tiles_x * (p.tw16 ? 16 : TW));
     }
 }
 
@@ -1623,7 +1704,10 @@ inline void launch_gg(const GG& g, float* ws, hipStream_t s, const float* prepac
 // weight image and partial-slab area of the class.
 struct ClsIn { GG g; ConvPlan p; const float* zeros; const float* wp; float* part; };
 
-inline size_t smem_cls(const ConvPlan& p, int tps) { return (size_t)(2 * tps * p.ck * p.bm + 2 * p.ck * p.PS) * sizeof(float); }
+inline size_t smem_cls(const ConvPlan& p, int tps) {
+    const size_t b = (size_t)(2 * tps * p.ck * p.bm + 2 * p.ck * p.PS) * sizeof(float);
+    return (p.bm >= 32 && b < 16384) ? 16384 : b;            // epilogue transpose: 4 KB per wave
+}
 
 inline bool launch_classes(const ClsIn* cs, int n, hipStream_t s, bool idle_taps = false) {
     if (n < 1 || n > MAXCLS) return false;
@@ -1653,10 +1737,12 @@ inline bool launch_classes(const ClsIn* cs, int n, hipStream_t s, bool idle_taps
         const bool empty = g.Cin == 0;
         EPC& c = e.c[k];
         c.part = empty ? nullptr : cs[k].part; c.bias = g.bias; c.res = g.res; c.add = g.add; c.y = g.y;
-        c.part_stride = (long)g.B * g.M * g.OHt * g.OWt;
+        c.Hp = empty ? g.OHt : p.tiles_y * (p.tw16 ? 8 : TH);
+        c.Wp = empty ? g.OWt : p.tiles_x * (p.tw16 ? 16 : TW);
+        c.part_stride = (long)g.B * g.M * c.Hp * c.Wp;
         c.nsplit = empty ? 0 : p.nsplit;
         c.OHt = g.OHt; c.OWt = g.OWt; c.oy0 = g.oy0; c.ox0 = g.ox0;
-        c.total = (empty || p.nsplit > 1) ? c.part_stride : 0;
+        c.total = (empty || p.nsplit > 1) ? (long)g.B * g.M * g.OHt * g.OWt : 0;
         c.M = g.M; c.so = g.so; c.OH = g.OH; c.OW = g.OW; c.y_bs = g.y_bs; c.res_bs = g.res_bs; c.add_bs = g.add_bs;
         c.act = g.act; c.act_a = g.act_a; c.act_b = g.act_b; c.res_mul = g.res_mul;
         ebx += (int)((c.total + 255) / 256);
@@ -1965,7 +2051,7 @@ static int dgrad_group_impl(int G, const long* gy, const long* w, const long* bi
                     const long total = (long)g.B * g.M * g.OHt * g.OWt;
                     hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)nullptr,
                                        0, total, g.bias, g.res, g.y, g.M, g.OHt, g.OWt, g.so, g.oy0, g.ox0, g.OH, g.OW, g.y_bs, g.res_bs,
-                                       total, g.act, g.act_a, g.act_b, g.res_mul, g.add, g.add_bs);
+                                       total, g.act, g.act_a, g.act_b, g.res_mul, g.add, g.add_bs, g.OHt, g.OWt);
                 } else if (pk) {
                     const ConvPlan p = plan_conv(g);
                     launch_gg(g, wk, s, pk + off, pk);
@@ -2092,7 +2178,7 @@ static void list_plan_splits(ListCls** cls, int n, int target) {
             p.cps = (int)((nchunk + want - 1) / want);
             p.nsplit = (nchunk + p.cps - 1) / p.cps;
         }
-        p.part_floats = p.nsplit > 1 ? (size_t)p.nsplit * g.B * g.M * g.OHt * g.OWt : 0;
+        p.part_floats = p.nsplit > 1 ? (size_t)p.nsplit * g.B * g.M * (p.tiles_y * (p.tw16 ? 8 : TH)) * (p.tiles_x * (p.tw16 ? 16 : TW)) : 0;
     }
 }
 

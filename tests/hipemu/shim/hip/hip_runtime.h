@@ -367,4 +367,6 @@ static inline void hipemu_glds(const void* src, void* dst, unsigned size) {
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define CC_HIPEMU 1
 #define __builtin_amdgcn_s_barrier() hipemu::block_barrier()
+#define __builtin_amdgcn_wave_barrier() hipemu::wave_barrier()
