@@ -221,6 +221,13 @@ def test_step_with_rccl_process_group_of_one(monkeypatch):
     try:
         tr, b1, b2, b3 = run()
         assert tr.split_graphs and tr.graph_b is not None
+        # the record the N > 1 bench line carries: exposed time of each segment's all-reduce (events around work.wait()),
+        # each segment alone on an idle device, their difference
+        alone = tr.calibrate_comm(reps=2)
+        st = tr.comm_stats()
+        assert len(alone) == 2 and all(a > 0 for a in alone)
+        assert st["steps_sampled"] == 3 and len(st["exposed_ms"]) == 2 and len(st["segments_mb"]) == 2
+        assert abs(sum(st["segments_mb"]) - 4e-6 * tr.opt.flat_g.numel()) < 0.2 and st["overlapped_ms"] >= 0
     finally:
         dist.destroy_process_group()
     for a, b in ((a1, b1), (a2, b2), (a3, b3)):
