@@ -397,8 +397,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs HIP devices (there is no CPU path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # CC_FORCE_COMM=1 on one GPU: a 1-rank RCCL group, so that the N > 1 code path (two graphs, segment all-reduces, the
+    # communication record of the JSON line) can be exercised where only one GPU is available
+    use_dist = world > 1 or os.environ.get("CC_FORCE_COMM", "0") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)     # nccl == RCCL on ROCm
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
@@ -425,7 +429,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -438,7 +442,7 @@ def main():
             if i < 2:
                 first_losses.append({k: float(v) for k, v in losses.items()})
             log("warm-up step %d done at %.1f s" % (i, time.perf_counter() - t_w))
-    comm_cal = tr.calibrate_comm() if world > 1 else None            # each segment's all-reduce alone (outside the timed region)
+    comm_cal = tr.calibrate_comm() if use_dist else None            # each segment's all-reduce alone (outside the timed region)
     sync()
     # per-step device time stamps: an event after every step on the compute stream (no host synchronisation inside the region)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -455,14 +459,14 @@ def main():
         return round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 3)
     step_ms = {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": round(per_step[0], 3), "max": round(per_step[-1], 3),
                "source": "HIP events after every step on the compute stream; `ms_per_step` is the wall-clock mean of the region"}
-    comm = tr.comm_stats() if world > 1 else None
+    comm = tr.comm_stats() if use_dist else None
     rank_losses = None
-    if world > 1:
+    if use_dist:
         lt = torch.tensor([float(losses["loss"])], device=dev, dtype=torch.float64)
         allv = [torch.zeros_like(lt) for _ in range(world)]
         dist.all_gather(allv, lt)
         rank_losses = [round(float(v.item()), 6) for v in allv]
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -542,7 +546,7 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "height": H, "width": W, "scales": 6,
                        "frames": 5, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph,
                        "trained_nets": "disp+pose (mask, flow frozen: README --fix-masknet --fix-flownet)" if args.freeze else "all",
-                       "loss": round(loss_val, 6), "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                       "loss": round(loss_val, 6), "rccl_ranks": dist.get_world_size() if use_dist else 1,
                        "rank_losses": rank_losses,
                        "dead_occlusion_decoders_elided": bool(args.elide_occ)},
             "step_ms": step_ms, "comm": comm,
@@ -562,7 +566,7 @@ def main():
             par["ok"] = bool(worst <= 1e-4) if par["steps_compared"] else None
             line["parity"] = par
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
