@@ -496,12 +496,17 @@ def main():
             # ran the timed region above keeps no state
             with _lib.use_library(tools_lib) as teng:
                 assert teng.fn["cc_is_tools_build"]() == 1
+                tr_e.step(batch)                       # first launches from this library image (code object load) stay untimed
+                torch.cuda.synchronize()
                 teng.call("cc_timing_enable", 1)
                 tr_e.step(batch)
                 torch.cuda.synchronize()
-                buf = ctypes.create_string_buffer(1 << 16)
-                nchar = teng.fn["cc_timing_collect"](ctypes.addressof(buf), 1 << 16)
+                buf = ctypes.create_string_buffer(1 << 18)
+                nchar = teng.fn["cc_timing_collect"](ctypes.addressof(buf), 1 << 18)
                 dev_lines = buf.raw[:nchar].decode().splitlines()
+                if os.environ.get("CC_TIMING_DUMP"):      # tools/layer_rates.py: the per-shape table (CC_TIMING_DETAIL=1)
+                    with open(os.environ["CC_TIMING_DUMP"], "w") as f:
+                        f.write("\n".join(dev_lines) + "\n")
         except (RuntimeError, OSError, AssertionError) as e:
             log("tools build unavailable (%r): no per-device-kernel timing" % (e,))
         dev_k = {}

@@ -43,8 +43,8 @@ static std::mutex mtx;
 struct Scope {
     hipEvent_t e1 = nullptr;
     hipStream_t s;
-    Scope(const char* name, double gflop, hipStream_t st) : s(st) {
-        if (!recs) return;
+    Scope(const char* name, double gflop, hipStream_t st, bool active = true) : s(st) {
+        if (!recs || !active) return;
         hipEvent_t e0 = nullptr;
         (void)hipEventCreate(&e0);
         (void)hipEventCreate(&e1);
@@ -58,7 +58,7 @@ struct Scope {
     ~Scope() { if (e1) (void)hipEventRecord(e1, s); }
 };
 #else
-struct Scope { Scope(const char*, double, hipStream_t) {} };      // product build: no registry, no events
+struct Scope { Scope(const char*, double, hipStream_t, bool = true) {} };      // product build: no registry, no events
 #endif
 }  // namespace cctiming
 
@@ -649,12 +649,15 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
         auto tile = [&](const f32x16& A, const int a, const int b) {
             stage(A);
             const int ty = ty0 + rowstep * (row0 + b) + lr4;
+            // the slab is padded so that every store is aligned and in bounds, but the padding is never read: quads that start
+            // outside the image are not written (the 2x7 / 4x13 layers would otherwise write 5-18x their partial sums)
+            const bool live = ty < g.OHt && tx < g.OWt;
             float* pb = g.part + (long)blockIdx.z * g.part_stride + (((long)n * g.M + (m0 + wm * WM + a * 32 + rsub)) * Hp + ty) * Wp + tx;
             const long mstep = (long)8 * Hp * Wp;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const float4 v = *reinterpret_cast<const float4*>(&Tt[(8 * k + rsub) * 32 + c4]);
-                if (m0 + wm * WM + a * 32 + 8 * k + rsub < g.M) {
+                if (m0 + wm * WM + a * 32 + 8 * k + rsub < g.M && live) {
                     *reinterpret_cast<float4*>(pb + k * mstep) = v;
 #ifdef CC_ABLATE_STORE
                     *reinterpret_cast<volatile float4*>(pb + k * mstep) = v;
@@ -1684,7 +1687,10 @@ inline void launch_gg(const GG& g, float* ws, hipStream_t s, const float* prepac
     dim3 grid((unsigned)(g.B * p.tiles_x * p.tiles_y), (unsigned)(p.Mpad / p.bm), (unsigned)p.nsplit);
     {
         char nm[96];
-        snprintf(nm, sizeof nm, "k_conv_patch<%d, %d, %d, %d>", p.bm, p.ck, p.tps, p.nsplit > 1 ? 1 : 0);
+        int nl = snprintf(nm, sizeof nm, "k_conv_patch<%d, %d, %d, %d>", p.bm, p.ck, p.tps, p.nsplit > 1 ? 1 : 0);
+        if (cctools::env_flag("CC_TIMING_DETAIL"))
+            snprintf(nm + nl, sizeof nm - nl, " B%d M%d C%d %dx%d t%d k%d wg%d", g.B, g.M, g.Cin, g.OHt, g.OWt, g.Rt * g.St, p.nsplit,
+                     (int)(grid.x * grid.y * grid.z));
         cctiming::Scope tsc(nm, 2e-9 * g.B * g.OHt * g.OWt * (double)g.M * g.Cin * g.Rt * g.St, s);
         dispatch_patch(p.bm, p.ck, p.tps, c, grid, p.smem, s);
     }
@@ -1761,8 +1767,26 @@ inline bool launch_classes(const ClsIn* cs, int n, hipStream_t s, bool idle_taps
     if (smem > 80 * 1024) return false;
     if (nc > 0) {
         dim3 grid((unsigned)bx, (unsigned)maxy, (unsigned)maxsplit);
-        char nm[96];
-        snprintf(nm, sizeof nm, "k_conv_patch_multi<%d, %d, %d>", cs[ref].p.bm, cs[ref].p.ck, tps);
+        char nm[224];
+        int nl = snprintf(nm, sizeof nm, "k_conv_patch_multi<%d, %d, %d>", cs[ref].p.bm, cs[ref].p.ck, tps);
+        if (cctools::env_flag("CC_TIMING_DETAIL")) {
+            // classes with the same geometry are counted, not repeated
+            for (int k = 0; k < n && nl < (int)sizeof nm - 48; k++) {
+                const GG& g = cs[k].g;
+                if (g.Cin == 0) continue;
+                int same = 0, first = 1;
+                for (int j = 0; j < n; j++) {
+                    const GG& h = cs[j].g;
+                    const bool eq = h.Cin == g.Cin && h.M == g.M && h.OHt == g.OHt && h.OWt == g.OWt && h.Rt * h.St == g.Rt * g.St &&
+                                    cs[j].p.nsplit == cs[k].p.nsplit;
+                    if (eq) { same++; if (j < k) first = 0; }
+                }
+                if (!first) continue;
+                nl += snprintf(nm + nl, sizeof nm - nl, " %dx[B%d M%d C%d %dx%d t%d k%d]", same, g.B, g.M, g.Cin, g.OHt, g.OWt,
+                               g.Rt * g.St, cs[k].p.nsplit);
+            }
+            snprintf(nm + nl, sizeof nm - nl, " wg%d", (int)(grid.x * grid.y * grid.z));
+        }
         cctiming::Scope tsc(nm, gf, s);
         dispatch_patch(cs[ref].p.bm, cs[ref].p.ck, tps, a, grid, smem, s);
     }
@@ -2234,8 +2258,9 @@ static int env_int(const char* name, int dflt) { return cctools::env_int(name, d
 
 inline W3Plan plan_w3(int B, int M, int AH, int AW, int Cin, int R, int S, int si, int pad, int IH, int IW, int G = 1) {
     W3Plan p = {};
-    p.ok = (R == 3 && S == 3 && si == 1 && pad == 1 && IH == AH && IW == AW && (AW % 4) == 0 && AW >= 16 && Cin >= 32 && M > 64 &&
-            !dbg_flag("CC_NO_WGRAD3X3"));   // measured (tools/wgrad_ablate.py): wins for M > 64 (1.2-1.45x), loses below
+    p.ok = (R == 3 && S == 3 && si == 1 && pad == 1 && IH == AH && IW == AW && (AW % 4) == 0 && AW >= 16 && Cin >= 32 && M >= env_int("CC_W3_MINM", 64) &&
+            !dbg_flag("CC_NO_WGRAD3X3"));   // measured (tools/wgrad_ablate.py): wins for M > 64 (1.2-1.45x), loses below 64;
+                                            // M = 64 (<2, 2> tiles): -0.2 ms/step against the thin / generic kernels (r3o A/B)
     if (!p.ok) return p;
     p.mt = (M > 64) ? 4 : ((M > 32 && Cin > 32) ? 2 : ((Cin > 64) ? 1 : 2));
     p.nbuf = 1;
@@ -2298,6 +2323,16 @@ static int wgrad_group_impl(int G, const long* a, const long* x, const long* gw,
     const size_t stride_f = cc_conv2d_wgrad_ws_bytes(B, M, AH, AW, Cin, R, S, si) / sizeof(float);
     {   // thin layers fill the chip on their own: one launch per problem
         bool thin = true;
+        char nm[128];
+        ccint::wgrad_thin_name(B, M, AH, AW, Cin, IH, IW, R, S, si, pad, nm, 64);
+        if (nm[0] && cctools::env_flag("CC_TIMING_DETAIL")) {
+            const size_t nl = strlen(nm);
+            snprintf(nm + nl, sizeof nm - nl, " G%d B%d M%d C%d %dx%d r%d s%d", G, B, M, Cin, AH, AW, R, si);
+        }
+        // (recorded only when the thin path is taken: the name is empty otherwise; alignment can still turn a problem away, then
+        // the record brackets nothing)
+        cctiming::Scope tsc(nm[0] ? nm : "k_wgrad_thin<declined>", nm[0] ? 2e-9 * G * B * AH * AW * (double)M * Cin * R * S : 0.0,
+                            nm[0] ? s : nullptr, nm[0] != 0);
         for (int k = 0; k < G && thin; k++)
             thin = ccint::wgrad_thin_launch((const float*)a[k], (const float*)x[k], (float*)gw[k], ws + k * stride_f, B, M, AH, AW, a_bs,
                                             Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, accumulate, s, sink);
@@ -2324,8 +2359,11 @@ static int wgrad_group_impl(int G, const long* a, const long* x, const long* gw,
         dim3 grid((unsigned)(((M + BM - 1) / BM) * (q.Cp32 / BC)), (unsigned)G, (unsigned)q.nsplit);
         w.dbg = env_int("CC_W3_DBG", 0);
         {
-            char nm[64];
-            snprintf(nm, sizeof nm, "k_wgrad3x3<%d, %d>", q.mt, 4 / q.mt);
+            char nm[128];
+            int nl = snprintf(nm, sizeof nm, "k_wgrad3x3<%d, %d>", q.mt, 4 / q.mt);
+            if (cctools::env_flag("CC_TIMING_DETAIL"))
+                snprintf(nm + nl, sizeof nm - nl, " G%d B%d M%d C%d %dx%d k%d wg%d", G, B, M, Cin, AH, AW, q.nsplit,
+                         (int)(grid.x * grid.y * grid.z));
             cctiming::Scope tsc(nm, 2e-9 * G * B * AH * AW * (double)M * Cin * 9, s);
             if (q.mt == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<4, 1>), grid, dim3(256), q.smem, s, w);
             else if (q.mt == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad3x3<2, 2>), grid, dim3(256), q.smem, s, w);
@@ -2396,8 +2434,11 @@ static int wgrad_group_impl(int G, const long* a, const long* x, const long* gw,
     g.pix_per_split = (int)pps;
     dim3 grid((unsigned)((Ntot + BN - 1) / BN), (unsigned)((M + bm - 1) / bm), (unsigned)(nsplit * G));
     {
-        char nm[64];
-        snprintf(nm, sizeof nm, "k_wgrad<%d>", bm);
+        char nm[128];
+        int nl = snprintf(nm, sizeof nm, "k_wgrad<%d>", bm);
+        if (cctools::env_flag("CC_TIMING_DETAIL"))
+            snprintf(nm + nl, sizeof nm - nl, " G%d B%d M%d C%d %dx%d r%d s%d k%ld wg%d", G, B, M, Cin, AH, AW, R, si, (long)nsplit,
+                     (int)(grid.x * grid.y * grid.z));
         cctiming::Scope tsc(nm, 2e-9 * G * B * AH * AW * (double)M * Cin * R * S, s);
         if (bm == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<128>), grid, dim3(256), 0, s, g);
         else if (bm == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<64>), grid, dim3(256), 0, s, g);

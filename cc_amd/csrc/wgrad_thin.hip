@@ -225,7 +225,8 @@ ThinPlan plan_thin(int B, int M, int AH, int AW, int Cin, int R, int S, int si) 
     p.ngm = (M + 15) / 16;
     p.ngc = (Cin + 15) / 16;
     const long P = (long)B * AH * AW;
-    if ((AW & 3) || p.ngm * p.ngc > env_int("CC_WGRAD_THIN_MAXCOMBO", 16) || P < env_int("CC_WGRAD_THIN_MINPIX", 8192) ||
+    // <= 15 (M, Cin) 16-channel combinations: the 64 x 64 layers (16) run faster on the 3x3 kernel's <2, 2> tiles (r3o A/B)
+    if ((AW & 3) || p.ngm * p.ngc > env_int("CC_WGRAD_THIN_MAXCOMBO", 15) || P < env_int("CC_WGRAD_THIN_MINPIX", 8192) ||
         (S == 7 && Cin < 8)) return p;
     p.ngt = (R + p.TR - 1) / p.TR;
     p.TS = p.TR * S;

@@ -9,12 +9,14 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "cc_amd", "csrc")
-BUILD = os.path.join(HERE, "_build")
+# CC_EMU_EXTRA="-DCC_LOADER_WAVE=1": a variant build of the kernel sources (A/B experiments) in its own directory
+EXTRA = os.environ.get("CC_EMU_EXTRA", "").split()
+BUILD = os.path.join(HERE, "_build" + ("_" + "".join(c if c.isalnum() else "_" for c in " ".join(EXTRA)) if EXTRA else ""))
 OUT = os.path.join(BUILD, "libccengine_emu.so")
 CXX = "/opt/rocm/lib/llvm/bin/clang++"
 FLAGS = ["-x", "c++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fopenmp", "-mfma", "-mavx2",
          "-Wno-unknown-attributes", "-Wno-unused-value", "-DCC_TOOLS",      # tools switches: tests steer kernel selection with them
-         "-I", os.path.join(HERE, "shim"), "-I", os.path.join(ROOT, "include")]
+         "-I", os.path.join(HERE, "shim"), "-I", os.path.join(ROOT, "include")] + EXTRA
 
 
 def build(only=None):
