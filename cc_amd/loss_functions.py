@@ -849,6 +849,33 @@ class _ScaleJobsFn(torch.autograd.Function):
         return (None,) + tuple(ctx.arena.scaled(gout))
 
 
+class _WeightedTotalFn(torch.autograd.Function):
+    """train.py:509 ``loss = w1*loss_1 + w2*loss_2 + ...`` over 0-dim device scalars: stack + dot (two launches) and ONE scaling
+    launch in the backward pass, instead of a multiply and an add per term in either direction."""
+
+    @staticmethod
+    def forward(ctx, wvec, *terms):
+        ctx.save_for_backward(wvec)
+        return torch.dot(torch.stack([t.reshape(()) for t in terms]), wvec)
+
+    @staticmethod
+    def backward(ctx, g):
+        (wvec,) = ctx.saved_tensors
+        return (None,) + tuple((g * wvec).unbind(0))
+
+
+_WVEC = {}
+
+
+def weighted_total(weights, terms):
+    """sum_i weights[i] * terms[i] (python floats x 0-dim tensors).  The weight vector lives on the device, built once per
+    (weights, device) -- never inside a stream capture: the trainer's eager warm-up steps come first."""
+    key = (tuple(float(w) for w in weights), terms[0].device)
+    if key not in _WVEC:
+        _WVEC[key] = torch.tensor(key[0], dtype=torch.float32, device=key[1])
+    return _WeightedTotalFn.apply(_WVEC[key], *terms)
+
+
 def _partials_for(shapes, planes_of):
     """Per-job partial-sum areas laid out back to back: -> (flat buffer allocator, [float offsets])."""
     offs, tot = [], 0

@@ -15,7 +15,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from . import config, models, ops
+from . import config, models, ops, tape
 from . import loss_functions as LF
 from ._lib import engine, STREAM
 from .inverse_warp import pose2flow
@@ -96,15 +96,18 @@ def cc_forward(nets, batch, cfg, keep=False, cut=None):
                                             lambda_oob=cfg.lambda_oob, qch=cfg.qch, wssim=cfg.wssim)   # :490
     l2 = LF.explainability_loss(exp_mask) if cfg.w2 > 0 else 0                         # :492-495
     if cfg.smoothness_type == "regular":                                               # :497-501
-        l3 = LF.smooth_loss(depth) + LF.smooth_loss(flow_fwd) + LF.smooth_loss(flow_bwd) + LF.smooth_loss(exp_mask)
+        l3s = [LF.smooth_loss(depth), LF.smooth_loss(flow_fwd), LF.smooth_loss(flow_bwd), LF.smooth_loss(exp_mask)]
     else:
-        l3 = LF.edge_aware_smoothness_loss(tgt, depth) + LF.edge_aware_smoothness_loss(tgt, flow_fwd)
-        l3 = l3 + LF.edge_aware_smoothness_loss(tgt, flow_bwd) + LF.edge_aware_smoothness_loss(tgt, exp_mask)
+        l3s = [LF.edge_aware_smoothness_loss(tgt, depth), LF.edge_aware_smoothness_loss(tgt, flow_fwd),
+               LF.edge_aware_smoothness_loss(tgt, flow_bwd), LF.edge_aware_smoothness_loss(tgt, exp_mask)]
+    with torch.no_grad():
+        l3 = torch.stack(l3s).sum()                                                    # reported; the total below takes the terms
     l4 = LF.photometric_flow_loss(tgt, refs[1:3], [flow_bwd, flow_fwd], flow_exp_mask,
                                   lambda_oob=cfg.lambda_oob, qch=cfg.qch, wssim=cfg.wssim)             # :503
     l5 = LF.consensus_depth_flow_mask(exp_mask, rig_bwd, rig_fwd, target, target,
                                       THRESH=cfg.THRESH, wbce=cfg.wbce)                # :506
-    loss = cfg.w1 * l1 + cfg.w2 * l2 + cfg.w3 * l3 + cfg.w4 * l4 + cfg.w5 * l5         # :509
+    terms = [(cfg.w1, l1)] + ([(cfg.w2, l2)] if cfg.w2 > 0 else []) + [(cfg.w3, t) for t in l3s] + [(cfg.w4, l4), (cfg.w5, l5)]
+    loss = LF.weighted_total([w for w, _ in terms], [t for _, t in terms])             # :509  w1*l1 + w2*l2 + w3*l3 + w4*l4 + w5*l5
     out.update(loss=loss, loss_1=l1, loss_2=l2, loss_3=l3, loss_4=l4, loss_5=l5)
     if keep:
         out.update(disparities=disparities, pose=pose, exp_mask=exp_mask, flow_fwd=flow_fwd, flow_bwd=flow_bwd,
@@ -221,6 +224,7 @@ class CCTrainer:
                 n.train()                                                   # train.py:438-441
         self.opt = FlatAdam(nets, cfg)
         self.opt.broadcast_from_rank0()
+        self.bn_counters = tape.BnCounters(nets)
         self.use_graph = use_graph
         self.graph = None
         self.graph_b = None
@@ -244,6 +248,8 @@ class CCTrainer:
     #   B: backward of MaskNet6 + Back2Future                                    -> all-reduce(flat_g[n_dp:]) (exposed)
     # The nets only meet in the losses, so the two backward stages are independent given the output gradients.
     def _stage_a(self, batch):
+        tape.BN_COUNTERS = self.bn_counters
+        self.bn_counters.begin()
         LF.pyramid_cache.clear()
         ops.packs.prepack_all()            # every conv layer's [tap][c][m] weight images, one launch (weights changed in Adam)
         self.opt.zero_grad()                                                # :566
@@ -251,6 +257,7 @@ class CCTrainer:
         LF.scalar_pool.begin(batch[0].device)
         cut = {}
         out = cc_forward(self.nets, batch, self.cfg, cut=cut)
+        self.bn_counters.commit()
         pairs = cut.get("dp", []) + cut.get("mf", [])
         g = torch.autograd.grad(out["loss"], [d for _, d in pairs], allow_unused=True) if pairs else ()   # :567, losses only
         ndp = len(cut.get("dp", []))
@@ -269,6 +276,7 @@ class CCTrainer:
         ops.wgrad_queue.flush()
 
     def _stage_end(self):
+        tape.BN_COUNTERS = None
         ops.wgrad_queue.flush()
         ops.wgrad_queue.enabled = False
         LF.scalar_pool.end()

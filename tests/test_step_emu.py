@@ -38,6 +38,22 @@ def test_full_cc_step_matches_oracle():
         po = torch.cat([p.detach().reshape(-1) for n in onets for p in n.parameters()])
         d = (tr.opt.flat_p[:po.numel()] - po).abs()
         assert float((d > 1e-6).float().mean()) < 1e-3 and float(d.max()) <= 2.001e-4, (float((d > 1e-6).float().mean()), float(d.max()))
+        # module buffers after the step: BatchNorm running statistics and num_batches_tracked (the trainer keeps the counters of
+        # all layers in one buffer and bumps them with one add) -- same keys, same values as the reference modules'
+        nb = 0
+        for a, b in zip(nets, onets):
+            sa, sb = a.state_dict(), b.state_dict()
+            assert list(sa.keys()) == list(sb.keys())
+            for k in sb:
+                if k.endswith("num_batches_tracked"):
+                    assert sa[k].shape == sb[k].shape and int(sa[k]) == int(sb[k]) == 1, k
+                    nb += 1
+                elif "running_" in k:
+                    assert torch.allclose(sa[k], sb[k], rtol=1e-4, atol=1e-6), k
+        assert nb == 13
+        got2 = tr.step(batch)
+        assert all(int(v) == 2 for k, v in nets[0].state_dict().items() if k.endswith("num_batches_tracked"))
+        assert abs(float(got2["loss"])) < 1e3
 
 
 def test_flat_adam_matches_torch_adam():
