@@ -2595,6 +2595,57 @@ int cc_conv2d_wgrad_kernel(int B, int M, int AH, int AW, int Cin, int IH, int IW
     return CC_OK;
 }
 
+// Bias gradients of a whole backward stage in ONE launch.  With the activation derivative applied in the data-gradient epilogues
+// (planned backward), the per-layer pass left over is a pure reduction of the pre-activation gradient over (B, H, W): 84 launches
+// of 5-8 us per step.  The trainer parks them (the gradients stay alive for the parked weight-gradient launches anyway) and
+// cc_bias_grad_table sums up to NBJ layers per launch; per-chunk partials are finished by cc_wgrad_reduce_table (kind 4), small
+// maps are written directly -- block decomposition and summation order are k_act_bwd's.
+constexpr int NBJ = 32;
+struct BJ {
+    const float* gy; float* partial; float* gbias; long gy_bs;
+    int B, C, HW, cpp, single, accum, vec4, blk_end;
+};
+struct BT { BJ j[NBJ]; int n; };
+
+__global__ __launch_bounds__(256) void k_bias_table(BT t) {
+    __shared__ float red[4];
+    int k = 0, first = 0;
+#pragma unroll 1
+    for (int q = 0; q + 1 < t.n; q++)
+        if ((int)blockIdx.x >= t.j[q].blk_end) { k = q + 1; first = t.j[q].blk_end; }
+    const BJ& j = t.j[k];
+    const int bid = (int)blockIdx.x - first;
+    const int per_m = j.single ? 1 : j.B * j.cpp;                 // workgroups per channel
+    const int m = bid / per_m, rem = bid - m * per_m;
+    const int zimg = j.single ? 0 : rem / j.cpp, chunk = j.single ? 0 : rem - zimg * j.cpp;
+    const int cpp = j.single ? 1 : j.cpp, nb = j.single ? j.B : 1, HW = j.HW;
+    float s[1] = {0.f};
+    for (int nn = 0; nn < nb; nn++) {
+        const float* __restrict__ gp = j.gy + (long)(zimg + nn) * j.gy_bs + (long)m * HW;
+        if (j.vec4) {
+            const int nq = HW >> 2, stp = cpp * 256;
+            for (int q0 = chunk * 256 + threadIdx.x; q0 < nq; q0 += 4 * stp) {
+                float4 gg[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int q = q0 + u * stp;
+                    gg[u] = (q < nq) ? ((const float4*)gp)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (q0 + u * stp < nq) s[0] += (gg[u].x + gg[u].y) + (gg[u].z + gg[u].w);
+            }
+        } else {
+            for (int e = chunk * 256 + threadIdx.x; e < HW; e += cpp * 256) s[0] += gp[e];
+        }
+    }
+    cc::block_sum_256<1>(s, red);
+    if (threadIdx.x == 0) {
+        if (j.single) j.gbias[m] = j.accum ? (j.gbias[m] + s[0]) : s[0];
+        else j.partial[(long)m * (j.cpp * j.B) + zimg * j.cpp + chunk] = s[0];
+    }
+}
+
 size_t cc_act_bwd_ws_bytes(int C) { return (size_t)C * 64 * sizeof(float); }
 
 /* geff = gy * act'(y) (geff may alias gy or be null), gbias[c] = sum_{n,p} geff (gbias may be null).
@@ -2672,6 +2723,57 @@ int cc_act_bwd_bias_group_defer(int G, const long* gy, const long* y, const long
                                      stream, &sink);
     *nred_host = sink.n;
     return rc;
+}
+
+/* Bias gradient gbias[c] (+)= sum_{n,h,w} gy[n,c,h,w], parked: nothing is launched.  job_host[12] receives the job for
+ * cc_bias_grad_table; when the map is large enough to be summed in chunks, red_host[16] receives the descriptor of the second
+ * stage for cc_wgrad_reduce_table and *nred_host = 1 (else 0).  ws: cc_act_bwd_ws_bytes(C) bytes, untouched until both ran. */
+int cc_bias_grad_defer(const float* gy, float* gbias, float* ws, int B, int C, int H, int W, long gy_bs, int accumulate,
+                       long* job_host, long* red_host, int* nred_host) {
+    if (!gy || !gbias || !job_host || !red_host || !nred_host || B <= 0 || B > 64 || C <= 0 || H <= 0 || W <= 0) return CC_ERR_ARG;
+    const int HW = H * W;
+    int cpp = (HW + 8191) / 8192;                       // as act_bwd_bias_impl
+    const int cap = 64 / B > 0 ? 64 / B : 1;
+    cpp = cpp < 1 ? 1 : (cpp > cap ? cap : cpp);
+    const bool vec4 = (HW % 4 == 0) && (gy_bs % 4 == 0) && (((uintptr_t)gy) % 16 == 0);
+    // one workgroup per channel (no second stage) only where it walks <= 4096 elements: in a table launch the longest job
+    // sets the duration (k_act_bwd's own threshold is 32768: there a second launch would cost more than the walk)
+    const bool single = (long)B * HW <= 4096;
+    if (!single && !ws) return CC_ERR_ARG;
+    const long job[12] = {(long)gy, single ? 0 : (long)ws, (long)gbias, gy_bs, B, C, HW, cpp, single ? 1 : 0, accumulate ? 1 : 0,
+                          vec4 ? 1 : 0, 0};
+    for (int i = 0; i < 12; i++) job_host[i] = job[i];
+    *nred_host = 0;
+    if (!single) {
+        const long d[ccint::RD_LONGS] = {4, (long)ws, (long)gbias, (long)cpp * B, accumulate ? 1 : 0, 0, 0, C};
+        for (int i = 0; i < ccint::RD_LONGS; i++) red_host[i] = d[i];
+        *nred_host = 1;
+    }
+    return CC_OK;
+}
+
+/* Run n parked bias-gradient jobs (12 longs each, from cc_bias_grad_defer): one launch per 32. */
+int cc_bias_grad_table(const long* jobs_host, int n, void* stream) {
+    if (!jobs_host || n <= 0) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    for (int j0 = 0; j0 < n; j0 += NBJ) {
+        BT t = {};
+        int bx = 0;
+        t.n = n - j0 < NBJ ? n - j0 : NBJ;
+        for (int k = 0; k < t.n; k++) {
+            const long* d = jobs_host + (long)(j0 + k) * 12;
+            BJ& j = t.j[k];
+            j.gy = (const float*)d[0]; j.partial = (float*)d[1]; j.gbias = (float*)d[2]; j.gy_bs = d[3];
+            j.B = (int)d[4]; j.C = (int)d[5]; j.HW = (int)d[6]; j.cpp = (int)d[7]; j.single = (int)d[8]; j.accum = (int)d[9];
+            j.vec4 = (int)d[10];
+            if (!j.gy || !j.gbias || j.B <= 0 || j.C <= 0 || j.HW <= 0 || j.cpp <= 0 || (!j.single && !j.partial)) return CC_ERR_ARG;
+            bx += j.single ? j.C : j.C * j.B * j.cpp;
+            j.blk_end = bx;
+        }
+        hipLaunchKernelGGL(k_bias_table, dim3((unsigned)bx), dim3(256), 0, s, t);
+    }
+    CC_CHECK_LAUNCH();
+    return CC_OK;
 }
 
 int cc_act_bwd_bias(const float* gy, const float* y_or_null, float* geff_or_null, float* gbias_or_null, float* ws, int B,

@@ -176,18 +176,39 @@ class _WgradReduces:
         self.desc = []
         self.keep = []
         self.targets = set()
+        self.bias_jobs = []      # parked pure bias-gradient sums (cc_bias_grad_defer): one cc_bias_grad_table launch per 32
 
     def flush(self):
+        import ctypes
+        if self.bias_jobs:
+            arr = (ctypes.c_long * len(self.bias_jobs))(*self.bias_jobs)
+            engine().call("cc_bias_grad_table", ctypes.addressof(arr), len(self.bias_jobs) // 12, STREAM)
         if self.desc:
-            import ctypes
             arr = (ctypes.c_long * len(self.desc))(*self.desc)
             engine().call("cc_wgrad_reduce_table", ctypes.addressof(arr), len(self.desc) // 16, STREAM)
-        self.desc, self.keep, self.targets = [], [], set()
+        self.desc, self.keep, self.targets, self.bias_jobs = [], [], set(), []
+
+    def park_bias(self, gy, gbias, B, C, H, W, gy_bs):
+        """gbias += sum over (n, h, w) of gy, at the end of the stage (gy is kept alive until then)"""
+        import ctypes
+        if gbias.data_ptr() in self.targets:
+            self.flush()
+        self.targets.add(gbias.data_ptr())
+        E = engine()
+        ws = _ws(E.call("cc_act_bwd_ws_bytes", C), gy)
+        job, red, nred = (ctypes.c_long * 12)(), (ctypes.c_long * 16)(), ctypes.c_int(0)
+        E.call("cc_bias_grad_defer", gy, gbias, ws, B, C, H, W, gy_bs, 1, ctypes.addressof(job), ctypes.addressof(red),
+               ctypes.addressof(nred))
+        self.bias_jobs.extend(job[:])
+        if nred.value:
+            self.desc.extend(red[:])
+        self.keep.append((ws, gbias, gy))
 
 
 wgrad_queue = _WgradQueue()
 wgrad_reduces = _WgradReduces()
 _NO_DEFER = __import__("os").environ.get("CC_NO_WGRAD_DEFER", "0") == "1"       # A/B switch (tools/)
+_NO_BIAS_TABLE = __import__("os").environ.get("CC_NO_BIAS_TABLE", "0") == "1"   # A/B switch: one bias-gradient pass per layer
 
 
 def _act_bwd_bias(gys, ys, geffs, gbs, ref, B, C, H, W, gy_bs, act, act_a, act_b, accumulate):

@@ -264,6 +264,11 @@ class Tape:
                     self._act_bias([gs[k]], [ys[k]], act, act_a, act_b, [biases[k]], ref)
                 return geffs if act != 0 else list(gs)
             gbs = [t for t, _ in tgt]
+        if act == 0 and acc and ops.wgrad_queue.enabled and not ops._NO_DEFER and not ops._NO_BIAS_TABLE:
+            # pure bias sums inside a trainer stage: parked, all layers of the stage in one launch (cc_bias_grad_table)
+            for g, gb in zip(gs, gbs):
+                ops.wgrad_reduces.park_bias(g, gb, B, C, H, W, _bs(g))
+            return list(gs)
         gy_bs = _bs(gs[0])
         uniform = all(_bs(g) == gy_bs for g in gs) and (act == 0 or all(_bs(y) == _bs(ys[0]) for y in ys))
         if not uniform:

@@ -313,6 +313,14 @@ size_t cc_act_bwd_ws_bytes(int C);
 int cc_act_bwd_bias_group_defer(int G, const long* gy, const long* y, const long* geff, const long* gbias, float* ws, int B, int C,
                                 int H, int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b,
                                 int accumulate_bias, long* red_host, int red_cap, int* nred_host, void* stream);
+/* Pure bias gradients (gbias[c] (+)= sum over (n, h, w) of gy) of a whole backward stage in one launch: cc_bias_grad_defer
+ * launches nothing and fills job_host[12] (+ red_host[16], *nred_host = 1, when the map is summed in chunks: the second stage
+ * goes to cc_wgrad_reduce_table); cc_bias_grad_table runs n parked jobs, 32 per launch, BEFORE that reduce table.  gy and ws
+ * (cc_act_bwd_ws_bytes(C)) stay untouched in between.  Replaces: autograd's per-layer bias sum of nn.Conv2d
+ * (torch ConvolutionBackward, as run by train.py:567 loss.backward()). */
+int cc_bias_grad_defer(const float* gy, float* gbias, float* ws, int B, int C, int H, int W, long gy_bs, int accumulate,
+                       long* job_host, long* red_host, int* nred_host);
+int cc_bias_grad_table(const long* jobs_host, int n, void* stream);
 int cc_act_bwd_bias(const float* gy, const float* y_or_null, float* geff_or_null, float* gbias_or_null, float* ws, int B,
                     int C, int H, int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b,
                     int accumulate_bias, void* stream);

@@ -771,6 +771,46 @@ def check_corr_patch(dev, cases=((2, 6, 9, 14, 5, 1), (1, 4, 12, 10, 7, 2), (1, 
         assert max(rel(x, y) for x, y in zip(g1, g0)) < 5e-6, ("corr patch grads", (B, C, H, W, P, D))
 
 
+def check_bias_grad_table(dev, cases=None, tol=2e-5):
+    """cc_bias_grad_defer + cc_bias_grad_table (+ the parked second stage, cc_wgrad_reduce_table kind 4): the bias gradients of
+    many layers in one launch = the (n, h, w) sums of the pre-activation gradients accumulated onto the existing bias gradients --
+    small maps (written directly), chunked planes, planes that are not a multiple of four, channel slices of a larger buffer
+    (batch-strided), and more than 32 jobs (two launches)."""
+    import ctypes
+    from cc_amd import ops
+    E = ops.engine()
+    g = torch.Generator().manual_seed(11)
+    cases = cases or ((2, 16, 9, 13, 0), (2, 8, 64, 160, 0), (1, 130, 5, 6, 0), (2, 4, 33, 70, 3), (3, 24, 12, 40, 8), (2, 1, 128, 130, 0),
+                      (4, 3, 8, 8, 0))
+    cases = tuple(cases) * 6 if len(cases) * 6 > 32 else tuple(cases)
+    jobs, reds, keep, want, gbs = [], [], [], [], []
+    for (B, C, H, W, extra) in cases:
+        full = torch.randn(B, C + extra, H, W, generator=g).to(dev)
+        gy = full[:, extra:]                                   # a channel slice: batch stride (C + extra) * H * W
+        gb = torch.randn(C, generator=g).to(dev)
+        want.append(gb.double().cpu() + gy.double().sum((0, 2, 3)).cpu())
+        ws = torch.empty(max(E.call("cc_act_bwd_ws_bytes", C) // 4, 4), device=dev, dtype=torch.float32)
+        job, red, nred = (ctypes.c_long * 12)(), (ctypes.c_long * 16)(), ctypes.c_int(0)
+        E.call("cc_bias_grad_defer", gy, gb, ws, B, C, H, W, (C + extra) * H * W, 1, ctypes.addressof(job), ctypes.addressof(red),
+               ctypes.addressof(nred))
+        jobs.extend(job[:])
+        if nred.value:
+            reds.extend(red[:])
+        keep.append((full, ws))
+        gbs.append(gb)
+    assert len(jobs) // 12 > 32 and reds, "the cases must cover two table launches and the chunked second stage"
+    arr = (ctypes.c_long * len(jobs))(*jobs)
+    E.call("cc_bias_grad_table", ctypes.addressof(arr), len(jobs) // 12, ops.STREAM)
+    arr2 = (ctypes.c_long * len(reds))(*reds)
+    E.call("cc_wgrad_reduce_table", ctypes.addressof(arr2), len(reds) // 16, ops.STREAM)
+    worst = 0.0
+    for gb, w in zip(gbs, want):
+        err = float((gb.double().cpu() - w).abs().max() / (w.abs().max() + 1e-30))
+        worst = max(worst, err)
+        assert err <= tol, err
+    return {"bias_grad_table": worst}
+
+
 def check_concat_gradient_slices(dev, tol=2e-5):
     """The producers of a torch.cat receive narrow() views of the concat gradient: conv / transposed conv (with activation) and
     the x2 up-sampling read them in place through the kernels' batch-stride arguments (ops._slice_or_c) -- same gradients as

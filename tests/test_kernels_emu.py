@@ -95,3 +95,7 @@ def test_feature_warp_deterministic_scatter():
 
 def test_pixel2cam_cam2pixel_gradients():
     parity.check_pixel2cam_cam2pixel_grads("cpu")
+
+
+def test_bias_gradient_table():
+    parity.check_bias_grad_table("cpu")

@@ -124,3 +124,8 @@ def test_feature_warp_deterministic_scatter():
 def test_pixel2cam_cam2pixel_gradients():
     parity.check_pixel2cam_cam2pixel_grads("cuda")
     parity.check_pixel2cam_cam2pixel_grads("cuda", B=2, H=128, W=416)
+
+
+def test_bias_gradient_table():
+    parity.check_bias_grad_table("cuda")
+    parity.check_bias_grad_table("cuda", cases=((4, 64, 64, 208, 0), (4, 16, 256, 832, 1), (4, 512, 2, 7, 0), (4, 32, 128, 416, 33)) * 9)

@@ -12,7 +12,10 @@ rows.sort()
 adam = [i for i, r in enumerate(rows) if "k_adam" in r[2]]
 adam = [i for j, i in enumerate(adam) if j + 1 == len(adam) or adam[j + 1] != i + 1]     # the optimizer is 2 back-to-back launches
 assert len(adam) >= 2, "need two optimizer launches"
-step = rows[adam[-2] + 1: adam[-1] + 1]
+# of the last (up to) three replayed steps, the one with the shortest wall time: the profiler's buffer flushes now and then stall
+# a step for milliseconds in the middle of the graph
+cands = [rows[adam[i - 1] + 1: adam[i] + 1] for i in range(max(1, len(adam) - 3), len(adam))]
+step = min(cands, key=lambda st: st[-1][1] - st[0][0])
 t0, t1 = step[0][0], step[-1][1]
 busy = sum(e - s for s, e, _ in step)
 gaps = sum(max(0, step[i + 1][0] - step[i][1]) for i in range(len(step) - 1))
