@@ -285,6 +285,37 @@ __global__ __launch_bounds__(256) void k_consensus_bce(const float* __restrict__
 }
 
 // out = a * s   (device scalar s) -- used to apply grad_output to stashed gradients without a host sync
+// out[b][e] (=, +=) src_0[b][e] + src_1[b][e] + ... (fixed order): the gradient of a tensor with several consumers, whose parts
+// are channel slices of different buffers (own batch stride each), summed in ONE launch instead of n - 1 adds.
+constexpr int SUMN_MAX = 8;
+struct SumN { const float* src[SUMN_MAX]; long bs[SUMN_MAX]; int n; };
+template <bool VEC4>
+__global__ __launch_bounds__(256) void k_sum_strided(SumN t, float* __restrict__ out, long out_bs, long chw, int accumulate) {
+    const int b = blockIdx.y;
+    if (VEC4) {
+        const long q = (long)blockIdx.x * 256 + threadIdx.x;
+        if (q * 4 >= chw) return;
+        float4 v[SUMN_MAX];
+#pragma unroll
+        for (int k = 0; k < SUMN_MAX; k++)
+            v[k] = (k < t.n) ? ((const float4*)(t.src[k] + (long)b * t.bs[k]))[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 a = v[0];
+#pragma unroll
+        for (int k = 1; k < SUMN_MAX; k++)
+            if (k < t.n) { a.x += v[k].x; a.y += v[k].y; a.z += v[k].z; a.w += v[k].w; }
+        float4* o = (float4*)(out + (long)b * out_bs) + q;
+        if (accumulate) { const float4 g = *o; a.x = g.x + a.x; a.y = g.y + a.y; a.z = g.z + a.z; a.w = g.w + a.w; }
+        *o = a;
+    } else {
+        const long e = (long)blockIdx.x * 256 + threadIdx.x;
+        if (e >= chw) return;
+        float a = t.src[0][(long)b * t.bs[0] + e];
+        for (int k = 1; k < t.n; k++) a += t.src[k][(long)b * t.bs[k] + e];
+        float* o = out + (long)b * out_bs + e;
+        *o = accumulate ? (*o + a) : a;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_scale_by_scalar(const float* __restrict__ a, const float* __restrict__ s,
                                                          float* __restrict__ out, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -579,6 +610,25 @@ int cc_consensus_bce_fwd_bwd(const float* exp_mask, const float* census_bwd, con
                        target_fwd, gmask_or_null, partials, HW, thresh, wbce, 1.f - wbce, 1.f / ((float)B * 4 * HW),
                        gscale);
     hipLaunchKernelGGL(k_reduce_add, dim3(1), dim3(256), 0, s, (const float*)partials, nb * B, 1.0f, loss_accum);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_sum_strided(int n, const long* src, const long* src_bs, float* out, long out_bs, int B, long chw, int accumulate,
+                   void* stream) {
+    if (n <= 0 || n > SUMN_MAX || !src || !src_bs || !out || B <= 0 || chw <= 0) return CC_ERR_ARG;
+    SumN t = {};
+    t.n = n;
+    bool vec4 = (chw % 4 == 0) && (out_bs % 4 == 0) && (((uintptr_t)out) % 16 == 0);
+    for (int k = 0; k < n; k++) {
+        if (!src[k]) return CC_ERR_ARG;
+        t.src[k] = (const float*)src[k];
+        t.bs[k] = src_bs[k];
+        vec4 = vec4 && (src_bs[k] % 4 == 0) && (((uintptr_t)src[k]) % 16 == 0);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (vec4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sum_strided<true>), dim3((unsigned)((chw / 4 + 255) / 256), (unsigned)B), dim3(256), 0, s, t, out, out_bs, chw, accumulate);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sum_strided<false>), dim3((unsigned)((chw + 255) / 256), (unsigned)B), dim3(256), 0, s, t, out, out_bs, chw, accumulate);
     CC_CHECK_LAUNCH();
     return CC_OK;
 }

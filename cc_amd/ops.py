@@ -208,6 +208,7 @@ class _WgradReduces:
 wgrad_queue = _WgradQueue()
 wgrad_reduces = _WgradReduces()
 _NO_DEFER = __import__("os").environ.get("CC_NO_WGRAD_DEFER", "0") == "1"       # A/B switch (tools/)
+_NO_SUM_N = __import__("os").environ.get("CC_NO_SUM_N", "0") == "1"             # A/B switch: pairwise adds for multi-consumer gradients
 _NO_BIAS_TABLE = __import__("os").environ.get("CC_NO_BIAS_TABLE", "0") == "1"   # A/B switch: one bias-gradient pass per layer
 
 

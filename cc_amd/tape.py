@@ -110,11 +110,30 @@ class TT:
             self.pend.append(g)
 
     def _fold_extra_pend(self):
-        """at most one pending alias can ride in an epilogue: sum the others into an own buffer"""
-        while len(self.pend) > 1 or (self.pend and self.grad is not None):
-            g = self.pend.pop()
+        """at most one pending alias can ride in an epilogue: sum the others into an own buffer -- one cc_sum_strided launch per
+        eight parts (the parts are channel slices of concat gradients with their own batch strides)"""
+        if not (len(self.pend) > 1 or (self.pend and self.grad is not None)):
+            return
+        parts = self.pend
+        self.pend = []
+        if self.t.dim() == 4 and all(p.dim() == 4 and p.dtype == torch.float32 and _dense(p) and p.shape == self.t.shape for p in parts) \
+                and (self.grad is None or _dense(self.grad)) and not ops._NO_SUM_N:
+            acc = self.grad is not None
+            if not acc:
+                self.grad = _new(self.t.shape, self.t)
+            B, C, H, W = self.t.shape
+            for c0 in range(0, len(parts), 8):
+                ch = parts[c0:c0 + 8]
+                src = (ctypes.c_long * len(ch))(*[p.data_ptr() for p in ch])
+                sbs = (ctypes.c_long * len(ch))(*[p.stride(0) if B > 1 else C * H * W for p in ch])
+                engine().call("cc_sum_strided", len(ch), ctypes.addressof(src), ctypes.addressof(sbs), self.grad,
+                              self.grad.stride(0) if B > 1 else C * H * W, B, C * H * W, int(acc), STREAM)
+                acc = True
+            return                      # (stream-ordered: the parts may be released right after the launch is queued)
+        while parts:
+            g = parts.pop()
             if self.grad is None:
-                self.grad = self.pend.pop() + g
+                self.grad = (parts.pop() + g) if parts else g.clone()
             else:
                 self.grad.add_(g)
 

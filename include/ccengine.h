@@ -177,6 +177,11 @@ int cc_consensus_bce_fwd_bwd(const float* exp_mask, const float* census_bwd, con
                              const float* target_bwd, const float* target_fwd, float* gmask_or_null, float* partials,
                              float* loss_accum, float thresh, float wbce, float gscale, int B, int H, int W,
                              void* stream);
+/* out[b, e] (=, +=) sum_k src_k[b, e], e < chw: n <= 8 tensors [B, chw] with their own batch strides (channel slices of
+ * larger buffers), summed in a fixed order by one launch; src / src_bs: HOST arrays of device addresses / strides in floats.
+ * Replaces: the autograd engine's pairwise accumulation of a multi-consumer tensor's gradient (train.py:567). */
+int cc_sum_strided(int n, const long* src, const long* src_bs, float* out, long out_bs, int B, long chw, int accumulate,
+                   void* stream);
 /* out = a * scalar_dev[0] */
 int cc_scale_by_scalar(const float* a, const float* scalar_dev, float* out, int n, void* stream);
 

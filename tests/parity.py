@@ -771,6 +771,39 @@ def check_corr_patch(dev, cases=((2, 6, 9, 14, 5, 1), (1, 4, 12, 10, 7, 2), (1, 
         assert max(rel(x, y) for x, y in zip(g1, g0)) < 5e-6, ("corr patch grads", (B, C, H, W, P, D))
 
 
+def check_sum_strided(dev, cases=None):
+    """cc_sum_strided: out (=, +=) sum of n <= 8 [B, C, H, W] tensors that are channel slices of wider buffers (own batch strides),
+    16-byte and scalar paths -- against the same sum in torch, bit for bit (same left-to-right order)."""
+    import ctypes
+    from cc_amd import ops
+    E = ops.engine()
+    g = torch.Generator().manual_seed(13)
+    cases = cases or ((2, 4, 6, 8, 2, 0), (2, 3, 5, 7, 3, 1), (1, 2, 8, 12, 8, 0), (3, 2, 4, 4, 5, 1), (2, 6, 9, 16, 1, 1))
+    worst = 0.0
+    for (B, C, H, W, n, accumulate) in cases:
+        parts, keep = [], []
+        for k in range(n):
+            extra = (k % 3)
+            full = torch.randn(B, C + extra, H, W, generator=g).to(dev)
+            keep.append(full)
+            parts.append(full[:, extra:] if k % 2 == 0 else full[:, :C])
+        wide = torch.randn(B, C + 2, H, W, generator=g).to(dev)
+        out = wide[:, 1:1 + C]
+        want = out.clone() if accumulate else None
+        acc = parts[0].clone()
+        for p in parts[1:]:
+            acc = acc + p
+        want = (want + acc) if accumulate else acc
+        src = (ctypes.c_long * n)(*[p.data_ptr() for p in parts])
+        sbs = (ctypes.c_long * n)(*[p.stride(0) for p in parts])
+        guard = wide.clone()
+        E.call("cc_sum_strided", n, ctypes.addressof(src), ctypes.addressof(sbs), out, out.stride(0), B, C * H * W, accumulate, ops.STREAM)
+        assert torch.equal(out.cpu(), want.cpu()), (B, C, H, W, n, accumulate, float((out - want).abs().max()))
+        assert torch.equal(wide[:, 0].cpu(), guard[:, 0].cpu()) and torch.equal(wide[:, 1 + C:].cpu(), guard[:, 1 + C:].cpu())
+        worst = max(worst, float((out - want).abs().max()))
+    return {"sum_strided": worst}
+
+
 def check_bias_grad_table(dev, cases=None, tol=2e-5):
     """cc_bias_grad_defer + cc_bias_grad_table (+ the parked second stage, cc_wgrad_reduce_table kind 4): the bias gradients of
     many layers in one launch = the (n, h, w) sums of the pre-activation gradients accumulated onto the existing bias gradients --

@@ -99,3 +99,7 @@ def test_pixel2cam_cam2pixel_gradients():
 
 def test_bias_gradient_table():
     parity.check_bias_grad_table("cpu")
+
+
+def test_sum_strided():
+    parity.check_sum_strided("cpu")

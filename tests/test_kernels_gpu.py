@@ -129,3 +129,8 @@ def test_pixel2cam_cam2pixel_gradients():
 def test_bias_gradient_table():
     parity.check_bias_grad_table("cuda")
     parity.check_bias_grad_table("cuda", cases=((4, 64, 64, 208, 0), (4, 16, 256, 832, 1), (4, 512, 2, 7, 0), (4, 32, 128, 416, 33)) * 9)
+
+
+def test_sum_strided():
+    parity.check_sum_strided("cuda")
+    parity.check_sum_strided("cuda", cases=((4, 2, 64, 208, 4, 0), (4, 128, 32, 104, 3, 1), (4, 34, 16, 52, 8, 1)))
