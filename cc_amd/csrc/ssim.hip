@@ -68,7 +68,9 @@ __device__ __forceinline__ void ssim_tile_body(const PhotoArgs& a, const Gauss13
     // The horizontal pass reads its 16-pixel input windows straight from global memory (8-byte loads, 16 in flight per work
     // item) instead of staging the two 44x44 input tiles in LDS first: 28 KB of LDS instead of 43 KB, one barrier less per
     // channel, no scalar staging loop with an integer division per element.
-    __shared__ __attribute__((aligned(16))) float hb[5][TIN * TS];
+    // four moment planes: E[x], E[y], E[xx + yy], E[xy] -- the SSIM map and its adjoints need sigma_x^2 + sigma_y^2 only as a sum
+    // (ssim.py:33 `sigma1_sq + sigma2_sq + C2`), so E[xx] and E[yy] are filtered together (a fifth of the filter arithmetic less)
+    __shared__ __attribute__((aligned(16))) float hb[4][TIN * TS];
     __shared__ float red[4 * 3];
 
     const int H = a.H, W = a.W, HW = H * W;
@@ -142,15 +144,15 @@ __device__ __forceinline__ void ssim_tile_body(const PhotoArgs& a, const Gauss13
                     yv[k] = in ? yr[xx] : 0.f;
                 }
             }
-            float o[5][4];
+            float o[4][4];
 #pragma unroll
-            for (int mi = 0; mi < 5; mi++)
+            for (int mi = 0; mi < 4; mi++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) o[mi][j] = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const float vx = xv[k], vy = yv[k];
-                const float pxx = vx * vx, pyy = vy * vy, pxy = vx * vy;
+                const float pq = fmaf(vy, vy, vx * vx), pxy = vx * vy;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int t = k - j;
@@ -158,21 +160,20 @@ __device__ __forceinline__ void ssim_tile_body(const PhotoArgs& a, const Gauss13
                         const float g = gw.g[t];
                         o[0][j] = fmaf(g, vx, o[0][j]);
                         o[1][j] = fmaf(g, vy, o[1][j]);
-                        o[2][j] = fmaf(g, pxx, o[2][j]);
-                        o[3][j] = fmaf(g, pyy, o[3][j]);
-                        o[4][j] = fmaf(g, pxy, o[4][j]);
+                        o[2][j] = fmaf(g, pq, o[2][j]);
+                        o[3][j] = fmaf(g, pxy, o[3][j]);
                     }
                 }
             }
 #pragma unroll
-            for (int mi = 0; mi < 5; mi++)
+            for (int mi = 0; mi < 4; mi++)
                 *reinterpret_cast<float4*>(&hb[mi][r * TS + 4 * cg]) = make_float4(o[mi][0], o[mi][1], o[mi][2], o[mi][3]);
         }
         __syncthreads();
         // ---- V pass
-        float mo[5][4];
+        float mo[4][4];
 #pragma unroll
-        for (int mi = 0; mi < 5; mi++) {
+        for (int mi = 0; mi < 4; mi++) {
 #pragma unroll
             for (int j = 0; j < 4; j++) mo[mi][j] = 0.f;
 #pragma unroll
@@ -192,9 +193,9 @@ __device__ __forceinline__ void ssim_tile_body(const PhotoArgs& a, const Gauss13
             const int p = (oy0 + 4 * rg + j) * W + gx;
             const float mu1 = mo[0][j], mu2 = mo[1][j];
             const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-            const float s1 = mo[2][j] - mu1_sq, s2 = mo[3][j] - mu2_sq, s12 = mo[4][j] - mu12;
+            const float s12 = mo[3][j] - mu12;
             const float num1 = 2.f * mu12 + C1, num2 = 2.f * s12 + C2;
-            const float den1 = mu1_sq + mu2_sq + C1, den2 = s1 + s2 + C2;
+            const float den1 = mu1_sq + mu2_sq + C1, den2 = ((mo[2][j] - mu1_sq) - mu2_sq) + C2;       // sigma1_sq + sigma2_sq + C2
             const float S = (num1 * num2) / (den1 * den2);
             if (MODE == MODE_MAP) {
                 a.out_map[((size_t)b * 3 + c) * HW + p] = S;
