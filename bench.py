@@ -26,6 +26,14 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Data-parallel ranks (and the one-rank rehearsal, CC_FORCE_COMM=1) run the HIP runtime with AMD_DIRECT_DISPATCH=0 -- set before
+# the runtime is loaded.  With direct dispatch (the default) a stream-wait on ANOTHER stream's event -- what work.wait() of an
+# asynchronous collective is -- blocks the calling thread until that event has completed; the host then enqueues the optimizer
+# launch and the next hipGraph replay with an idle GPU: measured +0.6 ms per step on one GPU with a one-rank RCCL group, gone with
+# the per-queue submission thread (profiles/r03_ab_round3.txt, r3z).  A single rank keeps the default (0.18 ms faster there).
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("CC_FORCE_COMM", "0") == "1":
+    os.environ.setdefault("AMD_DIRECT_DISPATCH", "0")
+
 import torch                      # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -52,6 +60,9 @@ def parse():
                          "forward, only DispResNet6 + PoseNetB6 are trained (227 MB gradient bucket); reported beside the metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--split-graphs", choices=("auto", "0", "1"), default="auto",
+                    help="data-parallel step form: two hipGraphs with the first all-reduce between them (auto: when both gradient "
+                         "segments exist and a process group is active), or one graph and both all-reduces after it")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU steps after one warm-up (median is reported)")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="0 = min(usable threads (affinity / cgroup quota), 64): with all 256 hardware threads of the GPU box the "
@@ -425,7 +436,8 @@ def main():
     B, H, W = args.batch, args.height, args.width
     batch_cpu = syn.sample(B, H, W, seed=1 + rank, smooth=3)
     batch = (batch_cpu[0].to(dev), [r.to(dev) for r in batch_cpu[1]], batch_cpu[2].to(dev), batch_cpu[3].to(dev))
-    tr = T.CCTrainer(nets, cfg, use_graph=not args.no_graph)
+    tr = T.CCTrainer(nets, cfg, use_graph=not args.no_graph,
+                     split_graphs=None if args.split_graphs == "auto" else args.split_graphs == "1")
 
     def sync():
         torch.cuda.synchronize()
@@ -553,6 +565,7 @@ def main():
                        "trained_nets": "disp+pose (mask, flow frozen: README --fix-masknet --fix-flownet)" if args.freeze else "all",
                        "loss": round(loss_val, 6), "rccl_ranks": dist.get_world_size() if use_dist else 1,
                        "rank_losses": rank_losses,
+                       "hip_runtime": {"AMD_DIRECT_DISPATCH": os.environ.get("AMD_DIRECT_DISPATCH", "default (1)")},
                        "dead_occlusion_decoders_elided": bool(args.elide_occ)},
             "step_ms": step_ms, "comm": comm,
             "roofline": roof, "kernels": kernels,

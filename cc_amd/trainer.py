@@ -115,6 +115,28 @@ def cc_forward(nets, batch, cfg, keep=False, cut=None):
     return out
 
 
+class _NoWork:
+    def wait(self):
+        pass
+
+
+class _SideStreamWork:
+    """measurement aid (CC_COMM_PROBE=sidestream): the stream / event hand-offs of an asynchronous collective -- compute stream ->
+    side stream -> compute stream -- around a 16-byte kernel instead of the collective"""
+    side = None
+
+    def __init__(self, t):
+        if _SideStreamWork.side is None:
+            _SideStreamWork.side = torch.cuda.Stream()
+        cur = torch.cuda.current_stream()
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side):
+            t.add_(0.0)
+
+    def wait(self):
+        torch.cuda.current_stream().wait_stream(self.side)
+
+
 class FlatAdam:
     """train.py:307-310 ``torch.optim.Adam(chain(all params), lr, betas)`` as ONE flat bucket + ONE kernel."""
 
@@ -163,6 +185,11 @@ class FlatAdam:
         if self.comm_active():
             hi = self.flat_g.numel() if hi is None else hi
             if hi > lo:
+                probe = os.environ.get("CC_COMM_PROBE", "")       # tools/gpu_r3z.sh: what does the step form cost without RCCL?
+                if probe == "skip":
+                    return _NoWork()
+                if probe == "sidestream":
+                    return _SideStreamWork(self.flat_g[lo:lo + 4])
                 return dist.all_reduce(self.flat_g[lo:hi], async_op=async_op)
         return None
 
@@ -447,7 +474,18 @@ class CCTrainer:
                 works.append(opt.all_reduce(0, self.n_dp, async_op=True))
             works.append(opt.all_reduce(self.n_dp, None, async_op=True))      # mask + flow segment (70 MB): exposed
             cut = self.n_dp // 4 * 4            # float4 update: cut at a 16-byte boundary (the <= 3 elements left go second)
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if losses["loss"].is_cuda else None
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] \
+                if (losses["loss"].is_cuda and os.environ.get("CC_NO_COMM_EVENTS", "0") != "1") else None
+            join = os.environ.get("CC_COMM_JOIN", "segmented")       # A/B (tools/gpu_r3z.sh): "single" = one join, one Adam launch
+            if join == "single" and all(w is not None for w in works):
+                if ev:
+                    ev[0].record()
+                works[-1].wait()              # the group's collectives complete in issue order on its stream: the last one covers all
+                if ev:
+                    ev[1].record()
+                    self.comm_events = (self.comm_events + [ev[:2]])[-64:]
+                opt.step(opt.grad_scale())
+                return losses
             if 0 < cut < opt.n and len(works) == 2 and all(w is not None for w in works):
                 # the big segment's update runs while the small segment is still being exchanged.  work.wait() makes the
                 # compute stream wait for the collective: the stream time between the events around it is the EXPOSED part

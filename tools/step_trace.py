@@ -16,6 +16,11 @@ assert len(adam) >= 2, "need two optimizer launches"
 # a step for milliseconds in the middle of the graph
 cands = [rows[adam[i - 1] + 1: adam[i] + 1] for i in range(max(1, len(adam) - 3), len(adam))]
 step = min(cands, key=lambda st: st[-1][1] - st[0][0])
+# step period: end of the optimizer launch to the end of the next one (includes whatever idles BETWEEN two replays)
+ends = [rows[i][1] for i in adam]
+periods = [(b - a) / 1e6 for a, b in zip(ends[:-1], ends[1:])][-4:]
+if periods:
+    print("step period (optimizer end to optimizer end), last %d steps: %s ms" % (len(periods), " ".join("%.3f" % p for p in periods)))
 t0, t1 = step[0][0], step[-1][1]
 busy = sum(e - s for s, e, _ in step)
 gaps = sum(max(0, step[i + 1][0] - step[i][1]) for i in range(len(step) - 1))
