@@ -916,10 +916,10 @@ inline ConvPlan plan_conv(const GG& g, int mult = 1) {
     const int nchunk = p.Cpad / p.ck;
     p.nsplit = 1;
     p.cps = nchunk;
-    if (blocks < 256 && nchunk >= 4 && !(g.so != 1 && dbg_flag_early("CC_DBG_NO_PARITY_SPLIT"))) {
+    if (blocks < env_int_early("CC_CONV_SPLIT_BELOW", 384) && nchunk >= 4 && !(g.so != 1 && dbg_flag_early("CC_DBG_NO_PARITY_SPLIT"))) {
         long want = (env_int_early("CC_CONV_SPLIT_TARGET", 512) + blocks - 1) / blocks;
-        if (want > nchunk / 2) want = nchunk / 2;
-        if (want > 32) want = 32;
+        if (want > nchunk / env_int_early("CC_CONV_MINCHUNKS", 1)) want = nchunk / env_int_early("CC_CONV_MINCHUNKS", 1);
+        if (want > env_int_early("CC_CONV_MAXSPLIT", 32)) want = env_int_early("CC_CONV_MAXSPLIT", 32);
         if (want >= 2) {
             p.cps = (int)((nchunk + want - 1) / want);
             p.nsplit = (nchunk + p.cps - 1) / p.cps;
@@ -2189,14 +2189,15 @@ static void list_plan_splits(ListCls** cls, int n, int target) {
         const GG& g = cls[k]->c.g;
         const int nchunk = p.Cpad / p.ck;
         long want = 1;
-        if (fill < 256 && nchunk >= 4) want = (target + fill - 1) / fill;
+        if (fill < env_int_early("CC_CONV_FILL_BELOW", 256) && nchunk >= 4) want = (target + fill - 1) / fill;
         else if (nchunk >= 8) {
             const double len = (double)nchunk * ((g.Rt * g.St + 2) / 3);
-            const double cap = t_ideal > 24 ? t_ideal : 24;
+            const double cmin = env_int_early("CC_CONV_CLASS_STAGES", 24);
+            const double cap = t_ideal > cmin ? t_ideal : cmin;
             if (len > 2 * cap) want = (long)(len / cap + 0.999);
         }
-        if (want > nchunk / 2) want = nchunk / 2;
-        if (want > 32) want = 32;
+        if (want > nchunk / env_int_early("CC_CONV_MINCHUNKS", 1)) want = nchunk / env_int_early("CC_CONV_MINCHUNKS", 1);
+        if (want > env_int_early("CC_CONV_MAXSPLIT", 32)) want = env_int_early("CC_CONV_MAXSPLIT", 32);
         p.nsplit = 1; p.cps = nchunk;
         if (want >= 2) {
             p.cps = (int)((nchunk + want - 1) / want);
@@ -2271,7 +2272,8 @@ inline W3Plan plan_w3(int B, int M, int AH, int AW, int Cin, int R, int S, int s
     p.ntiles = B * p.tiles_x * p.tiles_y;
     const long base = (long)((M + BM - 1) / BM) * (p.Cp32 / BC) * (G > 1 ? G : 1);
     long nsplit = (env_int("CC_W3_SPLIT", 512) + base - 1) / base;      // 512: measured -0.27 ms/step vs 256 (r02f A/B)
-    const long cap = (p.ntiles + 5) / 6;          // >= 6 pixel tiles per split: every split writes a 9*M*Cpad partial slab
+    const long mt_ = env_int("CC_W3_MINTILES", 3);
+    const long cap = (p.ntiles + mt_ - 1) / mt_;  // >= 6 pixel tiles per split: every split writes a 9*M*Cpad partial slab
     if (nsplit > cap) nsplit = cap;
     if (nsplit > p.ntiles) nsplit = p.ntiles;
     if (nsplit < 1) nsplit = 1;
@@ -2303,7 +2305,8 @@ static size_t wgrad_ws_bytes_base(int B, int M, int AH, int AW, int Cin, int R, 
     const int bm = pick_bm(M);
     const long tiles = ((Ntot + BN - 1) / BN) * ((M + bm - 1) / bm);
     long nsplit = (env_int_early("CC_WGRAD_SPLIT_TARGET", 512) + tiles - 1) / tiles;
-    const long maxsplit = (P + 63) / 64;      // small maps still need >= 256 workgroups: split down to 64-pixel ranges
+    const long mr = env_int_early("CC_WGRAD_MINRANGE", 32);
+    const long maxsplit = (P + mr - 1) / mr;  // small maps still need >= 256 workgroups: split down to 32-pixel ranges (-0.16 ms/step against 64, r3s3)
     if (nsplit > maxsplit) nsplit = maxsplit;
     if (nsplit < 1) nsplit = 1;
     return nsplit <= 1 ? 16 : (size_t)nsplit * M * Ntot * sizeof(float);
@@ -2412,7 +2415,8 @@ static int wgrad_group_impl(int G, const long* a, const long* x, const long* gw,
     const int bm = pick_bm(M);
     const long tiles = ((Ntot + BN - 1) / BN) * ((M + bm - 1) / bm) * G;
     long nsplit = (env_int_early("CC_WGRAD_SPLIT_TARGET", 512) + tiles - 1) / tiles;
-    const long maxsplit = (P + 63) / 64;      // small maps still need >= 256 workgroups: split down to 64-pixel ranges
+    const long mr = env_int_early("CC_WGRAD_MINRANGE", 32);
+    const long maxsplit = (P + mr - 1) / mr;  // small maps still need >= 256 workgroups: split down to 32-pixel ranges (-0.16 ms/step against 64, r3s3)
     if (nsplit > maxsplit) nsplit = maxsplit;
     if (nsplit < 1) nsplit = 1;
     long pps = (P + nsplit - 1) / nsplit;
