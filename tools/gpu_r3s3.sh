@@ -1,3 +1,4 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-bash tools/gpu_ab_env.sh r3s3 "CC_CONV_SPLIT_BELOW=320" "CC_CONV_SPLIT_BELOW=448" "CC_WGRAD_MINRANGE=16" "CC_WGRAD_MINRANGE=48" "CC_WGRAD_THIN_MAXCOMBO=12" "CC_WGRAD_SPLIT_TARGET=384" "CC_WGRAD_SPLIT_TARGET=768" "CC_W3_MINM=96"
+bash tools/gpu_r3u.sh 2>&1 | tail -5
+bash tools/gpu_ab_env.sh r3s3 "CC_BIAS_CHUNK=4096" "CC_BIAS_CHUNK=16384" "CC_BIAS_SINGLE=1024" "CC_BIAS_SINGLE=16384" "CC_ACT_CHUNK=4096" "CC_ACT_CHUNK=16384"
