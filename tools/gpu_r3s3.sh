@@ -1,4 +1,3 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-bash tools/gpu_ab_env.sh r3s3 "CC_W3_MT_REM=1" "CC_W3_MT_REM=2"
-CC_W3_MT_REM=1 CC_LIB_PATH=$PWD/tools/_bin/libccengine_tools.so timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "convs or groups" 2>&1 | tail -2
+bash tools/gpu_ab_env.sh r3s3 "CC_CONV_BALANCE=0" "CC_W3_MINM=65 CC_WGRAD_THIN_MAXCOMBO=16" "CC_NO_WGRAD_QUEUE=1" "CC_CONV_BALANCE_PCT=90"
