@@ -22,6 +22,62 @@
 #ifndef CC_KEEP4
 #define CC_KEEP4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
 #endif
+
+// Raw buffer loads (wino.hip): a 128-bit buffer resource over [ptr, ptr + bytes) lets the hardware bounds-check every lane --
+// a byte offset >= `bytes` (CC_BUF_OOB) reads 0.0f, so zero padding at the image border costs no compare / select.
+// voff: per-lane byte offset (VGPR), soff: wave-uniform byte offset (SGPR, not part of the range check).
+#ifndef CC_BUF_RSRC
+typedef __amdgpu_buffer_rsrc_t cc_buf_t;
+#define CC_BUF_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
+#define CC_BUF_LOAD_F32(rsrc, voff, soff) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32((rsrc), (int)(voff), (int)(soff), 0))
+#endif
+#define CC_BUF_OOB 0x80000000u
+
+// Four 16-byte LDS-DMA transfers per lane (1 KB per wave each), rows 1 KB apart in BOTH global memory and LDS (the immediate
+// offset of global_load_lds applies to both addresses), issued from inline assembly: hipcc waits vmcnt(0) before the next ds_read
+// whenever a compiler-visible LDS-DMA is in flight (it cannot tell which LDS bytes the DMA writes), which serialises a
+// double-buffered stage; an asm DMA is outside its bookkeeping -- the kernel waits for it itself (CC_WAIT_VMCNT0 + barrier before
+// the buffer is read).  lds_dst: wave-uniform LDS byte address (M0), gsrc: this lane's source.
+#ifndef CC_GLDS16X4
+__device__ __forceinline__ void cc_glds16x4(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+#define CC_GLDS16X4(gsrc, lds_ptr) cc_glds16x4((gsrc), __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)CC_LDS_PTR(lds_ptr)))
+#endif
+
+// One 16-byte LDS-DMA transfer per lane through a buffer resource (bounds-checked: lanes whose offset lies at or beyond the
+// resource's size move zeros), from inline assembly for the same reason as CC_GLDS16X4.  lds_ptr: wave-uniform destination (lane l
+// lands at lds_ptr + 16 l bytes); voff: per-lane byte offset; soff: wave-uniform byte offset (not range-checked).
+#ifndef CC_BUF_GLDS16
+__device__ __forceinline__ void cc_buf_glds16(cc_buf_t rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff)
+        : "memory");
+}
+#define CC_BUF_GLDS16(rsrc, voff, soff, lds_ptr) \
+    cc_buf_glds16((rsrc), (voff), __builtin_amdgcn_readfirstlane(soff), __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)CC_LDS_PTR(lds_ptr)))
+// s_waitcnt vmcnt(0) the compiler cannot move LDS reads across (for data that arrived by an asm LDS-DMA)
+#define CC_WAIT_VMCNT0_FENCE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
 // s_waitcnt vmcnt(0) with expcnt/lgkmcnt left at their maxima (gfx9 encoding)
 #define CC_WAIT_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)
 

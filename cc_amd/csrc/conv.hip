@@ -27,6 +27,8 @@
 #include "cc_common.h"
 #include "conv_internal.h"
 #include "cc_tools.h"
+#include "conv_tail.h"
+#include "wino_weights.h"
 #include "../../include/ccengine.h"
 #include <vector>
 #include <string>
@@ -77,7 +79,7 @@ inline int pick_bm_fwd(int M) {
 constexpr int BN = 128;   // pixels per workgroup tile
 constexpr int BK = 16;    // reduction chunk
 
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_SIGMOID = 3 };
+using namespace cctail;
 
 struct GG {
     const float* x; const float* w; const float* bias; const float* res; float* y;
@@ -89,33 +91,6 @@ struct GG {
     int res_mul;
     const float* add; long add_bs;      // res_mul mode only: tensor of y's shape added before act'(res) is applied (may alias y)
 };
-
-__device__ __forceinline__ float apply_act(float v, int act, float a, float b) {
-    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == ACT_LRELU) return v > 0.f ? v : (b != 0.f ? b : 0.2f) * v;       // slope: act_b, 0 -> the 0.2 of Back2Future
-    if (act == ACT_SIGMOID) return a * (1.f / (1.f + expf(-v))) + b;
-    return v;
-}
-
-// d act(pre) / d pre expressed through the activation's OUTPUT v, times the upstream gradient g
-__device__ __forceinline__ float act_grad(float g, float v, int act, float act_a, float act_b) {
-    if (act == ACT_RELU) return v > 0.f ? g : 0.f;
-    if (act == ACT_LRELU) return v > 0.f ? g : (act_b != 0.f ? act_b : 0.2f) * g;
-    const float sg = (v - act_b) / act_a;
-    return g * act_a * sg * (1.f - sg);
-}
-
-// epilogue tail shared by every conv kernel: res_mul == 0: act(v + res);  res_mul == 1 (data-gradient calls): the gradient
-// w.r.t. the PRE-activation of the layer that produced this conv's input, v * act'(r), r = that layer's output (= this
-// conv's input, same shape as the gradient) -- the producer's separate activation-backward pass disappears
-// (round 3) ... and with `add`: (v + add) * act'(r) -- the other gradient contributions of a fan-out tensor (a residual
-// shortcut, a skip connection, what earlier data-gradients left in the same buffer: add may alias the output) are summed
-// here instead of by separate accumulation launches
-__device__ __forceinline__ float conv_tail(float v, bool has_res, float r, int res_mul, int act, float a, float b, float addv = 0.f) {
-    if (has_res && res_mul) return act_grad(v + addv, r, act, a, b);
-    if (has_res) v += r;
-    return apply_act(v, act, a, b);
-}
 
 template <int BM>
 __global__ __launch_bounds__(256) void k_gather_gemm(GG g) {
@@ -381,6 +356,11 @@ __global__ __launch_bounds__(256) void k_repack_table(const long* __restrict__ d
     const long* d = desc + 16 * lo;
     const int bid = (int)((long)blockIdx.x - d[14]);
     if (bid >= (int)d[15]) return;
+    if ((int)d[6] == ccwino::WINO_T) {         // Winograd layers: U = G g G^T in the staging layout of wino.hip (d[7] < 0: flipped taps)
+        ccwino::wino_weight_body(reinterpret_cast<const float*>(d[0]), reinterpret_cast<float*>(d[1]), (int)d[2], (int)d[3], (int)d[5],
+                                 d[8], d[9], d[10], d[11], d[12], d[7] < 0 ? 1 : 0, bid);
+        return;
+    }
     switch ((int)d[6]) {                       // tap counts of the CC networks (3x3, 7x7, 5x5, 4x4 and their parity classes)
         case 9: repack_body<9>(d, tile, bid); break;
         case 1: repack_body<1>(d, tile, bid); break;
@@ -856,6 +836,9 @@ static int dbg_flag_early(const char* name) { return cctools::env_flag(name); }
 
 struct ConvPlan {
     bool use_patch;
+    int wino;                  // Winograd F(2x2, 3x3) kernel (wino.hip): wn holds its plan, wp_floats the size of the U image
+    ccint::WinoPlan wn;
+    int Hp, Wp;                // rows / pitch of the split-K partial slabs [split][n][m][Hp][Wp]
     int tw16;
     int bm, ck, tps, Mpad, Cpad, PH, PWr, PS, ymin, xmin, tiles_x, tiles_y, nsplit, cps, aligned, shift;
     size_t smem, wp_floats, part_floats;
@@ -864,8 +847,31 @@ struct ConvPlan {
 static int env_int_early(const char* name, int dflt) { return cctools::env_int(name, dflt); }
 
 // mult: number of same-shaped problems that share the launch (split-K only has to fill what they leave empty)
+// 3x3 / stride 1 / pad 1 on the full lattice, taps forwards (conv2d) or backwards (its data-gradient)
+inline bool wino_geometry(const GG& g) {
+    return g.Rt == 3 && g.St == 3 && g.si == 1 && g.so == 1 && g.oy0 == 0 && g.ox0 == 0 && (g.dstep == 1 || g.dstep == -1) &&
+           g.dy0 == -g.dstep && g.dx0 == -g.dstep && g.IH == g.OH && g.IW == g.OW && g.OHt == g.OH && g.OWt == g.OW && g.Cin > 0 &&
+           (long)g.B * g.Cin * g.IH * g.IW < (1l << 26);
+}
+
 inline ConvPlan plan_conv(const GG& g, int mult = 1) {
     ConvPlan p = {};
+    if (wino_geometry(g)) {
+        // the algorithm is a function of the geometry alone (the per-step weight image is laid out for it); `mult` only moves split-K
+        const ccint::WinoPlan w = ccint::wino_plan(g.B, g.Cin, g.IH, g.IW, g.M, mult);
+        if (w.ok) {
+            p.wino = 1;
+            p.wn = w;
+            p.use_patch = true;
+            p.bm = ccwino::WBM; p.ck = ccwino::WCK; p.tps = 1;
+            p.Mpad = w.Mpad; p.Cpad = w.Cpad;
+            p.nsplit = w.nsplit; p.cps = w.cps;
+            p.Hp = w.Hp; p.Wp = w.Wp;
+            p.wp_floats = w.u_floats;
+            p.part_floats = w.part_floats;
+            return p;
+        }
+    }
     p.bm = pick_bm_fwd(g.M);
     {   // a narrower channel tile when it saves >= 25 % of the PADDED output channels: M = 65 / 96 -> 3 x 32 instead of 128,
         // 129 -> 3 x 64 instead of 256, 260 -> 9 x 32 instead of 384 (concatenations with a 1-2 channel map, the 96-channel
@@ -966,7 +972,9 @@ inline ConvPlan plan_conv(const GG& g, int mult = 1) {
         }
     }
     // partial slabs are padded to whole tiles (16-byte stores without guards): [split][n][m][tiles_y * th][tiles_x * tw]
-    p.part_floats = p.nsplit > 1 ? (size_t)p.nsplit * g.B * g.M * (p.tiles_y * th) * (p.tiles_x * tw) : 0;
+    p.Hp = p.tiles_y * th;
+    p.Wp = p.tiles_x * tw;
+    p.part_floats = p.nsplit > 1 ? (size_t)p.nsplit * g.B * g.M * p.Hp * p.Wp : 0;
     return p;
 }
 
@@ -1680,6 +1688,26 @@ inline CP make_cp(const GG& g, const ConvPlan& p, const float* zeros, const floa
     return c;
 }
 
+// ---- Winograd path (wino.hip): nprob same-shaped problems of geometry g[0] in one launch
+inline ccint::WinoGeom wino_geom(const GG& g) {
+    ccint::WinoGeom w = {};
+    w.B = g.B; w.Cin = g.Cin; w.H = g.IH; w.W = g.IW; w.x_bs = g.x_bs; w.M = g.M; w.y_bs = g.y_bs; w.res_bs = g.res_bs; w.add_bs = g.add_bs;
+    w.act = g.act; w.act_a = g.act_a; w.act_b = g.act_b; w.res_mul = g.res_mul;
+    return w;
+}
+
+inline void wino_scope_name(const GG& g, const ConvPlan& p, int nprob, char* nm, int cap) {
+    int nl = snprintf(nm, cap, "k_wino_f2x3<%d>", p.nsplit > 1 ? 1 : 0);
+    if (cctools::env_flag("CC_TIMING_DETAIL"))
+        snprintf(nm + nl, cap - nl, " %dx[B%d M%d C%d %dx%d t9 k%d] wg%d", nprob, g.B, g.M, g.Cin, g.OH, g.OW, p.nsplit,
+                 nprob * p.wn.nqb * p.wn.nmb * p.nsplit);
+}
+
+// MFMA FLOPs the Winograd kernel executes: 16 multiply-adds per 2x2 output tile and channel pair (the direct form: 36)
+inline double wino_gflop(const GG& g, const ConvPlan& p) { return 2e-9 * 16.0 * g.B * p.wn.TY * p.wn.TX * (double)g.M * g.Cin; }
+
+inline int wino_flip(const GG& g) { return g.dstep < 0 ? 1 : 0; }
+
 // ws: [64 zeros][repacked weights][split-K partial slabs]; sized by conv_ws_floats(plan_conv(g))
 // prepacked (optional): {64 zeros, wp} produced earlier by k_repack_table -> no repack launch here
 inline void launch_gg(const GG& g, float* ws, hipStream_t s, const float* prepacked = nullptr, const float* pre_zeros = nullptr) {
@@ -1689,6 +1717,26 @@ inline void launch_gg(const GG& g, float* ws, hipStream_t s, const float* prepac
     const float* wp = ws + 64;
     float* part = ws + 64 + (prepacked ? 0 : p.wp_floats);
     const int T = g.Rt * g.St;
+    if (p.wino) {
+        if (!prepacked)
+            ccint::wino_weights_launch(g.w, ws + 64, g.M, g.Cin, p.Cpad, p.Mpad, g.w_sm, g.w_sc, g.w0, g.w_ri, g.w_sj, wino_flip(g), s);
+        const ccint::WinoProb pr = {g.x, prepacked ? prepacked : wp, g.bias, g.res, g.add, g.y, part};
+        bool ok;
+        {
+            char nm[128];
+            wino_scope_name(g, p, 1, nm, sizeof nm);
+            cctiming::Scope tsc(nm, wino_gflop(g, p), s);
+            ok = ccint::wino_launch(wino_geom(g), p.wn, &pr, 1, s);
+        }
+        if (!ok) { launch_gg_flat(g, s); return; }      // x not 16-byte aligned (an odd view): the gather kernel reads the weights as they lie
+        if (p.nsplit > 1) {
+            const long total = (long)g.B * g.M * g.OHt * g.OWt;
+            hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)part,
+                               p.nsplit, (long)g.B * g.M * p.Hp * p.Wp, g.bias, g.res, g.y, g.M, g.OHt, g.OWt, g.so, g.oy0, g.ox0, g.OH,
+                               g.OW, g.y_bs, g.res_bs, total, g.act, g.act_a, g.act_b, g.res_mul, g.add, g.add_bs, p.Hp, p.Wp);
+        }
+        return;
+    }
     if (prepacked) {
         zeros = pre_zeros;
         wp = prepacked;
@@ -1712,7 +1760,7 @@ inline void launch_gg(const GG& g, float* ws, hipStream_t s, const float* prepac
         hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)part,
                            p.nsplit, c.part_stride, g.bias, g.res, g.y, g.M, g.OHt, g.OWt, g.so, g.oy0, g.ox0, g.OH, g.OW,
                            g.y_bs, g.res_bs, total, g.act, g.act_a, g.act_b, g.res_mul, g.add, g.add_bs,
-                           p.tiles_y * (p.tw16 ? 8 : TH), p.tiles_x * (p.tw16 ? 16 : TW));
+                           p.Hp, p.Wp);
     }
 }
 
@@ -1728,8 +1776,51 @@ inline size_t smem_cls(const ConvPlan& p, int tps) {
     return (p.bm >= 32 && b < 16384) ? 16384 : b;            // epilogue transpose: 4 KB per wave
 }
 
+// same geometry and epilogue form (the Winograd launch shares them between its problems)
+inline bool same_problem_shape(const GG& a, const GG& b) {
+    return a.B == b.B && a.Cin == b.Cin && a.IH == b.IH && a.IW == b.IW && a.x_bs == b.x_bs && a.M == b.M && a.y_bs == b.y_bs &&
+           a.res_bs == b.res_bs && a.add_bs == b.add_bs && a.act == b.act && a.act_a == b.act_a && a.act_b == b.act_b &&
+           a.res_mul == b.res_mul && a.dstep == b.dstep;
+}
+
 inline bool launch_classes(const ClsIn* cs, int n, hipStream_t s, bool idle_taps = false) {
     if (n < 1 || n > MAXCLS) return false;
+    {   // Winograd problems: all of the launch or none (a mixed list goes back to the caller, which launches one by one)
+        int nw = 0;
+        for (int k = 0; k < n; k++) nw += cs[k].p.wino ? 1 : 0;
+        if (nw) {
+            if (nw != n) return false;
+            ccint::WinoProb pr[MAXCLS];
+            EPM e = {};
+            e.n = n;
+            int ebx = 0;
+            const ConvPlan& p = cs[0].p;
+            for (int k = 0; k < n; k++) {
+                const GG& g = cs[k].g;
+                if (!cs[k].wp || !same_problem_shape(g, cs[0].g) || cs[k].p.nsplit != p.nsplit || cs[k].p.cps != p.cps) return false;
+                pr[k] = ccint::WinoProb{g.x, cs[k].wp, g.bias, g.res, g.add, g.y, cs[k].part};
+                EPC& c = e.c[k];
+                c.part = cs[k].part; c.bias = g.bias; c.res = g.res; c.add = g.add; c.y = g.y;
+                c.Hp = p.Hp; c.Wp = p.Wp;
+                c.part_stride = (long)g.B * g.M * c.Hp * c.Wp;
+                c.nsplit = p.nsplit;
+                c.OHt = g.OHt; c.OWt = g.OWt; c.oy0 = g.oy0; c.ox0 = g.ox0;
+                c.total = p.nsplit > 1 ? (long)g.B * g.M * g.OHt * g.OWt : 0;
+                c.M = g.M; c.so = g.so; c.OH = g.OH; c.OW = g.OW; c.y_bs = g.y_bs; c.res_bs = g.res_bs; c.add_bs = g.add_bs;
+                c.act = g.act; c.act_a = g.act_a; c.act_b = g.act_b; c.res_mul = g.res_mul;
+                ebx += (int)((c.total + 255) / 256);
+                e.bx_end[k] = ebx;
+            }
+            {
+                char nm[128];
+                wino_scope_name(cs[0].g, p, n, nm, sizeof nm);
+                cctiming::Scope tsc(nm, n * wino_gflop(cs[0].g, p), s);
+                if (!ccint::wino_launch(wino_geom(cs[0].g), p.wn, pr, n, s)) return false;
+            }
+            if (p.nsplit > 1) hipLaunchKernelGGL(k_splitk_epilogue_multi, dim3((unsigned)ebx), dim3(256), 0, s, e);
+            return true;
+        }
+    }
     size_t smem = 0;
     int tps = 3, maxsplit = 1, maxy = 1, ref = -1;
     if (cctools::env_int("CC_CONV_IDLE_TAPS", 1)) idle_taps = true;
@@ -1756,8 +1847,8 @@ inline bool launch_classes(const ClsIn* cs, int n, hipStream_t s, bool idle_taps
         const bool empty = g.Cin == 0;
         EPC& c = e.c[k];
         c.part = empty ? nullptr : cs[k].part; c.bias = g.bias; c.res = g.res; c.add = g.add; c.y = g.y;
-        c.Hp = empty ? g.OHt : p.tiles_y * (p.tw16 ? 8 : TH);
-        c.Wp = empty ? g.OWt : p.tiles_x * (p.tw16 ? 16 : TW);
+        c.Hp = empty ? g.OHt : p.Hp;
+        c.Wp = empty ? g.OWt : p.Wp;
         c.part_stride = (long)g.B * g.M * c.Hp * c.Wp;
         c.nsplit = empty ? 0 : p.nsplit;
         c.OHt = g.OHt; c.OWt = g.OWt; c.oy0 = g.oy0; c.ox0 = g.ox0;
@@ -1838,6 +1929,12 @@ static GG make_fwd(const float* x, const float* w, const float* bias, const floa
 }
 
 static void fill_desc(const GG& g, const ConvPlan& p, long src, long dst, long* d) {
+    if (p.wino) {        // U = G g G^T (wino_weights.h); d[6] marks the descriptor, the sign of d[7] the tap direction
+        d[0] = src; d[1] = dst; d[2] = g.M; d[3] = g.Cin; d[4] = p.Mpad; d[5] = p.Cpad; d[6] = ccwino::WINO_T; d[7] = wino_flip(g) ? -3 : 3;
+        d[8] = g.w_sm; d[9] = g.w_sc; d[10] = g.w0; d[11] = g.w_ri; d[12] = g.w_sj; d[13] = (long)p.wp_floats; d[14] = 0;
+        d[15] = ccwino::wino_weight_blocks(p.Mpad, p.Cpad);
+        return;
+    }
     d[0] = src; d[1] = dst; d[2] = g.M; d[3] = g.Cin; d[4] = p.Mpad; d[5] = p.Cpad; d[6] = (long)g.Rt * g.St; d[7] = g.St;
     d[8] = g.w_sm; d[9] = g.w_sc; d[10] = g.w0; d[11] = g.w_ri; d[12] = g.w_sj; d[13] = (long)p.wp_floats; d[14] = 0;
     d[15] = repack_blocks(p.Mpad, p.Cpad, g.Rt * g.St);
@@ -2216,7 +2313,7 @@ static void list_plan_splits(ListCls** cls, int n, int target) {
             p.cps = (int)((nchunk + want - 1) / want);
             p.nsplit = (nchunk + p.cps - 1) / p.cps;
         }
-        p.part_floats = p.nsplit > 1 ? (size_t)p.nsplit * g.B * g.M * (p.tiles_y * (p.tw16 ? 8 : TH)) * (p.tiles_x * (p.tw16 ? 16 : TW)) : 0;
+        p.part_floats = p.nsplit > 1 ? (size_t)p.nsplit * g.B * g.M * p.Hp * p.Wp : 0;
     }
 }
 
@@ -2234,10 +2331,17 @@ static long list_run(int n, const long* d, float* ws, int target, bool launch, h
             if (launch) launch_gg_flat(all[i].c.g, s);
             continue;
         }
+        if (all[i].c.p.wino) {       // Winograd problems keep the plan of their own geometry: one launch each
+            done[i] = 1;
+            all[i].c.part = ws ? ws + off : nullptr;
+            off += (long)all[i].c.p.part_floats;
+            if (launch && !launch_classes(&all[i].c, 1, s)) return -1;
+            continue;
+        }
         ListCls* grp[MAXCLS];
         int m = 0;
         for (size_t j = i; j < all.size() && m < MAXCLS; j++)
-            if (!done[j] && all[j].c.p.use_patch && all[j].c.p.bm == all[i].c.p.bm && all[j].c.p.ck == all[i].c.p.ck) {
+            if (!done[j] && all[j].c.p.use_patch && !all[j].c.p.wino && all[j].c.p.bm == all[i].c.p.bm && all[j].c.p.ck == all[i].c.p.ck) {
                 grp[m++] = &all[j];
                 done[j] = 1;
             }

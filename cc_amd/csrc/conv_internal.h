@@ -23,4 +23,30 @@ bool wgrad_thin_launch(const float* a, const float* x, float* gw, float* ws, int
 // name of the kernel wgrad_thin_launch would use ("" when not eligible)
 void wgrad_thin_name(int B, int M, int AH, int AW, int Cin, int IH, int IW, int R, int S, int si, int pad, char* out, int cap);
 
+
+// ---- Winograd F(2x2, 3x3) convolution (wino.hip): the 3x3 / stride-1 / pad-1 layers (forward and data-gradient arithmetic)
+struct WinoGeom {
+    int B, Cin, H, W; long x_bs;                 // input [B, Cin, H, W]; output [B, M, H, W]
+    int M; long y_bs, res_bs, add_bs;
+    int act; float act_a, act_b; int res_mul;    // epilogue (conv_tail.h)
+};
+struct WinoProb { const float* x; const float* U; const float* bias; const float* res; const float* add; float* y; float* part; };
+struct WinoPlan {
+    int ok;                     // geometry runs on the Winograd kernel
+    int Mpad, Cpad, nchunk;     // M padded to 64, Cin padded to 8, 8-channel chunks
+    int TY, TX, nqb, nmb;       // 2x2 output tiles per image (rows, columns), 64-tile blocks over all images, 64-row blocks
+    int nsplit, cps;            // split-K over channel chunks (deterministic second pass: conv.hip k_splitk_epilogue*)
+    int Hp, Wp;                 // partial slab rows / pitch: [split][n][m][Hp][Wp]
+    size_t u_floats, part_floats;
+};
+constexpr int WINO_MAXP = 12;   // problems per launch (= conv.hip MAXCLS)
+// eligibility (geometry only: the weight image is laid out for the algorithm the plan names) + split-K for `mult` problems per launch
+WinoPlan wino_plan(int B, int Cin, int H, int W, int M, int mult);
+// nprob same-shaped problems in one launch; p[k].part: partial slabs of problem k when plan.nsplit > 1 (the caller runs the
+// split-K epilogue).  -> false (nothing launched) when x is not 16-byte aligned / too large for 32-bit byte offsets
+bool wino_launch(const WinoGeom& g, const WinoPlan& p, const WinoProb* probs, int nprob, hipStream_t s);
+// U = G g G^T of one layer into `U` (plan.u_floats floats); strides / flip as in wino_weights.h
+void wino_weights_launch(const float* w, float* U, int M, int Cin, int Cpad, int Mpad, long w_sm, long w_sc, long w0, long w_ri,
+                         long w_sj, int flip, hipStream_t s);
+
 }  // namespace ccint

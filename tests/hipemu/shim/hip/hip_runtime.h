@@ -364,6 +364,31 @@ static inline void hipemu_glds(const void* src, void* dst, unsigned size) {
     memcpy(static_cast<char*>(dst) + (size_t)hipemu::lane_id() * size, src, size);
 }
 #define __builtin_amdgcn_global_load_lds(src, dst, size, off, aux) hipemu_glds(src, dst, size)
+// raw buffer loads with hardware bounds check (cc_common.h): offsets at or beyond the resource's size read 0
+struct cc_buf_t { const char* base; unsigned bytes; };
+#define CC_BUF_RSRC(ptr, nbytes) (cc_buf_t{reinterpret_cast<const char*>(ptr), (unsigned)(nbytes)})
+static inline float hipemu_buf_load(cc_buf_t r, unsigned voff, unsigned soff) {
+    if (voff >= r.bytes) return 0.f;
+    float v;
+    memcpy(&v, r.base + (size_t)voff + soff, 4);
+    return v;
+}
+#define CC_BUF_LOAD_F32(rsrc, voff, soff) hipemu_buf_load((rsrc), (unsigned)(voff), (unsigned)(soff))
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
+// four LDS-DMA rows, 1 KB apart on both sides (cc_common.h CC_GLDS16X4)
+static inline void hipemu_glds16x4(const void* src, void* dst) {
+    for (int i = 0; i < 4; i++)
+        memcpy(static_cast<char*>(dst) + 1024 * i + (size_t)hipemu::lane_id() * 16, static_cast<const char*>(src) + 1024 * i, 16);
+}
+#define CC_GLDS16X4(gsrc, lds_ptr) hipemu_glds16x4((gsrc), (lds_ptr))
+// bounds-checked 16-byte LDS-DMA (cc_common.h CC_BUF_GLDS16): out-of-range lanes move zeros
+static inline void hipemu_buf_glds16(cc_buf_t r, unsigned voff, unsigned soff, void* dst) {
+    char* d = static_cast<char*>(dst) + (size_t)hipemu::lane_id() * 16;
+    if (voff >= r.bytes) memset(d, 0, 16);
+    else memcpy(d, r.base + (size_t)voff + soff, 16);
+}
+#define CC_BUF_GLDS16(rsrc, voff, soff, lds_ptr) hipemu_buf_glds16((rsrc), (unsigned)(voff), (unsigned)(soff), (lds_ptr))
+#define CC_WAIT_VMCNT0_FENCE() hipemu::wave_barrier()      // lanes run one after the other here: the wave must have issued its DMA
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)

@@ -417,6 +417,31 @@ CONV_CASES = [  # B, Cin, H, W, Cout, k, stride, pad, act, bias, residual
     (1, 3, 32, 72, 16, 3, 1, 1, "relu", True, False),
     (2, 2, 35, 66, 5, 3, 1, 1, "lrelu", False, False),
 ]
+# 3x3 / stride 1 / pad 1 layers on the Winograd F(2x2, 3x3) kernel (wino.hip; forward and data-gradient): odd map sizes (tiles that
+# hang over the border), channel counts that are not multiples of 4 / 8 / 64, residual + every activation, tile blocks that span
+# images, split-K over channel chunks (deep layer, few tiles)
+CONV_CASES_WINO = [      # (the kernel takes maps whose width is a multiple of 4 with >= 16 tile columns, or exactly 8)
+    (2, 64, 5, 40, 64, 3, 1, 1, "relu", False, True),
+    (1, 40, 6, 32, 96, 3, 1, 1, "lrelu", True, False),
+    (2, 33, 7, 36, 70, 3, 1, 1, "relu", True, False),
+    (3, 26, 9, 44, 40, 3, 1, 1, None, False, False),
+    (2, 129, 8, 32, 65, 3, 1, 1, "sigmoid", True, False),
+    (1, 196, 6, 16, 128, 3, 1, 1, "lrelu", True, False),
+    (2, 48, 16, 52, 48, 3, 1, 1, "relu", True, True),
+    (4, 256, 4, 16, 130, 3, 1, 1, "relu", True, False),
+    (1, 24, 5, 104, 40, 3, 1, 1, "lrelu", True, False),
+]
+# ... at sizes whose launches are large enough to keep the whole reduction in one workgroup (fused bias / residual / activation
+# epilogue in the Winograd kernel): GPU only (the reference is torch on the CPU: a few GFLOP each)
+# (smooth epilogues only: among millions of outputs a few pre-activations lie within the summation-order noise of zero, and a
+# ReLU / LeakyReLU derivative that flips there moves single gradient elements by O(1) -- in ANY two implementations)
+CONV_CASES_WINO_LARGE = [
+    (4, 32, 64, 208, 128, 3, 1, 1, None, True, False),
+    (4, 64, 64, 208, 64, 3, 1, 1, None, False, True),
+    (2, 40, 63, 204, 130, 3, 1, 1, "sigmoid", True, False),
+    (4, 128, 32, 104, 128, 3, 1, 1, None, True, True),
+    (4, 129, 33, 100, 65, 3, 1, 1, "sigmoid", True, False),
+]
 # few channels x many pixels (wgrad_thin.hip; the pixel threshold is lowered for the small test maps)
 CONV_CASES_THIN = [
     (2, 16, 9, 16, 16, 3, 1, 1, "relu", True, False),

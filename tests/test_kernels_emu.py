@@ -54,6 +54,16 @@ def test_convs_prepacked_weight_images():
     parity.check_convs("cpu", prepack=True)
 
 
+def test_convs_winograd():
+    parity.check_convs("cpu", cases=parity.CONV_CASES_WINO, tcases=[], prepack=True)      # the small maps run split-K
+
+
+def test_convs_winograd_fused_epilogue(monkeypatch):
+    monkeypatch.setenv("CC_WINO_MINQ", "1")              # every case on the Winograd kernel ...
+    monkeypatch.setenv("CC_WINO_SPLIT_BELOW", "0")       # ... with the whole reduction in one workgroup: bias / residual / act in the kernel
+    parity.check_convs("cpu", cases=parity.CONV_CASES_WINO, tcases=[], prepack=True)
+
+
 def test_convs_thin_wgrad(monkeypatch):
     monkeypatch.setenv("CC_WGRAD_THIN_MINPIX", "0")      # route the small test maps through wgrad_thin.hip
     monkeypatch.setenv("CC_WGRAD_THIN_UPB", "8")

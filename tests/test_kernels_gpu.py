@@ -59,6 +59,13 @@ def test_convs():
     parity.check_convs("cuda")
 
 
+def test_convs_winograd():
+    # 3x3 / stride-1 layers on the Winograd F(2x2, 3x3) kernel: split-K cases (small maps), then launches whose workgroups hold the
+    # whole reduction (fused epilogue), each per call and through the per-step weight images
+    parity.check_convs("cuda", cases=parity.CONV_CASES_WINO, tcases=[], prepack=True)
+    parity.check_convs("cuda", cases=parity.CONV_CASES_WINO_LARGE, tcases=[], prepack=True)
+
+
 def test_convs_prepacked_weight_images():
     parity.check_convs("cuda", prepack=True)
 
