@@ -77,6 +77,8 @@ __device__ __forceinline__ void cc_buf_glds16(cc_buf_t rsrc, unsigned voff, unsi
     cc_buf_glds16((rsrc), (voff), __builtin_amdgcn_readfirstlane(soff), __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)CC_LDS_PTR(lds_ptr)))
 // s_waitcnt vmcnt(0) the compiler cannot move LDS reads across (for data that arrived by an asm LDS-DMA)
 #define CC_WAIT_VMCNT0_FENCE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// ... all but the N most recently issued VMEM operations have completed (memory reads return in issue order)
+#define CC_WAIT_VMCNT_FENCE(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #endif
 // s_waitcnt vmcnt(0) with expcnt/lgkmcnt left at their maxima (gfx9 encoding)
 #define CC_WAIT_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)

@@ -55,8 +55,10 @@ struct WN {
 };
 
 constexpr int VBLK = 16 * WCK * 64;       // floats of one V chunk (64 tiles)
-// raw input patch of ONE wave (its 16 consecutive tiles) for one 8-channel chunk: [channel 8][input row 4][12 float4] floats
-constexpr int RROW = 12 * 4, RCH = 4 * RROW, RWAVE = WCK * RCH;      // 48, 192, 1536 floats (6 KB per wave)
+// raw input patch of ONE wave (16 consecutive tiles x 4 channels = the items it transforms) for one chunk:
+// [channel 4][input row 4][12 float4] floats
+constexpr int RROW = 12 * 4, RCH = 4 * RROW, RWAVE = 4 * RCH;      // 48, 192, 768 floats (3 KB per wave)
+constexpr int WTHREADS = 512;
 
 // epilogue forms (template parameter EPI; chosen on the host): branch-free code for what the step uses, the generic tail otherwise
 //   EPI_LIN : y = act(v + bias + res),       act in {none, ReLU, LeakyReLU}  as  t > 0 ? t : slope * t   (slope 1 / 0 / s)
@@ -64,18 +66,24 @@ constexpr int RROW = 12 * 4, RCH = 4 * RROW, RWAVE = WCK * RCH;      // 48, 192,
 //   EPI_GEN : conv_tail() (sigmoid forms)
 enum { EPI_LIN = 0, EPI_GRAD = 1, EPI_GEN = 2 };
 
+// Workgroup = 8 waves, two per SIMD.  Wave w = (sub-tile st = w & 3: 32 m x 32 tiles, frequency half fh = w >> 2: rows 2 fh, 2 fh + 1
+// of the 4 x 4 frequency matrix = 8 accumulator tiles = 128 registers).  The two waves of a SIMD (st, 0) and (st, 1) run the same
+// stream; while one of them is held up issuing a VMEM instruction (an LDS-DMA costs the issuing wave 100-180 cycles of its in-order
+// stream, measured: profiles/r04_wino_probe_a.txt) the other one feeds the matrix pipe -- with ONE wave per SIMD and all 16
+// frequencies in it (256 accumulator registers, the first version of this kernel) every such cycle was lost to the MFMAs.
 // ABL (tools build only, CC_WINO_ABL): timing ablations that compute garbage -- 1: no raw-patch DMA, 2: no input transform / V
 // writes, 4: no U DMA, 8: no MFMAs, 16: no fragment reads, 32: no epilogue
 template <int SPLIT, int EPI, int ABL>
-__global__ __launch_bounds__(256, 1) void k_wino_f2x3(WN g) {
+__global__ __launch_bounds__(WTHREADS, 2) void k_wino_f2x3(WN g) {
     HIP_DYNAMIC_SHARED(float, smem)
     float* Us = smem;                          // [2][UBLK]
     float* Vs = smem + 2 * UBLK;               // [2][VBLK]
-    float* Rs = smem + 2 * UBLK + 2 * VBLK;    // [4 waves][RWAVE]
+    float* Rs = smem + 2 * UBLK + 2 * VBLK;    // [8 waves][RWAVE]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 1, wt = wid & 1;
+    const int st = wid & 3, fh = wid >> 2;
+    const int wm = st >> 1, wt = st & 1;
     const int l31 = lane & 31, lk = lane >> 5;
 
     // workgroup -> (problem, tile block, m block); blocks b, b + 8, b + 16 ... run on one XCD: give them consecutive work items
@@ -96,15 +104,16 @@ __global__ __launch_bounds__(256, 1) void k_wino_f2x3(WN g) {
     int c_end = c_beg + g.cps;
     if (c_end > g.nchunk) c_end = g.nchunk;
 
-    // ---- input path.  Every VMEM instruction costs the issuing wave 60-75 cycles of its in-order stream (measured: 32 dword loads
-    // per thread and chunk cost 2 800 cycles per stage even when all of them were out of range, profiles/r04_wino_probe.txt), so
-    // the raw input goes the way that needs the fewest: 16-byte LDS-DMA.  A wave stages the input rows of ITS 16 consecutive
-    // tiles (it transforms exactly those): the tiles form one or two runs inside a tile row (TX >= 16, or TX == 8 and two whole
-    // rows); per channel and input row a run is 2 len + 2 floats, fetched as the 16-byte-aligned float4s that cover it (the rows of
-    // x are 16-byte aligned: W % 4 == 0) -- at most 12 float4 per (channel, row), 384 per chunk = SIX DMA instructions per wave.
-    // Out-of-image float4s and channels past Cin are out-of-range offsets of the buffer resource (they move zeros).
+    // ---- input path.  Every VMEM instruction is expensive for the wave that issues it, so the raw input goes the way that needs
+    // the fewest: 16-byte LDS-DMA.  Transform role of wave w: the 16 consecutive tiles tg = w & 3 of the block x the channel quad
+    // qd = w >> 2 of the chunk (one 4 x 4 input block per thread); it stages exactly the input rows of those items itself
+    // (wave-private: its own vmcnt wait, no barrier).  The 16 tiles form one or two runs inside a tile row (TX >= 16, or TX == 8
+    // and two whole rows); per channel and input row a run is 2 len + 2 floats, fetched as the 16-byte-aligned float4s that cover
+    // it (rows of x are 16-byte aligned: W % 4 == 0) -- at most 12 float4 per (channel, row), 192 per chunk = THREE DMA
+    // instructions per wave.  Out-of-image float4s and channels past Cin are out-of-range offsets of the buffer resource (zeros).
+    const int tg = st, qd = fh;
     float* Rw = Rs + wid * RWAVE;
-    const int q0 = qb * 64 + 16 * wid;
+    const int q0 = qb * 64 + 16 * tg;
     int rn[2], riy[2], rxal[2], rlen[2], rjb[2], rxs[2];
     {
         int q = q0;
@@ -128,10 +137,10 @@ __global__ __launch_bounds__(256, 1) void k_wino_f2x3(WN g) {
             q += len;
         }
     }
-    unsigned doff[6];
+    unsigned doff[3];
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const int piece = i * 64 + lane;                   // (channel, input row, float4 slot) = (piece / 48, piece % 48 / 12, piece % 12)
+    for (int i = 0; i < 3; i++) {
+        const int piece = i * 64 + lane;                   // (channel of the quad, input row, float4 slot) = (piece / 48, piece % 48 / 12, piece % 12)
         const int cl = piece / 48, rem = piece - cl * 48;
         const int a = rem / 12, j = rem - a * 12;
         const int r = (rlen[1] > 0 && j >= rjb[1]) ? 1 : 0;
@@ -145,13 +154,14 @@ __global__ __launch_bounds__(256, 1) void k_wino_f2x3(WN g) {
     auto dma_raw = [&](int kc, int i) {
         if constexpr (ABL & 1) return;
         const int cl = (i * 64 + lane) / 48;
-        const unsigned inv = (kc * WCK + cl < g.Cin) ? 0u : CC_BUF_OOB;       // OR-ed in (a select becomes a branch)
-        CC_BUF_GLDS16(xr, doff[i] | inv, (unsigned)(kc * WCK) * (unsigned)g.HW * 4u, Rw + i * 256);
+        const int cb = kc * WCK + qd * 4;
+        const unsigned inv = (cb + cl < g.Cin) ? 0u : CC_BUF_OOB;       // OR-ed in (a select becomes a branch)
+        CC_BUF_GLDS16(xr, doff[i] | inv, (unsigned)cb * (unsigned)g.HW * 4u, Rw + i * 256);
     };
-    // transform role: thread = (tile tl16 of the wave's 16, channel c3 of a quad), two quads per chunk; this tile's 4 x 4 input block
-    // starts at float roff of a channel's [4][48] image (+ 48 per input row)
+    // this thread's item: tile tl16 of the wave's 16, channel c3 of its quad; the 4 x 4 input block starts at float roff of the
+    // channel's [4][48] image (+ 48 per input row)
     const int tl16 = lane & 15, c3 = lane >> 4;
-    const int tl = wid * 16 + tl16;
+    const int tl = tg * 16 + tl16;
     int roff;
     {
         const int r = tl16 < rlen[0] ? 0 : 1;
@@ -159,63 +169,64 @@ __global__ __launch_bounds__(256, 1) void k_wino_f2x3(WN g) {
         roff = (r ? rjb[1] : rjb[0]) * 4 + (r ? rxs[1] : rxs[0]) + 2 * tt - (r ? rxal[1] : rxal[0]);
         if (tt >= (r ? rlen[1] : rlen[0])) roff = 0;          // tile past the end of the problem: any in-range address (its column is dropped)
     }
-    float raw[2][16];
-    auto read_raw = [&](int rr) {
-        const float* src = Rw + (rr * 4 + c3) * RCH + roff;
+    float raw[16];
+    auto read_raw = [&]() {
+        const float* src = Rw + c3 * RCH + roff;
 #pragma unroll
         for (int a = 0; a < 4; a++)
 #pragma unroll
-            for (int b = 0; b < 4; b++) raw[rr][4 * a + b] = (ABL & 2) ? 0.f : src[a * RROW + b];
+            for (int b = 0; b < 4; b++) raw[4 * a + b] = (ABL & 2) ? 0.f : src[a * RROW + b];
     };
-    // V = B^T d B,  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]], in 8 steps per item (column b of B^T d, then row i of the
-    // result) so that the main loop can spread them between its MFMAs
-    float tt[2][4][4];
-    auto col_step = [&](int rr, int b) {
+    // V = B^T d B,  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]], in 8 steps (column b of B^T d, then row i of the result) so
+    // that the main loop can spread them between its MFMAs
+    float tt[4][4];
+    auto col_step = [&](int b) {
         if constexpr (ABL & 2) return;
-        const float d0 = raw[rr][b], d1 = raw[rr][4 + b], d2 = raw[rr][8 + b], d3 = raw[rr][12 + b];
-        tt[rr][0][b] = d0 - d2;
-        tt[rr][1][b] = d1 + d2;
-        tt[rr][2][b] = d2 - d1;
-        tt[rr][3][b] = d1 - d3;
+        const float d0 = raw[b], d1 = raw[4 + b], d2 = raw[8 + b], d3 = raw[12 + b];
+        tt[0][b] = d0 - d2;
+        tt[1][b] = d1 + d2;
+        tt[2][b] = d2 - d1;
+        tt[3][b] = d1 - d3;
     };
-    auto row_step = [&](int rr, int i, int buf) {
+    auto row_step = [&](int i, int buf) {
         if constexpr (ABL & 2) return;
-        float* o = Vs + buf * VBLK + rr * 256 + tl * 4 + c3;
-        o[(4 * i + 0) * 512] = tt[rr][i][0] - tt[rr][i][2];
-        o[(4 * i + 1) * 512] = tt[rr][i][1] + tt[rr][i][2];
-        o[(4 * i + 2) * 512] = tt[rr][i][2] - tt[rr][i][1];
-        o[(4 * i + 3) * 512] = tt[rr][i][1] - tt[rr][i][3];
+        float* o = Vs + buf * VBLK + qd * 256 + tl * 4 + c3;
+        o[(4 * i + 0) * 512] = tt[i][0] - tt[i][2];
+        o[(4 * i + 1) * 512] = tt[i][1] + tt[i][2];
+        o[(4 * i + 2) * 512] = tt[i][2] - tt[i][1];
+        o[(4 * i + 3) * 512] = tt[i][1] - tt[i][3];
     };
-    auto dma_U = [&](int kc, int buf, int half) {
-        const float* src = P.U + ((long)mb * g.nchunk + kc) * UBLK + wid * 2048 + lane * 4;
-        float* dst = Us + buf * UBLK + wid * 2048;
+    auto dma_U = [&](int kc, int buf) {      // this wave's eighth (4 KB) of the 32 KB block
         if constexpr (ABL & 4) return;
-        if (half == 0) CC_GLDS16X4(src, dst);
-        else CC_GLDS16X4(src + 1024, dst + 1024);
+        const float* src = P.U + ((long)mb * g.nchunk + kc) * UBLK + wid * 1024 + lane * 4;
+        CC_GLDS16X4(src, Us + buf * UBLK + wid * 1024);
     };
 
-    f32x16 acc[16];
+    f32x16 acc[8];
 #pragma unroll
-    for (int f = 0; f < 16; f++)
+    for (int f = 0; f < 8; f++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[f][r] = 0.f;
 
     // the patch starts as zeros (slots that are out of range for every chunk must read as the conv's zero padding whether or not an
     // out-of-range DMA lane writes its zeros)
 #pragma unroll
-    for (int i = 0; i < 6; i++) *reinterpret_cast<float4*>(Rw + i * 256 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 3; i++) *reinterpret_cast<float4*>(Rw + i * 256 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): before the first DMA into the patch
 
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
 
-    // One stage = one 8-channel chunk = 16 frequencies x 4 k-steps = 64 MFMAs per wave, straight-line and hand-placed: every
-    // MFMA (64 cycles on the SIMD's matrix pipe) is followed by a small piece of the NEXT chunk's preparation, fenced so that
-    // hipcc keeps it in that MFMA's shadow instead of clustering it in front of the matrix work:
-    //   gaps 0-1    the next U block (two LDS-DMA groups of 4 KB per wave)
-    //   gaps 2-7    the next chunk's raw patch of this wave (one LDS-DMA each)
-    //   gap  44     wait for them (wave-private data: no barrier), gaps 44-45 read the two 4 x 4 blocks of this thread
-    //   gaps 46-61  the input transform (one of 16 steps per gap) -> the other V buffer
+    // One stage = one 8-channel chunk = 8 frequencies x 4 k-steps = 32 MFMAs per wave (64 per SIMD), straight-line and hand-placed:
+    // every MFMA is followed by a small piece of the NEXT chunk's preparation, fenced so that hipcc keeps it in that MFMA's shadow
+    // instead of clustering it in front of the matrix work:
+    //   gap  0 / 2    this wave's eighth of the next U block (one LDS-DMA group of 4 x 1 KB; frequency half 0 / 1)
+    //   gap  18       the next chunk's raw patch of this wave -- requested a whole stage ago -- has landed (a counted wait:
+    //                 wave-private data, no barrier); read this thread's 4 x 4 block
+    //   gaps 19-26    the input transform (one of 8 steps per gap) -> the other V buffer
+    //   gap  27 / 29  request the patch of the chunk after the next (three LDS-DMA; the patch buffer is free again).  A request
+    //                 that is consumed inside the stage it is issued in leaves ~2 000 cycles for L2 / HBM and the wave waits at
+    //                 the fence most of the time (measured: DMA removed = -650 / -890 cycles per stage)
     // and the fragments of frequency pair fp + 1 are read before the MFMAs of pair fp.  Frequencies go in pairs whose MFMAs
     // alternate (f, f+1, f, f+1 ...): two MFMAs on ONE accumulator are never adjacent, so the pieces placed between them do not
     // sit inside a dependent-accumulator pair.  The last stage prefetches a chunk that is never used (out of range / the last U
@@ -223,18 +234,18 @@ __global__ __launch_bounds__(256, 1) void k_wino_f2x3(WN g) {
     auto stage = [&](auto PAR, int kc) {
         constexpr int buf = decltype(PAR)::value;
         const int kd = kc + 1 < g.nchunk ? kc + 1 : g.nchunk - 1;
-        const float4* Ua = reinterpret_cast<const float4*>(Us + buf * UBLK) + lk * 64 + wm * 32 + l31;
-        const float4* Vb = reinterpret_cast<const float4*>(Vs + buf * VBLK) + lk * 64 + wt * 32 + l31;
+        const float4* Ua = reinterpret_cast<const float4*>(Us + buf * UBLK) + fh * 1024 + lk * 64 + wm * 32 + l31;
+        const float4* Vb = reinterpret_cast<const float4*>(Vs + buf * VBLK) + fh * 1024 + lk * 64 + wt * 32 + l31;
         float4 a[2][2], b[2][2];
         a[0][0] = Ua[0];   b[0][0] = Vb[0];
         a[0][1] = Ua[128]; b[0][1] = Vb[128];
 #pragma unroll
-        for (int fp = 0; fp < 8; fp++) {
+        for (int fp = 0; fp < 4; fp++) {
             const int cur = fp & 1, nxt = cur ^ 1;
-            if (fp < 7 && !(ABL & 16)) {
+            if (fp < 3 && !(ABL & 16)) {
                 a[nxt][0] = Ua[(2 * fp + 2) * 128]; b[nxt][0] = Vb[(2 * fp + 2) * 128];
                 a[nxt][1] = Ua[(2 * fp + 3) * 128]; b[nxt][1] = Vb[(2 * fp + 3) * 128];
-            } else if (fp < 7) {
+            } else if (fp < 3) {
                 a[nxt][0] = a[cur][1]; b[nxt][0] = b[cur][1]; a[nxt][1] = a[cur][0]; b[nxt][1] = b[cur][0];
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -246,42 +257,47 @@ __global__ __launch_bounds__(256, 1) void k_wino_f2x3(WN g) {
                 if constexpr (ABL & 8) acc[f][0] = fmaf(av[i & 1][j], bv[i & 1][j], acc[f][0]);
                 else acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i & 1][j], bv[i & 1][j], acc[f], 0, 0, 0);
                 const int gap = 8 * fp + i;
-                if (gap < 2) dma_U(kd, buf ^ 1, gap);
-                else if (gap < 8) dma_raw(kc + 1, gap - 2);
-                else if (gap == 44) { CC_WAIT_VMCNT0_FENCE(); read_raw(0); }
-                else if (gap == 45) read_raw(1);
-                else if (gap >= 46 && gap < 62) {
-                    const int st = gap - 46, rr = st >> 3, s8 = st & 7;       // steps 0-3: columns, 4-7: rows
-                    if (s8 < 4) col_step(rr, s8);
-                    else row_step(rr, s8 - 4, buf ^ 1);
+                // (the two waves of a SIMD, fh = 0 / 1, issue their DMA in different gaps; uniform branches: fh is wave-uniform)
+                if (gap == 0) { if (fh == 0) dma_U(kd, buf ^ 1); }
+                else if (gap == 2) { if (fh == 1) dma_U(kd, buf ^ 1); }
+                else if (gap == 18) { CC_WAIT_VMCNT_FENCE(4); read_raw(); }       // the patch (requested one stage ago) is in; the U group may be out
+                else if (gap >= 19 && gap < 27) {
+                    const int s8 = gap - 19;                   // steps 0-3: columns, 4-7: rows
+                    if (s8 < 4) col_step(s8);
+                    else row_step(s8 - 4, buf ^ 1);
                 }
-                if (gap < 8 || (gap >= 44 && gap < 62)) __builtin_amdgcn_sched_barrier(0);
+                else if (gap == 27) { if (fh == 0) { dma_raw(kc + 2, 0); dma_raw(kc + 2, 1); dma_raw(kc + 2, 2); } }
+                else if (gap == 29) { if (fh == 1) { dma_raw(kc + 2, 0); dma_raw(kc + 2, 1); dma_raw(kc + 2, 2); } }
+                if (gap == 0 || gap == 2 || (gap >= 18 && gap < 30)) __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // end of the stage: this wave's V writes and raw-patch reads are done (the U block and the patch were waited for at gap 44)
+        // end of the stage: this wave's V writes are done and its part of the next U block has landed (it is older than the three
+        // patch requests, which stay in flight across the barrier: memory reads return in issue order)
+        if constexpr (ABL & 1) CC_WAIT_VMCNT0_FENCE();
+        else CC_WAIT_VMCNT_FENCE(3);
         __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
     };
 
     if (c_beg < c_end) {
         // An odd number of stages starts on parity 1 (LDS buffers 1; the peeled stage sits IN FRONT of the loop: behind it, the
-        // 256 accumulators of the two paths would meet and hipcc spills them).  The prologue fills the buffers of the first parity.
+        // accumulators of the two paths would meet and hipcc copies them).  The prologue fills the buffers of the first parity.
         const int odd = (c_end - c_beg) & 1;
-        dma_U(c_beg, odd, 0);
-        dma_U(c_beg, odd, 1);
+        dma_U(c_beg, odd);
 #pragma unroll
-        for (int i = 0; i < 6; i++) dma_raw(c_beg, i);
+        for (int i = 0; i < 3; i++) dma_raw(c_beg, i);
         CC_WAIT_VMCNT0_FENCE();
+        read_raw();
 #pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            read_raw(rr);
+        for (int b = 0; b < 4; b++) col_step(b);
 #pragma unroll
-            for (int b = 0; b < 4; b++) col_step(rr, b);
+        for (int i = 0; i < 4; i++) row_step(i, odd);
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the patch has been read
+        __builtin_amdgcn_wave_barrier();         // (no instruction; the CPU emulation of the kernels runs a wave's lanes one after the other)
 #pragma unroll
-            for (int i = 0; i < 4; i++) row_step(rr, i, odd);
-        }
-        __syncthreads();
+        for (int i = 0; i < 3; i++) dma_raw(c_beg + 1, i);       // stays in flight across the barrier
+        __builtin_amdgcn_s_barrier();
         int kc = c_beg;
         if (odd) {
             stage(I1(), kc);
@@ -293,12 +309,42 @@ __global__ __launch_bounds__(256, 1) void k_wino_f2x3(WN g) {
         }
     }
 
-    // ---- output transform Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]: this lane holds tile t = wt*32 + l31 (MFMA D column) and the
-    // 16 rows m = wm*32 + (r & 3) + 8*(r >> 2) + 4*lk of every frequency
+    // ---- output transform Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]].  This lane holds tile t = wt*32 + l31 (MFMA D column) and the 16
+    // rows m = wm*32 + (r & 3) + 8*(r >> 2) + 4*lk of frequency rows 2 fh, 2 fh + 1.  A^T M is linear in the rows of M: each wave
+    // forms its part P = A^T[:, 2fh : 2fh+2] M[2fh : 2fh+2, :] (2 x 4), applies the column transform (P A: 2 x 2) and the two parts
+    // of a sub-tile are added: the wave finishes rows r in [8 fh, 8 fh + 8) and hands the parts of the other eight rows to its
+    // partner through LDS (the U buffers are free: every wave has passed the last stage's barrier).
     if constexpr (ABL & 32) {
         if (acc[3][5] == 12345.f) P.y[tid] = acc[7][1] + acc[0][0];
         return;
     }
+    auto part_tile = [&](int r, float& z00, float& z01, float& z10, float& z11) {
+        float p0[4], p1[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (fh == 0) { p0[j] = acc[j][r] + acc[4 + j][r]; p1[j] = acc[4 + j][r]; }           // rows 0, 1:  (m0 + m1, m1)
+            else { p0[j] = acc[j][r]; p1[j] = (0.f - acc[j][r]) - acc[4 + j][r]; }                // rows 2, 3:  (m2, -m2 - m3)
+        }
+        z00 = (p0[0] + p0[1]) + p0[2];
+        z01 = (p0[1] - p0[2]) - p0[3];
+        z10 = (p1[0] + p1[1]) + p1[2];
+        z11 = (p1[1] - p1[2]) - p1[3];
+    };
+    float* Xs = smem;                                          // [sub-tile 4][sender fh 2][row 8][value 4][lane 64]
+    {
+        float* xo = Xs + ((st * 2 + fh) * 32) * 64 + lane;
+#pragma unroll
+        for (int r8 = 0; r8 < 8; r8++) {
+            const int r = 8 * (fh ^ 1) + r8;                   // the partner's rows
+            float z00, z01, z10, z11;
+            part_tile(r, z00, z01, z10, z11);
+            xo[(r8 * 4 + 0) * 64] = z00;
+            xo[(r8 * 4 + 1) * 64] = z01;
+            xo[(r8 * 4 + 2) * 64] = z10;
+            xo[(r8 * 4 + 3) * 64] = z11;
+        }
+    }
+    __syncthreads();
     const int q = qb * 64 + wt * 32 + l31;
     if (q >= g.Q) return;
     const int n = q / g.TPI;
@@ -307,26 +353,23 @@ __global__ __launch_bounds__(256, 1) void k_wino_f2x3(WN g) {
     const int oy = 2 * ty, ox = 2 * tx;
     const int m_base = mb * WBM + wm * 32 + 4 * lk;
     const bool hr = P.res != nullptr, ha = P.add != nullptr;
-    auto out_tile = [&](int r, float& y00, float& y01, float& y10, float& y11) {
-        float s[2][4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            s[0][j] = (acc[j][r] + acc[4 + j][r]) + acc[8 + j][r];
-            s[1][j] = (acc[4 + j][r] - acc[8 + j][r]) - acc[12 + j][r];
-        }
-        y00 = (s[0][0] + s[0][1]) + s[0][2];
-        y01 = (s[0][1] - s[0][2]) - s[0][3];
-        y10 = (s[1][0] + s[1][1]) + s[1][2];
-        y11 = (s[1][1] - s[1][2]) - s[1][3];
+    const float* xi = Xs + ((st * 2 + (fh ^ 1)) * 32) * 64 + lane;
+    auto out_tile = [&](int r8, float& y00, float& y01, float& y10, float& y11) {
+        part_tile(8 * fh + r8, y00, y01, y10, y11);
+        y00 += xi[(r8 * 4 + 0) * 64];
+        y01 += xi[(r8 * 4 + 1) * 64];
+        y10 += xi[(r8 * 4 + 2) * 64];
+        y11 += xi[(r8 * 4 + 3) * 64];
     };
     if constexpr (SPLIT) {
         float* pb0 = P.part + (long)blockIdx.z * g.part_stride + (((long)n * g.M) * g.Hp + oy) * g.Wp + ox;
         const long mstride = (long)g.Hp * g.Wp;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
+        for (int r8 = 0; r8 < 8; r8++) {
+            const int r = 8 * fh + r8;
             const int m = m_base + (r & 3) + 8 * (r >> 2);
             float y00, y01, y10, y11;
-            out_tile(r, y00, y01, y10, y11);
+            out_tile(r8, y00, y01, y10, y11);
             if (m < g.M) {
                 float* pb = pb0 + (long)m * mstride;
                 *reinterpret_cast<float2*>(pb) = make_float2(y00, y01);
@@ -351,74 +394,70 @@ __global__ __launch_bounds__(256, 1) void k_wino_f2x3(WN g) {
         }
     };
     if (g.vec2) {
-        // even W, 8-byte aligned rows: both columns of the tile exist.  Every load of a half of the epilogue (bias, residual /
-        // multiplier, add) is issued BEFORE that half's first store: on gfx9 one counter tracks loads and stores, so a load behind
-        // a store waits for the store's round trip (two halves of 8 rows: 16 rows of operands would not fit beside the accumulators)
-        float bias_r[16];
+        // even W, 8-byte aligned rows: both columns of the tile exist.  Every load of the epilogue (bias, residual / multiplier, add)
+        // is issued BEFORE the first store: on gfx9 one counter tracks loads and stores, so a load behind a store waits for the
+        // store's round trip
+        float bias_r[8];
+        float2 res_r[8][2], add_r[8][2];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
+        for (int r8 = 0; r8 < 8; r8++) {
+            const int r = 8 * fh + r8;
             const int m = m_base + (r & 3) + 8 * (r >> 2);
             const int mc = m < g.M ? m : g.M - 1;
-            bias_r[r] = P.bias ? P.bias[mc] : 0.f;
+            bias_r[r8] = P.bias ? P.bias[mc] : 0.f;
+            res_r[r8][0] = res_r[r8][1] = add_r[r8][0] = add_r[r8][1] = make_float2(0.f, 0.f);
         }
         float* yb = P.y + (long)n * g.y_bs + o0;
-        const float* rb = hr ? P.res + (long)n * g.res_bs + o0 : nullptr;
-        const float* ab = ha ? P.add + (long)n * g.add_bs + o0 : nullptr;
         const int w1 = row1 ? g.W : 0;
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            float2 res_r[8][2], add_r[8][2];
-#pragma unroll
-            for (int r8 = 0; r8 < 8; r8++) {
-                res_r[r8][0] = res_r[r8][1] = add_r[r8][0] = add_r[r8][1] = make_float2(0.f, 0.f);
-            }
-            if (hr) {
-#pragma unroll
-                for (int r8 = 0; r8 < 8; r8++) {
-                    const int r = 8 * h + r8;
-                    const int m = m_base + (r & 3) + 8 * (r >> 2);
-                    const int mc = m < g.M ? m : g.M - 1;
-                    res_r[r8][0] = *reinterpret_cast<const float2*>(rb + (long)mc * g.HW);
-                    res_r[r8][1] = *reinterpret_cast<const float2*>(rb + (long)mc * g.HW + w1);
-                }
-            }
-            if (ha) {
-#pragma unroll
-                for (int r8 = 0; r8 < 8; r8++) {
-                    const int r = 8 * h + r8;
-                    const int m = m_base + (r & 3) + 8 * (r >> 2);
-                    const int mc = m < g.M ? m : g.M - 1;
-                    add_r[r8][0] = *reinterpret_cast<const float2*>(ab + (long)mc * g.HW);
-                    add_r[r8][1] = *reinterpret_cast<const float2*>(ab + (long)mc * g.HW + w1);
-                }
-            }
+        if (hr) {
+            const float* rb = P.res + (long)n * g.res_bs + o0;
 #pragma unroll
             for (int r8 = 0; r8 < 8; r8++) {
-                const int r = 8 * h + r8;
+                const int r = 8 * fh + r8;
                 const int m = m_base + (r & 3) + 8 * (r >> 2);
-                float y00, y01, y10, y11;
-                out_tile(r, y00, y01, y10, y11);
-                const float bv = bias_r[r];
-                float2 o0v, o1v;
-                o0v.x = tail(y00 + bv, res_r[r8][0].x, add_r[r8][0].x);
-                o0v.y = tail(y01 + bv, res_r[r8][0].y, add_r[r8][0].y);
-                o1v.x = tail(y10 + bv, res_r[r8][1].x, add_r[r8][1].x);
-                o1v.y = tail(y11 + bv, res_r[r8][1].y, add_r[r8][1].y);
-                if (m < g.M) {
-                    float* yo = yb + (long)m * g.HW;
-                    *reinterpret_cast<float2*>(yo) = o0v;
-                    if (row1) *reinterpret_cast<float2*>(yo + g.W) = o1v;
-                }
+                const int mc = m < g.M ? m : g.M - 1;
+                res_r[r8][0] = *reinterpret_cast<const float2*>(rb + (long)mc * g.HW);
+                res_r[r8][1] = *reinterpret_cast<const float2*>(rb + (long)mc * g.HW + w1);
+            }
+        }
+        if (ha) {
+            const float* ab = P.add + (long)n * g.add_bs + o0;
+#pragma unroll
+            for (int r8 = 0; r8 < 8; r8++) {
+                const int r = 8 * fh + r8;
+                const int m = m_base + (r & 3) + 8 * (r >> 2);
+                const int mc = m < g.M ? m : g.M - 1;
+                add_r[r8][0] = *reinterpret_cast<const float2*>(ab + (long)mc * g.HW);
+                add_r[r8][1] = *reinterpret_cast<const float2*>(ab + (long)mc * g.HW + w1);
+            }
+        }
+#pragma unroll
+        for (int r8 = 0; r8 < 8; r8++) {
+            const int r = 8 * fh + r8;
+            const int m = m_base + (r & 3) + 8 * (r >> 2);
+            float y00, y01, y10, y11;
+            out_tile(r8, y00, y01, y10, y11);
+            const float bv = bias_r[r8];
+            float2 o0v, o1v;
+            o0v.x = tail(y00 + bv, res_r[r8][0].x, add_r[r8][0].x);
+            o0v.y = tail(y01 + bv, res_r[r8][0].y, add_r[r8][0].y);
+            o1v.x = tail(y10 + bv, res_r[r8][1].x, add_r[r8][1].x);
+            o1v.y = tail(y11 + bv, res_r[r8][1].y, add_r[r8][1].y);
+            if (m < g.M) {
+                float* yo = yb + (long)m * g.HW;
+                *reinterpret_cast<float2*>(yo) = o0v;
+                if (row1) *reinterpret_cast<float2*>(yo + g.W) = o1v;
             }
         }
         return;
     }
-    // odd heights / unaligned tensors: element by element (rare: not unrolled twice)
+    // odd heights / unaligned tensors: element by element (rare)
     const bool col1 = ox + 1 < g.W;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
+    for (int r8 = 0; r8 < 8; r8++) {
+        const int r = 8 * fh + r8;
         float y00, y01, y10, y11;
-        out_tile(r, y00, y01, y10, y11);
+        out_tile(r8, y00, y01, y10, y11);
         const int m = m_base + (r & 3) + 8 * (r >> 2);
         if (m >= g.M) continue;
         const float bv = P.bias ? P.bias[m] : 0.f;
@@ -521,7 +560,7 @@ bool wino_launch(const WinoGeom& gg, const WinoPlan& p, const WinoProb* probs, i
     if (cctools::env_flag("CC_WINO_TRACE"))
         fprintf(stderr, "wino: %dx[B%d M%d C%d %dx%d] nqb %d nmb %d nsplit %d cps %d act %d res_mul %d vec2 %d\n", nprob, gg.B, gg.M, gg.Cin,
                 gg.H, gg.W, p.nqb, p.nmb, p.nsplit, p.cps, gg.act, gg.res_mul, a.vec2);
-    const size_t smem = (size_t)(2 * UBLK + 2 * VBLK + 4 * RWAVE) * sizeof(float);
+    const size_t smem = (size_t)(2 * UBLK + 2 * VBLK + 8 * RWAVE) * sizeof(float);
     dim3 grid((unsigned)(((a.total + 7) / 8) * 8), 1, (unsigned)p.nsplit);
     const bool grad = gg.res_mul != 0;          // (every problem of a launch has the multiplier or none has: conv.hip same_problem_shape)
     const int epi = (!grad && (gg.act == ACT_NONE || gg.act == ACT_RELU || gg.act == ACT_LRELU)) ? EPI_LIN
@@ -531,7 +570,7 @@ bool wino_launch(const WinoGeom& gg, const WinoPlan& p, const WinoProb* probs, i
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr = true;
         }
-        hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+        hipLaunchKernelGGL(kern, grid, dim3(WTHREADS), smem, s, a);
     };
     static bool attr_set[4] = {false, false, false, false};
 #ifdef CC_TOOLS

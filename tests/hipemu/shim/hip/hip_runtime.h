@@ -388,6 +388,7 @@ static inline void hipemu_buf_glds16(cc_buf_t r, unsigned voff, unsigned soff, v
     else memcpy(d, r.base + (size_t)voff + soff, 16);
 }
 #define CC_BUF_GLDS16(rsrc, voff, soff, lds_ptr) hipemu_buf_glds16((rsrc), (unsigned)(voff), (unsigned)(soff), (lds_ptr))
+#define CC_WAIT_VMCNT_FENCE(N) hipemu::wave_barrier()
 #define CC_WAIT_VMCNT0_FENCE() hipemu::wave_barrier()      // lanes run one after the other here: the wave must have issued its DMA
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
