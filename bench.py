@@ -436,8 +436,15 @@ def main():
     B, H, W = args.batch, args.height, args.width
     batch_cpu = syn.sample(B, H, W, seed=1 + rank, smooth=3)
     batch = (batch_cpu[0].to(dev), [r.to(dev) for r in batch_cpu[1]], batch_cpu[2].to(dev), batch_cpu[3].to(dev))
+    # measurement switches of the data-parallel step (tools/gpu_r3y.sh, gpu_r3z.sh): read HERE, by the measuring script -- the
+    # product step (cc_amd/trainer.py) reads no environment variable
+    comm_debug = {"events": os.environ.get("CC_NO_COMM_EVENTS", "0") != "1"}
+    if os.environ.get("CC_COMM_JOIN"):
+        comm_debug["join"] = os.environ["CC_COMM_JOIN"]
+    if os.environ.get("CC_COMM_PROBE"):
+        comm_debug["probe"] = os.environ["CC_COMM_PROBE"]
     tr = T.CCTrainer(nets, cfg, use_graph=not args.no_graph,
-                     split_graphs=None if args.split_graphs == "auto" else args.split_graphs == "1")
+                     split_graphs=None if args.split_graphs == "auto" else args.split_graphs == "1", comm_debug=comm_debug)
 
     def sync():
         torch.cuda.synchronize()

@@ -619,33 +619,48 @@ class _BNEvalFn(torch.autograd.Function):
         y = torch.empty_like(x)
         engine().call("cc_bn_eval_fwd", x, weight, bias, running_mean, running_var, y, _ws(8 * C, x), B, C, H, W, float(eps), 0,
                       STREAM)
-        ctx.save_for_backward(weight, running_mean, running_var)
+        need_affine = (weight is not None and weight.requires_grad) or (bias is not None and bias.requires_grad)
+        ctx.save_for_backward(weight, running_mean, running_var, x if need_affine else None)
         ctx.eps = float(eps)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        weight, running_mean, running_var = ctx.saved_tensors
+        weight, running_mean, running_var, x = ctx.saved_tensors
         gy = _c(gy)
         B, C, H, W = gy.shape
-        gx = torch.empty_like(gy)
-        engine().call("cc_bn_eval_fwd", gy, weight, None, running_mean, running_var, gx, _ws(8 * C, gy), B, C, H, W, ctx.eps, 1,
-                      STREAM)
-        return gx, None, None, None, None, None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(gy)
+            engine().call("cc_bn_eval_fwd", gy, weight, None, running_mean, running_var, gx, _ws(8 * C, gy), B, C, H, W, ctx.eps, 1,
+                          STREAM)
+        gw, gb = bn_eval_affine_grads(gy, x, running_mean, running_var, ctx.eps, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        return gx, gw, gb, None, None, None
+
+
+def bn_eval_affine_grads(gy, x, running_mean, running_var, eps, want_w=True, want_b=True):
+    """d/d(weight, bias) of eval-mode BatchNorm  y = (x - mean) / sqrt(var + eps) * weight + bias  (fixed statistics): per-channel
+    sums over (n, h, w).  Outside the training step (the step runs the layer in train() mode; train.py's --fix-* variants freeze
+    the parameters): stock tensor reductions on the device."""
+    gw = gb = None
+    if want_w and x is not None:
+        inv = torch.rsqrt(running_var + eps).view(1, -1, 1, 1)
+        gw = (gy * ((x - running_mean.view(1, -1, 1, 1)) * inv)).sum(dim=(0, 2, 3))
+    if want_b:
+        gb = gy.sum(dim=(0, 2, 3))
+    return gw, gb
 
 
 def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps):
     """nn.BatchNorm2d.forward on csrc/bnorm.hip.  Training mode: three launches for >= 16 k values per channel, one
-    workgroup-per-channel launch below.  Eval mode: the affine map of the running statistics (cc_bn_eval_fwd).  Outside the
-    reference's use of the layer (4-d input, fixed momentum, tracked statistics, eval-mode parameter gradients) it raises."""
+    workgroup-per-channel launch below.  Eval mode: the affine map of the running statistics (cc_bn_eval_fwd), differentiable
+    w.r.t. the input and the affine parameters.  Outside the reference's use of the layer (4-d input, fixed momentum, tracked
+    statistics) it raises."""
     if x.dim() != 4:
         raise NotImplementedError("ccengine BatchNorm: 4-d NCHW input (the reference's nn.BatchNorm2d use)")
     if not training:
         if running_mean is None or running_var is None:
             raise NotImplementedError("ccengine BatchNorm: eval mode needs tracked running statistics")
-        if torch.is_grad_enabled() and ((weight is not None and weight.requires_grad) or (bias is not None and bias.requires_grad)):
-            raise NotImplementedError("ccengine BatchNorm: parameter gradients in eval mode (freeze the affine parameters, as "
-                                      "train.py's --fix-* flags do, or train in train() mode)")
         return _BNEvalFn.apply(x, weight, bias, running_mean, running_var, eps)
     if momentum is None:
         raise NotImplementedError("ccengine BatchNorm: a fixed momentum (the reference's nn.BatchNorm2d use)")

@@ -64,19 +64,50 @@ class _SSIMFn(torch.autograd.Function):
         return g1, g2
 
 
+def _ssim_any_channels(img1, img2):
+    """The 13-tap HIP kernels take planes in groups of three (the step's RGB frames); the map is per channel (depth-wise window), so any
+    channel count is the same computation on [B * C] planes, padded with zero planes to a multiple of three."""
+    B, C, H, W = img1.shape
+    a, b = img1.contiguous().float().reshape(B * C, H, W), img2.contiguous().float().reshape(B * C, H, W)
+    pad = (-B * C) % 3
+    if pad:
+        z = a.new_zeros(pad, H, W)
+        a, b = torch.cat([a, z]), torch.cat([b, z])
+    out = _SSIMFn.apply(a.reshape(-1, 3, H, W), b.reshape(-1, 3, H, W)).reshape(-1, H, W)
+    return out[:B * C].reshape(B, C, H, W)
+
+
+def _ssim_generic(img1, img2, window_size):
+    """ssim.py:19-36 for window sizes other than the 13 taps the training losses use (the module form defaults to 11): depth-wise
+    Gaussian windows as stock grouped convolutions + the SSIM algebra.  NOT on the training step's path (loss_functions.py:80 calls
+    ssim(..., window_size 13)): a generality fallback that runs on the vendor convolution library."""
+    import torch.nn.functional as F
+    C = img1.size(1)
+    window = create_window(window_size, C).to(device=img1.device, dtype=img1.dtype)
+    pad = window_size // 2
+    mu1, mu2 = F.conv2d(img1, window, padding=pad, groups=C), F.conv2d(img2, window, padding=pad, groups=C)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    sigma1_sq = F.conv2d(img1 * img1, window, padding=pad, groups=C) - mu1_sq
+    sigma2_sq = F.conv2d(img2 * img2, window, padding=pad, groups=C) - mu2_sq
+    sigma12 = F.conv2d(img1 * img2, window, padding=pad, groups=C) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    return ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
+
+
 def ssim(img1, img2, window_size=13, size_average=True):
-    """ssim.py:68-76: the un-reduced per-channel SSIM map (size_average is ignored there too)."""
+    """ssim.py:68-76: the un-reduced per-channel SSIM map (size_average is ignored there too).  Window 13 (the reference's default
+    and what its losses use) runs on the HIP kernels for any channel count; other window sizes take the generic path."""
     if window_size != WINDOW_SIZE:
-        raise NotImplementedError("the HIP SSIM kernel is specialised for the 13-tap window the reference uses")
+        return _ssim_generic(img1, img2, window_size)
     if img1.size(1) != 3:
-        raise NotImplementedError("the HIP SSIM kernel is specialised for 3-channel images")
+        return _ssim_any_channels(img1, img2)
     return _SSIMFn.apply(img1, img2)
 
 
 class SSIM(torch.nn.Module):
-    """ssim.py:42-66 (module form; window 13 only)."""
+    """ssim.py:42-66 (module form; its default window is 11, as in the reference)."""
 
-    def __init__(self, window_size=13, size_average=True):
+    def __init__(self, window_size=11, size_average=True):
         super().__init__()
         self.window_size = window_size
         self.size_average = size_average

@@ -265,24 +265,27 @@ class Tape:
         return out
 
     # ------------------------------------------------------------------ activation backward + bias gradient
-    def _act_bias(self, gs, ys, act, act_a, act_b, biases, ref):
+    def _act_bias(self, gs, ys, act, act_a, act_b, biases, ref, targets=None):
         """geff_k = g_k * act'(y_k) (act 0: geff_k = g_k, no pass unless a bias gradient is wanted); bias gradients summed
-        over (B, H, W).  -> list of geff."""
+        over (B, H, W).  -> list of geff.  targets: the (gradient buffer, accumulate) pairs of the biases when the caller has
+        resolved them already -- _param_grad hands out a FRESH buffer with accumulate = False exactly once per parameter, so the
+        per-member calls below must not ask again (they would be told to accumulate into the uninitialised buffer)."""
         G = len(gs)
         B, C, H, W = gs[0].shape
         want_b = biases is not None and biases[0] is not None and biases[0].requires_grad
         if act == 0 and not want_b:
             return list(gs)
-        geffs = [_new((B, C, H, W), ref) for _ in range(G)] if act != 0 else [None] * G
-        gbs, acc = [None] * G, False
+        gbs, acc, tgt = [None] * G, False, None
         if want_b:
-            tgt = [self._param_grad(b) for b in biases]
+            tgt = targets if targets is not None else [self._param_grad(b) for b in biases]
             acc = all(a for _, a in tgt)
-            if not acc and any(a for _, a in tgt):       # mixed: first use of some, second use of others -> one by one below
+            if not acc and any(a for _, a in tgt):       # mixed: first use of some, second use of others -> one by one
+                out = []
                 for k in range(G):
-                    self._act_bias([gs[k]], [ys[k]], act, act_a, act_b, [biases[k]], ref)
-                return geffs if act != 0 else list(gs)
+                    out += self._act_bias([gs[k]], [ys[k]], act, act_a, act_b, [biases[k]], ref, targets=[tgt[k]])
+                return out
             gbs = [t for t, _ in tgt]
+        geffs = [_new((B, C, H, W), ref) for _ in range(G)] if act != 0 else [None] * G
         if act == 0 and acc and ops.wgrad_queue.enabled and not ops._NO_DEFER and not ops._NO_BIAS_TABLE:
             # pure bias sums inside a trainer stage: parked, all layers of the stage in one launch (cc_bias_grad_table)
             for g, gb in zip(gs, gbs):
@@ -293,7 +296,8 @@ class Tape:
         if not uniform:
             out = []
             for k in range(G):
-                out += self._act_bias([gs[k]], [ys[k]], act, act_a, act_b, [biases[k]] if want_b else None, ref)
+                out += self._act_bias([gs[k]], [ys[k]], act, act_a, act_b, [biases[k]] if want_b else None, ref,
+                                      targets=[tgt[k]] if want_b else None)
             return out
         for c0 in range(0, G, 4):
             sl = slice(c0, c0 + 4)
@@ -417,20 +421,24 @@ class Tape:
             for k in live:
                 xs_[k].from_conv(lambda gx, add, mul, k=k: plan.__setitem__(k, (gx, add, mul)))
             todo = [k for k in live if k in plan]
-            groups, seen = [], []
+            groups, last = [], {}
             for k in todo:
                 sg = (plan[k][1] is not None, plan[k][2] is not None, _bs(gz[k]), _bs(plan[k][0]),
                       _bs(plan[k][1]) if plan[k][1] is not None else 0, _bs(xs_[k].t), xs_[k].act, xs_[k].act_a, xs_[k].act_b)
-                for gi, (sg2, idx) in enumerate(groups):
-                    # one launch only for problems with the same epilogue form AND distinct targets (x used twice in the group:
-                    # the second contribution accumulates onto the first, in a later launch)
-                    if sg2 == sg and plan[k][0].data_ptr() not in seen[gi]:
-                        idx.append(k)
-                        seen[gi].add(plan[k][0].data_ptr())
+                # One launch only for problems with the same epilogue form AND distinct targets; and the launches run in creation
+                # order, so a problem may only join a launch that comes AFTER the one holding the previous write of its target (x
+                # used twice: the second contribution accumulates onto the first -- its `add` aliases the target -- and must not be
+                # pulled into an earlier launch of its epilogue form, where it would read the target before it is written)
+                tgt = plan[k][0].data_ptr()
+                first = last.get(tgt, -1) + 1
+                for gi in range(first, len(groups)):
+                    if groups[gi][0] == sg:
+                        groups[gi][1].append(k)
+                        last[tgt] = gi
                         break
                 else:
                     groups.append((sg, [k]))
-                    seen.append({plan[k][0].data_ptr()})
+                    last[tgt] = len(groups) - 1
             for sg, idx in groups:
                 n = len(idx)
                 has_add, has_mul = sg[0], sg[1]
@@ -505,6 +513,15 @@ class Tape:
                         x.skip()
                         return
                     B, C, H, W = g.shape
+                    # affine parameters that still train in eval mode (not the reference's use, but nn.BatchNorm2d allows it)
+                    want_w = mod.weight is not None and mod.weight.requires_grad
+                    want_b = mod.bias is not None and mod.bias.requires_grad
+                    if want_w or want_b:
+                        gw, gb = ops.bn_eval_affine_grads(g.contiguous(), x.t, mod.running_mean, mod.running_var, mod.eps, want_w, want_b)
+                        for p_, gp in ((mod.weight, gw), (mod.bias, gb)):
+                            if gp is not None:
+                                buf, acc = self._param_grad(p_)
+                                buf.add_(gp) if acc else buf.copy_(gp)
 
                     def write(gx, accumulate):
                         dst = gx if not accumulate else torch.empty_like(gx)

@@ -143,6 +143,10 @@ class FlatAdam:
     def __init__(self, nets, cfg):
         params = [p for n in nets if n is not None for p in n.parameters() if p.requires_grad]
         self.params = params
+        # module buffers (BatchNorm running statistics / counters) and frozen parameters: not in the bucket, but part of what rank 0
+        # hands to the other ranks at start-up (train.py:300-303: DataParallel replicates the whole module from device 0)
+        self.extra_state = [b for n in nets if n is not None for b in n.buffers()] + \
+                           [p for n in nets if n is not None for p in n.parameters() if not p.requires_grad]
         dev = params[0].device
         n = sum(p.numel() for p in params)
         pad = (-n) % 4
@@ -164,6 +168,9 @@ class FlatAdam:
         # (the trainer switches ops.grad_sinks to this table for the duration of its own forward+backward only)
         self.sinks = {p.data_ptr(): p.grad for p in params}
         ops.packs.reset()          # weight images registered against the pre-bucket storages are stale now
+        # measurement aid (tools/gpu_r3z.sh: what does the data-parallel step form cost without RCCL?): "skip" / "sidestream" REPLACE
+        # the gradient exchange -- the ranks diverge.  Off unless a tools script sets it on the instance AND says so loudly.
+        self.comm_probe = ""
 
     def zero_grad(self):
         engine().call("cc_fill", self.flat_g, self.flat_g.numel(), 0.0, STREAM)
@@ -185,10 +192,9 @@ class FlatAdam:
         if self.comm_active():
             hi = self.flat_g.numel() if hi is None else hi
             if hi > lo:
-                probe = os.environ.get("CC_COMM_PROBE", "")       # tools/gpu_r3z.sh: what does the step form cost without RCCL?
-                if probe == "skip":
+                if self.comm_probe == "skip":
                     return _NoWork()
-                if probe == "sidestream":
+                if self.comm_probe == "sidestream":
                     return _SideStreamWork(self.flat_g[lo:lo + 4])
                 return dist.all_reduce(self.flat_g[lo:hi], async_op=async_op)
         return None
@@ -237,19 +243,34 @@ class FlatAdam:
         self.lr, self.betas = g["lr"], tuple(g["betas"])
 
     def broadcast_from_rank0(self):
+        """Start-up: every rank continues from rank 0's parameters AND buffers (a --resume that only rank 0 read from disk, per-rank
+        initialisation, a pretrained net loaded on one rank: train.py:257-295 run once, then DataParallel replicates)."""
         if self.comm_active():
             dist.broadcast(self.flat_p, 0)
+            for t in self.extra_state:
+                dist.broadcast(t.data, 0)
 
 
 class CCTrainer:
     """One rank of the data-parallel CC training job."""
 
-    def __init__(self, nets, cfg, use_graph=True, split_graphs=None):
+    def __init__(self, nets, cfg, use_graph=True, split_graphs=None, comm_debug=None):
+        """comm_debug (measurement scripts only; default: plain product step): dict with any of
+             'events': True  -- record HIP events around the waits for the gradient all-reduces (comm_stats(); bench.py asks for it)
+             'join': 'single' -- one join + one optimizer launch instead of the segmented update (A/B)
+             'probe': 'skip' | 'sidestream' -- REPLACE the all-reduces by nothing / a 16-byte side-stream kernel: the ranks diverge;
+                      announced on stderr."""
         self.nets, self.cfg = nets, cfg
+        self.comm_debug = dict(comm_debug or {})
         for n in nets:
             if n is not None:
                 n.train()                                                   # train.py:438-441
         self.opt = FlatAdam(nets, cfg)
+        self.opt.comm_probe = self.comm_debug.get("probe", "")
+        if self.opt.comm_probe:
+            import sys
+            print("[ccengine] WARNING: comm_debug['probe'] = %r -- gradient all-reduces are NOT performed (measurement only)"
+                  % self.opt.comm_probe, file=sys.stderr, flush=True)
         self.opt.broadcast_from_rank0()
         self.bn_counters = tape.BnCounters(nets)
         self.use_graph = use_graph
@@ -475,8 +496,8 @@ class CCTrainer:
             works.append(opt.all_reduce(self.n_dp, None, async_op=True))      # mask + flow segment (70 MB): exposed
             cut = self.n_dp // 4 * 4            # float4 update: cut at a 16-byte boundary (the <= 3 elements left go second)
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] \
-                if (losses["loss"].is_cuda and os.environ.get("CC_NO_COMM_EVENTS", "0") != "1") else None
-            join = os.environ.get("CC_COMM_JOIN", "segmented")       # A/B (tools/gpu_r3z.sh): "single" = one join, one Adam launch
+                if (losses["loss"].is_cuda and self.comm_debug.get("events")) else None
+            join = self.comm_debug.get("join", "segmented")          # A/B (tools/gpu_r3z.sh): "single" = one join, one Adam launch
             if join == "single" and all(w is not None for w in works):
                 if ev:
                     ev[0].record()

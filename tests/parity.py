@@ -96,6 +96,20 @@ def check_ssim(dev, cases=((2, 40, 70, 0), (1, 64, 96, 3), (2, 8, 26, 0), (1, 33
         assert rel(g1[0], g0[0]) < 5e-5 and rel(g1[1], g0[1]) < 5e-5
     xx = torch.rand(1, 3, 20, 30)
     assert float((SS.ssim(xx.to(dev), xx.to(dev)).cpu() - 1).abs().max()) < 1e-5     # ssim(x, x) == 1
+    # the reference's ssim() takes any channel count and window size (ssim.py:42-76; the module form defaults to 11 taps): other
+    # channel counts run on the same 13-tap kernels, other windows on the generic depth-wise path
+    gen = torch.Generator().manual_seed(6)
+    for C, win in ((1, 13), (4, 13), (2, 11), (3, 7)):
+        a0, b0 = torch.rand(2, C, 24, 36, generator=gen), torch.rand(2, C, 24, 36, generator=gen)
+        a1, b1 = leaf(a0, dev), leaf(b0, dev)
+        a0, b0 = leaf(a0, "cpu"), leaf(b0, "cpu")
+        o = SS.ssim(a1, b1, win) if win != 11 else SS.SSIM()(a1, b1)
+        r = SS._ssim_generic(a0, b0, win)                                         # the reference's formula on the CPU
+        assert o.shape == r.shape and float((o.detach().cpu() - r.detach()).abs().max()) < 2e-4, (C, win)
+        go = torch.randn(r.shape, generator=gen)
+        g1 = torch.autograd.grad(o, [a1, b1], go.to(dev))
+        g0 = torch.autograd.grad(r, [a0, b0], go)
+        assert rel(g1[0], g0[0]) < 5e-5 and rel(g1[1], g0[1]) < 5e-5, (C, win)
 
 
 def _pyr(dev, B, H, W, smooth=0):
@@ -119,7 +133,7 @@ def _cmp(name, l1, l0, w1, w0, ltol=1e-4, gtol=1e-4):
         if b is not None:
             # max-norm where the two sides are arithmetic-identical, flip-tolerant otherwise (see frac_bad)
             # pose gradients are pixel sums over every (possibly flipped) tap: small tensors, 1e-2 of their max
-            ok = rel(a, b) < gtol or (b.numel() < 1000 and rel(a, b) < 1e-2) or (
+            ok = rel(a, b) < gtol or (b.numel() < 1000 and _note("cmp:small_grad_rel", rel(a, b)) < 5e-3) or (
                 frac_bad(a, b, gtol * float(b.abs().max()), 1e-3) < 2e-3 and
                 float((a.detach().cpu() - b.detach()).norm() / (b.detach().norm() + 1e-30)) < 5e-2)
             assert ok, (name, rel(a, b))
@@ -260,19 +274,31 @@ def check_warps_bit_exact_vs_golden(dev, golden_dir):
     return out
 
 
+MEASURED = {}      # worst value seen per bar (printed by the tests: the bars below are held at ~2x what is measured)
+
+
+def _note(key, v):
+    MEASURED[key] = max(MEASURED.get(key, 0.0), float(v))
+    return v
+
+
 def _grad_ok(gr, ref, tight):
     """tight: max-norm 2e-4 of the gradient's max.  Otherwise (white-noise frames, where the last-ulp difference
     between this device's P = K.[R|t] and the reference's can move a bilinear tap across a pixel boundary):
-    all but 2e-3 of the elements within 1e-4 of the max, and 5 % in L2."""
+    all but 5e-4 of the elements within 1e-4 of the max, and 5e-3 in L2 (the elements that ARE off are pinned to tap
+    boundaries by _flip_pinned)."""
     mx = float(ref.abs().max())
     l2 = float((gr.detach().cpu() - ref).norm() / (ref.norm() + 1e-30))
     if tight:
         # low-pass frames: a flipped tap changes the interpolation SLOPE at that pixel only slightly -> 5e-3 in L2
         return rel(gr, ref) < 2e-4 or (ref.numel() < 1000 and rel(gr, ref) < 2e-3) or \
             (frac_bad(gr, ref, 1e-4 * mx, 1e-3) < 2e-3 and l2 < 5e-3)
-    if ref.numel() < 1000:          # pose gradient: a pixel sum over every (possibly flipped) tap
-        return rel(gr, ref) < 1e-2
-    return rel(gr, ref) < 2e-4 or (frac_bad(gr, ref, 1e-4 * mx, 1e-3) < 2e-3 and l2 < 5e-2)
+    if ref.numel() < 1000:          # pose gradient: a pixel sum over every (possibly flipped) tap (measured worst 2.5e-3)
+        return _note("noise:pose_grad_rel", rel(gr, ref)) < 5e-3
+    if rel(gr, ref) < 2e-4:
+        return True
+    # measured (emulator and MI355X): 1.6e-4 of the elements off the tight bar, 1.5e-3 in L2 -> bars at ~3x that
+    return _note("noise:frac_bad", frac_bad(gr, ref, 1e-4 * mx, 1e-3)) < 5e-4 and _note("noise:l2", l2) < 5e-3
 
 
 def _tap_boundary_distance(a, i, ac):
@@ -775,6 +801,13 @@ def check_batch_norm(dev, cases=((2, 5, 7, 12), (3, 16, 9, 13), (2, 8, 32, 64), 
         ge1, = torch.autograd.grad(ye, [xd], go.to(dev))
         ge0, = torch.autograd.grad(re, [xc], go)
         assert rel(ge1, ge0) < 2e-6, ("bn eval grad", (B, C, H, W), rel(ge1, ge0))
+        # ... and with affine parameters that still train in eval mode (nn.BatchNorm2d allows it): all three gradients
+        ye2 = ops.batch_norm(xd, wd, bd, rmd, rvd, None, False, 0.1, 1e-5)
+        re2 = F.batch_norm(xc, rmc, rvc, wc, bc, False, 0.1, 1e-5)
+        ga1 = torch.autograd.grad(ye2, [xd, wd, bd], go.to(dev))
+        ga0 = torch.autograd.grad(re2, [xc, wc, bc], go)
+        errs = [rel(a, b) for a, b in zip(ga1, ga0)]
+        assert max(errs) < 1e-5, ("bn eval affine grads", (B, C, H, W), errs)
     with pytest.raises(ValueError):          # torch's own check: one value per channel cannot be normalised
         ops.batch_norm(torch.zeros(1, 3, 1, 1, device=dev), None, None, None, None, None, True, 0.1, 1e-5)
 

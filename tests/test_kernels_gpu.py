@@ -15,6 +15,16 @@ def test_library_is_the_hip_build():
     assert torch.cuda.is_available()
 
 
+def test_library_is_built_from_the_sources_in_the_tree():
+    """The .so travels prebuilt with the snapshot (it is git-ignored): a stale one must fail loudly -- cc_version() carries the
+    hash of the kernel sources + headers it was compiled from (cc_amd/build.py source_hash, csrc/version.hip)."""
+    from cc_amd import _lib, build
+    v = int(_lib.engine().fn["cc_version"]())
+    assert v & 0xFFFFFFFF == build.source_hash(), "cc_amd/libccengine.so was built from other sources: run python -m cc_amd.build"
+    assert v >> 32 == 2
+    assert _lib.engine().fn["cc_is_tools_build"]() == 0
+
+
 def test_warps():
     parity.check_warps("cuda")
 
@@ -53,6 +63,7 @@ def test_warps_bit_exact_vs_reference_golden(golden_dir):
 
 def test_losses_vs_reference_golden(golden_dir):
     print(parity.check_losses_vs_golden("cuda", golden_dir))
+    print("measured against the bars:", parity.MEASURED)
 
 
 def test_convs():

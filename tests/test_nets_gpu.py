@@ -56,8 +56,10 @@ def test_net_forward_backward(name):
         num += float((p1.grad.cpu().double() - p2.grad.double()).pow(2).sum())
         den += float(p2.grad.double().pow(2).sum())
     # fp32 accumulation-order noise through ~60 layers + BatchNorm over as few as 4 values (the oracle runs on this
-    # host's CPU, whose conv kernels round differently from the build container's): 1e-3 of the gradient norm
-    assert (num / den) ** 0.5 < 1e-3
+    # host's CPU, whose conv kernels round differently from the build container's): 1e-4 of the gradient norm (measured on
+    # the emulator: 2.4e-6; a mis-accumulated fan-out in the tape shows up at 1e-2 and above)
+    print(name, "parameter-gradient error / norm:", (num / den) ** 0.5)
+    assert (num / den) ** 0.5 < 1e-4
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
@@ -204,7 +206,7 @@ def test_step_with_rccl_process_group_of_one(monkeypatch):
         nets = T.build_nets(dev, init=False)
         for n in nets:
             n.load_state_dict(syn.seeded_state_dict(n, 0))
-        tr = T.CCTrainer(nets, T.StepConfig(), use_graph=True)
+        tr = T.CCTrainer(nets, T.StepConfig(), use_graph=True, comm_debug={"events": True})
         l1 = {k: float(v) for k, v in tr.step(batch).items()}
         l2 = {k: float(v) for k, v in tr.step(batch).items()}
         l3 = {k: float(v) for k, v in tr.step(batch).items()}
@@ -233,3 +235,60 @@ def test_step_with_rccl_process_group_of_one(monkeypatch):
     for a, b in ((a1, b1), (a2, b2), (a3, b3)):
         for k in a:
             assert abs(a[k] - b[k]) <= 2e-5 * abs(a[k]) + 1e-9, (k, a[k], b[k])
+
+
+def test_checkpoint_resume_on_device(tmp_path):
+    """SURVEY.md 8(f) rank 3 on the device (utils.py:55-63, train.py:286-295,311-315,396-413): a device-resident, hipGraph-replayed
+    CCTrainer (parameters = views of the flat bucket, device step counter, BatchNorm buffers updated inside the graph) is saved
+    after two steps; a fresh set of networks + trainer resumes from the files and runs step 3: identical to step 3 of the trainer
+    that never stopped (bit for bit in config.deterministic).  The files load into nets that carry the reference's keys (the
+    oracle's) and into a real torch.optim.Adam."""
+    import os
+    from cc_amd import config, utils
+    import oracle.nets as ON
+    dev = torch.device("cuda")
+    bc = syn.sample(2, 128, 192, seed=1)
+    batch = (bc[0].to(dev), [r.to(dev) for r in bc[1]], bc[2].to(dev), bc[3].to(dev))
+    old = config.deterministic
+    config.deterministic = True
+    try:
+        nets = T.build_nets(dev, init=False)
+        for n in nets:
+            n.load_state_dict(syn.seeded_state_dict(n, 0))
+        tr = T.CCTrainer(nets, T.StepConfig(), use_graph=True)
+        tr.step(batch)
+        tr.step(batch)
+        torch.cuda.synchronize()
+        tr.save_checkpoint(tmp_path, epoch=0, is_best=False)
+        l3 = {k: float(v) for k, v in tr.step(batch).items()}
+        torch.cuda.synchronize()
+        p3 = tr.opt.flat_p.clone()
+        m3 = tr.opt.exp_avg.clone()
+        bn3 = torch.cat([b.detach().double().reshape(-1) for n in nets for b in n.buffers()])
+        # files are per-tensor storages (not 297 MB bucket views) with the reference's layout
+        for prefix in utils.FILE_PREFIXES:
+            assert os.path.getsize(os.path.join(tmp_path, prefix + "_checkpoint.pth.tar")) < 4.5e8
+        ref_nets = [ON.DispResNet6(), ON.PoseNetB6(nb_ref_imgs=4), ON.MaskNet6(nb_ref_imgs=4, output_exp=True), ON.Back2Future(nlevels=6)]
+        for prefix, net in zip(utils.FILE_PREFIXES, ref_nets):
+            w = torch.load(os.path.join(tmp_path, prefix + "_checkpoint.pth.tar"), map_location="cpu")
+            assert set(w.keys()) == {"epoch", "state_dict"} and w["epoch"] == 1
+            net.load_state_dict(w["state_dict"])                       # strict: the reference's keys and shapes
+        params = [p for n in ref_nets for p in n.parameters()]
+        topt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.999))
+        topt.load_state_dict(torch.load(os.path.join(tmp_path, "optimizer_checkpoint.pth.tar"), map_location="cpu")["state_dict"])
+        assert float(topt.state[params[0]]["step"]) == 2.0
+        # resume: train.py's order -- networks first, then the optimizer over them
+        nets2 = T.build_nets(dev, init=True)
+        assert utils.resume(tmp_path, *nets2, map_location=dev) == 1
+        tr2 = T.CCTrainer(nets2, T.StepConfig(), use_graph=True)
+        assert utils.resume_optimizer(tmp_path, tr2, map_location=dev) is True
+        assert float(tr2.opt.step_dev) == 2.0
+        r3 = {k: float(v) for k, v in tr2.step(batch).items()}
+        torch.cuda.synchronize()
+        for k in l3:
+            assert l3[k] == r3[k], (k, l3[k], r3[k])
+        assert torch.equal(tr2.opt.flat_p, p3) and torch.equal(tr2.opt.exp_avg, m3)
+        bn3b = torch.cat([b.detach().double().reshape(-1) for n in nets2 for b in n.buffers()])
+        assert torch.equal(bn3, bn3b)
+    finally:
+        config.deterministic = old

@@ -142,12 +142,18 @@ def _cc_dp_worker(rank, world, port, ret):
         nets = T.build_nets("cpu", init=False)
         for n in nets:
             n.load_state_dict(syn.seeded_state_dict(n, 0))
-            if rank == 1:                                   # the start-up broadcast must bring rank 1 back to rank 0's weights
+            if rank == 1:                                   # the start-up broadcast must bring rank 1 back to rank 0's weights ...
                 for p in n.parameters():
                     p.data.mul_(1.01)
+                for b in n.buffers():                       # ... and buffers (BatchNorm running statistics / counters: a resume
+                    if b.dtype.is_floating_point:           # that only rank 0 read from disk)
+                        b.data.add_(0.5)
+                    else:
+                        b.data.add_(7)
         tr = T.CCTrainer(nets, T.StepConfig(), use_graph=False)
         assert tr.split_graphs and 0 < tr.n_dp < tr.opt.n
         p0 = tr.opt.flat_p.clone()
+        buf0 = torch.cat([b.detach().double().reshape(-1) for n in nets for b in n.buffers()])
         local = torch.zeros_like(tr.opt.flat_g)
         calls = []
         orig = tr.opt.all_reduce
@@ -159,7 +165,7 @@ def _cc_dp_worker(rank, world, port, ret):
             return orig(lo, hi, async_op)
         tr.opt.all_reduce = spy
         losses = tr.step(batch)
-        ret[rank] = dict(p0=p0, local=local, reduced=tr.opt.flat_g.clone(), p1=tr.opt.flat_p.clone(), calls=calls,
+        ret[rank] = dict(p0=p0, buf0=buf0, local=local, reduced=tr.opt.flat_g.clone(), p1=tr.opt.flat_p.clone(), calls=calls,
                          n_dp=tr.n_dp, loss=float(losses["loss"]))
     dist.destroy_process_group()
 
@@ -175,6 +181,7 @@ def test_cc_step_data_parallel_two_ranks_gloo():
     mp.spawn(_cc_dp_worker, args=(world, port, ret), nprocs=world, join=True)
     r0, r1 = ret[0], ret[1]
     assert torch.equal(r0["p0"], r1["p0"]), "broadcast from rank 0 did not equalise the start weights"
+    assert r0["buf0"].numel() > 0 and torch.equal(r0["buf0"], r1["buf0"]), "broadcast from rank 0 did not equalise the module buffers"
     assert torch.equal(r0["reduced"], r1["reduced"]) and torch.equal(r0["p1"], r1["p1"]), "ranks diverged"
     assert torch.equal(r0["reduced"], r0["local"] + r1["local"])
     assert float(r0["local"].abs().sum()) > 0 and not torch.equal(r0["local"], r1["local"])
