@@ -30,6 +30,12 @@
 typedef __amdgpu_buffer_rsrc_t cc_buf_t;
 #define CC_BUF_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
 #define CC_BUF_LOAD_F32(rsrc, voff, soff) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32((rsrc), (int)(voff), (int)(soff), 0))
+typedef unsigned cc_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 cc_buf_load_f32x2(cc_buf_t rsrc, unsigned voff, unsigned soff) {
+    const cc_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)soff, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+#define CC_BUF_LOAD_F32X2(rsrc, voff, soff) cc_buf_load_f32x2((rsrc), (voff), (soff))
 #endif
 #define CC_BUF_OOB 0x80000000u
 

@@ -2402,6 +2402,7 @@ inline W3Plan plan_w3(int B, int M, int AH, int AW, int Cin, int R, int S, int s
 }
 
 static size_t wgrad_ws_bytes_base(int B, int M, int AH, int AW, int Cin, int R, int S, int si);
+static size_t wgrad_ws_bytes_rest(int B, int M, int AH, int AW, int Cin, int R, int S, int si);
 
 size_t cc_conv2d_wgrad_ws_bytes(int B, int M, int AH, int AW, int Cin, int R, int S, int si) {
     // the thin path is confirmed at launch (pad, input width): size for it AND for the path it would fall back to
@@ -2411,6 +2412,18 @@ size_t cc_conv2d_wgrad_ws_bytes(int B, int M, int AH, int AW, int Cin, int R, in
 }
 
 static size_t wgrad_ws_bytes_base(int B, int M, int AH, int AW, int Cin, int R, int S, int si) {
+    size_t wino = 0;
+    if (R == 3 && S == 3 && si == 1) {       // Winograd path (pad / input size are implied by "same" convolutions: checked again at launch)
+        for (int G = 1; G <= MAXGRP; G += MAXGRP - 1) {
+            const ccint::WinoWgradPlan wp = ccint::wino_wgrad_plan(B, M, AH, AW, Cin, G);
+            if (wp.ok && wp.ws_floats * sizeof(float) > wino) wino = wp.ws_floats * sizeof(float);
+        }
+    }
+    const size_t rest = wgrad_ws_bytes_rest(B, M, AH, AW, Cin, R, S, si);
+    return wino > rest ? wino : rest;
+}
+
+static size_t wgrad_ws_bytes_rest(int B, int M, int AH, int AW, int Cin, int R, int S, int si) {
     {   // the 3x3/s1/p1 path (pad and input size are implied by "same" convolutions: checked again at launch)
         const W3Plan q = plan_w3(B, M, AH, AW, Cin, R, S, si, 1, AH, AW);
         if (q.ok) return q.ws_floats * sizeof(float);
@@ -2441,6 +2454,34 @@ static int wgrad_group_impl(int G, const long* a, const long* x, const long* gw,
     hipStream_t s = (hipStream_t)stream;
     long rd[MAXGRP][ccint::RD_LONGS];
     const size_t stride_f = cc_conv2d_wgrad_ws_bytes(B, M, AH, AW, Cin, R, S, si) / sizeof(float);
+    if (R == 3 && S == 3 && si == 1 && pad == 1 && IH == AH && IW == AW) {
+        // Winograd F(3x3, 2x2): 16 instead of 36 multiply-adds per 2x2 tile (wino_wgrad.hip); same slab layout / reduction as k_wgrad3x3
+        const ccint::WinoWgradPlan wp = ccint::wino_wgrad_plan(B, M, AH, AW, Cin, G);
+        if (wp.ok) {
+            const float *ap[MAXGRP], *xp[MAXGRP];
+            float* wsp[MAXGRP];
+            for (int k = 0; k < G; k++) { ap[k] = (const float*)a[k]; xp[k] = (const float*)x[k]; wsp[k] = ws + k * stride_f + 64; }
+            bool ok;
+            {
+                char nm[128];
+                int nl = snprintf(nm, sizeof nm, "k_wino_wgrad");
+                if (cctools::env_flag("CC_TIMING_DETAIL"))
+                    snprintf(nm + nl, sizeof nm - nl, " G%d B%d M%d C%d %dx%d k%d wg%d", G, B, M, Cin, AH, AW, wp.nsplit,
+                             wp.nmb * wp.ncb * G * wp.nsplit);
+                cctiming::Scope tsc(nm, 2e-9 * 16.0 * G * B * ((AH + 1) / 2) * ((AW + 1) / 2) * (double)M * Cin, s);
+                ok = ccint::wino_wgrad_launch(wp, ap, xp, wsp, G, B, M, AH, AW, a_bs, Cin, x_bs, s);
+            }
+            if (ok) {
+                for (int k = 0; k < G; k++) {
+                    const long d[ccint::RD_LONGS] = {1, (long)wsp[k], (long)gw[k], wp.nsplit, accumulate, o_sm, o_sc, 9, M, Cin, wp.Cp};
+                    for (int i = 0; i < ccint::RD_LONGS; i++) rd[k][i] = d[i];
+                }
+                if (ccint::wgrad_reduce_emit(sink, &rd[0][0], G, s) != CC_OK) return CC_ERR_ARG;
+                CC_CHECK_LAUNCH();
+                return CC_OK;
+            }
+        }
+    }
     {   // thin layers fill the chip on their own: one launch per problem
         bool thin = true;
         char nm[128];

@@ -49,4 +49,18 @@ bool wino_launch(const WinoGeom& g, const WinoPlan& p, const WinoProb* probs, in
 void wino_weights_launch(const float* w, float* U, int M, int Cin, int Cpad, int Mpad, long w_sm, long w_sc, long w0, long w_ri,
                          long w_sj, int flip, hipStream_t s);
 
+// ---- Winograd F(3x3, 2x2) weight gradient (wino_wgrad.hip): 3x3 / stride-1 / pad-1 layers, dY [B, M, H, W], x [B, Cin, H, W]
+struct WinoWgradPlan {
+    int ok;
+    int TX, CPR, CPI, NCH;      // tile columns; 8-tile chunks per tile row / per image / in total
+    int nmb, ncb, Cp;           // 64-row blocks of dY / of the input, padded input channels (slab pitch)
+    int nsplit, cps;            // split of the chunk range, chunks per split
+    size_t ws_floats;           // 64 + partial slabs ws[split][tap 9][m][Cp] (the layout of k_wgrad3x3: reduce kind 1)
+};
+WinoWgradPlan wino_wgrad_plan(int B, int M, int H, int W, int Cin, int G);
+// G (<= 4) same-shaped problems in one launch; ws[k]: slab area of problem k.  -> false (nothing launched) when the tensors are not
+// 8- / 16-byte aligned
+bool wino_wgrad_launch(const WinoWgradPlan& p, const float* const* a, const float* const* x, float* const* ws, int G, int B, int M,
+                       int H, int W, long a_bs, int Cin, long x_bs, hipStream_t s);
+
 }  // namespace ccint

@@ -374,6 +374,12 @@ static inline float hipemu_buf_load(cc_buf_t r, unsigned voff, unsigned soff) {
     return v;
 }
 #define CC_BUF_LOAD_F32(rsrc, voff, soff) hipemu_buf_load((rsrc), (unsigned)(voff), (unsigned)(soff))
+static inline float2 hipemu_buf_load2(cc_buf_t r, unsigned voff, unsigned soff) {
+    float2 v{0.f, 0.f};
+    if (voff + 4 < r.bytes) memcpy(&v, r.base + (size_t)voff + soff, 8);
+    return v;
+}
+#define CC_BUF_LOAD_F32X2(rsrc, voff, soff) hipemu_buf_load2((rsrc), (unsigned)(voff), (unsigned)(soff))
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 // four LDS-DMA rows, 1 KB apart on both sides (cc_common.h CC_GLDS16X4)
 static inline void hipemu_glds16x4(const void* src, void* dst) {

@@ -65,6 +65,17 @@ def test_convs_winograd_fused_epilogue(monkeypatch):
     parity.check_convs("cpu", cases=parity.CONV_CASES_WINO, tcases=[], prepack=True)
 
 
+def test_convs_winograd_weight_gradient(monkeypatch):
+    # the small test maps on the Winograd F(3x3, 2x2) weight-gradient kernel (wino_wgrad.hip): odd heights, channel counts that are
+    # not multiples of 64, tile rows that are not multiples of the 8-tile chunks, several splits
+    monkeypatch.setenv("CC_WW_MINQ", "1")
+    monkeypatch.setenv("CC_WW_MINM", "1")
+    monkeypatch.setenv("CC_WW_MINC", "1")
+    monkeypatch.setenv("CC_WW_MINCHUNKS", "2")
+    parity.check_convs("cpu", cases=parity.CONV_CASES_WINO, tcases=[])
+    parity.check_conv_groups("cpu", cases=((2, 40, 5, 8, 136, 16, 1), (1, 32, 4, 16, 72, 8, 1)))        # G = 3 problems per launch
+
+
 def test_convs_thin_wgrad(monkeypatch):
     monkeypatch.setenv("CC_WGRAD_THIN_MINPIX", "0")      # route the small test maps through wgrad_thin.hip
     monkeypatch.setenv("CC_WGRAD_THIN_UPB", "8")

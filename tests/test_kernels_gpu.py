@@ -75,6 +75,8 @@ def test_convs_winograd():
     # whole reduction (fused epilogue), each per call and through the per-step weight images
     parity.check_convs("cuda", cases=parity.CONV_CASES_WINO, tcases=[], prepack=True)
     parity.check_convs("cuda", cases=parity.CONV_CASES_WINO_LARGE, tcases=[], prepack=True)
+    # (the large cases also run their weight gradients on the Winograd F(3x3, 2x2) kernel, wino_wgrad.hip; grouped form below)
+    parity.check_conv_groups("cuda", cases=((2, 48, 16, 32, 64, 48, 1),))
 
 
 def test_convs_prepacked_weight_images():
