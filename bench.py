@@ -543,19 +543,37 @@ def main():
             eager = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                          "tflops": round(v["gflop"] / v["ms"], 2) if v["ms"] > 0 else 0.0}
                      for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:6]} if groups else None
+            wino = kn.startswith("k_wino")        # Winograd kernels: the numerator is the MFMA FLOPs they EXECUTE (16 multiply-adds per
+            #                                         2x2 tile and channel pair; the direct form of the same layers has 36)
+
+            def _k(k, v):
+                r = {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["gflop"] / v["ms"], 2) if v["ms"] > 0 else 0.0}
+                if k.startswith("k_wino"):
+                    r["direct_equivalent_tflops"] = round(2.25 * r["tflops"], 2)
+                return r
+            mfma_k = {k: v for k, v in dev_k.items() if v["gflop"] > 0}
+            ex_ms, ex_gf = sum(v["ms"] for v in mfma_k.values()), sum(v["gflop"] for v in mfma_k.values())
             roof = {"bound": "mfma", "kernel": kn, "achieved": round(ach, 2), "peak": PEAK_MFMA_F32, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_MFMA_F32, 4), "traffic": traffic, "traffic_source": src,
                     "launches": a["launches"], "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2),
                     "timing": "HIP events around the kernel launch on its stream (cc_timing_enable / cc_timing_collect), one "
                               "eager step; all launches of this device kernel in the step (grouped, split-K and plain)",
                     "algorithmic_gflop_per_launch": round(a["gflop"] / a["launches"], 3),
+                    "flops": ("MFMA FLOPs executed by the Winograd F(2x2, 3x3) kernel = 4/9 of the direct form's 2*MACs of the same layers"
+                              if wino else "2*MACs of the layers"),
+                    "direct_equivalent_tflops": round(2.25 * ach, 2) if wino else None,
                     "ms_per_step": round(a["ms"], 3),
                     "conv_family": {"achieved": round(fam, 2), "frac": round(fam / PEAK_MFMA_F32, 4),
                                     "launches": sum(v["calls"] for v in convs.values()), "ms_per_step": round(tot_ms, 3),
+                                    "flops": "direct-form 2*MACs of every conv / data-gradient / weight-gradient call (the layers on the "
+                                             "Winograd kernels execute 4/9 of theirs: see mfma_executed)",
                                     "timing": "HIP events around each C-ABI call (kernel + its epilogue / reduction launches)"},
-                    "by_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
-                                      "tflops": round(v["gflop"] / v["ms"], 2) if v["ms"] > 0 else 0.0}
-                                  for k, v in sorted(dev_k.items(), key=lambda kv: -kv[1]["ms"])[:8]},
+                    "mfma_executed": {"achieved": round(ex_gf / ex_ms, 2) if ex_ms > 0 else 0.0,
+                                      "frac": round(ex_gf / ex_ms / PEAK_MFMA_F32, 4) if ex_ms > 0 else 0.0,
+                                      "gflop_per_step": round(ex_gf, 1), "ms_per_step": round(ex_ms, 3),
+                                      "what": "FLOPs the matrix cores execute in one step / time of the MFMA kernels themselves "
+                                              "(HIP events around each main kernel; epilogue and reduction launches not included)"},
+                    "by_kernel": {k: _k(k, v) for k, v in sorted(dev_k.items(), key=lambda kv: -kv[1]["ms"])[:10]},
                     "by_call_group": eager}
 
     if rank == 0:

@@ -2702,6 +2702,7 @@ int cc_is_tools_build(void) {
 
 /* ---- introspection (bench.py groups its per-call timings by the kernel a call dispatches to) */
 static void patch_name(const ConvPlan& p, bool multi, char* out, int cap) {
+    if (p.wino) { snprintf(out, cap, "k_wino_f2x3<%d>%s", p.nsplit > 1 ? 1 : 0, p.nsplit > 1 ? "+splitk" : ""); return; }
     if (!p.use_patch) { snprintf(out, cap, "k_gather_gemm<%d>", pick_bm(p.Mpad ? p.Mpad : 32)); return; }
     if (multi) snprintf(out, cap, "k_conv_patch_multi<%d, %d, %d>%s", p.bm, p.ck, p.tps, p.nsplit > 1 ? "+splitk" : "");
     else snprintf(out, cap, "k_conv_patch<%d, %d, %d, %d>%s", p.bm, p.ck, p.tps, p.nsplit > 1 ? 1 : 0, p.nsplit > 1 ? "+splitk" : "");
@@ -2747,6 +2748,10 @@ int cc_conv2d_dgrad_kernel(int B, int K, int OH, int OW, int C, int R, int S, in
 int cc_conv2d_wgrad_kernel(int B, int M, int AH, int AW, int Cin, int IH, int IW, int R, int S, int si, int pad,
                            void* name_out_host, int cap) {
     char* out = (char*)name_out_host;
+    if (R == 3 && S == 3 && si == 1 && pad == 1 && IH == AH && IW == AW && ccint::wino_wgrad_plan(B, M, AH, AW, Cin, 1).ok) {
+        snprintf(out, cap, "k_wino_wgrad");
+        return CC_OK;
+    }
     ccint::wgrad_thin_name(B, M, AH, AW, Cin, IH, IW, R, S, si, pad, out, cap);
     if (out[0]) return CC_OK;
     const W3Plan q = plan_w3(B, M, AH, AW, Cin, R, S, si, pad, IH, IW);

@@ -103,6 +103,16 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_wino_f2x3(WN g) {
     const int c_beg = (int)blockIdx.z * g.cps;
     int c_end = c_beg + g.cps;
     if (c_end > g.nchunk) c_end = g.nchunk;
+    // An odd number of stages starts on parity 1 (LDS buffers 1; the peeled stage sits IN FRONT of the loop: behind it, the
+    // accumulators of the two paths would meet and hipcc copies them).  The prologue fills the buffers of the first parity.
+    const int odd = (c_end - c_beg) & 1;
+    auto dma_U = [&](int kc, int buf) {      // this wave's eighth (4 KB) of the 32 KB block
+        if constexpr (ABL & 4) return;
+        const float* src = P.U + ((long)mb * g.nchunk + kc) * UBLK + wid * 1024 + lane * 4;
+        CC_GLDS16X4(src, Us + buf * UBLK + wid * 1024);
+    };
+
+    if (c_beg < c_end) dma_U(c_beg, odd);      // first request of the workgroup: in flight while the patch geometry is worked out
 
     // ---- input path.  Every VMEM instruction is expensive for the wave that issues it, so the raw input goes the way that needs
     // the fewest: 16-byte LDS-DMA.  Transform role of wave w: the 16 consecutive tiles tg = w & 3 of the block x the channel quad
@@ -196,23 +206,22 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_wino_f2x3(WN g) {
         o[(4 * i + 2) * 512] = tt[i][2] - tt[i][1];
         o[(4 * i + 3) * 512] = tt[i][1] - tt[i][3];
     };
-    auto dma_U = [&](int kc, int buf) {      // this wave's eighth (4 KB) of the 32 KB block
-        if constexpr (ABL & 4) return;
-        const float* src = P.U + ((long)mb * g.nchunk + kc) * UBLK + wid * 1024 + lane * 4;
-        CC_GLDS16X4(src, Us + buf * UBLK + wid * 1024);
-    };
+    // the patch starts as zeros (slots that are out of range for every chunk must read as the conv's zero padding whether or not an
+    // out-of-range DMA lane writes its zeros)
+#pragma unroll
+    for (int i = 0; i < 3; i++) *reinterpret_cast<float4*>(Rw + i * 256 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): before the first DMA into the patch
+    __builtin_amdgcn_wave_barrier();
+    if (c_beg < c_end) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) dma_raw(c_beg, i);
+    }
 
     f32x16 acc[8];
 #pragma unroll
     for (int f = 0; f < 8; f++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[f][r] = 0.f;
-
-    // the patch starts as zeros (slots that are out of range for every chunk must read as the conv's zero padding whether or not an
-    // out-of-range DMA lane writes its zeros)
-#pragma unroll
-    for (int i = 0; i < 3; i++) *reinterpret_cast<float4*>(Rw + i * 256 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): before the first DMA into the patch
 
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
@@ -281,12 +290,6 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_wino_f2x3(WN g) {
     };
 
     if (c_beg < c_end) {
-        // An odd number of stages starts on parity 1 (LDS buffers 1; the peeled stage sits IN FRONT of the loop: behind it, the
-        // accumulators of the two paths would meet and hipcc copies them).  The prologue fills the buffers of the first parity.
-        const int odd = (c_end - c_beg) & 1;
-        dma_U(c_beg, odd);
-#pragma unroll
-        for (int i = 0; i < 3; i++) dma_raw(c_beg, i);
         CC_WAIT_VMCNT0_FENCE();
         read_raw();
 #pragma unroll
@@ -330,6 +333,62 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_wino_f2x3(WN g) {
         z10 = (p1[0] + p1[1]) + p1[2];
         z11 = (p1[1] - p1[2]) - p1[3];
     };
+    // output geometry of this lane and, for the common case (even W, 8-byte aligned rows: both columns of the tile exist), EVERY
+    // load of the epilogue (bias, residual / multiplier, add) -- issued here, in front of the exchange, so that their latency runs
+    // under it, and in front of the first store: on gfx9 one counter tracks loads and stores, so a load behind a store waits for
+    // the store's round trip
+    const int q = qb * 64 + wt * 32 + l31;
+    const bool qv = q < g.Q;
+    const int qq = qv ? q : 0;
+    const int n = qq / g.TPI;
+    const int qr = qq - n * g.TPI;
+    const int ty = qr / g.TX, tx = qr - ty * g.TX;
+    const int oy = 2 * ty, ox = 2 * tx;
+    const int m_base = mb * WBM + wm * 32 + 4 * lk;
+    const bool hr = P.res != nullptr, ha = P.add != nullptr;
+    const bool row1 = oy + 1 < g.H;
+    const long o0 = (long)oy * g.W + ox;
+    float bias_r[8];
+    float2 res_r[8][2], add_r[8][2];
+    if constexpr (!SPLIT) {
+#pragma unroll
+        for (int r8 = 0; r8 < 8; r8++) {
+            bias_r[r8] = 0.f;
+            res_r[r8][0] = res_r[r8][1] = add_r[r8][0] = add_r[r8][1] = make_float2(0.f, 0.f);
+        }
+        if (g.vec2 && qv) {
+            const int w1 = row1 ? g.W : 0;
+#pragma unroll
+            for (int r8 = 0; r8 < 8; r8++) {
+                const int r = 8 * fh + r8;
+                const int m = m_base + (r & 3) + 8 * (r >> 2);
+                const int mc = m < g.M ? m : g.M - 1;
+                if (P.bias) bias_r[r8] = P.bias[mc];
+            }
+            if (hr) {
+                const float* rb = P.res + (long)n * g.res_bs + o0;
+#pragma unroll
+                for (int r8 = 0; r8 < 8; r8++) {
+                    const int r = 8 * fh + r8;
+                    const int m = m_base + (r & 3) + 8 * (r >> 2);
+                    const int mc = m < g.M ? m : g.M - 1;
+                    res_r[r8][0] = *reinterpret_cast<const float2*>(rb + (long)mc * g.HW);
+                    res_r[r8][1] = *reinterpret_cast<const float2*>(rb + (long)mc * g.HW + w1);
+                }
+            }
+            if (ha) {
+                const float* ab = P.add + (long)n * g.add_bs + o0;
+#pragma unroll
+                for (int r8 = 0; r8 < 8; r8++) {
+                    const int r = 8 * fh + r8;
+                    const int m = m_base + (r & 3) + 8 * (r >> 2);
+                    const int mc = m < g.M ? m : g.M - 1;
+                    add_r[r8][0] = *reinterpret_cast<const float2*>(ab + (long)mc * g.HW);
+                    add_r[r8][1] = *reinterpret_cast<const float2*>(ab + (long)mc * g.HW + w1);
+                }
+            }
+        }
+    }
     float* Xs = smem;                                          // [sub-tile 4][sender fh 2][row 8][value 4][lane 64]
     {
         float* xo = Xs + ((st * 2 + fh) * 32) * 64 + lane;
@@ -345,14 +404,7 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_wino_f2x3(WN g) {
         }
     }
     __syncthreads();
-    const int q = qb * 64 + wt * 32 + l31;
-    if (q >= g.Q) return;
-    const int n = q / g.TPI;
-    const int qr = q - n * g.TPI;
-    const int ty = qr / g.TX, tx = qr - ty * g.TX;
-    const int oy = 2 * ty, ox = 2 * tx;
-    const int m_base = mb * WBM + wm * 32 + 4 * lk;
-    const bool hr = P.res != nullptr, ha = P.add != nullptr;
+    if (!qv) return;
     const float* xi = Xs + ((st * 2 + (fh ^ 1)) * 32) * 64 + lane;
     auto out_tile = [&](int r8, float& y00, float& y01, float& y10, float& y11) {
         part_tile(8 * fh + r8, y00, y01, y10, y11);
@@ -378,8 +430,6 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_wino_f2x3(WN g) {
         }
         return;
     }
-    const bool row1 = oy + 1 < g.H;
-    const long o0 = (long)oy * g.W + ox;
     // slope of the branch-free activation forms: t > 0 ? t : slope * t  (none 1, ReLU 0, LeakyReLU act_b, 0 -> 0.2: conv_tail.h)
     const float slope = g.act == ACT_RELU ? 0.f : (g.act == ACT_LRELU ? (g.act_b != 0.f ? g.act_b : 0.2f) : 1.f);
     auto tail = [&](float v, float r, float ad) -> float {
@@ -394,43 +444,7 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_wino_f2x3(WN g) {
         }
     };
     if (g.vec2) {
-        // even W, 8-byte aligned rows: both columns of the tile exist.  Every load of the epilogue (bias, residual / multiplier, add)
-        // is issued BEFORE the first store: on gfx9 one counter tracks loads and stores, so a load behind a store waits for the
-        // store's round trip
-        float bias_r[8];
-        float2 res_r[8][2], add_r[8][2];
-#pragma unroll
-        for (int r8 = 0; r8 < 8; r8++) {
-            const int r = 8 * fh + r8;
-            const int m = m_base + (r & 3) + 8 * (r >> 2);
-            const int mc = m < g.M ? m : g.M - 1;
-            bias_r[r8] = P.bias ? P.bias[mc] : 0.f;
-            res_r[r8][0] = res_r[r8][1] = add_r[r8][0] = add_r[r8][1] = make_float2(0.f, 0.f);
-        }
         float* yb = P.y + (long)n * g.y_bs + o0;
-        const int w1 = row1 ? g.W : 0;
-        if (hr) {
-            const float* rb = P.res + (long)n * g.res_bs + o0;
-#pragma unroll
-            for (int r8 = 0; r8 < 8; r8++) {
-                const int r = 8 * fh + r8;
-                const int m = m_base + (r & 3) + 8 * (r >> 2);
-                const int mc = m < g.M ? m : g.M - 1;
-                res_r[r8][0] = *reinterpret_cast<const float2*>(rb + (long)mc * g.HW);
-                res_r[r8][1] = *reinterpret_cast<const float2*>(rb + (long)mc * g.HW + w1);
-            }
-        }
-        if (ha) {
-            const float* ab = P.add + (long)n * g.add_bs + o0;
-#pragma unroll
-            for (int r8 = 0; r8 < 8; r8++) {
-                const int r = 8 * fh + r8;
-                const int m = m_base + (r & 3) + 8 * (r >> 2);
-                const int mc = m < g.M ? m : g.M - 1;
-                add_r[r8][0] = *reinterpret_cast<const float2*>(ab + (long)mc * g.HW);
-                add_r[r8][1] = *reinterpret_cast<const float2*>(ab + (long)mc * g.HW + w1);
-            }
-        }
 #pragma unroll
         for (int r8 = 0; r8 < 8; r8++) {
             const int r = 8 * fh + r8;

@@ -314,7 +314,7 @@ WinoWgradPlan wino_wgrad_plan(int B, int M, int H, int W, int Cin, int G) {
     p.ncb = (Cin + 63) / 64;
     p.Cp = p.ncb * 64;
     const long base = (long)p.nmb * p.ncb * (G > 1 ? G : 1);
-    long nsplit = (cctools::env_int("CC_WW_SPLIT", 512) + base - 1) / base;
+    long nsplit = (cctools::env_int("CC_WW_SPLIT", 256) + base - 1) / base;
     const long cap = (p.NCH + cctools::env_int("CC_WW_MINCHUNKS", 8) - 1) / cctools::env_int("CC_WW_MINCHUNKS", 8);
     if (nsplit > cap) nsplit = cap;
     if (nsplit < 1) nsplit = 1;
