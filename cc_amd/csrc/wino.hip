@@ -257,7 +257,7 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_wino_f2x3(WN g) {
             } else if (fp < 3) {
                 a[nxt][0] = a[cur][1]; b[nxt][0] = b[cur][1]; a[nxt][1] = a[cur][0]; b[nxt][1] = b[cur][0];
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(ABL & 64)) __builtin_amdgcn_sched_barrier(0);
             const float av[2][4] = {{a[cur][0].x, a[cur][0].y, a[cur][0].z, a[cur][0].w}, {a[cur][1].x, a[cur][1].y, a[cur][1].z, a[cur][1].w}};
             const float bv[2][4] = {{b[cur][0].x, b[cur][0].y, b[cur][0].z, b[cur][0].w}, {b[cur][1].x, b[cur][1].y, b[cur][1].z, b[cur][1].w}};
 #pragma unroll
@@ -267,8 +267,9 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_wino_f2x3(WN g) {
                 else acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i & 1][j], bv[i & 1][j], acc[f], 0, 0, 0);
                 const int gap = 8 * fp + i;
                 // (the two waves of a SIMD, fh = 0 / 1, issue their DMA in different gaps; uniform branches: fh is wave-uniform)
-                if (gap == 0) { if (fh == 0) dma_U(kd, buf ^ 1); }
-                else if (gap == 2) { if (fh == 1) dma_U(kd, buf ^ 1); }
+                constexpr int GU = (ABL & 128) ? 8 : 0;       // variant: U requests later in the stage
+                if (gap == GU) { if (fh == 0) dma_U(kd, buf ^ 1); }
+                else if (gap == GU + 2) { if (fh == 1) dma_U(kd, buf ^ 1); }
                 else if (gap == 18) { CC_WAIT_VMCNT_FENCE(4); read_raw(); }       // the patch (requested one stage ago) is in; the U group may be out
                 else if (gap >= 19 && gap < 27) {
                     const int s8 = gap - 19;                   // steps 0-3: columns, 4-7: rows
@@ -277,9 +278,10 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_wino_f2x3(WN g) {
                 }
                 else if (gap == 27) { if (fh == 0) { dma_raw(kc + 2, 0); dma_raw(kc + 2, 1); dma_raw(kc + 2, 2); } }
                 else if (gap == 29) { if (fh == 1) { dma_raw(kc + 2, 0); dma_raw(kc + 2, 1); dma_raw(kc + 2, 2); } }
-                if (gap == 0 || gap == 2 || (gap >= 18 && gap < 30)) __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!(ABL & 64))
+                    if (gap == GU || gap == GU + 2 || (gap >= 18 && gap < 30)) __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(ABL & 64)) __builtin_amdgcn_sched_barrier(0);
         }
         // end of the stage: this wave's V writes are done and its part of the next U block has landed (it is older than the three
         // patch requests, which stay in flight across the barrier: memory reads return in issue order)
@@ -601,6 +603,8 @@ bool wino_launch(const WinoGeom& gg, const WinoPlan& p, const WinoProb* probs, i
             case 16: go(k_wino_f2x3<0, 0, 16>, attr_abl[7]); return true;
             case 23: go(k_wino_f2x3<0, 0, 23>, attr_abl[8]); return true;
             case 32: go(k_wino_f2x3<0, 0, 32>, attr_abl[9]); return true;
+            case 64: go(k_wino_f2x3<0, 0, 64>, attr_abl[10]); return true;
+            case 128: go(k_wino_f2x3<0, 0, 128>, attr_abl[11]); return true;
             default: break;
         }
     }
