@@ -113,6 +113,13 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_wino_f2x3(WN g) {
     };
 
     if (c_beg < c_end) dma_U(c_beg, odd);      // first request of the workgroup: in flight while the patch geometry is worked out
+    // bias of this wave's 32 output rows: ONE load now (lane l31 -> row wm*32 + l31), handed to the rows' owners by lane shuffles in
+    // the epilogue (eight scalar loads per lane there cost eight VMEM issues and a memory round trip per workgroup)
+    float bias_w = 0.f;
+    if constexpr (!SPLIT) {
+        const int mr = mb * WBM + wm * 32 + l31;
+        if (P.bias) bias_w = P.bias[mr < g.M ? mr : g.M - 1];
+    }
 
     // ---- input path.  Every VMEM instruction is expensive for the wave that issues it, so the raw input goes the way that needs
     // the fewest: 16-byte LDS-DMA.  Transform role of wave w: the 16 consecutive tiles tg = w & 3 of the block x the channel quad
@@ -335,10 +342,11 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_wino_f2x3(WN g) {
         z10 = (p1[0] + p1[1]) + p1[2];
         z11 = (p1[1] - p1[2]) - p1[3];
     };
-    // output geometry of this lane and, for the common case (even W, 8-byte aligned rows: both columns of the tile exist), EVERY
-    // load of the epilogue (bias, residual / multiplier, add) -- issued here, in front of the exchange, so that their latency runs
-    // under it, and in front of the first store: on gfx9 one counter tracks loads and stores, so a load behind a store waits for
-    // the store's round trip
+    // output geometry of this lane.  Lanes 2k / 2k + 1 hold horizontally adjacent tiles of one tile row (TX is even), i.e. 4 x 2
+    // pixels: the even lane takes row oy of the pair, the odd lane row oy + 1, and every access of the epilogue (residual /
+    // multiplier, add, the result) is ONE 16-byte operation per lane and output channel instead of two 8-byte ones.  The loads are
+    // issued here, in front of the exchange, so that their latency runs under it, and in front of the first store: on gfx9 one
+    // counter tracks loads and stores, so a load behind a store waits for the store's round trip.
     const int q = qb * 64 + wt * 32 + l31;
     const bool qv = q < g.Q;
     const int qq = qv ? q : 0;
@@ -350,43 +358,31 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_wino_f2x3(WN g) {
     const bool hr = P.res != nullptr, ha = P.add != nullptr;
     const bool row1 = oy + 1 < g.H;
     const long o0 = (long)oy * g.W + ox;
-    float bias_r[8];
-    float2 res_r[8][2], add_r[8][2];
+    const int odd_lane = lane & 1;
+    // this lane's 16-byte piece: row oy + odd_lane, columns 4 * (tx >> 1) .. + 3
+    const long o4 = (long)(oy + odd_lane) * g.W + (ox - 2 * odd_lane);
+    const bool row_ok = odd_lane ? row1 : true;
+    float4 res_r[8], add_r[8];
     if constexpr (!SPLIT) {
 #pragma unroll
-        for (int r8 = 0; r8 < 8; r8++) {
-            bias_r[r8] = 0.f;
-            res_r[r8][0] = res_r[r8][1] = add_r[r8][0] = add_r[r8][1] = make_float2(0.f, 0.f);
-        }
-        if (g.vec2 && qv) {
-            const int w1 = row1 ? g.W : 0;
-#pragma unroll
-            for (int r8 = 0; r8 < 8; r8++) {
-                const int r = 8 * fh + r8;
-                const int m = m_base + (r & 3) + 8 * (r >> 2);
-                const int mc = m < g.M ? m : g.M - 1;
-                if (P.bias) bias_r[r8] = P.bias[mc];
-            }
+        for (int r8 = 0; r8 < 8; r8++) res_r[r8] = add_r[r8] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.vec2 && qv && row_ok) {
             if (hr) {
-                const float* rb = P.res + (long)n * g.res_bs + o0;
+                const float* rb = P.res + (long)n * g.res_bs + o4;
 #pragma unroll
                 for (int r8 = 0; r8 < 8; r8++) {
                     const int r = 8 * fh + r8;
                     const int m = m_base + (r & 3) + 8 * (r >> 2);
-                    const int mc = m < g.M ? m : g.M - 1;
-                    res_r[r8][0] = *reinterpret_cast<const float2*>(rb + (long)mc * g.HW);
-                    res_r[r8][1] = *reinterpret_cast<const float2*>(rb + (long)mc * g.HW + w1);
+                    res_r[r8] = *reinterpret_cast<const float4*>(rb + (long)(m < g.M ? m : g.M - 1) * g.HW);
                 }
             }
             if (ha) {
-                const float* ab = P.add + (long)n * g.add_bs + o0;
+                const float* ab = P.add + (long)n * g.add_bs + o4;
 #pragma unroll
                 for (int r8 = 0; r8 < 8; r8++) {
                     const int r = 8 * fh + r8;
                     const int m = m_base + (r & 3) + 8 * (r >> 2);
-                    const int mc = m < g.M ? m : g.M - 1;
-                    add_r[r8][0] = *reinterpret_cast<const float2*>(ab + (long)mc * g.HW);
-                    add_r[r8][1] = *reinterpret_cast<const float2*>(ab + (long)mc * g.HW + w1);
+                    add_r[r8] = *reinterpret_cast<const float4*>(ab + (long)(m < g.M ? m : g.M - 1) * g.HW);
                 }
             }
         }
@@ -406,7 +402,6 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_wino_f2x3(WN g) {
         }
     }
     __syncthreads();
-    if (!qv) return;
     const float* xi = Xs + ((st * 2 + (fh ^ 1)) * 32) * 64 + lane;
     auto out_tile = [&](int r8, float& y00, float& y01, float& y10, float& y11) {
         part_tile(8 * fh + r8, y00, y01, y10, y11);
@@ -415,8 +410,15 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_wino_f2x3(WN g) {
         y10 += xi[(r8 * 4 + 2) * 64];
         y11 += xi[(r8 * 4 + 3) * 64];
     };
+    // the pair exchange: the even lane hands its row oy + 1 to the odd lane and receives the odd lane's row oy -> (4 pixels of one
+    // row) per lane.  Every lane of the wave takes part (lanes past the end of the problem carry garbage that is never stored).
+    auto pair4 = [&](float y00, float y01, float y10, float y11) -> float4 {
+        const float sx = odd_lane ? y00 : y10, sy = odd_lane ? y01 : y11;
+        const float rx = __shfl_xor(sx, 1), ry = __shfl_xor(sy, 1);
+        return odd_lane ? make_float4(rx, ry, y10, y11) : make_float4(y00, y01, rx, ry);
+    };
     if constexpr (SPLIT) {
-        float* pb0 = P.part + (long)blockIdx.z * g.part_stride + (((long)n * g.M) * g.Hp + oy) * g.Wp + ox;
+        float* pb0 = P.part + (long)blockIdx.z * g.part_stride + (((long)n * g.M) * g.Hp + oy + odd_lane) * g.Wp + (ox - 2 * odd_lane);
         const long mstride = (long)g.Hp * g.Wp;
 #pragma unroll
         for (int r8 = 0; r8 < 8; r8++) {
@@ -424,11 +426,8 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_wino_f2x3(WN g) {
             const int m = m_base + (r & 3) + 8 * (r >> 2);
             float y00, y01, y10, y11;
             out_tile(r8, y00, y01, y10, y11);
-            if (m < g.M) {
-                float* pb = pb0 + (long)m * mstride;
-                *reinterpret_cast<float2*>(pb) = make_float2(y00, y01);
-                *reinterpret_cast<float2*>(pb + g.Wp) = make_float2(y10, y11);
-            }
+            const float4 v = pair4(y00, y01, y10, y11);
+            if (qv && m < g.M) *reinterpret_cast<float4*>(pb0 + (long)m * mstride) = v;      // (slab rows 2 TY x 2 TX: both rows exist)
         }
         return;
     }
@@ -446,27 +445,24 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_wino_f2x3(WN g) {
         }
     };
     if (g.vec2) {
-        float* yb = P.y + (long)n * g.y_bs + o0;
+        float* yb = P.y + (long)n * g.y_bs + o4;
 #pragma unroll
         for (int r8 = 0; r8 < 8; r8++) {
             const int r = 8 * fh + r8;
             const int m = m_base + (r & 3) + 8 * (r >> 2);
             float y00, y01, y10, y11;
             out_tile(r8, y00, y01, y10, y11);
-            const float bv = bias_r[r8];
-            float2 o0v, o1v;
-            o0v.x = tail(y00 + bv, res_r[r8][0].x, add_r[r8][0].x);
-            o0v.y = tail(y01 + bv, res_r[r8][0].y, add_r[r8][0].y);
-            o1v.x = tail(y10 + bv, res_r[r8][1].x, add_r[r8][1].x);
-            o1v.y = tail(y11 + bv, res_r[r8][1].y, add_r[r8][1].y);
-            if (m < g.M) {
-                float* yo = yb + (long)m * g.HW;
-                *reinterpret_cast<float2*>(yo) = o0v;
-                if (row1) *reinterpret_cast<float2*>(yo + g.W) = o1v;
-            }
+            const float bv = __shfl(bias_w, 4 * lk + (r & 3) + 8 * (r >> 2));      // row m of this lane: lane m - (mb*64 + wm*32) of the wave's load
+            float4 v = pair4(y00, y01, y10, y11);
+            v.x = tail(v.x + bv, res_r[r8].x, add_r[r8].x);
+            v.y = tail(v.y + bv, res_r[r8].y, add_r[r8].y);
+            v.z = tail(v.z + bv, res_r[r8].z, add_r[r8].z);
+            v.w = tail(v.w + bv, res_r[r8].w, add_r[r8].w);
+            if (qv && row_ok && m < g.M) *reinterpret_cast<float4*>(yb + (long)m * g.HW) = v;
         }
         return;
     }
+    if (!qv) return;
     // odd heights / unaligned tensors: element by element (rare)
     const bool col1 = ox + 1 < g.W;
 #pragma unroll
@@ -569,9 +565,10 @@ bool wino_launch(const WinoGeom& gg, const WinoPlan& p, const WinoProb* probs, i
     a.Hp = p.Hp; a.Wp = p.Wp;
     a.part_stride = (long)gg.B * gg.M * p.Hp * p.Wp;
     a.act = gg.act; a.act_a = gg.act_a; a.act_b = gg.act_b; a.res_mul = gg.res_mul;
-    bool v2 = (gg.W % 2 == 0) && (gg.y_bs % 2 == 0) && (gg.res_bs % 2 == 0) && (gg.add_bs % 2 == 0);
+    // 16-byte epilogue accesses (lane pairs: 4 pixels of one row): rows and batch strides of y / res / add 16-byte aligned
+    bool v2 = (gg.W % 4 == 0) && (gg.y_bs % 4 == 0) && (gg.res_bs % 4 == 0) && (gg.add_bs % 4 == 0);
     for (int k = 0; k < nprob; k++)
-        v2 = v2 && ((((uintptr_t)probs[k].y) | (uintptr_t)probs[k].res | (uintptr_t)probs[k].add) % 8 == 0);
+        v2 = v2 && ((((uintptr_t)probs[k].y) | (uintptr_t)probs[k].res | (uintptr_t)probs[k].add | (uintptr_t)probs[k].part) % 16 == 0);
     a.vec2 = v2 ? 1 : 0;
     if (cctools::env_flag("CC_WINO_TRACE"))
         fprintf(stderr, "wino: %dx[B%d M%d C%d %dx%d] nqb %d nmb %d nsplit %d cps %d act %d res_mul %d vec2 %d\n", nprob, gg.B, gg.M, gg.Cin,
