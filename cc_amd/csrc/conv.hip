@@ -261,6 +261,8 @@ struct CP {
     int Rt, St, si, dstep, dy_base, dx_base, ymin, xmin;
     int PH, PWr, PS;
     int tw16;              // tile = 8 rows x 16 columns instead of 4 x 32
+    int ipt, phi;          // ipt > 1: maps of <= 4 lattice rows -- the 8 tile rows stack the rows of ipt consecutive images, each with
+                           // its own phi patch rows (halo included) in the LDS patch
     int aligned, shift;    // aligned: patch rows start on a 16-byte boundary of x (PWr = padded row length) -> dwordx4 LDS-DMA
     int OHt, OWt, so, oy0, ox0, OH, OW; long y_bs, res_bs;
     int tiles_x, tiles_y;
@@ -386,7 +388,9 @@ __device__ __forceinline__ float abl_fix(float v) { return (v == v && fabsf(v) <
 __device__ __forceinline__ float abl_fix(float v) { return v; }
 #endif
 
-template <int BM, int CK, int TPS, int SPLIT>
+// STK: the tile stacks the rows of CP::ipt images (maps of <= 4 lattice rows); a separate instantiation -- the row mapping costs
+// scalar registers the common kernels do not have (they sit at the SGPR limit: +10 spills and -6 % measured with it compiled in)
+template <int BM, int CK, int TPS, int SPLIT, int STK>
 __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
     constexpr int WM = (BM >= 64) ? BM / 2 : 32;
     constexpr int TM = WM / 32;
@@ -405,7 +409,9 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
     const int tile_x = bx % g.tiles_x;
     bx /= g.tiles_x;
     const int tile_y = bx % g.tiles_y;
-    const int n = bx / g.tiles_y;
+    const int ipt = STK ? g.ipt : 1;
+    const int n = (bx / g.tiles_y) * ipt;                       // (first) image of the tile
+    const int n_tile = n;
     const int rowstep = g.tw16 ? 2 : 1;                         // lattice rows per MFMA column group
     const int lr = g.tw16 ? (l31 >> 4) : 0, lc = g.tw16 ? (l31 & 15) : l31;     // this lane's row / column inside the group
     const int ty0 = tile_y * (g.tw16 ? 8 : TH), tx0 = tile_x * (g.tw16 ? 16 : TW);
@@ -419,6 +425,19 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
     const int x_cs = g.IH * g.IW;
     const int R = g.PS >> 6;
     const float* xn = g.x + (long)n * g.x_bs;
+    // tile row -> (image of the tile, lattice row); rows past the stacked images are dead (their results are not stored)
+    auto rowmap = [&](int tyv, int& j, int& ty) -> bool {
+        if (!STK || ipt <= 1) { j = 0; ty = tyv; return true; }
+        j = tyv / g.OHt;
+        ty = tyv - j * g.OHt;
+        return j < ipt && n + j < g.B;
+    };
+    // patch offset of a tile row's first pixel (dead rows read row 0: any finite address inside the patch)
+    auto prow = [&](int tr) -> int {
+        if (!STK || ipt <= 1) return g.si * tr * g.PWr;
+        int j, ty;
+        return rowmap(tr, j, ty) ? (j * g.phi + g.si * ty) * g.PWr : 0;
+    };
 
     auto load_patch = [&](int chunk, int buf) {
         float* dst = Ps + buf * CK * g.PS;
@@ -429,10 +448,11 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
             const int nq = g.PS >> 2;                         // chunks per channel (multiple of 16)
             for (int q0 = 0; q0 < nq; q0 += 64) {
                 const int q = q0 + lane;
-                const int py = q / cpr, qx = q - py * cpr;
+                const int pyt = q / cpr, qx = q - pyt * cpr;
+                const int pj = (STK && ipt > 1) ? pyt / g.phi : 0, py = pyt - pj * g.phi;       // stacked images: patch rows [image][phi]
                 const int iy = gy0 + py, ix = gx0 - g.shift + 4 * qx;
-                const bool ok = (q < nq) && (py < g.PH) && ((unsigned)iy < (unsigned)g.IH) && ((unsigned)ix < (unsigned)g.IW);
-                const long go = (long)iy * g.IW + ix;
+                const bool ok = (q < nq) && (pyt < g.PH) && (!STK || n + pj < g.B) && ((unsigned)iy < (unsigned)g.IH) && ((unsigned)ix < (unsigned)g.IW);
+                const long go = (STK ? (long)pj * g.x_bs : 0l) + (long)iy * g.IW + ix;
 #pragma unroll
                 for (int k = 0; k < CK / 4; k++) {
                     const int cl = wid + 4 * k;
@@ -445,10 +465,11 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
         }
         for (int r = 0; r < R; r++) {
             const int pos = lane + 64 * r;
-            const int py = pos / g.PWr, px = pos - py * g.PWr;
+            const int pyt = pos / g.PWr, px = pos - pyt * g.PWr;
+            const int pj = (STK && ipt > 1) ? pyt / g.phi : 0, py = pyt - pj * g.phi;
             const int iy = gy0 + py, ix = gx0 + px;
-            const bool ok = (py < g.PH) && ((unsigned)iy < (unsigned)g.IH) && ((unsigned)ix < (unsigned)g.IW);
-            const long go = (long)iy * g.IW + ix;
+            const bool ok = (pyt < g.PH) && (!STK || n + pj < g.B) && ((unsigned)iy < (unsigned)g.IH) && ((unsigned)ix < (unsigned)g.IW);
+            const long go = (STK ? (long)pj * g.x_bs : 0l) + (long)iy * g.IW + ix;
 #pragma unroll
             for (int k = 0; k < CK / 4; k++) {
                 const int cl = wid + 4 * k;
@@ -488,6 +509,16 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
     f32x4 acc16[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // BM == 16 only
 
+    // patch offsets of this lane's pixels (one per lattice-row group of the wave)
+    int poff[2] = {0, 0};
+    if constexpr (STK && BM == 16) {
+        const int l15 = lane & 15;
+        poff[0] = prow(rowstep * row0) + g.si * l15;
+        poff[1] = g.tw16 ? prow(rowstep * row0 + 1) + g.si * l15 : poff[0] + g.si * 16;
+    } else if constexpr (STK != 0) {
+#pragma unroll
+        for (int b = 0; b < 2; b++) poff[b] = prow(rowstep * (row0 + (b < TN ? b : 0)) + lr) + g.si * lc;
+    }
     if (c_beg < c_end) {
         load_patch(c_beg, c_beg & 1);
         load_A(c_beg, 0, 0);
@@ -513,15 +544,15 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
                             // 16x16x4: lane (i = lane & 15, k = lane >> 4) feeds A[m = i][k] and B[k][pixel = i]; two 16-pixel
                             // halves of the wave's lattice row -> two independent accumulators (40-cycle dependent latency)
                             const int l15 = lane & 15, l4 = lane >> 4;
-                            const float* Pl = Pb + l4 * g.PS + (g.si * rowstep * row0) * g.PWr + g.si * l15 + tapoff;
+                            const float* Pl = Pb + l4 * g.PS + (STK ? 0 : (g.si * rowstep * row0) * g.PWr + g.si * l15) + tapoff;
                             const float* Al = Ab + l4 * BM + l15;
                             const int half = g.tw16 ? g.si * g.PWr : g.si * 16;      // second 16-pixel half: next row / next 16 columns
                             float af[CK / 4], bf[CK / 4][2];
 #pragma unroll
                             for (int ks = 0; ks < CK / 4; ks++) {
                                 af[ks] = Al[(4 * ks) * BM];
-                                bf[ks][0] = Pl[(4 * ks) * g.PS];
-                                bf[ks][1] = Pl[(4 * ks) * g.PS + half];
+                                bf[ks][0] = Pl[(4 * ks) * g.PS + (STK ? poff[0] : 0)];
+                                bf[ks][1] = Pl[(4 * ks) * g.PS + (STK ? poff[1] : half)];
                             }
 #pragma unroll
                             for (int ks = 0; ks < CK / 4; ks++) {
@@ -531,7 +562,7 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
                             if (++tj == g.St) { tj = 0; ti++; }
                             continue;
                         }
-                        const float* Pl = Pb + lk * g.PS + (g.si * (rowstep * row0 + lr)) * g.PWr + g.si * lc + tapoff;
+                        const float* Pl = Pb + lk * g.PS + (STK ? 0 : (g.si * (rowstep * row0 + lr)) * g.PWr + g.si * lc) + tapoff;
                         const float* Al = Ab + lk * BM + wm * WM + l31;
                         // all fragments of a tap are fetched up front (2*(TM+TN)*CK/2 VGPRs): one exposed LDS latency per
                         // tap instead of one per k-step; the MFMAs then issue back to back behind counted lgkmcnt waits
@@ -547,7 +578,7 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
 #pragma unroll
                             for (int a = 0; a < TM; a++) af[ks][a] = Al[(2 * ks) * BM + a * 32];
 #pragma unroll
-                            for (int b = 0; b < TN; b++) bf[ks][b] = Pl[(2 * ks) * g.PS + (g.si * rowstep * b) * g.PWr];
+                            for (int b = 0; b < TN; b++) bf[ks][b] = Pl[(2 * ks) * g.PS + (STK ? poff[b] : (g.si * rowstep * b) * g.PWr)];
 #endif
                         }
 #pragma unroll
@@ -579,9 +610,11 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
         const int HWt = g.OHt * g.OWt;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const int ty = ty0 + rowstep * row0 + (g.tw16 ? h : 0);
+            int ej, ty;
+            if (!rowmap(ty0 + rowstep * row0 + (g.tw16 ? h : 0), ej, ty)) continue;
             const int tx = tx0 + (g.tw16 ? 0 : 16 * h) + (lane & 15);
             if (ty >= g.OHt || tx >= g.OWt) continue;
+            const int n = STK ? n_tile + ej : n_tile;                          // (shadows the tile's first image)
             const long pix = (long)(g.oy0 + g.so * ty) * g.OW + (g.ox0 + g.so * tx);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -628,11 +661,12 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
     if (split) {
         auto tile = [&](const f32x16& A, const int a, const int b) {
             stage(A);
-            const int ty = ty0 + rowstep * (row0 + b) + lr4;
+            int ej, ty;
+            const bool rowok = rowmap(ty0 + rowstep * (row0 + b) + lr4, ej, ty);
             // the slab is padded so that every store is aligned and in bounds, but the padding is never read: quads that start
             // outside the image are not written (the 2x7 / 4x13 layers would otherwise write 5-18x their partial sums)
-            const bool live = ty < g.OHt && tx < g.OWt;
-            float* pb = g.part + (long)blockIdx.z * g.part_stride + (((long)n * g.M + (m0 + wm * WM + a * 32 + rsub)) * Hp + ty) * Wp + tx;
+            const bool live = rowok && ty < g.OHt && tx < g.OWt;
+            float* pb = g.part + (long)blockIdx.z * g.part_stride + (((long)(n + ej) * g.M + (m0 + wm * WM + a * 32 + rsub)) * Hp + ty) * Wp + tx;
             const long mstep = (long)8 * Hp * Wp;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -657,8 +691,10 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
     const bool hr = g.res != nullptr, ha = g.add != nullptr;
     auto tile = [&](const f32x16& A, const int a, const int b) {
         stage(A);
-        const int ty = ty0 + rowstep * (row0 + b) + lr4;
-        const bool inside = ty < g.OHt && tx < g.OWt;
+        int ej, ty;
+        const bool rowok = rowmap(ty0 + rowstep * (row0 + b) + lr4, ej, ty);
+        const bool inside = rowok && ty < g.OHt && tx < g.OWt;
+        const int n = STK ? n_tile + ej : n_tile;                              // (shadows the tile's first image)
         const long pix = (long)(g.oy0 + g.so * ty) * g.OW + (g.ox0 + g.so * tx);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -710,7 +746,11 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
 #endif
 template <int BM, int CK, int TPS, int SPLIT>
 __global__ __launch_bounds__(256, CC_PATCH_LB) void k_conv_patch(CP g) {
-    conv_patch_body<BM, CK, TPS, SPLIT>(g, (int)blockIdx.x);
+    conv_patch_body<BM, CK, TPS, SPLIT, 0>(g, (int)blockIdx.x);
+}
+template <int BM, int TPS, int SPLIT>          // stacked tiny maps (8-channel chunks only)
+__global__ __launch_bounds__(256, CC_PATCH_LB) void k_conv_patch_stk(CP g) {
+    conv_patch_body<BM, 8, TPS, SPLIT, 1>(g, (int)blockIdx.x);
 }
 
 // The (up to) four output-parity classes of a stride-2 data-gradient / transposed convolution in ONE launch:
@@ -728,23 +768,27 @@ struct CPM {
     int bx_end[MAXCLS];
 };
 
-template <int BM, int CK, int TPS>
-__global__ __launch_bounds__(256, CC_PATCH_LB) void k_conv_patch_multi(CPM a) {
-    int k = 0, first = 0;
-#pragma unroll
-    for (int q = 0; q < MAXCLS - 1; q++)
-        if (q + 1 < a.n && (int)blockIdx.x >= a.bx_end[q]) { k = q + 1; first = a.bx_end[q]; }
-    // the class descriptor is read straight from the kernel-argument segment (scalar loads at a run-time offset): indexing the
-    // by-value argument `a.c[k]` makes the compiler copy descriptors to scratch memory once the body is large
+// (a macro, not a function taking the argument block by reference: the kernel reads its class descriptor from the kernel-argument
+// segment, and the wrapper cost nine more scalar spills)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(CC_HIPEMU)
-    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
-    const CP& g = *(reinterpret_cast<const CP*>(ka + offsetof(CPM, c)) + k);
+#define CC_MULTI_DESC(a, k) (*(reinterpret_cast<const CP*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(CPM, c)) + (k)))
 #else
-    const CP& g = a.c[k];
+#define CC_MULTI_DESC(a, k) ((a).c[k])
 #endif
-    if ((int)blockIdx.z >= g.nsplit || (int)blockIdx.y * BM >= g.Mpad) return;       // grid.y / grid.z are the launch's maxima
-    conv_patch_body<BM, CK, TPS, 2>(g, (int)blockIdx.x - first);
-}
+// the class descriptor is read straight from the kernel-argument segment (scalar loads at a run-time offset): indexing the
+// by-value argument `a.c[k]` makes the compiler copy descriptors to scratch memory once the body is large
+#define CC_MULTI_BODY(BM_, CK_, TPS_, STK_)                                                                                   \
+    int k = 0, first = 0;                                                                                                     \
+    _Pragma("unroll") for (int q = 0; q < MAXCLS - 1; q++)                                                                    \
+        if (q + 1 < a.n && (int)blockIdx.x >= a.bx_end[q]) { k = q + 1; first = a.bx_end[q]; }                                \
+    const CP& g = CC_MULTI_DESC(a, k);                                                                                        \
+    if ((int)blockIdx.z >= g.nsplit || (int)blockIdx.y * BM_ >= g.Mpad) return;     /* grid.y / grid.z are the launch's maxima */ \
+    conv_patch_body<BM_, CK_, TPS_, 2, STK_>(g, (int)blockIdx.x - first);
+
+template <int BM, int CK, int TPS>
+__global__ __launch_bounds__(256, CC_PATCH_LB) void k_conv_patch_multi(CPM a) { CC_MULTI_BODY(BM, CK, TPS, 0) }
+template <int BM, int TPS>                     // at least one class with stacked tiny maps (the others have ipt = 1)
+__global__ __launch_bounds__(256, CC_PATCH_LB) void k_conv_patch_multi_stk(CPM a) { CC_MULTI_BODY(BM, 8, TPS, 1) }
 
 // y[lattice pixel] = act(bias + res + sum_k part[k])  (second, deterministic stage of split-K)
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict__ part, int nsplit, long part_stride,
@@ -840,11 +884,15 @@ struct ConvPlan {
     ccint::WinoPlan wn;
     int Hp, Wp;                // rows / pitch of the split-K partial slabs [split][n][m][Hp][Wp]
     int tw16;
+    int ipt, phi;              // stacked tiny maps (CP::ipt)
     int bm, ck, tps, Mpad, Cpad, PH, PWr, PS, ymin, xmin, tiles_x, tiles_y, nsplit, cps, aligned, shift;
     size_t smem, wp_floats, part_floats;
 };
 
 static int env_int_early(const char* name, int dflt) { return cctools::env_int(name, dflt); }
+
+// pixel tiles of a problem (grid.x of its launch): stacked tiny maps take one tile per ipt images
+inline long conv_tiles(const GG& g, const ConvPlan& p) { return (long)((g.B + p.ipt - 1) / p.ipt) * p.tiles_x * p.tiles_y; }
 
 // mult: number of same-shaped problems that share the launch (split-K only has to fill what they leave empty)
 // 3x3 / stride 1 / pad 1 on the full lattice, taps forwards (conv2d) or backwards (its data-gradient)
@@ -856,6 +904,7 @@ inline bool wino_geometry(const GG& g) {
 
 inline ConvPlan plan_conv(const GG& g, int mult = 1) {
     ConvPlan p = {};
+    p.ipt = 1;
     if (wino_geometry(g)) {
         // the algorithm is a function of the geometry alone (the per-step weight image is laid out for it); `mult` only moves split-K
         const ccint::WinoPlan w = ccint::wino_plan(g.B, g.Cin, g.IH, g.IW, g.M, mult);
@@ -891,6 +940,14 @@ inline ConvPlan plan_conv(const GG& g, int mult = 1) {
         // ties (all maps of <= 16x52: both shapes pad them equally) go to 8 x 16: -0.07 ms/step (r3s3)
         p.tw16 = ((a16 < a32 || (a16 == a32 && env_int_early("CC_CONV_TW16_TIES", 1))) && !dbg_flag_early("CC_CONV_NO_TW16")) ? 1 : 0;
     }
+    // Maps of <= 4 lattice rows (DispResNet6's 4x13 / 2x7 / 1x4 levels and their parity classes): one image fills 1-4 of the 8 tile
+    // rows and the matrix cores multiply padding (a 2x7 map: 14 live pixels of 128).  The 8 x 16 tile then stacks the rows of
+    // 8 / OHt consecutive images, each with its own halo rows in the patch.
+    p.ipt = 1;
+    if (g.OHt <= 4 && g.B >= 2 && env_int_early("CC_CONV_STACK", 1) && !dbg_flag_early("CC_CONV_CK16")) {
+        p.tw16 = 1;
+        p.ipt = 8 / g.OHt < g.B ? 8 / g.OHt : g.B;
+    }
     const int th = p.tw16 ? 8 : TH, tw = p.tw16 ? 16 : TW;
     {   // few pixel tiles: shrink the channel tile (more workgroups, every one over the whole reduction) before resorting to
         // split-K (partial slabs + an epilogue launch); CC_CONV_BM_MINBLOCKS: block count below which the tile is halved
@@ -905,6 +962,11 @@ inline ConvPlan plan_conv(const GG& g, int mult = 1) {
     p.xmin = g.dx0 < xlast ? g.dx0 : xlast;
     const int ymax = g.dy0 < ylast ? ylast : g.dy0, xmax = g.dx0 < xlast ? xlast : g.dx0;
     p.PH = (th - 1) * g.si + (ymax - p.ymin) + 1;
+    p.phi = 0;
+    if (p.ipt > 1) {
+        p.phi = (g.OHt - 1) * g.si + (ymax - p.ymin) + 1;
+        p.PH = p.ipt * p.phi;
+    }
     p.PWr = (tw - 1) * g.si + (xmax - p.xmin) + 1;
     // 16-byte aligned variant: start every patch row at the 4-float boundary at or below its first column
     p.aligned = (g.IW % 4 == 0) && !dbg_flag_early("CC_NO_ALIGNED_PATCH");
@@ -931,7 +993,7 @@ inline ConvPlan plan_conv(const GG& g, int mult = 1) {
     p.tiles_x = (g.OWt + tw - 1) / tw;
     p.tiles_y = (g.OHt + th - 1) / th;
     p.wp_floats = (size_t)g.Rt * g.St * p.Cpad * p.Mpad;
-    const long blocks = (long)g.B * p.tiles_x * p.tiles_y * (p.Mpad / p.bm) * (mult > 1 ? mult : 1);
+    const long blocks = conv_tiles(g, p) * (p.Mpad / p.bm) * (mult > 1 ? mult : 1);
     const int nchunk = p.Cpad / p.ck;
     p.nsplit = 1;
     p.cps = nchunk;
@@ -1612,32 +1674,57 @@ inline void launch_gg_flat(const GG& g, hipStream_t s) {
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_gemm<32>), grid, dim3(256), 0, s, g);
 }
 
-template <int BM, int CK, int TPS, int SPLIT>
-inline void launch_patch1(const CP& c, dim3 grid, size_t smem, hipStream_t s) {
-    static bool big_lds_enabled = false;       // > 64 KB of dynamic LDS has to be requested once per kernel
-    if (smem > 64 * 1024 && !big_lds_enabled) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_patch<BM, CK, TPS, SPLIT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+template <class K, class ARGS>
+inline void launch_patch_kernel(K kern, bool& big_lds_enabled, const ARGS& c, dim3 grid, size_t smem, hipStream_t s) {
+    if (smem > 64 * 1024 && !big_lds_enabled) {            // > 64 KB of dynamic LDS has to be requested once per kernel
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         big_lds_enabled = true;
     }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_patch<BM, CK, TPS, SPLIT>), grid, dim3(256), smem, s, c);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, c);
+}
+
+template <int BM, int CK, int TPS, int SPLIT>
+inline void launch_patch1(const CP& c, dim3 grid, size_t smem, hipStream_t s) {
+    static bool big = false;
+    launch_patch_kernel(&k_conv_patch<BM, CK, TPS, SPLIT>, big, c, grid, smem, s);
+}
+template <int BM, int TPS, int SPLIT>
+inline void launch_patch1_stk(const CP& c, dim3 grid, size_t smem, hipStream_t s) {
+    static bool big = false;
+    launch_patch_kernel(&k_conv_patch_stk<BM, TPS, SPLIT>, big, c, grid, smem, s);
+}
+
+inline bool stacked(const CP& c) { return c.ipt > 1; }
+inline bool stacked(const CPM& a) {
+    for (int k = 0; k < a.n; k++)
+        if (a.c[k].ipt > 1) return true;
+    return false;
 }
 
 template <int BM, int CK, int TPS>
 inline void launch_patch(const CP& c, dim3 grid, size_t smem, hipStream_t s) {
+    if constexpr (CK == 8) {
+        if (stacked(c)) {
+            if (c.nsplit > 1) launch_patch1_stk<BM, TPS, 1>(c, grid, smem, s);
+            else launch_patch1_stk<BM, TPS, 0>(c, grid, smem, s);
+            return;
+        }
+    }
     if (c.nsplit > 1) launch_patch1<BM, CK, TPS, 1>(c, grid, smem, s);
     else launch_patch1<BM, CK, TPS, 0>(c, grid, smem, s);
 }
 
 template <int BM, int CK, int TPS>
 inline void launch_patch(const CPM& c, dim3 grid, size_t smem, hipStream_t s) {
-    static bool big_lds_enabled = false;
-    if (smem > 64 * 1024 && !big_lds_enabled) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_patch_multi<BM, CK, TPS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        big_lds_enabled = true;
+    if constexpr (CK == 8) {
+        if (stacked(c)) {
+            static bool big = false;
+            launch_patch_kernel(&k_conv_patch_multi_stk<BM, TPS>, big, c, grid, smem, s);
+            return;
+        }
     }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_patch_multi<BM, CK, TPS>), grid, dim3(256), smem, s, c);
+    static bool big = false;
+    launch_patch_kernel(&k_conv_patch_multi<BM, CK, TPS>, big, c, grid, smem, s);
 }
 
 template <class ARGS>
@@ -1674,7 +1761,7 @@ inline CP make_cp(const GG& g, const ConvPlan& p, const float* zeros, const floa
     c.M = g.M; c.Mpad = p.Mpad; c.Cpad = p.Cpad;
     c.Rt = g.Rt; c.St = g.St; c.si = g.si; c.dstep = g.dstep;
     c.dy_base = g.dy0 - p.ymin; c.dx_base = g.dx0 - p.xmin; c.ymin = p.ymin; c.xmin = p.xmin;
-    c.PH = p.PH; c.PWr = p.PWr; c.PS = p.PS; c.tw16 = p.tw16; c.aligned = p.aligned; c.shift = p.shift;
+    c.PH = p.PH; c.PWr = p.PWr; c.PS = p.PS; c.tw16 = p.tw16; c.ipt = p.ipt; c.phi = p.phi; c.aligned = p.aligned; c.shift = p.shift;
     c.OHt = g.OHt; c.OWt = g.OWt; c.so = g.so; c.oy0 = g.oy0; c.ox0 = g.ox0; c.OH = g.OH; c.OW = g.OW;
     c.y_bs = g.y_bs; c.res_bs = g.res_bs;
     c.tiles_x = p.tiles_x; c.tiles_y = p.tiles_y;
@@ -1745,10 +1832,11 @@ inline void launch_gg(const GG& g, float* ws, hipStream_t s, const float* prepac
                            p.Mpad, p.Cpad, T, g.St, g.w_sm, g.w_sc, g.w0, g.w_ri, g.w_sj);
     }
     const CP c = make_cp(g, p, zeros, wp, part);
-    dim3 grid((unsigned)(g.B * p.tiles_x * p.tiles_y), (unsigned)(p.Mpad / p.bm), (unsigned)p.nsplit);
+    dim3 grid((unsigned)conv_tiles(g, p), (unsigned)(p.Mpad / p.bm), (unsigned)p.nsplit);
     {
         char nm[96];
-        int nl = snprintf(nm, sizeof nm, "k_conv_patch<%d, %d, %d, %d>", p.bm, p.ck, p.tps, p.nsplit > 1 ? 1 : 0);
+        int nl = p.ipt > 1 ? snprintf(nm, sizeof nm, "k_conv_patch_stk<%d, %d, %d>", p.bm, p.tps, p.nsplit > 1 ? 1 : 0)
+                           : snprintf(nm, sizeof nm, "k_conv_patch<%d, %d, %d, %d>", p.bm, p.ck, p.tps, p.nsplit > 1 ? 1 : 0);
         if (cctools::env_flag("CC_TIMING_DETAIL"))
             snprintf(nm + nl, sizeof nm - nl, " B%d M%d C%d %dx%d t%d k%d wg%d", g.B, g.M, g.Cin, g.OHt, g.OWt, g.Rt * g.St, p.nsplit,
                      (int)(grid.x * grid.y * grid.z));
@@ -1862,7 +1950,7 @@ inline bool launch_classes(const ClsIn* cs, int n, hipStream_t s, bool idle_taps
         const size_t sm = smem_cls(p, tps);          // A buffers follow the launch-wide TPS, the patch buffers this class's PS
         if (sm > smem) smem = sm;
         a.c[nc] = make_cp(g, p, cs[k].zeros, cs[k].wp, cs[k].part);
-        bx += g.B * p.tiles_x * p.tiles_y;
+        bx += (int)conv_tiles(g, p);
         a.bx_end[nc] = bx;
         nc++;
         gf += 2e-9 * g.B * g.OHt * g.OWt * (double)g.M * g.Cin * g.Rt * g.St;
@@ -1872,7 +1960,8 @@ inline bool launch_classes(const ClsIn* cs, int n, hipStream_t s, bool idle_taps
     if (nc > 0) {
         dim3 grid((unsigned)bx, (unsigned)maxy, (unsigned)maxsplit);
         char nm[224];
-        int nl = snprintf(nm, sizeof nm, "k_conv_patch_multi<%d, %d, %d>", cs[ref].p.bm, cs[ref].p.ck, tps);
+        int nl = stacked(a) ? snprintf(nm, sizeof nm, "k_conv_patch_multi_stk<%d, %d>", cs[ref].p.bm, tps)
+                            : snprintf(nm, sizeof nm, "k_conv_patch_multi<%d, %d, %d>", cs[ref].p.bm, cs[ref].p.ck, tps);
         if (cctools::env_flag("CC_TIMING_DETAIL")) {
             // classes with the same geometry are counted, not repeated
             for (int k = 0; k < n && nl < (int)sizeof nm - 48; k++) {
@@ -2288,7 +2377,7 @@ static void list_plan_splits(ListCls** cls, int n, int target) {
     for (int k = 0; k < n; k++) {
         const ConvPlan& p = cls[k]->c.p;
         const GG& g = cls[k]->c.g;
-        const long blocks = (long)g.B * p.tiles_x * p.tiles_y * (p.Mpad / p.bm);
+        const long blocks = conv_tiles(g, p) * (p.Mpad / p.bm);
         fill += blocks;
         work += (double)blocks * (p.Cpad / p.ck) * ((g.Rt * g.St + 2) / 3);
     }
@@ -2704,8 +2793,11 @@ int cc_is_tools_build(void) {
 static void patch_name(const ConvPlan& p, bool multi, char* out, int cap) {
     if (p.wino) { snprintf(out, cap, "k_wino_f2x3<%d>%s", p.nsplit > 1 ? 1 : 0, p.nsplit > 1 ? "+splitk" : ""); return; }
     if (!p.use_patch) { snprintf(out, cap, "k_gather_gemm<%d>", pick_bm(p.Mpad ? p.Mpad : 32)); return; }
-    if (multi) snprintf(out, cap, "k_conv_patch_multi<%d, %d, %d>%s", p.bm, p.ck, p.tps, p.nsplit > 1 ? "+splitk" : "");
-    else snprintf(out, cap, "k_conv_patch<%d, %d, %d, %d>%s", p.bm, p.ck, p.tps, p.nsplit > 1 ? 1 : 0, p.nsplit > 1 ? "+splitk" : "");
+    const char* sk = p.nsplit > 1 ? "+splitk" : "";
+    if (multi && p.ipt > 1) snprintf(out, cap, "k_conv_patch_multi_stk<%d, %d>%s", p.bm, p.tps, sk);
+    else if (multi) snprintf(out, cap, "k_conv_patch_multi<%d, %d, %d>%s", p.bm, p.ck, p.tps, sk);
+    else if (p.ipt > 1) snprintf(out, cap, "k_conv_patch_stk<%d, %d, %d>%s", p.bm, p.tps, p.nsplit > 1 ? 1 : 0, sk);
+    else snprintf(out, cap, "k_conv_patch<%d, %d, %d, %d>%s", p.bm, p.ck, p.tps, p.nsplit > 1 ? 1 : 0, sk);
 }
 
 int cc_conv2d_fwd_kernel(int B, int Cin, int IH, int IW, int Cout, int R, int S, int stride, int pad, int OH, int OW,

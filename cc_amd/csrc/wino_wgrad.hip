@@ -313,11 +313,20 @@ WinoWgradPlan wino_wgrad_plan(int B, int M, int H, int W, int Cin, int G) {
     p.nmb = (M + 63) / 64;
     p.ncb = (Cin + 63) / 64;
     p.Cp = p.ncb * 64;
+    // One workgroup per CU (the kernel takes the whole LDS), so the launch runs in rounds of 256 workgroups: pick the split count that
+    // minimises rounds x (chunks per split + the epilogue's cost in chunks), never more than 256-ish blocks that spill into a
+    // second round (r04_ab_round4.txt: 264 blocks ran at half the rate of 252).
     const long base = (long)p.nmb * p.ncb * (G > 1 ? G : 1);
-    long nsplit = (cctools::env_int("CC_WW_SPLIT", 256) + base - 1) / base;
-    const long cap = (p.NCH + cctools::env_int("CC_WW_MINCHUNKS", 8) - 1) / cctools::env_int("CC_WW_MINCHUNKS", 8);
-    if (nsplit > cap) nsplit = cap;
-    if (nsplit < 1) nsplit = 1;
+    const long cus = cctools::env_int("CC_WW_SPLIT", 256), minch = cctools::env_int("CC_WW_MINCHUNKS", 8);
+    const long epi = cctools::env_int("CC_WW_EPI", 4);
+    const long cap = (p.NCH + minch - 1) / minch;
+    long nsplit = 1, best = -1;
+    for (long ns = 1; ns <= (cap < 1 ? 1 : cap) && ns <= 256; ns++) {
+        const long cps = (p.NCH + ns - 1) / ns, eff = (p.NCH + cps - 1) / cps;
+        if (eff != ns) continue;
+        const long cost = ((base * ns + cus - 1) / cus) * (cps + epi);
+        if (best < 0 || cost < best) { best = cost; nsplit = ns; }
+    }
     p.cps = (int)((p.NCH + nsplit - 1) / nsplit);
     p.nsplit = (p.NCH + p.cps - 1) / p.cps;
     p.ws_floats = 64 + (size_t)p.nsplit * 9 * M * p.Cp;

@@ -442,6 +442,18 @@ CONV_CASES = [  # B, Cin, H, W, Cout, k, stride, pad, act, bias, residual
     (1, 16, 40, 64, 2, 3, 1, 1, None, True, False),
     (1, 3, 32, 72, 16, 3, 1, 1, "relu", True, False),
     (2, 2, 35, 66, 5, 3, 1, 1, "lrelu", False, False),
+    # maps of <= 4 lattice rows: the pixel tile stacks the rows of 2 / 4 / 8 consecutive images (conv.hip CP::ipt) -- every channel
+    # tile (16 / 32 / 64 / 128), a batch that does not fill the last tile, stride 2 onto such a map (and its data-gradient's parity
+    # classes), rows that are / are not 16-byte aligned, split-K (deep) and fused epilogues
+    (4, 40, 2, 7, 70, 3, 1, 1, "relu", True, True),
+    (4, 72, 4, 13, 130, 3, 1, 1, "lrelu", True, False),
+    (5, 24, 3, 5, 20, 3, 1, 1, None, True, False),
+    (8, 16, 1, 4, 10, 3, 1, 1, "sigmoid", True, False),
+    (3, 33, 8, 14, 40, 3, 2, 1, "relu", True, False),
+    (4, 20, 4, 8, 24, 3, 2, 1, "relu", False, False),
+    (4, 64, 2, 8, 64, 3, 1, 1, "relu", True, False),
+    (3, 12, 4, 12, 12, 1, 1, 0, None, True, False),
+    (4, 260, 2, 7, 48, 3, 1, 1, "relu", True, False),
 ]
 # 3x3 / stride 1 / pad 1 layers on the Winograd F(2x2, 3x3) kernel (wino.hip; forward and data-gradient): odd map sizes (tiles that
 # hang over the border), channel counts that are not multiples of 4 / 8 / 64, residual + every activation, tile blocks that span
@@ -489,6 +501,8 @@ CONVT_CASES = [  # B, Cin, H, W, Cout, k, stride, pad, output_padding, act
     (1, 40, 3, 5, 40, 3, 2, 1, 1, None),
     (2, 48, 6, 8, 16, 4, 2, 1, 0, "relu"),
     (2, 32, 5, 8, 16, 3, 2, 1, 1, None),
+    (4, 24, 2, 7, 16, 3, 2, 1, 1, "relu"),       # stacked tiny maps (see CONV_CASES)
+    (3, 40, 1, 4, 40, 4, 2, 1, 0, None),
 ]
 
 
