@@ -22,8 +22,6 @@
 
 namespace {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));       // v_pk_fma_f32 operands
-
 
 using ccjobs::JobTab;
 
@@ -205,10 +203,11 @@ __device__ __forceinline__ void ssim_tile_body(const PhotoArgs& a, const Gauss13
                 // adjoint maps of the SSIM map w.r.t. the SECOND image (call with swapped roles for the first)
                 const size_t o = ((size_t)b * 3 + c) * HW + p;
                 const float gS = a.upstream[o];
-                const float D = den1 * den2;
-                a.adjC[o] = gS * (2.f * num1 / D);
-                a.adjB[o] = gS * (-S / den2);
-                a.adjA[o] = gS * (2.f * mu1 * (num2 - num1) / D - 2.f * mu2 * S * (1.f / den1 - 1.f / den2));
+                // one reciprocal: 1 / den2 = den1 / D, 1 / den1 = den2 / D
+                const float iD = 1.f / (den1 * den2), id1 = den2 * iD, id2 = den1 * iD;
+                a.adjC[o] = gS * (2.f * num1 * iD);
+                a.adjB[o] = gS * (-S * id2);
+                a.adjA[o] = gS * (2.f * mu1 * (num2 - num1) * iD - 2.f * mu2 * S * (id1 - id2));
                 continue;
             }
             const float xc = xp[p], yc = yp[p];
@@ -232,11 +231,11 @@ __device__ __forceinline__ void ssim_tile_body(const PhotoArgs& a, const Gauss13
                 const float drob = (a.q == 0.5f) ? (d / rob) : (a.q * powf(base, a.q - 1.f) * 2.f * d);
                 const size_t o = ((size_t)b * 3 + c) * HW + p;
                 a.g0[o] = -drob * vm;                           // d/dy through diff
-                const float D = den1 * den2;
+                const float iD = 1.f / (den1 * den2), id1 = den2 * iD, id2 = den1 * iD;        // (one reciprocal, see MODE_GRAD)
                 const float gS = -vm * a.wssim;                 // d(wssim * sl)/dS
-                a.adjC[o] = gS * (2.f * num1 / D);              // dS/dE[xy]
-                a.adjB[o] = gS * (-S / den2);                   // dS/dE[yy]
-                a.adjA[o] = gS * (2.f * mu1 * (num2 - num1) / D - 2.f * mu2 * S * (1.f / den1 - 1.f / den2));  // dS/dmu_y
+                a.adjC[o] = gS * (2.f * num1 * iD);             // dS/dE[xy]
+                a.adjB[o] = gS * (-S * id2);                    // dS/dE[yy]
+                a.adjA[o] = gS * (2.f * mu1 * (num2 - num1) * iD - 2.f * mu2 * S * (id1 - id2));  // dS/dmu_y
                 // d/d mask_b: diff and ssim_loss are both linear in the mask product
                 acc_gm[j] += drob * (xc - yc) * valid[j] * ma[j] + a.wssim * (1.f - S * valid[j]) * ma[j];
             }
@@ -287,7 +286,14 @@ __device__ __forceinline__ void tile_of(const JobTab& t, int& j, int& b, int& ti
     int first;
     j = ccjobs::find(t, (int)blockIdx.x, first);
     const int tw = (t.W[j] + TS - 1) / TS, th = (t.H[j] + TS - 1) / TS;
-    local = (int)blockIdx.x - first;
+    // XCD-aware order: workgroup i runs on XCD i % 8 (each with its own L2), so the job's tiles are dealt out as eight contiguous
+    // runs -- neighbouring tiles, which share their 6-pixel halos, then meet in one L2 instead of re-reading them from HBM
+    // (measured: k_ssim_photo_jobs 195 -> 169 us, profiles/r04_ab_round4.txt)
+    {
+        const int n = t.blk_end[j] - first, l = (int)blockIdx.x - first;
+        const int k = l & 7, q = n >> 3, r = n & 7;
+        local = k * q + (k < r ? k : r) + (l >> 3);
+    }
     b = local / (tw * th);
     const int r = local - b * (tw * th);
     tile_y = r / tw;
@@ -370,7 +376,8 @@ __device__ __forceinline__ void ssim_adjoint_body(const float* __restrict__ adjA
         __syncthreads();
         for (int it = tid; it < TIN * (TS / 4); it += 256) {
             const int r = it >> 3, cg = it & 7;
-            // maps A and B as one packed pair (v_pk_fma_f32), C scalar: same FMAs per map, a third fewer VALU instructions
+            // (scalar FMAs: on gfx950 a v_pk_fma_f32 costs more than the two v_fma_f32 it replaces -- the packed forward filter ran
+            // 47 % slower with 25 % fewer VALU instructions, profiles/r04_ab_round4.txt)
             float va[16], vb[16], vc[16];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -381,50 +388,40 @@ __device__ __forceinline__ void ssim_adjoint_body(const float* __restrict__ adjA
                 vb[4 * k] = qb.x; vb[4 * k + 1] = qb.y; vb[4 * k + 2] = qb.z; vb[4 * k + 3] = qb.w;
                 vc[4 * k] = qc.x; vc[4 * k + 1] = qc.y; vc[4 * k + 2] = qc.z; vc[4 * k + 3] = qc.w;
             }
-            f32x2 oab[4];
-            float oc[4];
+            float oa[4], ob[4], oc[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) { oab[j] = f32x2{0.f, 0.f}; oc[j] = 0.f; }
+            for (int j = 0; j < 4; j++) { oa[j] = 0.f; ob[j] = 0.f; oc[j] = 0.f; }
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                const f32x2 vab = {va[k], vb[k]};
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int t = k - j;
                     if (t >= 0 && t < 13) {
-                        const f32x2 g2 = {gw.g[t], gw.g[t]};
-                        oab[j] = __builtin_elementwise_fma(g2, vab, oab[j]);
+                        oa[j] = fmaf(gw.g[t], va[k], oa[j]);
+                        ob[j] = fmaf(gw.g[t], vb[k], ob[j]);
                         oc[j] = fmaf(gw.g[t], vc[k], oc[j]);
                     }
                 }
             }
-            *reinterpret_cast<float4*>(&hb[0][r * TS + 4 * cg]) = make_float4(oab[0].x, oab[1].x, oab[2].x, oab[3].x);
-            *reinterpret_cast<float4*>(&hb[1][r * TS + 4 * cg]) = make_float4(oab[0].y, oab[1].y, oab[2].y, oab[3].y);
+            *reinterpret_cast<float4*>(&hb[0][r * TS + 4 * cg]) = make_float4(oa[0], oa[1], oa[2], oa[3]);
+            *reinterpret_cast<float4*>(&hb[1][r * TS + 4 * cg]) = make_float4(ob[0], ob[1], ob[2], ob[3]);
             *reinterpret_cast<float4*>(&hb[2][r * TS + 4 * cg]) = make_float4(oc[0], oc[1], oc[2], oc[3]);
         }
         __syncthreads();
         float mo[3][4];
-        {
-            f32x2 mab[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) { mab[j] = f32x2{0.f, 0.f}; mo[2][j] = 0.f; }
+        for (int mi = 0; mi < 3; mi++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) mo[mi][j] = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                const int q = (4 * rg + i) * TS + cx;
-                const f32x2 vab = {hb[0][q], hb[1][q]};
-                const float vc = hb[2][q];
+                const float v = hb[mi][(4 * rg + i) * TS + cx];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int t = i - j;
-                    if (t >= 0 && t < 13) {
-                        const f32x2 g2 = {gw.g[t], gw.g[t]};
-                        mab[j] = __builtin_elementwise_fma(g2, vab, mab[j]);
-                        mo[2][j] = fmaf(gw.g[t], vc, mo[2][j]);
-                    }
+                    if (t >= 0 && t < 13) mo[mi][j] = fmaf(gw.g[t], v, mo[mi][j]);
                 }
             }
-#pragma unroll
-            for (int j = 0; j < 4; j++) { mo[0][j] = mab[j].x; mo[1][j] = mab[j].y; }
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
