@@ -13,12 +13,17 @@
 //     window of NQ aligned float4 of the X row (global_load_dwordx4 straight into the MFMA source registers);
 //   * every tap (r, s) has its own 16x16 accumulator (4 VGPRs): 9 taps = 36 VGPRs, the window index of (step j, tap s)
 //     is a compile-time constant, so the inner loop is loads + v_cndmask (zero padding) + MFMAs only;
-//   * the loads of unit u+4 are issued before the MFMAs of unit u (register double buffer), addresses are clamped
-//     instead of predicated so that no branch sits between loads and MFMAs.
-// Work split: blockIdx.x = a contiguous range of units (4 waves interleave over it), blockIdx.y = (16-channel group of
+//   * the loads of the next unit are issued before the MFMAs of the current one (register double buffer), addresses are clamped
+//     instead of predicated so that no branch sits between loads and MFMAs;
+//   * round 4: the four waves of a workgroup walk DOWN a strip of four adjacent columns, so the window rows a unit shares with the
+//     unit above stay in registers (4 loads per unit instead of 10 for 3x3 / stride 1: -11 % on that kernel; with the loads or
+//     the MFMAs ablated it still runs at 80 % of its time -- what is left is the masks, the address arithmetic and the
+//     accumulator round trips of a one-wave-per-SIMD kernel, profiles/r04_ab_round4.txt).
+// Work split: blockIdx.x = a contiguous range of strip rows, blockIdx.y = (16-channel group of
 // a) x (16-channel group of X) x (group of TR tap rows).  Each workgroup reduces its 4 waves in LDS (fixed order) and
 // writes one partial slab; k_wgrad_thin_reduce sums the slabs in a fixed order (deterministic, no atomics).
 #include <stdio.h>
+#include <type_traits>
 #include <stdlib.h>
 #include "cc_common.h"
 #include "conv_internal.h"
@@ -81,27 +86,25 @@ __global__ __launch_bounds__(64 * THIN_NW) void k_wgrad_thin(WT g) {
     const int u0 = pb * g.upb;
     const int u1 = (u0 + g.upb < g.units) ? (u0 + g.upb) : g.units;
 
+    // The workgroup walks DOWN a strip of four adjacent 16-pixel columns, one column per wave, u = (b * ngx + strip) * AH + y:
+    // consecutive units of a wave share TR - SI of their TR window rows, which stay in registers (a rolling window) -- 1 + SI * NQ
+    // loads per unit instead of 1 + TR * NQ (3x3 / stride 1: 4 instead of 10).  The kernel was bound by its load path (header: the
+    // no-MFMA build ran at 95 % of the full one); every load instruction costs the issuing wave 100+ cycles whatever its latency.
+    // The four waves read neighbouring 64-byte pieces of the same rows at the same time (one wave walking a column alone touched
+    // half a cache line per row and ran 3.6x slower: profiles/r04_ab_round4.txt).
+    constexpr int KEEP = (TR > SI) ? TR - SI : 0;            // window rows carried over to the next unit of the column
     float4 An;
-    float4 Wn[TR][NQ];
-    // unit position (image b, row y, 16-pixel chunk xc): decoded once, then advanced incrementally on the scalar unit
-    // (per-unit integer divisions cost ~190 dependent SALU instructions = more issue time than the 36 MFMAs)
-    int nb, ny, nxcpos;
-    {
-        const int u = u0 + wave;
-        const int row = u / g.nxc;
-        nxcpos = u - row * g.nxc;
-        nb = row / g.AH;
-        ny = row - nb * g.AH;
-    }
-    // issue the loads of unit (b, y, xc) (clamped addresses: always in bounds, the padding mask is applied at use)
-    auto issue = [&](int b, int y, int xc, float4& A, float4 (&W)[TR][NQ]) {
+    float4 Wn[TR][NQ], Wc[TR][NQ];
+    // loads of unit (b, y, xc), window rows t >= t0 (clamped addresses: always in bounds, the padding mask is applied at use)
+    auto issue = [&](auto T0, int b, int y, int xc, float4& A, float4 (&W)[TR][NQ]) {
+        constexpr int t0 = decltype(T0)::value;
         const int x0 = xc * 16 + 4 * k;
         const int xa = (x0 < g.AW) ? x0 : 0;
         // 32-bit element offsets (the host side only takes this path for tensors below 2^31 elements)
         A = *(const float4*)(abase + (unsigned)(b * (int)g.a_bs + y * g.AW + xa));
         const unsigned xb = (unsigned)(b * (int)g.x_bs);
 #pragma unroll
-        for (int tr = 0; tr < TR; tr++) {
+        for (int tr = t0; tr < TR; tr++) {
             int iy = y * SI + r0 + tr - PAD;
             iy = iy < 0 ? 0 : (iy >= g.IH ? g.IH - 1 : iy);
             const unsigned xr = xb + (unsigned)(iy * g.IW);
@@ -114,25 +117,49 @@ __global__ __launch_bounds__(64 * THIN_NW) void k_wgrad_thin(WT g) {
         }
     };
 
-    int u = u0 + wave;
-    if (u < u1) {
-        issue(nb, ny, nxcpos, An, Wn);
-        for (; u < u1; u += THIN_NW) {
+    const int ngx = (g.nxc + THIN_NW - 1) / THIN_NW;          // strips per image row (a strip's surplus columns multiply zeros)
+    int u = u0;
+    const int ue = u1;
+    if (u < ue) {
+        // unit position: decoded once, then advanced incrementally on the scalar unit
+        int nb, ny, nxcpos;
+        {
+            const int colu = u / g.AH;
+            ny = u - colu * g.AH;
+            nb = colu / ngx;
+            nxcpos = (colu - nb * ngx) * THIN_NW + wave;
+        }
+        typedef std::integral_constant<int, 0> ALL;
+        typedef std::integral_constant<int, KEEP> NEW;
+        issue(ALL(), nb, ny, nxcpos, An, Wn);
+        bool fresh = true;                                    // the next-unit buffer holds a whole window (run / column start)
+        for (; u < ue; u++) {
             const float4 Ac = An;
-            float4 Wc[TR][NQ];
+            if (fresh) {
 #pragma unroll
-            for (int tr = 0; tr < TR; tr++)
+                for (int tr = 0; tr < TR; tr++)
 #pragma unroll
-                for (int q = 0; q < NQ; q++) Wc[tr][q] = Wn[tr][q];
+                    for (int q = 0; q < NQ; q++) Wc[tr][q] = Wn[tr][q];
+            } else {
+#pragma unroll
+                for (int tr = 0; tr < TR; tr++)
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) Wc[tr][q] = (tr < KEEP) ? Wc[tr + (TR - KEEP)][q] : Wn[tr][q];
+            }
             const int y = ny, xc = nxcpos;
-            if (u + THIN_NW < u1) {                             // the last iteration re-loads its own unit
-                nxcpos += THIN_NW;
-                while (nxcpos >= g.nxc) {
-                    nxcpos -= g.nxc;
-                    if (++ny == g.AH) { ny = 0; nb++; }
+            if (u + 1 < ue) {
+                fresh = false;
+                if (++ny == g.AH) {
+                    ny = 0;
+                    fresh = true;
+                    nxcpos += THIN_NW;
+                    if (nxcpos - wave >= g.nxc) { nxcpos = wave; nb++; }
+                }
+                if (DBG != 2) {
+                    if (fresh) issue(ALL(), nb, ny, nxcpos, An, Wn);
+                    else issue(NEW(), nb, ny, nxcpos, An, Wn);
                 }
             }
-            if (DBG != 2) issue(nb, ny, nxcpos, An, Wn);
 
             const int x0 = xc * 16 + 4 * k;
             const bool aok = mok && (x0 < g.AW);
@@ -231,14 +258,13 @@ ThinPlan plan_thin(int B, int M, int AH, int AW, int Cin, int R, int S, int si) 
     p.ngt = (R + p.TR - 1) / p.TR;
     p.TS = p.TR * S;
     p.nxc = (AW + 15) / 16;
-    const long units = (long)B * AH * p.nxc;
+    const long units = (long)B * AH * ((p.nxc + THIN_NW - 1) / THIN_NW);       // rows of four-column strips (one column per wave)
     if (units > (1l << 30)) return p;
     p.units = (int)units;
-    long npb = units / env_int("CC_WGRAD_THIN_UPB", 32);
+    long npb = units / env_int("CC_WGRAD_THIN_UPB", 8);
     const long cap = env_int("CC_WGRAD_THIN_NPB", 256);      // 256 (one round of the 256 CUs): -0.08 ms/step against 512 (r3s3 A/Bs)
     npb = npb < 1 ? 1 : (npb > cap ? cap : npb);
     p.upb = (int)((units + npb - 1) / npb);
-    p.upb = ((p.upb + THIN_NW - 1) / THIN_NW) * THIN_NW;
     p.npb = (p.units + p.upb - 1) / p.upb;
     if (p.npb >= 64) p.npb = ((p.npb + 7) / 8) * 8;       // XCD swizzle needs a multiple of 8 (surplus ranges are empty)
     p.ws_floats = (size_t)p.ngm * p.ngc * p.ngt * p.npb * p.TS * 256;
