@@ -349,11 +349,20 @@ def cpu_baseline(batch_cpu, init_sd, args):
     cfg = S.StepConfig()
     opt = S.make_optimizer(nets, cfg)
     losses, times = [], []
+    first = {}
     for i in range(1 + args.cpu_steps):
         t0 = time.time()
         losses.append(S.cc_step(nets, opt, batch_cpu, cfg, impl))
         times.append(time.time() - t0)
         log("cpu baseline step %d: %.1f s (%d threads)" % (i, times[-1], n))
+        if i == 0:      # for the parity gate: gradient norms of the first step and the parameters after its Adam update
+            first["grad_norm"] = [float(torch.sqrt(sum((p_.grad.double() ** 2).sum() for p_ in m.parameters()
+                                                       if p_.requires_grad and p_.grad is not None)))
+                                  for m in nets if m is not None and any(p_.requires_grad for p_ in m.parameters())]
+            first["params"] = torch.cat([p_.detach().reshape(-1) for m in nets if m is not None
+                                         for p_ in m.parameters() if p_.requires_grad]).clone()
+            first["grads"] = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).detach().reshape(-1)
+                                        for m in nets if m is not None for p_ in m.parameters() if p_.requires_grad]).clone()
     timed = sorted(times[1:])
     dt = timed[len(timed) // 2] if timed else times[0]
     what = ("the reference's own inverse_warp / loss_functions / ssim / models files (oracle/_ref/ccref.zip, unmodified; two "
@@ -365,12 +374,12 @@ def cpu_baseline(batch_cpu, init_sd, args):
             "sample": "median of %d full CC steps (fwd+bwd+Adam) after 1 warm-up, B=%d %dx%d, %s, torch %s, %d threads"
                       % (len(timed), batch_cpu[0].shape[0], batch_cpu[0].shape[3], batch_cpu[0].shape[2], what,
                          torch.__version__, n),
-            "s_per_step": round(dt, 3), "s_per_step_all": [round(t, 3) for t in times]}, losses
+            "s_per_step": round(dt, 3), "s_per_step_all": [round(t, 3) for t in times]}, losses, first
 
 
 def cpu_baseline_bounded(batch_cpu, init_sd, args):
     """Run cpu_baseline() in a child process with a wall-clock bound, so that a slow host can never eat the bench line.
-    -> (baseline dict or {'value': None, 'note': ...}, [losses per step])"""
+    -> (baseline dict or {'value': None, 'note': ...}, [losses per step], {'grad_norm': [...], 'params': tensor} of the first step)"""
     import subprocess
     import tempfile
     with tempfile.TemporaryDirectory() as td:
@@ -383,12 +392,15 @@ def cpu_baseline_bounded(batch_cpu, init_sd, args):
             subprocess.run(cmd, env=env, timeout=args.cpu_timeout, check=True, stdout=sys.stderr)
             with open(outp) as f:
                 r = json.load(f)
-            return r["baseline"], r["losses"]
+            first = {"grad_norm": r.get("grad_norm", [])}
+            if os.path.isfile(outp + ".params.pt"):
+                first["params"], first["grads"] = torch.load(outp + ".params.pt")
+            return r["baseline"], r["losses"], first
         except subprocess.TimeoutExpired:
             return {"value": None, "unit": "images/s", "kind": "port", "cpu": cpu_model(), "host_threads": os.cpu_count(),
-                    "note": "CPU baseline leg exceeded --cpu-timeout %.0f s" % args.cpu_timeout}, []
+                    "note": "CPU baseline leg exceeded --cpu-timeout %.0f s" % args.cpu_timeout}, [], {}
         except (subprocess.CalledProcessError, OSError, ValueError) as e:
-            return {"value": None, "unit": "images/s", "kind": "port", "note": "CPU baseline leg failed: %r" % (e,)}, []
+            return {"value": None, "unit": "images/s", "kind": "port", "note": "CPU baseline leg failed: %r" % (e,)}, [], {}
 
 
 def main():
@@ -396,9 +408,11 @@ def main():
     if args.cpu_baseline_child:
         inp, outp = args.cpu_baseline_child.split(",")
         d = torch.load(inp)
-        base, losses = cpu_baseline(d["batch"], d["init_sd"], args)
+        base, losses, first = cpu_baseline(d["batch"], d["init_sd"], args)
+        if "params" in first:
+            torch.save((first["params"], first["grads"]), outp + ".params.pt")
         with open(outp, "w") as f:
-            json.dump({"baseline": base, "losses": losses}, f)
+            json.dump({"baseline": base, "losses": losses, "grad_norm": first.get("grad_norm", [])}, f)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
@@ -460,6 +474,10 @@ def main():
             torch.cuda.synchronize()
             if i < 2:
                 first_losses.append({k: float(v) for k, v in losses.items()})
+            if i == 0 and want_cpu:      # (parity gate) gradient norms of the first step, parameters after its update
+                first_gn = [float(torch.sqrt(sum((p_.grad.double() ** 2).sum() for p_ in n_.parameters() if p_.requires_grad)))
+                            for n_ in nets if n_ is not None and any(p_.requires_grad for p_ in n_.parameters())]
+                first_params = tr.opt.flat_p[:tr.opt.n].detach().cpu().clone()
             log("warm-up step %d done at %.1f s" % (i, time.perf_counter() - t_w))
     comm_cal = tr.calibrate_comm() if use_dist else None            # each segment's all-reduce alone (outside the timed region)
     sync()
@@ -596,7 +614,7 @@ def main():
             "roofline": roof, "kernels": kernels,
         }
         if want_cpu:
-            base, cpu_losses = cpu_baseline_bounded(batch_cpu, init_sd, args)
+            base, cpu_losses, cpu_first = cpu_baseline_bounded(batch_cpu, init_sd, args)
             line["cpu_baseline"] = base
             # bench-time parity gate: the engine's first steps against the oracle's on identical weights and data
             # step 0 runs both sides on IDENTICAL weights: that is the parity gate (north_star: losses within 1e-4 relative).
@@ -616,6 +634,24 @@ def main():
             par["loss_rel"] = float("%.3e" % worst) if par["steps_compared"] else None
             par["loss_rel_after_update"] = float("%.3e" % worst_upd) if par["steps_compared"] > 1 else None
             par["ok"] = bool(worst <= 1e-4 and worst_upd <= 1e-3) if par["steps_compared"] else None
+            # ... so that the looser bound after the update is not the only check of the backward pass and the optimizer: the first
+            # step's gradient norm per network (1e-4) and the parameters after its update (tests/test_step_emu.py's bar: Adam's first
+            # step moves every parameter by lr * sign(g); elements whose ~0 gradient has the other sign end up 2 lr apart)
+            if cpu_first.get("grad_norm") and len(cpu_first["grad_norm"]) == len(first_gn):
+                gr = [abs(a_ - b_) / max(abs(b_), 1e-30) for a_, b_ in zip(first_gn, cpu_first["grad_norm"])]
+                par["grad_norm_rel"] = [float("%.3e" % v) for v in gr]
+                par["ok"] = bool(par["ok"] and max(gr) <= 1e-4)
+            if "params" in cpu_first and cpu_first["params"].numel() == first_params.numel():
+                d_ = (first_params - cpu_first["params"]).abs()
+                apart = d_ > 1e-6
+                frac, dmax = float(apart.float().mean()), float(d_.max())
+                g_ = cpu_first["grads"].abs()
+                rms = float(torch.sqrt((g_.double() ** 2).mean()))
+                gmax_apart = float(g_[apart].max()) if bool(apart.any()) else 0.0
+                par["update"] = {"lr": cfg.lr, "frac_apart": float("%.3e" % frac), "max_abs": float("%.4e" % dmax),
+                                 "grad_rms": float("%.3e" % rms), "largest_gradient_among_apart": float("%.3e" % gmax_apart),
+                                 "bar": "only elements whose gradient is < 1e-3 of the rms may end up apart; max_abs <= 2.001 lr"}
+                par["ok"] = bool(par["ok"] and gmax_apart <= 1e-3 * rms and dmax <= 2.001 * cfg.lr)
             line["parity"] = par
         print(json.dumps(line), flush=True)
     if use_dist:
