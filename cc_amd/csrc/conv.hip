@@ -2493,11 +2493,54 @@ inline W3Plan plan_w3(int B, int M, int AH, int AW, int Cin, int R, int S, int s
 static size_t wgrad_ws_bytes_base(int B, int M, int AH, int AW, int Cin, int R, int S, int si);
 static size_t wgrad_ws_bytes_rest(int B, int M, int AH, int AW, int Cin, int R, int S, int si);
 
+// ---- 3x3 / stride-1 layers on maps whose width is not a multiple of 4 (8x26, 4x13: the deep levels): the Winograd weight-gradient
+// kernel moves rows as 16-byte pieces, so dY and the input are first copied into rows padded with zeros to a multiple of 4 (zero
+// dY columns add nothing, zero input columns are the convolution's own padding) -- two 1-2 MB copies in one launch against half
+// the time of the im2col kernel on these 512-channel layers (profiles/r04_ab_round4.txt).
+struct PadJob { const float* src; float* dst; long bs; int rows_per_image; };        // rows of image n start at src + n * bs
+struct PadTab { PadJob j[2 * MAXGRP]; int n, B, W, Wp; long row_end[2 * MAXGRP]; };     // row_end: cumulative B * rows_per_image
+__global__ __launch_bounds__(256) void k_pad_rows(PadTab t) {
+    const int q4 = t.Wp >> 2;                                  // float4s per padded row
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;       // one float4 of one padded row
+    const long row = e / q4;
+    const int c4 = (int)(e - row * q4) * 4;
+    int k = 0;
+    long first = 0;
+#pragma unroll
+    for (int q = 0; q < 2 * MAXGRP - 1; q++)
+        if (q + 1 < t.n && row >= t.row_end[q]) { k = q + 1; first = t.row_end[q]; }
+    if (row >= t.row_end[t.n - 1]) return;
+    const PadJob& j = t.j[k];
+    const long r = row - first;
+    const int n = (int)(r / j.rows_per_image);
+    const long rr = r - (long)n * j.rows_per_image;
+    const float* s = j.src + (long)n * j.bs + rr * t.W;
+    float4 v;
+    v.x = c4 + 0 < t.W ? s[c4 + 0] : 0.f;
+    v.y = c4 + 1 < t.W ? s[c4 + 1] : 0.f;
+    v.z = c4 + 2 < t.W ? s[c4 + 2] : 0.f;
+    v.w = c4 + 3 < t.W ? s[c4 + 3] : 0.f;
+    *reinterpret_cast<float4*>(j.dst + (r * t.Wp + c4)) = v;
+}
+
+struct WinoPadPlan { bool ok; int Wp; ccint::WinoWgradPlan wp; size_t pad_floats; };     // pad_floats: padded x + dY of ONE problem
+inline WinoPadPlan wino_pad_plan(int B, int M, int AH, int AW, int Cin, int G) {
+    WinoPadPlan p = {};
+    if ((AW % 4) == 0 || AH < 2 || dbg_flag("CC_NO_WINO_WGRAD_PAD")) return p;
+    // large weight matrices only: the copies and the kernel's per-workgroup epilogue have to pay (measured per shape)
+    if (M < env_int_early("CC_WWP_MINM", 96) || Cin < env_int_early("CC_WWP_MINC", 96)) return p;
+    p.Wp = (AW + 3) & ~3;
+    p.wp = ccint::wino_wgrad_plan(B, M, AH, p.Wp, Cin, G, env_int_early("CC_WWP_MINQ", 64));
+    p.ok = p.wp.ok != 0;
+    p.pad_floats = ((size_t)B * (Cin + M) * AH * p.Wp + 3) & ~(size_t)3;
+    return p;
+}
+
 size_t cc_conv2d_wgrad_ws_bytes(int B, int M, int AH, int AW, int Cin, int R, int S, int si) {
     // the thin path is confirmed at launch (pad, input width): size for it AND for the path it would fall back to
     const size_t thin = ccint::wgrad_thin_ws_floats(B, M, AH, AW, Cin, R, S, si) * sizeof(float);
     const size_t base = wgrad_ws_bytes_base(B, M, AH, AW, Cin, R, S, si);
-    return thin > base ? thin : base;
+    return ((thin > base ? thin : base) + 15) & ~(size_t)15;        // (the areas of a group's problems follow each other: keep them 16-byte aligned)
 }
 
 static size_t wgrad_ws_bytes_base(int B, int M, int AH, int AW, int Cin, int R, int S, int si) {
@@ -2506,6 +2549,8 @@ static size_t wgrad_ws_bytes_base(int B, int M, int AH, int AW, int Cin, int R, 
         for (int G = 1; G <= MAXGRP; G += MAXGRP - 1) {
             const ccint::WinoWgradPlan wp = ccint::wino_wgrad_plan(B, M, AH, AW, Cin, G);
             if (wp.ok && wp.ws_floats * sizeof(float) > wino) wino = wp.ws_floats * sizeof(float);
+            const WinoPadPlan pp = wino_pad_plan(B, M, AH, AW, Cin, G);
+            if (pp.ok && (pp.wp.ws_floats + pp.pad_floats) * sizeof(float) > wino) wino = (pp.wp.ws_floats + pp.pad_floats) * sizeof(float);
         }
     }
     const size_t rest = wgrad_ws_bytes_rest(B, M, AH, AW, Cin, R, S, si);
@@ -2563,6 +2608,49 @@ static int wgrad_group_impl(int G, const long* a, const long* x, const long* gw,
             if (ok) {
                 for (int k = 0; k < G; k++) {
                     const long d[ccint::RD_LONGS] = {1, (long)wsp[k], (long)gw[k], wp.nsplit, accumulate, o_sm, o_sc, 9, M, Cin, wp.Cp};
+                    for (int i = 0; i < ccint::RD_LONGS; i++) rd[k][i] = d[i];
+                }
+                if (ccint::wgrad_reduce_emit(sink, &rd[0][0], G, s) != CC_OK) return CC_ERR_ARG;
+                CC_CHECK_LAUNCH();
+                return CC_OK;
+            }
+        }
+    }
+    if (R == 3 && S == 3 && si == 1 && pad == 1 && IH == AH && IW == AW) {
+        const WinoPadPlan pp = wino_pad_plan(B, M, AH, AW, Cin, G);
+        if (pp.ok) {
+            const float *ap[MAXGRP], *xp[MAXGRP];
+            float* wsp[MAXGRP];
+            PadTab t = {};
+            t.B = B; t.W = AW; t.Wp = pp.Wp;
+            long rows = 0;
+            for (int k = 0; k < G; k++) {
+                float* area = ws + k * stride_f;
+                wsp[k] = area + 64;
+                float* xpad = area + ((pp.wp.ws_floats + 3) & ~(size_t)3);
+                float* apad = xpad + (size_t)B * Cin * AH * pp.Wp;
+                t.j[2 * k] = PadJob{(const float*)x[k], xpad, x_bs, Cin * AH};
+                rows += (long)B * Cin * AH; t.row_end[2 * k] = rows;
+                t.j[2 * k + 1] = PadJob{(const float*)a[k], apad, a_bs, M * AH};
+                rows += (long)B * M * AH; t.row_end[2 * k + 1] = rows;
+                xp[k] = xpad; ap[k] = apad;
+            }
+            t.n = 2 * G;
+            const long nf4 = rows * (pp.Wp >> 2);
+            bool ok;
+            {
+                char nm[128];
+                int nl = snprintf(nm, sizeof nm, "k_wino_wgrad");
+                if (cctools::env_flag("CC_TIMING_DETAIL"))
+                    snprintf(nm + nl, sizeof nm - nl, " G%d B%d M%d C%d %dx%d(pad %d) k%d wg%d", G, B, M, Cin, AH, AW, pp.Wp, pp.wp.nsplit,
+                             pp.wp.nmb * pp.wp.ncb * G * pp.wp.nsplit);
+                cctiming::Scope tsc(nm, 2e-9 * 16.0 * G * B * ((AH + 1) / 2) * (pp.Wp / 2) * (double)M * Cin, s);
+                hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)((nf4 + 255) / 256)), dim3(256), 0, s, t);
+                ok = ccint::wino_wgrad_launch(pp.wp, ap, xp, wsp, G, B, M, AH, pp.Wp, (long)M * AH * pp.Wp, Cin, (long)Cin * AH * pp.Wp, s);
+            }
+            if (ok) {
+                for (int k = 0; k < G; k++) {
+                    const long d[ccint::RD_LONGS] = {1, (long)wsp[k], (long)gw[k], pp.wp.nsplit, accumulate, o_sm, o_sc, 9, M, Cin, pp.wp.Cp};
                     for (int i = 0; i < ccint::RD_LONGS; i++) rd[k][i] = d[i];
                 }
                 if (ccint::wgrad_reduce_emit(sink, &rd[0][0], G, s) != CC_OK) return CC_ERR_ARG;

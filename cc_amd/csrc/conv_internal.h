@@ -57,7 +57,7 @@ struct WinoWgradPlan {
     int nsplit, cps;            // split of the chunk range, chunks per split
     size_t ws_floats;           // 64 + partial slabs ws[split][tap 9][m][Cp] (the layout of k_wgrad3x3: reduce kind 1)
 };
-WinoWgradPlan wino_wgrad_plan(int B, int M, int H, int W, int Cin, int G);
+WinoWgradPlan wino_wgrad_plan(int B, int M, int H, int W, int Cin, int G, int minq = -1);      // minq: tile-count floor (-1: default)
 // G (<= 4) same-shaped problems in one launch; ws[k]: slab area of problem k.  -> false (nothing launched) when the tensors are not
 // 8- / 16-byte aligned
 bool wino_wgrad_launch(const WinoWgradPlan& p, const float* const* a, const float* const* x, float* const* ws, int G, int B, int M,

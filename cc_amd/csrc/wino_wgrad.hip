@@ -295,14 +295,14 @@ __global__ __launch_bounds__(WGT, 2) void k_wino_wgrad(WW g) {
 
 namespace ccint {
 
-WinoWgradPlan wino_wgrad_plan(int B, int M, int H, int W, int Cin, int G) {
+WinoWgradPlan wino_wgrad_plan(int B, int M, int H, int W, int Cin, int G, int minq) {
     WinoWgradPlan p = {};
     if (cctools::env_flag("CC_NO_WINO_WGRAD")) return p;
     const int TY = (H + 1) / 2, TX = (W + 1) / 2;
     // rows of both tensors as 16-byte / 8-byte pieces: W % 4 == 0; enough rows on both sides to fill 64 x 64 tiles, enough tiles to
     // reduce over (measured per layer shape: profiles/r04_wino_wgrad_layers.txt)
     if ((W % 4) != 0 || H < 2 || M < cctools::env_int("CC_WW_MINM", 48) || Cin < cctools::env_int("CC_WW_MINC", 48) ||
-        (long)B * TY * TX < cctools::env_int("CC_WW_MINQ", 256))
+        (long)B * TY * TX < (minq >= 0 ? minq : cctools::env_int("CC_WW_MINQ", 256)))
         return p;
     if ((long)B * (M > Cin ? M : Cin) * H * W >= (1l << 26)) return p;
     p.ok = 1;
@@ -317,7 +317,7 @@ WinoWgradPlan wino_wgrad_plan(int B, int M, int H, int W, int Cin, int G) {
     // minimises rounds x (chunks per split + the epilogue's cost in chunks), never more than 256-ish blocks that spill into a
     // second round (r04_ab_round4.txt: 264 blocks ran at half the rate of 252).
     const long base = (long)p.nmb * p.ncb * (G > 1 ? G : 1);
-    const long cus = cctools::env_int("CC_WW_SPLIT", 256), minch = cctools::env_int("CC_WW_MINCHUNKS", 8);
+    const long cus = cctools::env_int("CC_WW_SPLIT", 256), minch = cctools::env_int("CC_WW_MINCHUNKS", 2);
     const long epi = cctools::env_int("CC_WW_EPI", 4);
     const long cap = (p.NCH + minch - 1) / minch;
     long nsplit = 1, best = -1;

@@ -481,6 +481,18 @@ CONV_CASES_WINO_LARGE = [
     (4, 129, 33, 100, 65, 3, 1, 1, "sigmoid", True, False),
 ]
 # few channels x many pixels (wgrad_thin.hip; the pixel threshold is lowered for the small test maps)
+# 3x3 / stride-1 layers on maps whose width is NOT a multiple of 4 (8x26, 4x13 in the step): their weight gradients run on the Winograd
+# kernel over zero-padded copies of dY and the input (conv.hip k_pad_rows); smooth epilogues (see CONV_CASES_WINO_LARGE)
+CONV_CASES_WINO_PADW = [          # product thresholds (>= 96 channels on both sides, >= 64 tiles)
+    (4, 96, 8, 26, 128, 3, 1, 1, None, True, False),
+    (4, 100, 4, 13, 96, 3, 1, 1, "sigmoid", True, False),
+    (3, 128, 5, 10, 97, 3, 1, 1, None, False, False),
+]
+CONV_CASES_WINO_PADW_SMALL = [    # emulator sizes (thresholds lowered through the tools switches)
+    (2, 20, 4, 10, 24, 3, 1, 1, None, True, False),
+    (2, 33, 5, 13, 40, 3, 1, 1, "sigmoid", True, True),
+    (1, 16, 3, 7, 24, 3, 1, 1, None, True, False),
+]
 CONV_CASES_THIN = [
     (2, 16, 9, 16, 16, 3, 1, 1, "relu", True, False),
     (2, 17, 6, 20, 16, 3, 1, 1, "lrelu", True, False),

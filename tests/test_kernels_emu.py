@@ -76,6 +76,15 @@ def test_convs_winograd_weight_gradient(monkeypatch):
     parity.check_conv_groups("cpu", cases=((2, 40, 5, 8, 136, 16, 1), (1, 32, 4, 16, 72, 8, 1)))        # G = 3 problems per launch
 
 
+def test_convs_winograd_weight_gradient_padded_rows(monkeypatch):
+    # widths that are not multiples of 4: zero-padded copies of dY / x, then the same kernel (conv.hip k_pad_rows); single and grouped
+    for k in ("CC_WWP_MINQ", "CC_WWP_MINM", "CC_WWP_MINC", "CC_WW_MINM", "CC_WW_MINC"):
+        monkeypatch.setenv(k, "1")
+    monkeypatch.setenv("CC_WW_MINCHUNKS", "2")
+    parity.check_convs("cpu", cases=parity.CONV_CASES_WINO_PADW_SMALL, tcases=[])
+    parity.check_conv_groups("cpu", cases=((2, 12, 5, 10, 40, 16, 1),))
+
+
 def test_convs_thin_wgrad(monkeypatch):
     monkeypatch.setenv("CC_WGRAD_THIN_MINPIX", "0")      # route the small test maps through wgrad_thin.hip
     monkeypatch.setenv("CC_WGRAD_THIN_UPB", "8")

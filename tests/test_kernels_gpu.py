@@ -77,6 +77,9 @@ def test_convs_winograd():
     parity.check_convs("cuda", cases=parity.CONV_CASES_WINO_LARGE, tcases=[], prepack=True)
     # (the large cases also run their weight gradients on the Winograd F(3x3, 2x2) kernel, wino_wgrad.hip; grouped form below)
     parity.check_conv_groups("cuda", cases=((2, 48, 16, 32, 64, 48, 1),))
+    # widths that are not multiples of 4 (the 8x26 / 4x13 levels): weight gradients over zero-padded copies (conv.hip k_pad_rows)
+    parity.check_convs("cuda", cases=parity.CONV_CASES_WINO_PADW, tcases=[])
+    parity.check_conv_groups("cuda", cases=((4, 96, 8, 26, 128, 96, 1),))
 
 
 def test_convs_prepacked_weight_images():
