@@ -1059,8 +1059,8 @@ struct WG {
 };
 
 template <int BM>
-__global__ __launch_bounds__(256) void k_wgrad(WG g) {
-    const int grp = (int)blockIdx.z / g.nsplit, zsplit = (int)blockIdx.z - grp * g.nsplit;
+__device__ __forceinline__ void wgrad_body(const WG& g, const int bx_, const int by_, const int bz_) {
+    const int grp = bz_ / g.nsplit, zsplit = bz_ - grp * g.nsplit;
     const float* __restrict__ a_ = g.ga[grp];
     const float* __restrict__ x_ = g.gxp[grp];
     float* __restrict__ out_ = g.gout[grp];
@@ -1076,8 +1076,8 @@ __global__ __launch_bounds__(256) void k_wgrad(WG g) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (BM >= 64) ? (wid >> 1) : 0;
     const int wn = (BM >= 64) ? (wid & 1) : wid;
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    const int m0 = by_ * BM;
+    const int n0 = bx_ * BN;
     const int RS = g.Rt * g.St;
     const int Ntot = g.Cin * RS;
     const int HWa = g.AH * g.AW;
@@ -1207,6 +1207,31 @@ __global__ __launch_bounds__(256) void k_wgrad(WG g) {
                 }
             }
     }
+}
+
+template <int BM>
+__global__ __launch_bounds__(256) void k_wgrad(WG g) { wgrad_body<BM>(g, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z); }
+
+// Problems of DIFFERENT shapes in one launch (the single-layer weight gradients a backward stage leaves parked until its end -- the
+// stride-2 / 1x1 / small-map layers: 15-40 us launches of 30-600 workgroups each, mostly ramp-up and drain; cc_conv2d_wgrad_list).
+// blockIdx.x ranges over the classes' grids back to back; a class's grid is flattened x-fastest.
+constexpr int MAXWCLS = 12;
+struct WGM { WG c[MAXWCLS]; int n; int bx_end[MAXWCLS]; int gx[MAXWCLS], gy[MAXWCLS]; };
+template <int BM>
+__global__ __launch_bounds__(256) void k_wgrad_multi(WGM a) {
+    int k = 0, first = 0;
+#pragma unroll
+    for (int q = 0; q < MAXWCLS - 1; q++)
+        if (q + 1 < a.n && (int)blockIdx.x >= a.bx_end[q]) { k = q + 1; first = a.bx_end[q]; }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CC_HIPEMU)
+    const WG& g = *(reinterpret_cast<const WG*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WGM, c)) + k);
+#else
+    const WG& g = a.c[k];
+#endif
+    const int b = (int)blockIdx.x - first;
+    const int gx = a.gx[k], gy = a.gy[k];
+    const int bx = b % gx, r = b / gx;
+    wgrad_body<BM>(g, bx, r % gy, r / gy);
 }
 
 // ------------------------------------------------------------------ weight gradient, patch-staged (main path)
@@ -2581,9 +2606,43 @@ static size_t wgrad_ws_bytes_rest(int B, int M, int AH, int AW, int Cin, int R, 
  * ConvTranspose2d weight-gradient: a = input [B,Cin,IH,IW], x = dY, si = stride, o strides of [Cin,Cout,R,S].
  * Group form: G (<= 4) same-shaped problems in one launch (+ one reduction launch); a / x / gw: HOST arrays of device
  * addresses; ws: G consecutive areas of cc_conv2d_wgrad_ws_bytes() each. */
+// launches of the generic kernel collected by cc_conv2d_wgrad_list instead of issued one by one
+struct WgradParked { WG g; int bm; dim3 grid; double gflop; };
+struct WgradCollector { WgradParked* p; int cap, n; };
+
+static void launch_wgrad_parked(const WgradCollector& c, hipStream_t s) {
+    for (int bm = 128; bm >= 32; bm /= 2) {
+        int i = 0;
+        while (i < c.n) {
+            WGM m = {};
+            long blk = 0;
+            double gf = 0;
+            for (; i < c.n && m.n < MAXWCLS; i++) {
+                if (c.p[i].bm != bm) continue;
+                const dim3& gr = c.p[i].grid;
+                const long nb = (long)gr.x * gr.y * gr.z;
+                if (blk + nb >= (1l << 31)) break;
+                m.c[m.n] = c.p[i].g;
+                m.gx[m.n] = (int)gr.x; m.gy[m.n] = (int)gr.y;
+                blk += nb;
+                m.bx_end[m.n] = (int)blk;
+                gf += c.p[i].gflop;
+                m.n++;
+            }
+            if (!m.n) break;
+            char nm[64];
+            snprintf(nm, sizeof nm, "k_wgrad_multi<%d>%s", bm, "");
+            cctiming::Scope tsc(nm, gf, s);
+            if (bm == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad_multi<128>), dim3((unsigned)blk), dim3(256), 0, s, m);
+            else if (bm == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad_multi<64>), dim3((unsigned)blk), dim3(256), 0, s, m);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad_multi<32>), dim3((unsigned)blk), dim3(256), 0, s, m);
+        }
+    }
+}
+
 static int wgrad_group_impl(int G, const long* a, const long* x, const long* gw, float* ws, int B, int M, int AH, int AW, long a_bs,
                             int Cin, int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, int accumulate,
-                            void* stream, ccint::RedSink* sink, const float* zeros64 = nullptr) {
+                            void* stream, ccint::RedSink* sink, const float* zeros64 = nullptr, WgradCollector* park = nullptr) {
     if (G <= 0 || G > MAXGRP || B <= 0 || M <= 0 || Cin <= 0) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     long rd[MAXGRP][ccint::RD_LONGS];
@@ -2772,7 +2831,9 @@ static int wgrad_group_impl(int G, const long* a, const long* x, const long* gw,
     }
     g.pix_per_split = (int)pps;
     dim3 grid((unsigned)((Ntot + BN - 1) / BN), (unsigned)((M + bm - 1) / bm), (unsigned)(nsplit * G));
-    {
+    if (park && park->n < park->cap) {
+        park->p[park->n++] = WgradParked{g, bm, grid, 2e-9 * G * B * AH * AW * (double)M * Cin * R * S};
+    } else {
         char nm[128];
         int nl = snprintf(nm, sizeof nm, "k_wgrad<%d>", bm);
         if (cctools::env_flag("CC_TIMING_DETAIL"))
@@ -2814,6 +2875,50 @@ int cc_conv2d_wgrad_group_defer(int G, const long* a, const long* x, const long*
                                    stream, &sink, zeros64_or_null);
     *nred_host = sink.n;
     return r;
+}
+
+/* n groups of DIFFERENT shapes (what a backward stage has parked at its end): desc_host = n x 32 longs
+ *   {G, a[4], x[4], gw[4], ws, B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, accumulate, 0, 0}
+ * -- each group exactly as one cc_conv2d_wgrad_group_defer call (same kernels, same arithmetic, same reduce descriptors, in list
+ * order), except that the groups the planner sends to the generic kernel share launches (k_wgrad_multi: up to 12 per launch). */
+int cc_conv2d_wgrad_list(int n, const long* desc_host, const float* zeros64_or_null, long* red_host, int red_cap, int* nred_host,
+                         void* stream) {
+    if (n <= 0 || !desc_host || !red_host || !nred_host) return CC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int CAP = 64;
+    static thread_local WgradParked parked[CAP];
+    WgradCollector col = {parked, CAP, 0};
+    ccint::RedSink sink = {red_host, red_cap, 0};
+    for (int i = 0; i < n; i++) {
+        const long* d = desc_host + 32l * i;
+        const int G = (int)d[0];
+        if (G <= 0 || G > MAXGRP || sink.n + G > red_cap) return CC_ERR_ARG;
+        const int before = col.n;
+        const int r = wgrad_group_impl(G, d + 1, d + 5, d + 9, (float*)d[13], (int)d[14], (int)d[15], (int)d[16], (int)d[17], d[18],
+                                       (int)d[19], (int)d[20], (int)d[21], d[22], (int)d[23], (int)d[24], (int)d[25], (int)d[26], d[27],
+                                       d[28], (int)d[29], stream, &sink, zeros64_or_null, &col);
+        if (r != CC_OK) return r;
+        if (col.n > before && col.p[before].g.direct) {
+            // a problem that writes its gradient itself (no split): it must not share a launch with an earlier one of the same target
+            bool dup = false;
+            for (int j = 0; j < before && !dup; j++)
+                if (col.p[j].g.direct)
+                    for (int u = 0; u < MAXGRP && !dup; u++)
+                        for (int v = 0; v < MAXGRP; v++)
+                            if (col.p[j].g.gout[u] && col.p[j].g.gout[u] == col.p[before].g.gout[v]) { dup = true; break; }
+            if (dup) {
+                const WgradParked keep = col.p[before];
+                col.n = before;
+                launch_wgrad_parked(col, s);
+                col.p[0] = keep;
+                col.n = 1;
+            }
+        }
+    }
+    launch_wgrad_parked(col, s);
+    *nred_host = sink.n;
+    CC_CHECK_LAUNCH();
+    return CC_OK;
 }
 
 int cc_conv2d_wgrad(const float* a, const float* x, float* gw, float* ws, int B, int M, int AH, int AW, long a_bs, int Cin,

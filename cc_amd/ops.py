@@ -4,6 +4,8 @@
 Everything heavy is a HIP kernel.  What is still stock ATen (tiny tensors, listed in DESIGN.md as "torch
 plumbing"): nearest upsampling + channel softmax of the (unused-by-training) occlusion head, torch.cat.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -162,8 +164,18 @@ class _WgradQueue:
                      x_bs, R, S, si, pad, o_sm, o_sc, 1)
 
     def flush(self):
+        # what is still parked at the end of the stage (single layers of unique shapes, incomplete groups) goes out as ONE list call:
+        # the groups that take the generic weight-gradient kernel share launches (cc_conv2d_wgrad_list)
+        items = []
         for key in list(self.pending):
-            self._launch(key)
+            q = self.pending.pop(key, None)
+            if not q:
+                continue
+            B, M, AH, AW, Cin, IH, IW, R, S, si, pad, o_sm, o_sc, a_bs, x_bs = key
+            items.append(([t[0] for t in q], [t[1] for t in q], [t[2] for t in q],
+                          (B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc)))
+        if items:
+            _wgrad_list(items)
         wgrad_reduces.flush()
 
 
@@ -210,6 +222,7 @@ wgrad_reduces = _WgradReduces()
 _NO_DEFER = __import__("os").environ.get("CC_NO_WGRAD_DEFER", "0") == "1"       # A/B switch (tools/)
 _NO_SUM_N = __import__("os").environ.get("CC_NO_SUM_N", "0") == "1"             # A/B switch: pairwise adds for multi-consumer gradients
 _NO_BIAS_TABLE = __import__("os").environ.get("CC_NO_BIAS_TABLE", "0") == "1"   # A/B switch: one bias-gradient pass per layer
+_NO_WGRAD_LIST = __import__("os").environ.get("CC_NO_WGRAD_LIST", "0") == "1"   # A/B switch: the stage's last parked groups one by one
 
 
 def _act_bwd_bias(gys, ys, geffs, gbs, ref, B, C, H, W, gy_bs, act, act_a, act_b, accumulate):
@@ -279,6 +292,50 @@ def _wgrad_group(a_list, x_list, gw_list, ref, B, M, AH, AW, a_bs, Cin, IH, IW, 
         ws = _ws(per * G, ref)
         E.call("cc_conv2d_wgrad_group", G, _addr(a1), _addr(a2), _addr(a3), ws, B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad,
                o_sm, o_sc, int(accumulate), STREAM)
+
+
+def _wgrad_list(items):
+    """items: [(a_list, x_list, gw_list, (B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc))], gradients accumulated into
+    the optimizer's bucket, reductions parked (the queue is enabled): one cc_conv2d_wgrad_list call."""
+    import ctypes
+    E = engine()
+    if _NO_DEFER or not wgrad_queue.enabled or _NO_WGRAD_LIST:
+        for a_list, x_list, gw_list, geo in items:
+            B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc = geo
+            _wgrad_group(a_list, x_list, gw_list, a_list[0], B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, 1)
+        return
+    desc, keep, cap = [], [], 0
+
+    def run():
+        nonlocal desc, keep, cap
+        if not desc:
+            return
+        arr = (ctypes.c_long * len(desc))(*desc)
+        red = (ctypes.c_long * (16 * cap))()
+        nred = ctypes.c_int(0)
+        E.call("cc_conv2d_wgrad_list", len(desc) // 32, ctypes.addressof(arr), _zeros64(keep[0][0]), ctypes.addressof(red), cap,
+               ctypes.addressof(nred), STREAM)
+        if nred.value:
+            wgrad_reduces.desc.extend(red[:16 * nred.value])
+        wgrad_reduces.keep.extend(keep)
+        desc, keep, cap = [], [], 0
+
+    for a_list, x_list, gw_list, geo in items:
+        B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc = geo
+        ptrs = [t.data_ptr() for t in gw_list]
+        if len(set(ptrs)) != len(ptrs) or wgrad_reduces.targets.intersection(ptrs):
+            run()               # (their slabs must exist before the flush the per-group path may trigger)
+            _wgrad_group(a_list, x_list, gw_list, a_list[0], B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, 1)
+            continue
+        wgrad_reduces.targets.update(ptrs)
+        G = len(a_list)
+        ws = _ws(E.call("cc_conv2d_wgrad_ws_bytes", B, M, AH, AW, Cin, R, S, si) * G, a_list[0])
+        pad4 = lambda ts: [t.data_ptr() for t in ts] + [0] * (4 - len(ts))
+        desc.extend([G] + pad4(a_list) + pad4(x_list) + pad4(gw_list) +
+                    [ws.data_ptr(), B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, 1, 0, 0])
+        keep.append((ws, gw_list, a_list, x_list))
+        cap += G
+    run()
 
 
 # ----------------------------------------------------------------------------- convolution

@@ -277,6 +277,13 @@ int cc_conv2d_wgrad_group_defer(int G, const long* a, const long* x, const long*
                                 int accumulate, const float* zeros64_or_null, long* red_host, int red_cap, int* nred_host,
                                 void* stream);
 int cc_wgrad_reduce_table(const long* desc_host, int n, void* stream);
+/* n parked groups of DIFFERENT shapes at once (the end of a backward stage): desc_host = n x 32 longs
+ *   {G, a[4], x[4], gw[4], ws, B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, accumulate, 0, 0}
+ * Each group is computed exactly as by one cc_conv2d_wgrad_group_defer call (replaces the per-layer calls of
+ * torch.autograd's convolution_backward(weights) behind loss.backward(), train.py:567); the groups that take the generic kernel
+ * share launches.  red_host: room for the reduce descriptors of all groups (16 longs each, <= G per group). */
+int cc_conv2d_wgrad_list(int n, const long* desc_host, const float* zeros64_or_null, long* red_host, int red_cap, int* nred_host,
+                         void* stream);
 int cc_act_bwd_bias_group(int G, const long* gy, const long* y, const long* geff, const long* gbias, float* ws, int B, int C, int H,
                           int W, long gy_bs, long y_bs, long geff_bs, int act, float act_a, float act_b, int accumulate_bias,
                           void* stream);

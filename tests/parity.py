@@ -1003,3 +1003,54 @@ def check_adam(dev, n=10007, steps=3):
     assert torch.equal(pa.cpu(), pb.cpu()) and torch.equal(ma.cpu(), mb.cpu()) and torch.equal(va.cpu(), vb.cpu())
     err = float((pa.cpu() - ref_p.detach()).abs().max())
     assert err <= 1e-6, err          # a few ulp (different but equivalent operation order: lr / bc1 folded into the step size)
+
+
+def check_wgrad_list(dev, tol=2e-5):
+    """cc_conv2d_wgrad_list (ops._wgrad_list: what a backward stage's weight-gradient queue flushes at its end): groups of different
+    shapes in one call -- stride-2 / 1x1 / small-map layers on the generic kernel (k_wgrad_multi: several per launch), direct-mode
+    problems (no split) next to split ones, a G = 2 group, a weight that occurs twice (its two accumulations must not share a
+    launch), and 3x3 / stride-1 layers that take other kernels inside the same list -- against torch's convolution weight
+    gradients, accumulated into pre-filled buffers."""
+    import torch.nn.functional as F
+    from cc_amd import ops
+    g = torch.Generator().manual_seed(33)
+
+    def rn(*s):
+        return torch.randn(*s, generator=g)
+
+    def ref_grad(x, gy, shape, k, st, pad):
+        w = torch.zeros(*shape, requires_grad=True)
+        F.conv2d(x, w, None, st, pad).backward(gy)
+        return w.grad
+    # (B, Cin, H, W, Cout, k, stride, pad)
+    shapes = [(2, 12, 9, 14, 20, 3, 2, 1), (2, 24, 6, 10, 150, 1, 1, 0), (1, 40, 5, 7, 33, 3, 1, 1), (2, 8, 12, 16, 16, 5, 2, 2),
+              (2, 130, 2, 3, 140, 3, 1, 1), (2, 16, 8, 8, 24, 4, 2, 1), (2, 48, 6, 16, 64, 3, 1, 1)]
+    items, want, bufs = [], [], []
+    for si_, (B, Cin, H, W, Cout, k, st, pad) in enumerate(shapes):
+        G = 2 if si_ == 1 else 1
+        OH, OW = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
+        a_l, x_l, gw_l = [], [], []
+        for _ in range(G):
+            x, gy, init = rn(B, Cin, H, W), rn(B, Cout, OH, OW), rn(Cout, Cin, k, k) * 0.1
+            want.append(init + ref_grad(x, gy, (Cout, Cin, k, k), k, st, pad))
+            bufs.append(init.clone().to(dev))
+            a_l.append(gy.to(dev).contiguous())
+            x_l.append(x.to(dev).contiguous())
+            gw_l.append(bufs[-1])
+        items.append((a_l, x_l, gw_l, (B, Cout, OH, OW, Cout * OH * OW, Cin, H, W, Cin * H * W, k, k, st, pad, Cin * k * k, k * k)))
+    # problem 0 once more, with other operands, INTO THE SAME buffer (a weight used twice in one stage)
+    B, Cin, H, W, Cout, k, st, pad = shapes[0]
+    x2, gy2 = rn(B, Cin, H, W), rn(*items[0][0][0].shape)
+    want[0] = want[0] + ref_grad(x2, gy2, (Cout, Cin, k, k), k, st, pad)
+    items.append(([gy2.to(dev).contiguous()], [x2.to(dev).contiguous()], [bufs[0]], items[0][3]))
+    ops.wgrad_queue.enabled = True
+    try:
+        ops._wgrad_list(items)
+        ops.wgrad_reduces.flush()
+    finally:
+        ops.wgrad_queue.enabled = False
+    if dev != "cpu":
+        torch.cuda.synchronize()
+    for i, (b, w_) in enumerate(zip(bufs, want)):
+        err = float((b.cpu() - w_).abs().max()) / max(float(w_.abs().max()), 1e-30)
+        assert err <= tol, ("wgrad_list problem %d" % i, err)

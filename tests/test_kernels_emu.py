@@ -85,6 +85,10 @@ def test_convs_winograd_weight_gradient_padded_rows(monkeypatch):
     parity.check_conv_groups("cpu", cases=((2, 12, 5, 10, 40, 16, 1),))
 
 
+def test_weight_gradient_list():
+    parity.check_wgrad_list("cpu")
+
+
 def test_convs_thin_wgrad(monkeypatch):
     monkeypatch.setenv("CC_WGRAD_THIN_MINPIX", "0")      # route the small test maps through wgrad_thin.hip
     monkeypatch.setenv("CC_WGRAD_THIN_UPB", "8")

@@ -82,6 +82,11 @@ def test_convs_winograd():
     parity.check_conv_groups("cuda", cases=((4, 96, 8, 26, 128, 96, 1),))
 
 
+def test_weight_gradient_list():
+    # the end-of-stage flush of the weight-gradient queue: groups of different shapes in one cc_conv2d_wgrad_list call
+    parity.check_wgrad_list("cuda")
+
+
 def test_convs_prepacked_weight_images():
     parity.check_convs("cuda", prepack=True)
 
