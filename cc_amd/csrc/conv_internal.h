@@ -63,4 +63,20 @@ WinoWgradPlan wino_wgrad_plan(int B, int M, int H, int W, int Cin, int G, int mi
 bool wino_wgrad_launch(const WinoWgradPlan& p, const float* const* a, const float* const* x, float* const* ws, int G, int B, int M,
                        int H, int W, long a_bs, int Cin, long x_bs, hipStream_t s);
 
+// ---- 3x3 / stride-1 / pad-1 layers with <= 4 channels on one side (conv_heads.hip): the prediction heads and their data-gradients
+// as HBM-bound vector-ALU kernels instead of padded MFMA tiles.  Input [B, Cin, H, W] (batch stride x_bs), output [B, M, H, W];
+// weight element (m, c, i, j) at w[w0 + m * w_sm + c * w_sc + 3 i + j]; dstep +1: forward taps (input pixel p + (i - 1, j - 1)),
+// -1: data-gradient taps (p - (i - 1, j - 1)); epilogue operands as in conv_tail.h (res / add: tensors of the output's shape).
+struct HeadConv {
+    const float* x; const float* w; const float* bias; const float* res; const float* add; float* y;
+    int B, Cin, H, W, M;
+    long x_bs, y_bs, res_bs, add_bs;
+    long w_sm, w_sc, w0;
+    int dstep;
+    int act; float act_a, act_b; int res_mul;
+};
+// few REDUCTION channels (Cin <= 4): vector width the problem runs with (4 / 2 / 1 pixels per work-item), 0 = not eligible
+int head_conv_thinc_vec(const HeadConv& g);
+bool head_conv_thinc_launch(const HeadConv& g, hipStream_t s);      // -> false: not eligible, nothing launched
+
 }  // namespace ccint

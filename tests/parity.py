@@ -442,6 +442,7 @@ CONV_CASES = [  # B, Cin, H, W, Cout, k, stride, pad, act, bias, residual
     (1, 16, 40, 64, 2, 3, 1, 1, None, True, False),
     (1, 3, 32, 72, 16, 3, 1, 1, "relu", True, False),
     (2, 2, 35, 66, 5, 3, 1, 1, "lrelu", False, False),
+    (2, 7, 9, 13, 3, 3, 1, 1, "sigmoid", True, False),          # odd width: one pixel per work-item in conv_heads.hip
     # maps of <= 4 lattice rows: the pixel tile stacks the rows of 2 / 4 / 8 consecutive images (conv.hip CP::ipt) -- every channel
     # tile (16 / 32 / 64 / 128), a batch that does not fill the last tile, stride 2 onto such a map (and its data-gradient's parity
     # classes), rows that are / are not 16-byte aligned, split-K (deep) and fused epilogues
