@@ -1822,31 +1822,34 @@ inline int wino_flip(const GG& g) { return g.dstep < 0 ? 1 : 0; }
 
 // ws: [64 zeros][repacked weights][split-K partial slabs]; sized by conv_ws_floats(plan_conv(g))
 // prepacked (optional): {64 zeros, wp} produced earlier by k_repack_table -> no repack launch here
-// A 3x3 / stride-1 / pad-1 problem with <= 4 reduction channels (data-gradient of a prediction head, a layer with <= 4 inputs) as the
-// conv_heads.hip description, or ok = false
-inline bool head_thinc_of(const GG& g, ccint::HeadConv& h) {
-    static const int off = cctools::env_flag("CC_NO_HEAD_KERNELS");
-    if (off || g.Cin < 1 || g.Cin > 4 || g.Rt != 3 || g.St != 3 || g.si != 1 || g.so != 1 || g.oy0 != 0 || g.ox0 != 0) return false;
-    if (g.OHt != g.OH || g.OWt != g.OW || g.OH != g.IH || g.OW != g.IW || g.w_ri != 3 || g.w_sj != 1) return false;
-    if (!((g.dstep == 1 && g.dy0 == -1 && g.dx0 == -1) || (g.dstep == -1 && g.dy0 == 1 && g.dx0 == 1))) return false;
-    if (g.res_mul && !g.res) return false;
+// A 3x3 / stride-1 / pad-1 problem with <= 4 channels on one side (a prediction head or its data-gradient, a layer with <= 4 inputs)
+// as the conv_heads.hip description: 1 = few reduction channels (k_conv_thinc), 2 = few output channels (k_conv_thinm), 0 = neither
+inline int head_kernel_of(const GG& g, ccint::HeadConv& h) {
+    static const int off = cctools::env_int("CC_NO_HEAD_KERNELS", 0);       // tools: 1 = none, 2 = no thinm, 3 = no thinc
+    if (off == 1 || (g.Cin > 4 && g.M > 4) || g.Cin < 1 || g.Rt != 3 || g.St != 3 || g.si != 1 || g.so != 1 || g.oy0 != 0 || g.ox0 != 0) return 0;
+    if (g.OHt != g.OH || g.OWt != g.OW || g.OH != g.IH || g.OW != g.IW || g.w_ri != 3 || g.w_sj != 1) return 0;
+    if (!((g.dstep == 1 && g.dy0 == -1 && g.dx0 == -1) || (g.dstep == -1 && g.dy0 == 1 && g.dx0 == 1))) return 0;
+    if (g.res_mul && !g.res) return 0;
     h = ccint::HeadConv{g.x, g.w, g.bias, g.res, g.res_mul ? g.add : nullptr, g.y, g.B, g.Cin, g.IH, g.IW, g.M, g.x_bs, g.y_bs, g.res_bs,
                         g.add_bs, g.w_sm, g.w_sc, (long)g.w0, g.dstep, g.act, g.act_a, g.act_b, g.res_mul};
-    return ccint::head_conv_thinc_vec(h) != 0;
+    if (g.Cin <= 4 && off != 3 && ccint::head_conv_thinc_vec(h) != 0) return 1;
+    if (g.M <= 4 && off != 2 && ccint::head_conv_thinm_ok(h)) return 2;
+    return 0;
 }
 
 inline void launch_gg(const GG& g, float* ws, hipStream_t s, const float* prepacked = nullptr, const float* pre_zeros = nullptr) {
     {
         ccint::HeadConv h;
-        if (head_thinc_of(g, h)) {
+        const int hk = head_kernel_of(g, h);
+        if (hk) {
             char nm[96];
-            int nl = snprintf(nm, sizeof nm, "k_conv_thinc<%d>", g.Cin);
+            int nl = snprintf(nm, sizeof nm, hk == 1 ? "k_conv_thinc<%d>" : "k_conv_thinm<%d>", hk == 1 ? g.Cin : g.M);
             if (cctools::env_flag("CC_TIMING_DETAIL"))
                 snprintf(nm + nl, sizeof nm - nl, " B%d M%d C%d %dx%d t9", g.B, g.M, g.Cin, g.OHt, g.OWt);
             cctiming::Scope tsc(nm, 2e-9 * g.B * g.OHt * g.OWt * (double)g.M * g.Cin * 9, s);
             if (cctools::env_flag("CC_HEAD_TRACE"))
-                fprintf(stderr, "head thinc: B%d M%d C%d %dx%d dstep %d vec %d\n", g.B, g.M, g.Cin, g.OHt, g.OWt, g.dstep, ccint::head_conv_thinc_vec(h));
-            if (ccint::head_conv_thinc_launch(h, s)) return;
+                fprintf(stderr, "head kernel %d: B%d M%d C%d %dx%d dstep %d\n", hk, g.B, g.M, g.Cin, g.OHt, g.OWt, g.dstep);
+            if (hk == 1 ? ccint::head_conv_thinc_launch(h, s) : ccint::head_conv_thinm_launch(h, s)) return;
         }
     }
     const ConvPlan p = plan_conv(g);

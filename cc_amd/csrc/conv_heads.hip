@@ -11,9 +11,14 @@
 //       loop over the output channels of the block's range: 9 K VEC FMAs against weights read as wave-uniform LDS words, fused
 //       epilogue (conv_tail.h: bias / residual / activation, or (sum + add) * act'(mul) for data-gradients), one VEC-wide store.
 //       Algorithmic traffic: (K + M [+ M per epilogue operand]) x B H W floats; the input is re-read once per channel block from L2.
+//   k_conv_thinm<M, DS>        M <= 4 OUTPUT channels <- C <= 64 inputs on the large maps (the heads' forward pass): work-item = 4
+//       consecutive pixels x one share of the input channels (CS shares per workgroup, one per wave group); per channel nine loads
+//       (three rows: one 16-byte piece + the two halo columns) and 36 M FMAs against LDS-resident weights; the shares' partial
+//       sums meet in LDS, the first share applies the epilogue.  Algorithmic traffic: (C + M) x B H W floats (the input once).
 #include "cc_common.h"
 #include "conv_internal.h"
 #include "conv_tail.h"
+#include "cc_tools.h"
 
 namespace {
 
@@ -88,31 +93,200 @@ __global__ __launch_bounds__(256) void k_conv_thinc(HeadConv g, int Wg, long ngr
 
     const long pix = (long)y * g.W + x0;
     const bool hr = g.res != nullptr, ha = g.add != nullptr;
-    for (int m = m_beg; m < m_end; m++) {
-        const float* wm = wsm + (m - m_beg) * (K * 9);
-        float acc[VEC];
+    // four output channels per round: their epilogue operands (2 x 4 vector loads) are requested before the first FMA -- a loop of
+    // {load, wait, store} per channel would be a chain of memory round trips
+    for (int mq = m_beg; mq < m_end; mq += 4) {
+        float rv[4][VEC], av[4][VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; v++) acc[v] = 0.f;
+        for (int u = 0; u < 4; u++) {
+            const int m = mq + u < m_end ? mq + u : m_end - 1;
+            const long o = (long)m * HW + pix;
+            if (hr) vload<VEC>(g.res + (long)n * g.res_bs + o, rv[u]);
+            if (ha) vload<VEC>(g.add + (long)n * g.add_bs + o, av[u]);
+        }
 #pragma unroll
-        for (int c = 0; c < K; c++)
+        for (int u = 0; u < 4; u++) {
+            const int m = mq + u;
+            if (m >= m_end) break;
+            const float* wm = wsm + (m - m_beg) * (K * 9);
+            float acc[VEC];
 #pragma unroll
-            for (int i = 0; i < 3; i++)
+            for (int v = 0; v < VEC; v++) acc[v] = 0.f;
 #pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    const float wv = wm[c * 9 + 3 * i + j];
+            for (int c = 0; c < K; c++)
 #pragma unroll
-                    for (int v = 0; v < VEC; v++) acc[v] = fmaf(wv, nb[c][i][v + (DS > 0 ? j : 2 - j)], acc[v]);
-                }
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        const float wv = wm[c * 9 + 3 * i + j];
+#pragma unroll
+                        for (int v = 0; v < VEC; v++) acc[v] = fmaf(wv, nb[c][i][v + (DS > 0 ? j : 2 - j)], acc[v]);
+                    }
+            const float bias = g.bias ? g.bias[m] : 0.f;
+            float out[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; v++)
+                out[v] = cctail::conv_tail(acc[v] + bias, hr, hr ? rv[u][v] : 0.f, g.res_mul, g.act, g.act_a, g.act_b, ha ? av[u][v] : 0.f);
+            vstore<VEC>(g.y + (long)n * g.y_bs + (long)m * HW + pix, out);
+        }
+    }
+}
+
+constexpr int TM_MAXC = 64;         // input channels, at most (weights stay in LDS: 64 x 4 x 9 floats)
+constexpr int TM_MAXCS = 8;         // channel shares per workgroup, at most
+
+// y[m][p] = tail( sum_{c,i,j} w[m][c][i][j] x[c][p + DS (i - 1, j - 1)] ),  M <= 4.  Workgroup = NW waves = (NW / nshare) pixel
+// waves x nshare channel shares: wave w accumulates channels [cs * cpw, (cs + 1) * cpw), cs = w % nshare, for the 4-pixel groups
+// (blockIdx.x * (NW / nshare) + w / nshare) * 64 + lane.  Four channels per batch: all 36 loads are issued before the first FMA.
+template <int M, int DS>
+__global__ __launch_bounds__(64 * TM_MAXCS) void k_conv_thinm(HeadConv g, int Wg, long ngroups, int cpw, int nshare) {
+    __shared__ __attribute__((aligned(16))) float wsm[TM_MAXC * M * 9];       // [c][m][9]
+    __shared__ float red[TM_MAXCS * M * 4 * 64];                              // [wave][m][v][lane] (share 0's slots stay unused)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cs = wid % nshare, pw = wid / nshare;
+    const int pwpb = ((int)blockDim.x >> 6) / nshare;
+    const long gid = ((long)blockIdx.x * pwpb + pw) * 64 + lane;
+    const bool live = gid < ngroups;
+    const long gq = live ? gid : 0;
+    const int xg = (int)(gq % Wg);
+    const long rr = gq / Wg;
+    const int y = (int)(rr % g.H), n = (int)(rr / g.H);
+    const int x0 = xg * 4;
+    const int HW = g.H * g.W;
+    const int c_beg = cs * cpw;
+    int c_end = c_beg + cpw;
+    if (c_end > g.Cin) c_end = g.Cin;
+
+    float acc[M][4];
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) acc[m][v] = 0.f;
+    // rows y - DS, y, y + DS (tap rows 0, 1, 2); rows / halo columns outside the image contribute zero (their loads are redirected
+    // to the centre piece and the value masked)
+    bool rowin[3];
+    long roff[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int iy = y + (i - 1) * DS;
+        rowin[i] = live && (unsigned)iy < (unsigned)g.H;
+        roff[i] = (long)(rowin[i] ? iy : y) * g.W + x0;
+    }
+    const bool lin = x0 > 0, rin = x0 + 4 < g.W;
+    const int lo = lin ? -1 : 0, ro = rin ? 4 : 3;
+    const float* xc = g.x + (long)n * g.x_bs + (long)(c_beg < g.Cin ? c_beg : 0) * HW;      // (an empty share reads channel 0 and uses nothing)
+    // one batch = up to 4 channels: 36 loads in flight (channels past the share's end re-read its last channel and are not used)
+    struct Batch { float4 ctr[4][3]; float lft[4][3], rgt[4][3]; };
+    auto load = [&](const float* xp, int nch, Batch& bt) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float* xu = xp + (long)(u < nch ? u : (nch > 0 ? nch - 1 : 0)) * HW;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const float* row = xu + roff[i];
+                bt.ctr[u][i] = *reinterpret_cast<const float4*>(row);
+                bt.lft[u][i] = row[lo];
+                bt.rgt[u][i] = row[ro];
+            }
+        }
+    };
+    auto fma_batch = [&](int c0, int nch, const Batch& bt) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (u >= nch) break;
+            float nb[3][6];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                nb[i][0] = (rowin[i] && lin) ? bt.lft[u][i] : 0.f;
+                nb[i][1] = rowin[i] ? bt.ctr[u][i].x : 0.f; nb[i][2] = rowin[i] ? bt.ctr[u][i].y : 0.f;
+                nb[i][3] = rowin[i] ? bt.ctr[u][i].z : 0.f; nb[i][4] = rowin[i] ? bt.ctr[u][i].w : 0.f;
+                nb[i][5] = (rowin[i] && rin) ? bt.rgt[u][i] : 0.f;
+            }
+            const float* wc = wsm + (c0 + u) * (M * 9);
+#pragma unroll
+            for (int m = 0; m < M; m++)
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        const float wv = wc[m * 9 + 3 * i + j];
+#pragma unroll
+                        for (int v = 0; v < 4; v++) acc[m][v] = fmaf(wv, nb[i][v + (DS > 0 ? j : 2 - j)], acc[m][v]);
+                    }
+        }
+    };
+    // weights -> LDS (four loads in flight per work-item) with the first input batch requested behind them: one memory round trip
+    // covers both
+    Batch bt;
+    {
+        const int nw = g.Cin * M * 9;
+        bool first = true;
+        for (int e0 = tid; e0 < nw || first; e0 += 4 * (int)blockDim.x) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = e0 + u * (int)blockDim.x;
+                const int ee = e < nw ? e : 0;
+                const int c = ee / (M * 9), r = ee - c * (M * 9);
+                const int m = r / 9, t = r - m * 9;
+                v[u] = g.w[g.w0 + (long)m * g.w_sm + (long)c * g.w_sc + t];
+            }
+            if (first) {
+                const int nch = c_end - c_beg;
+                load(xc, nch < 4 ? nch : 4, bt);
+                first = false;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = e0 + u * (int)blockDim.x;
+                if (e < nw) wsm[e] = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = c_beg; c < c_end; c += 4) {
+        const int nch = c_end - c < 4 ? c_end - c : 4;
+        fma_batch(c, nch, bt);
+        const int left = c_end - c - 4;
+        if (left > 0) {
+            xc += 4 * (long)HW;
+            load(xc, left < 4 ? left : 4, bt);
+        }
+    }
+    if (cs > 0) {
+#pragma unroll
+        for (int m = 0; m < M; m++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) red[((wid * M + m) * 4 + v) * 64 + lane] = acc[m][v];
+    }
+    __syncthreads();
+    if (cs > 0 || !live) return;
+    for (int k = 1; k < nshare; k++)
+#pragma unroll
+        for (int m = 0; m < M; m++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) acc[m][v] += red[(((wid + k) * M + m) * 4 + v) * 64 + lane];
+    const long pix = (long)y * g.W + x0;
+    const bool hr = g.res != nullptr, ha = g.add != nullptr;
+#pragma unroll
+    for (int m = 0; m < M; m++) {
         const long o = (long)m * HW + pix;
         const float bias = g.bias ? g.bias[m] : 0.f;
-        float rv[VEC], av[VEC], out[VEC];
-        if (hr) vload<VEC>(g.res + (long)n * g.res_bs + o, rv);
-        if (ha) vload<VEC>(g.add + (long)n * g.add_bs + o, av);
+        float rv[4], av[4], out[4];
+        if (hr) vload<4>(g.res + (long)n * g.res_bs + o, rv);
+        if (ha) vload<4>(g.add + (long)n * g.add_bs + o, av);
 #pragma unroll
-        for (int v = 0; v < VEC; v++)
-            out[v] = cctail::conv_tail(acc[v] + bias, hr, hr ? rv[v] : 0.f, g.res_mul, g.act, g.act_a, g.act_b, ha ? av[v] : 0.f);
-        vstore<VEC>(g.y + (long)n * g.y_bs + o, out);
+        for (int v = 0; v < 4; v++)
+            out[v] = cctail::conv_tail(acc[m][v] + bias, hr, hr ? rv[v] : 0.f, g.res_mul, g.act, g.act_a, g.act_b, ha ? av[v] : 0.f);
+        vstore<4>(g.y + (long)n * g.y_bs + o, out);
     }
+}
+
+template <int M>
+void launch_thinm(const HeadConv& g, int Wg, long ngroups, int cpw, int nshare, dim3 grid, int threads, hipStream_t s) {
+    if (g.dstep > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_thinm<M, 1>), grid, dim3(threads), 0, s, g, Wg, ngroups, cpw, nshare);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_thinm<M, -1>), grid, dim3(threads), 0, s, g, Wg, ngroups, cpw, nshare);
 }
 
 template <int K, int VEC>
@@ -170,6 +344,39 @@ bool head_conv_thinc_launch(const HeadConv& g, hipStream_t s) {
     if (vec == 4) launch_thinc_k<4>(g, Wg, ngroups, mpb, grid, s);
     else if (vec == 2) launch_thinc_k<2>(g, Wg, ngroups, mpb, grid, s);
     else launch_thinc_k<1>(g, Wg, ngroups, mpb, grid, s);
+    return true;
+}
+
+// few OUTPUT channels (M <= 4) from <= 64 inputs on maps of >= 32768 pixels in total
+bool head_conv_thinm_ok(const HeadConv& g) {
+    if (g.M < 1 || g.M > 4 || g.Cin < 1 || g.Cin > TM_MAXC || (g.dstep != 1 && g.dstep != -1)) return false;
+    if ((long)g.B * g.H * g.W < cctools::env_int("CC_HEAD_MINPIX", 32768)) return false;
+    if ((g.W % 4) != 0 || (g.x_bs % 4) != 0 || (g.y_bs % 4) != 0) return false;
+    if ((g.res && (g.res_bs % 4) != 0) || (g.add && (g.add_bs % 4) != 0)) return false;
+    return aligned_to(g.x, 16) && aligned_to(g.y, 16) && aligned_to(g.res, 16) && aligned_to(g.add, 16);
+}
+
+bool head_conv_thinm_launch(const HeadConv& g, hipStream_t s) {
+    if (!head_conv_thinm_ok(g)) return false;
+    const int Wg = g.W / 4;
+    const long ngroups = (long)g.B * g.H * Wg;
+    const long npw = (ngroups + 63) / 64;                      // pixel waves
+    // channel shares: the kernel is a chain of memory round trips per wave (weights + first batch, further batches, epilogue), so
+    // short chains in many waves: >= ~8000 waves, >= 4 channels (one batch) per share; workgroup = 4 waves (8 with 8 shares)
+    int nshare = 1;
+    while (nshare < TM_MAXCS && npw * nshare < cctools::env_int("CC_HEAD_WAVES", 8000) && g.Cin / (nshare * 2) >= 4) nshare *= 2;
+    const int cpw = (g.Cin + nshare - 1) / nshare;
+    const int nwaves = nshare > 4 ? nshare : 4;
+    const int pwpb = nwaves / nshare;
+    const long nbx = (npw + pwpb - 1) / pwpb;
+    if (nbx >= (1l << 31)) return false;
+    dim3 grid((unsigned)nbx);
+    switch (g.M) {
+        case 1: launch_thinm<1>(g, Wg, ngroups, cpw, nshare, grid, 64 * nwaves, s); break;
+        case 2: launch_thinm<2>(g, Wg, ngroups, cpw, nshare, grid, 64 * nwaves, s); break;
+        case 3: launch_thinm<3>(g, Wg, ngroups, cpw, nshare, grid, 64 * nwaves, s); break;
+        default: launch_thinm<4>(g, Wg, ngroups, cpw, nshare, grid, 64 * nwaves, s); break;
+    }
     return true;
 }
 

@@ -78,5 +78,8 @@ struct HeadConv {
 // few REDUCTION channels (Cin <= 4): vector width the problem runs with (4 / 2 / 1 pixels per work-item), 0 = not eligible
 int head_conv_thinc_vec(const HeadConv& g);
 bool head_conv_thinc_launch(const HeadConv& g, hipStream_t s);      // -> false: not eligible, nothing launched
+// few OUTPUT channels (M <= 4) from <= 64 input channels on large maps (the heads' forward pass)
+bool head_conv_thinm_ok(const HeadConv& g);
+bool head_conv_thinm_launch(const HeadConv& g, hipStream_t s);      // -> false: not eligible, nothing launched
 
 }  // namespace ccint

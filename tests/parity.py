@@ -494,6 +494,17 @@ CONV_CASES_WINO_PADW_SMALL = [    # emulator sizes (thresholds lowered through t
     (2, 33, 5, 13, 40, 3, 1, 1, "sigmoid", True, True),
     (1, 16, 3, 7, 24, 3, 1, 1, None, True, False),
 ]
+# prediction heads (<= 4 output channels from <= 64 inputs) on the VALU kernel of conv_heads.hip (k_conv_thinm; the pixel threshold is
+# lowered for the small test maps): 1 / 2 / 4 / 8 channel shares per workgroup, a channel count that does not divide by the shares
+CONV_CASES_HEADS = [
+    (1, 16, 40, 64, 2, 3, 1, 1, None, True, False),
+    (2, 8, 10, 12, 1, 3, 1, 1, "sigmoid", True, False),
+    (1, 16, 7, 36, 4, 3, 1, 1, "sigmoid", True, False),
+    (2, 40, 8, 16, 4, 3, 1, 1, "relu", True, False),
+    (2, 64, 6, 8, 3, 3, 1, 1, "lrelu", False, False),
+    (1, 5, 9, 20, 1, 3, 1, 1, None, False, False),
+    (1, 37, 5, 24, 2, 3, 1, 1, "sigmoid", True, False),
+]
 CONV_CASES_THIN = [
     (2, 16, 9, 16, 16, 3, 1, 1, "relu", True, False),
     (2, 17, 6, 20, 16, 3, 1, 1, "lrelu", True, False),

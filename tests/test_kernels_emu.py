@@ -95,6 +95,11 @@ def test_convs_thin_wgrad(monkeypatch):
     parity.check_convs("cpu", cases=parity.CONV_CASES_THIN)
 
 
+def test_convs_head_kernels(monkeypatch):
+    monkeypatch.setenv("CC_HEAD_MINPIX", "1")            # the heads' forward pass on k_conv_thinm (conv_heads.hip)
+    parity.check_convs("cpu", cases=parity.CONV_CASES_HEADS, tcases=[])
+
+
 def test_cost_volume():
     parity.check_corr("cpu")
     parity.check_corr_patch("cpu")

@@ -103,6 +103,15 @@ def test_convs_thin_wgrad(monkeypatch):
     assert _lib.engine().fn["cc_is_tools_build"]() == 0
 
 
+def test_convs_head_kernels(monkeypatch):
+    # small maps steered onto the heads' VALU forward kernel (tools build); the product thresholds: test_convs_full_size_thin_layers
+    from cc_amd import _lib, build
+    monkeypatch.setenv("CC_HEAD_MINPIX", "1")
+    with _lib.use_library(build.build_tools()) as e:
+        assert e.fn["cc_is_tools_build"]() == 1
+        parity.check_convs("cuda", cases=parity.CONV_CASES_HEADS, tcases=[])
+
+
 def test_convs_full_size_thin_layers():
     # the real thin layers of the 256x832 step (default thresholds): DispResNet6 iconv1 / head, MaskNet6 conv1, B2F feat1
     cases = [(2, 17, 256, 832, 16, 3, 1, 1, "relu", True, False), (2, 16, 256, 832, 1, 3, 1, 1, "sigmoid", True, False),
