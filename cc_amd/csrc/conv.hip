@@ -2637,7 +2637,7 @@ static size_t wgrad_ws_bytes_rest(int B, int M, int AH, int AW, int Cin, int R, 
  * addresses; ws: G consecutive areas of cc_conv2d_wgrad_ws_bytes() each. */
 // launches of the generic kernel collected by cc_conv2d_wgrad_list instead of issued one by one
 struct WgradParked { WG g; int bm; dim3 grid; double gflop; };
-struct WgradCollector { WgradParked* p; int cap, n; };
+struct WgradCollector { WgradParked* p; int cap, n; ccint::WinoWgradParked* wino; };      // wino: parked Winograd problems (or null)
 
 static void launch_wgrad_parked(const WgradCollector& c, hipStream_t s) {
     for (int bm = 128; bm >= 32; bm /= 2) {
@@ -2690,8 +2690,10 @@ static int wgrad_group_impl(int G, const long* a, const long* x, const long* gw,
                 if (cctools::env_flag("CC_TIMING_DETAIL"))
                     snprintf(nm + nl, sizeof nm - nl, " G%d B%d M%d C%d %dx%d k%d wg%d", G, B, M, Cin, AH, AW, wp.nsplit,
                              wp.nmb * wp.ncb * G * wp.nsplit);
-                cctiming::Scope tsc(nm, 2e-9 * 16.0 * G * B * ((AH + 1) / 2) * ((AW + 1) / 2) * (double)M * Cin, s);
-                ok = ccint::wino_wgrad_launch(wp, ap, xp, wsp, G, B, M, AH, AW, a_bs, Cin, x_bs, s);
+                ccint::WinoWgradParked* wpark = park ? park->wino : nullptr;
+                cctiming::Scope tsc(nm, 2e-9 * 16.0 * G * B * ((AH + 1) / 2) * ((AW + 1) / 2) * (double)M * Cin, s,
+                                    !(wpark && wpark->n + G <= ccint::WINO_WGRAD_PARK_CAP));
+                ok = ccint::wino_wgrad_launch(wp, ap, xp, wsp, G, B, M, AH, AW, a_bs, Cin, x_bs, s, wpark);
             }
             if (ok) {
                 for (int k = 0; k < G; k++) {
@@ -2732,9 +2734,11 @@ static int wgrad_group_impl(int G, const long* a, const long* x, const long* gw,
                 if (cctools::env_flag("CC_TIMING_DETAIL"))
                     snprintf(nm + nl, sizeof nm - nl, " G%d B%d M%d C%d %dx%d(pad %d) k%d wg%d", G, B, M, Cin, AH, AW, pp.Wp, pp.wp.nsplit,
                              pp.wp.nmb * pp.wp.ncb * G * pp.wp.nsplit);
-                cctiming::Scope tsc(nm, 2e-9 * 16.0 * G * B * ((AH + 1) / 2) * (pp.Wp / 2) * (double)M * Cin, s);
+                ccint::WinoWgradParked* wpark = park ? park->wino : nullptr;
+                cctiming::Scope tsc(nm, 2e-9 * 16.0 * G * B * ((AH + 1) / 2) * (pp.Wp / 2) * (double)M * Cin, s,
+                                    !(wpark && wpark->n + G <= ccint::WINO_WGRAD_PARK_CAP));
                 hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)((nf4 + 255) / 256)), dim3(256), 0, s, t);
-                ok = ccint::wino_wgrad_launch(pp.wp, ap, xp, wsp, G, B, M, AH, pp.Wp, (long)M * AH * pp.Wp, Cin, (long)Cin * AH * pp.Wp, s);
+                ok = ccint::wino_wgrad_launch(pp.wp, ap, xp, wsp, G, B, M, AH, pp.Wp, (long)M * AH * pp.Wp, Cin, (long)Cin * AH * pp.Wp, s, wpark);
             }
             if (ok) {
                 for (int k = 0; k < G; k++) {
@@ -2916,7 +2920,9 @@ int cc_conv2d_wgrad_list(int n, const long* desc_host, const float* zeros64_or_n
     hipStream_t s = (hipStream_t)stream;
     constexpr int CAP = 64;
     static thread_local WgradParked parked[CAP];
-    WgradCollector col = {parked, CAP, 0};
+    static thread_local ccint::WinoWgradParked wino_parked;
+    wino_parked.n = 0;
+    WgradCollector col = {parked, CAP, 0, cctools::env_flag("CC_NO_WINO_WGRAD_LIST") ? nullptr : &wino_parked};
     ccint::RedSink sink = {red_host, red_cap, 0};
     for (int i = 0; i < n; i++) {
         const long* d = desc_host + 32l * i;
@@ -2945,6 +2951,12 @@ int cc_conv2d_wgrad_list(int n, const long* desc_host, const float* zeros64_or_n
         }
     }
     launch_wgrad_parked(col, s);
+    if (wino_parked.n > 0) {
+        double gf = 0;
+        for (int i = 0; i < wino_parked.n; i++) gf += wino_parked.d[i].gflop;
+        cctiming::Scope tsc("k_wino_wgrad_multi", gf, s);
+        ccint::wino_wgrad_launch_parked(&wino_parked, s);
+    }
     *nred_host = sink.n;
     CC_CHECK_LAUNCH();
     return CC_OK;

@@ -60,8 +60,22 @@ struct WinoWgradPlan {
 WinoWgradPlan wino_wgrad_plan(int B, int M, int H, int W, int Cin, int G, int minq = -1);      // minq: tile-count floor (-1: default)
 // G (<= 4) same-shaped problems in one launch; ws[k]: slab area of problem k.  -> false (nothing launched) when the tensors are not
 // 8- / 16-byte aligned
+// park != nullptr (and room left): the G problems are appended to the collector instead of launched; wino_wgrad_launch_parked then
+// runs everything collected in multi-geometry launches (problems of different shapes share a launch, longest chains first)
+constexpr int WINO_WGRAD_PARK_CAP = 96;
+struct WinoWgradParked {
+    struct Desc {
+        const float* a; const float* x; float* ws;
+        int M, C, H, W; long a_bs, x_bs; unsigned a_bytes, x_bytes;
+        int TX, CPR, CPI, NCH, cps, ncb, Cp, nxy, nsplit;
+        double gflop;
+    };
+    Desc d[WINO_WGRAD_PARK_CAP];
+    int n;
+};
 bool wino_wgrad_launch(const WinoWgradPlan& p, const float* const* a, const float* const* x, float* const* ws, int G, int B, int M,
-                       int H, int W, long a_bs, int Cin, long x_bs, hipStream_t s);
+                       int H, int W, long a_bs, int Cin, long x_bs, hipStream_t s, WinoWgradParked* park = nullptr);
+void wino_wgrad_launch_parked(WinoWgradParked* c, hipStream_t s);
 
 // ---- 3x3 / stride-1 / pad-1 layers with <= 4 channels on one side (conv_heads.hip): the prediction heads and their data-gradients
 // as HBM-bound vector-ALU kernels instead of padded MFMA tiles.  Input [B, Cin, H, W] (batch stride x_bs), output [B, M, H, W];

@@ -47,9 +47,23 @@ struct WW {
     int TX, CPR, CPI, NCH, cps;            // tile columns, chunks per tile row / per image / in total, chunks per split
     int ncb, Cp;                           // 64-channel blocks of the input, padded input channels (slab pitch)
 };
+// one problem of a multi-geometry launch (k_wino_wgrad_multi): the fields the kernel body reads from WW, per problem
+struct WW1 {
+    const float* a; const float* x; float* ws;
+    int M, C, H, W, HW;
+    long a_bs, x_bs;
+    unsigned a_bytes, x_bytes;
+    int TX, CPR, CPI, NCH, cps;
+    int ncb, Cp;
+    int nxy;                               // 64 x 64 blocks of the problem (its grid is nxy x nsplit, x fastest)
+};
+constexpr int WWM_MAX = 24;                // problems per multi-geometry launch
+struct WWM { WW1 p[WWM_MAX]; int blk_end[WWM_MAX]; int n; };
 
-template <int ABL>
-__global__ __launch_bounds__(WGT, 2) void k_wino_wgrad(WW g) {
+// bx: 64 x 64 block of the weight matrix (mb * ncb + cb), bz: split of the chunk range
+template <int ABL, class D>
+__device__ __forceinline__ void wino_wgrad_body(const D& g, const float* __restrict__ a_, const float* __restrict__ x_,
+                                                float* __restrict__ ws_, const int bx_, const int bz_) {
     HIP_DYNAMIC_SHARED(float, smem)
     float* As = smem;                      // [2][OBLK]
     float* Vs = smem + 2 * OBLK;           // [2][OBLK]
@@ -60,11 +74,8 @@ __global__ __launch_bounds__(WGT, 2) void k_wino_wgrad(WW g) {
     const int st = wid & 3, fh = wid >> 2;
     const int wm = st >> 1, wc = st & 1;
     const int l31 = lane & 31, lk = lane >> 5;
-    const int mb = (int)blockIdx.x / g.ncb, cb = (int)blockIdx.x - mb * g.ncb;
-    const float* __restrict__ a_ = g.ga[blockIdx.y];
-    const float* __restrict__ x_ = g.gx[blockIdx.y];
-    float* __restrict__ ws_ = g.gws[blockIdx.y];
-    const int c_beg = (int)blockIdx.z * g.cps;
+    const int mb = bx_ / g.ncb, cb = bx_ - mb * g.ncb;
+    const int c_beg = bz_ * g.cps;
     int c_end = c_beg + g.cps;
     if (c_end > g.NCH) c_end = g.NCH;
 
@@ -284,11 +295,34 @@ __global__ __launch_bounds__(WGT, 2) void k_wino_wgrad(WW g) {
 #pragma unroll
         for (int k = 0; k < 9; k++) o[k] += xi[(r8 * 9 + k) * 64];
         if (m < g.M) {
-            float* w = ws_ + (long)blockIdx.z * 9 * tstride + (long)m * g.Cp + c;
+            float* w = ws_ + (long)bz_ * 9 * tstride + (long)m * g.Cp + c;
 #pragma unroll
             for (int k = 0; k < 9; k++) w[k * tstride] = o[k];
         }
     }
+}
+
+template <int ABL>
+__global__ __launch_bounds__(WGT, 2) void k_wino_wgrad(WW g) {
+    wino_wgrad_body<ABL>(g, g.ga[blockIdx.y], g.gx[blockIdx.y], g.gws[blockIdx.y], (int)blockIdx.x, (int)blockIdx.z);
+}
+
+// Problems of DIFFERENT shapes in one launch (what a backward stage leaves parked until its end: the single layers and incomplete
+// groups of the small pyramid levels, 8-250 workgroups each -- a launch of its own is mostly ramp-up and drain for them;
+// cc_conv2d_wgrad_list).  blockIdx.x ranges over the problems' grids back to back, longest chains first.
+__global__ __launch_bounds__(WGT, 2) void k_wino_wgrad_multi(WWM a) {
+    int k = 0, first = 0;
+#pragma unroll 1
+    for (int q = 0; q + 1 < a.n; q++)
+        if ((int)blockIdx.x >= a.blk_end[q]) { k = q + 1; first = a.blk_end[q]; }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CC_HIPEMU)
+    const WW1& g = *(reinterpret_cast<const WW1*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WWM, p)) + k);
+#else
+    const WW1& g = a.p[k];
+#endif
+    const int b = (int)blockIdx.x - first;
+    const int bz = b / g.nxy;
+    wino_wgrad_body<0>(g, g.a, g.x, g.ws, b - bz * g.nxy, bz);
 }
 
 }  // namespace
@@ -333,15 +367,68 @@ WinoWgradPlan wino_wgrad_plan(int B, int M, int H, int W, int Cin, int G, int mi
     return p;
 }
 
+static bool g_attr_multi = false;
+
+void wino_wgrad_launch_parked(WinoWgradParked* c, hipStream_t s) {
+    if (!c || c->n <= 0) return;
+    // longest chains first (chunks per split): the short ones fill the tail
+    int order[WINO_WGRAD_PARK_CAP];
+    for (int i = 0; i < c->n; i++) order[i] = i;
+    for (int i = 1; i < c->n; i++) {
+        const int v = order[i];
+        int j = i - 1;
+        while (j >= 0 && c->d[order[j]].cps < c->d[v].cps) { order[j + 1] = order[j]; j--; }
+        order[j + 1] = v;
+    }
+    const size_t smem = (size_t)(4 * OBLK + 8 * XPW) * sizeof(float);
+    int i = 0;
+    while (i < c->n) {
+        WWM m = {};
+        long blk = 0;
+        for (; i < c->n && m.n < WWM_MAX; i++) {
+            const WinoWgradParked::Desc& d = c->d[order[i]];
+            const long nb = (long)d.nxy * d.nsplit;
+            if (blk + nb >= (1l << 31)) break;
+            WW1& w = m.p[m.n];
+            w.a = d.a; w.x = d.x; w.ws = d.ws;
+            w.M = d.M; w.C = d.C; w.H = d.H; w.W = d.W; w.HW = d.H * d.W;
+            w.a_bs = d.a_bs; w.x_bs = d.x_bs; w.a_bytes = d.a_bytes; w.x_bytes = d.x_bytes;
+            w.TX = d.TX; w.CPR = d.CPR; w.CPI = d.CPI; w.NCH = d.NCH; w.cps = d.cps; w.ncb = d.ncb; w.Cp = d.Cp; w.nxy = d.nxy;
+            blk += nb;
+            m.blk_end[m.n] = (int)blk;
+            m.n++;
+        }
+        if (!m.n) break;
+        if (!g_attr_multi) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wino_wgrad_multi), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            g_attr_multi = true;
+        }
+        if (cctools::env_flag("CC_WINO_TRACE")) fprintf(stderr, "wino_wgrad_multi: %d problems, %ld workgroups\n", m.n, blk);
+        hipLaunchKernelGGL(k_wino_wgrad_multi, dim3((unsigned)blk), dim3(WGT), smem, s, m);
+    }
+    c->n = 0;
+}
+
 bool wino_wgrad_launch(const WinoWgradPlan& p, const float* const* a, const float* const* x, float* const* ws, int G, int B, int M,
-                       int H, int W, long a_bs, int Cin, long x_bs, hipStream_t s) {
+                       int H, int W, long a_bs, int Cin, long x_bs, hipStream_t s, WinoWgradParked* park) {
     const long afl = ((long)B - 1) * a_bs + (long)M * H * W, xfl = ((long)B - 1) * x_bs + (long)Cin * H * W;
     if (G < 1 || G > WG_MAXP || (a_bs % 2) != 0 || (x_bs % 4) != 0 || afl * 4 >= (long)CC_BUF_OOB || xfl * 4 >= (long)CC_BUF_OOB) return false;
-    WW w = {};
-    for (int k = 0; k < G; k++) {
+    for (int k = 0; k < G; k++)
         if (((uintptr_t)a[k] % 8) != 0 || ((uintptr_t)x[k] % 16) != 0) return false;
-        w.ga[k] = a[k]; w.gx[k] = x[k]; w.gws[k] = ws[k];
+    if (park && park->n + G <= WINO_WGRAD_PARK_CAP) {
+        for (int k = 0; k < G; k++) {
+            WinoWgradParked::Desc& d = park->d[park->n++];
+            d.a = a[k]; d.x = x[k]; d.ws = ws[k];
+            d.M = M; d.C = Cin; d.H = H; d.W = W; d.a_bs = a_bs; d.x_bs = x_bs;
+            d.a_bytes = (unsigned)(afl * 4); d.x_bytes = (unsigned)(xfl * 4);
+            d.TX = p.TX; d.CPR = p.CPR; d.CPI = p.CPI; d.NCH = p.NCH; d.cps = p.cps; d.ncb = p.ncb; d.Cp = p.Cp;
+            d.nxy = p.nmb * p.ncb; d.nsplit = p.nsplit;
+            d.gflop = 2e-9 * 16.0 * B * ((H + 1) / 2) * ((W + 1) / 2) * (double)M * Cin;
+        }
+        return true;
     }
+    WW w = {};
+    for (int k = 0; k < G; k++) { w.ga[k] = a[k]; w.gx[k] = x[k]; w.gws[k] = ws[k]; }
     w.M = M; w.C = Cin; w.H = H; w.W = W; w.HW = H * W;
     w.a_bs = a_bs; w.x_bs = x_bs; w.a_bytes = (unsigned)(afl * 4); w.x_bytes = (unsigned)(xfl * 4);
     w.TX = p.TX; w.CPR = p.CPR; w.CPI = p.CPI; w.NCH = p.NCH; w.cps = p.cps;

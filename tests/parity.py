@@ -1017,7 +1017,16 @@ def check_adam(dev, n=10007, steps=3):
     assert err <= 1e-6, err          # a few ulp (different but equivalent operation order: lr / bc1 folded into the step size)
 
 
-def check_wgrad_list(dev, tol=2e-5):
+WGRAD_LIST_SHAPES = [(2, 12, 9, 14, 20, 3, 2, 1), (2, 24, 6, 10, 150, 1, 1, 0), (1, 40, 5, 7, 33, 3, 1, 1), (2, 8, 12, 16, 16, 5, 2, 2),
+                     (2, 130, 2, 3, 140, 3, 1, 1), (2, 16, 8, 8, 24, 4, 2, 1), (2, 48, 6, 16, 64, 3, 1, 1)]
+# 3x3 / stride-1 layers that take the Winograd weight-gradient kernel (thresholds lowered by the caller): their launches are parked
+# too and share multi-geometry launches (wino_wgrad.hip k_wino_wgrad_multi) -- different channel counts / map sizes / split counts,
+# a G = 2 group (index 1), a width that is not a multiple of 4 (zero-padded copies first), next to a generic-kernel problem
+WGRAD_LIST_SHAPES_WINO = [(2, 48, 6, 16, 64, 3, 1, 1), (1, 20, 8, 24, 40, 3, 1, 1), (2, 33, 5, 13, 40, 3, 1, 1), (2, 16, 4, 8, 24, 3, 1, 1),
+                          (2, 12, 9, 14, 20, 3, 2, 1), (1, 70, 9, 32, 130, 3, 1, 1)]
+
+
+def check_wgrad_list(dev, tol=2e-5, shapes=None):
     """cc_conv2d_wgrad_list (ops._wgrad_list: what a backward stage's weight-gradient queue flushes at its end): groups of different
     shapes in one call -- stride-2 / 1x1 / small-map layers on the generic kernel (k_wgrad_multi: several per launch), direct-mode
     problems (no split) next to split ones, a G = 2 group, a weight that occurs twice (its two accumulations must not share a
@@ -1035,8 +1044,7 @@ def check_wgrad_list(dev, tol=2e-5):
         F.conv2d(x, w, None, st, pad).backward(gy)
         return w.grad
     # (B, Cin, H, W, Cout, k, stride, pad)
-    shapes = [(2, 12, 9, 14, 20, 3, 2, 1), (2, 24, 6, 10, 150, 1, 1, 0), (1, 40, 5, 7, 33, 3, 1, 1), (2, 8, 12, 16, 16, 5, 2, 2),
-              (2, 130, 2, 3, 140, 3, 1, 1), (2, 16, 8, 8, 24, 4, 2, 1), (2, 48, 6, 16, 64, 3, 1, 1)]
+    shapes = list(shapes or WGRAD_LIST_SHAPES)
     items, want, bufs = [], [], []
     for si_, (B, Cin, H, W, Cout, k, st, pad) in enumerate(shapes):
         G = 2 if si_ == 1 else 1

@@ -89,6 +89,13 @@ def test_weight_gradient_list():
     parity.check_wgrad_list("cpu")
 
 
+def test_weight_gradient_list_winograd(monkeypatch):
+    for k in ("CC_WW_MINQ", "CC_WW_MINM", "CC_WW_MINC", "CC_WWP_MINQ", "CC_WWP_MINM", "CC_WWP_MINC"):
+        monkeypatch.setenv(k, "1")
+    monkeypatch.setenv("CC_WW_MINCHUNKS", "2")
+    parity.check_wgrad_list("cpu", shapes=parity.WGRAD_LIST_SHAPES_WINO)
+
+
 def test_convs_thin_wgrad(monkeypatch):
     monkeypatch.setenv("CC_WGRAD_THIN_MINPIX", "0")      # route the small test maps through wgrad_thin.hip
     monkeypatch.setenv("CC_WGRAD_THIN_UPB", "8")

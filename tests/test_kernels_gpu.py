@@ -87,6 +87,22 @@ def test_weight_gradient_list():
     parity.check_wgrad_list("cuda")
 
 
+def test_weight_gradient_list_winograd(monkeypatch):
+    # ... with 3x3 / stride-1 layers on the Winograd weight-gradient kernel in the list: they share multi-geometry launches
+    # (k_wino_wgrad_multi); small shapes steered there through the tools build's switches, product-size shapes at product thresholds
+    from cc_amd import _lib, build
+    for k in ("CC_WW_MINQ", "CC_WW_MINM", "CC_WW_MINC", "CC_WWP_MINQ", "CC_WWP_MINM", "CC_WWP_MINC"):
+        monkeypatch.setenv(k, "1")
+    monkeypatch.setenv("CC_WW_MINCHUNKS", "2")
+    with _lib.use_library(build.build_tools()) as e:
+        assert e.fn["cc_is_tools_build"]() == 1
+        parity.check_wgrad_list("cuda", shapes=parity.WGRAD_LIST_SHAPES_WINO)
+    for k in ("CC_WW_MINQ", "CC_WW_MINM", "CC_WW_MINC", "CC_WWP_MINQ", "CC_WWP_MINM", "CC_WWP_MINC", "CC_WW_MINCHUNKS"):
+        monkeypatch.delenv(k)
+    parity.check_wgrad_list("cuda", shapes=[(4, 128, 8, 28, 128, 3, 1, 1), (4, 96, 16, 52, 96, 3, 1, 1), (4, 128, 8, 26, 96, 3, 1, 1),
+                                             (4, 64, 32, 104, 64, 3, 1, 1), (2, 12, 9, 14, 20, 3, 2, 1), (4, 192, 4, 16, 192, 3, 1, 1)])
+
+
 def test_convs_prepacked_weight_images():
     parity.check_convs("cuda", prepack=True)
 
