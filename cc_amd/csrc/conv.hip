@@ -2678,7 +2678,8 @@ static int wgrad_group_impl(int G, const long* a, const long* x, const long* gw,
     const size_t stride_f = cc_conv2d_wgrad_ws_bytes(B, M, AH, AW, Cin, R, S, si) / sizeof(float);
     if (R == 3 && S == 3 && si == 1 && pad == 1 && IH == AH && IW == AW) {
         // Winograd F(3x3, 2x2): 16 instead of 36 multiply-adds per 2x2 tile (wino_wgrad.hip); same slab layout / reduction as k_wgrad3x3
-        const ccint::WinoWgradPlan wp = ccint::wino_wgrad_plan(B, M, AH, AW, Cin, G);
+        ccint::WinoWgradPlan wp = ccint::wino_wgrad_plan(B, M, AH, AW, Cin, G);
+        if (wp.ok && park && park->wino && park->wino->n + G <= ccint::WINO_WGRAD_PARK_CAP) wp = ccint::wino_wgrad_plan_parked(wp, M);
         if (wp.ok) {
             const float *ap[MAXGRP], *xp[MAXGRP];
             float* wsp[MAXGRP];
@@ -2707,7 +2708,12 @@ static int wgrad_group_impl(int G, const long* a, const long* x, const long* gw,
         }
     }
     if (R == 3 && S == 3 && si == 1 && pad == 1 && IH == AH && IW == AW) {
-        const WinoPadPlan pp = wino_pad_plan(B, M, AH, AW, Cin, G);
+        WinoPadPlan pp = wino_pad_plan(B, M, AH, AW, Cin, G);
+        if (pp.ok && park && park->wino && park->wino->n + G <= ccint::WINO_WGRAD_PARK_CAP) {
+            const size_t slabs = (pp.wp.ws_floats + 3) & ~(size_t)3;          // the padded copies keep their place behind the stand-alone plan's slabs
+            pp.wp = ccint::wino_wgrad_plan_parked(pp.wp, M);
+            pp.wp.ws_floats = slabs;
+        }
         if (pp.ok) {
             const float *ap[MAXGRP], *xp[MAXGRP];
             float* wsp[MAXGRP];

@@ -58,6 +58,7 @@ struct WinoWgradPlan {
     size_t ws_floats;           // 64 + partial slabs ws[split][tap 9][m][Cp] (the layout of k_wgrad3x3: reduce kind 1)
 };
 WinoWgradPlan wino_wgrad_plan(int B, int M, int H, int W, int Cin, int G, int minq = -1);      // minq: tile-count floor (-1: default)
+WinoWgradPlan wino_wgrad_plan_parked(const WinoWgradPlan& alone, int M);      // split count for a problem that shares a multi-geometry launch
 // G (<= 4) same-shaped problems in one launch; ws[k]: slab area of problem k.  -> false (nothing launched) when the tensors are not
 // 8- / 16-byte aligned
 // park != nullptr (and room left): the G problems are appended to the collector instead of launched; wino_wgrad_launch_parked then

@@ -367,6 +367,25 @@ WinoWgradPlan wino_wgrad_plan(int B, int M, int H, int W, int Cin, int G, int mi
     return p;
 }
 
+// A problem that will share a multi-geometry launch (wino_wgrad_launch_parked) does not have to fill the chip on its own: fewer,
+// longer splits -- the epilogue (worth ~4 chunks) weighs less and fewer partial slabs are written and reduced.  Never more splits
+// than the stand-alone plan (the workspace is sized for that one).
+WinoWgradPlan wino_wgrad_plan_parked(const WinoWgradPlan& alone, int M) {
+    WinoWgradPlan p = alone;
+    if (!p.ok) return p;
+    const int target = cctools::env_int("CC_WW_PARK_CPS", 16);
+    if (target <= 0 || p.cps >= target) return p;
+    int cps = target < p.NCH ? target : p.NCH;
+    int nsplit = (p.NCH + cps - 1) / cps;
+    cps = (p.NCH + nsplit - 1) / nsplit;                 // even shares
+    nsplit = (p.NCH + cps - 1) / cps;
+    if (nsplit >= alone.nsplit) return p;
+    p.cps = cps;
+    p.nsplit = nsplit;
+    p.ws_floats = 64 + (size_t)p.nsplit * 9 * M * p.Cp;
+    return p;
+}
+
 static bool g_attr_multi = false;
 
 void wino_wgrad_launch_parked(WinoWgradParked* c, hipStream_t s) {
