@@ -150,6 +150,8 @@ def kernel_of(eng, name, d):
             return base
         if name == "cc_conv2d_wgrad_group":
             return base + " xG"
+        if base.startswith("k_conv_thin"):          # few-channel layers: the VALU kernels take single problems only, groups run merged
+            return "k_conv_patch_multi<few-channel group> xG"
         # merged launch of the G problems (x their parity classes) on the multi-problem kernel
         return base.replace("k_conv_patch<", "k_conv_patch_multi<").replace(", 1>+", ">+").replace(", 0>", ">") + " xG"
     if name == "cc_conv2d_fwd":

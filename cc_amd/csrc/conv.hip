@@ -3044,6 +3044,11 @@ int cc_conv2d_fwd_kernel(int B, int Cin, int IH, int IW, int Cout, int R, int S,
                          void* name_out_host, int cap) {
     GG g = make_fwd(nullptr, nullptr, nullptr, nullptr, nullptr, B, Cin, IH, IW, 0, Cout, R, S, stride, pad, OH, OW, 0, 0, 0,
                     1.f, 0.f);
+    ccint::HeadConv h;
+    if (const int hk = head_kernel_of(g, h)) {       // (geometry only: the launch also checks the tensors' alignment)
+        snprintf((char*)name_out_host, cap, hk == 1 ? "k_conv_thinc<%d>" : "k_conv_thinm<%d>", hk == 1 ? g.Cin : g.M);
+        return CC_OK;
+    }
     patch_name(plan_conv(g), false, (char*)name_out_host, cap);
     return CC_OK;
 }
@@ -3060,6 +3065,13 @@ int cc_conv2d_dgrad_kernel(int B, int K, int OH, int OW, int C, int R, int S, in
             n++;
         }
     if (n == 0) { ((char*)name_out_host)[0] = 0; return CC_OK; }
+    if (n == 1 && stride == 1) {
+        ccint::HeadConv h;
+        if (const int hk = head_kernel_of(gs[0], h)) {
+            snprintf((char*)name_out_host, cap, hk == 1 ? "k_conv_thinc<%d>" : "k_conv_thinm<%d>", hk == 1 ? gs[0].Cin : gs[0].M);
+            return CC_OK;
+        }
+    }
     ConvPlan p = plan_conv(gs[0]);
     bool multi = false;
     if (stride == 2 && prepacked && all && n >= 2 && !dbg_flag_early("CC_NO_CLASS_MERGE")) {

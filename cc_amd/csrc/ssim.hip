@@ -111,35 +111,51 @@ __device__ __forceinline__ void ssim_tile_body(const PhotoArgs& a, const Gauss13
 
     // even width + 8-byte aligned planes: rows start 8-byte aligned and a pair never straddles the image edge
     const bool pairs = !(W & 1) && ((((uintptr_t)a.x) | ((uintptr_t)a.y)) & 7) == 0;
+    const bool colsafe = (ox0 >= HALO) && (ox0 + TS + HALO <= W);          // no column of the tile's input window leaves the image
     for (int c = 0; c < 3; c++) {
         const float* xp = a.x + ((size_t)b * 3 + c) * HW;
         const float* yp = a.y + ((size_t)b * 3 + c) * HW;
         if (c > 0) __syncthreads();          // everyone is done with the previous channel's V pass
-        // ---- H pass
+        // ---- H pass.  Every load is unconditional: rows outside the image are clamped to an image row and the item's outputs zeroed
+        // afterwards; columns outside the image are clamped and the loaded value zeroed (only the first / last tile column of an
+        // image has any: `colsafe` tiles skip that too).  A load under `in ? *p : 0` compiles to a branch around each load (16 basic
+        // blocks with ~17 instructions of mask bookkeeping each: 40 % of the pass).
         for (int it = tid; it < TIN * (TS / 4); it += 256) {
             const int r = it >> 3, cg = it & 7;
             const int yy = oy0 - HALO + r, x0 = ox0 - HALO + 4 * cg;
             const bool rowin = (yy >= 0) && (yy < H);
-            const float* xr = xp + (long)yy * W;
-            const float* yr = yp + (long)yy * W;
+            const int yc = yy < 0 ? 0 : (yy < H ? yy : H - 1);
+            const float* xr = xp + (long)yc * W;
+            const float* yr = yp + (long)yc * W;
             float xv[16], yv[16];
-            if (pairs) {
+            if (pairs && colsafe) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const float2 vx = *reinterpret_cast<const float2*>(xr + x0 + 2 * k);
+                    const float2 vy = *reinterpret_cast<const float2*>(yr + x0 + 2 * k);
+                    xv[2 * k] = vx.x; xv[2 * k + 1] = vx.y;
+                    yv[2 * k] = vy.x; yv[2 * k + 1] = vy.y;
+                }
+            } else if (pairs) {
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     const int xx = x0 + 2 * k;
-                    const bool in = rowin && (xx >= 0) && (xx < W);
-                    const float2 vx = in ? *reinterpret_cast<const float2*>(xr + xx) : make_float2(0.f, 0.f);
-                    const float2 vy = in ? *reinterpret_cast<const float2*>(yr + xx) : make_float2(0.f, 0.f);
-                    xv[2 * k] = vx.x; xv[2 * k + 1] = vx.y;
-                    yv[2 * k] = vy.x; yv[2 * k + 1] = vy.y;
+                    const bool in = (xx >= 0) && (xx < W);
+                    const int xc = in ? xx : 0;
+                    const float2 vx = *reinterpret_cast<const float2*>(xr + xc);
+                    const float2 vy = *reinterpret_cast<const float2*>(yr + xc);
+                    xv[2 * k] = in ? vx.x : 0.f; xv[2 * k + 1] = in ? vx.y : 0.f;
+                    yv[2 * k] = in ? vy.x : 0.f; yv[2 * k + 1] = in ? vy.y : 0.f;
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const int xx = x0 + k;
-                    const bool in = rowin && (xx >= 0) && (xx < W);
-                    xv[k] = in ? xr[xx] : 0.f;
-                    yv[k] = in ? yr[xx] : 0.f;
+                    const bool in = (xx >= 0) && (xx < W);
+                    const int xc = in ? xx : 0;
+                    const float vx = xr[xc], vy = yr[xc];
+                    xv[k] = in ? vx : 0.f;
+                    yv[k] = in ? vy : 0.f;
                 }
             }
             float o[4][4];
@@ -165,7 +181,8 @@ __device__ __forceinline__ void ssim_tile_body(const PhotoArgs& a, const Gauss13
             }
 #pragma unroll
             for (int mi = 0; mi < 4; mi++)
-                *reinterpret_cast<float4*>(&hb[mi][r * TS + 4 * cg]) = make_float4(o[mi][0], o[mi][1], o[mi][2], o[mi][3]);
+                *reinterpret_cast<float4*>(&hb[mi][r * TS + 4 * cg]) =
+                    rowin ? make_float4(o[mi][0], o[mi][1], o[mi][2], o[mi][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
         // ---- V pass
@@ -362,10 +379,12 @@ __device__ __forceinline__ void ssim_adjoint_body(const float* __restrict__ adjA
                 const int r = i / TIN, col = i - r * TIN;
                 const int yy = oy0 - HALO + r, xx = ox0 - HALO + col;
                 const bool in = (i < TIN * TIN) && (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
-                const size_t o = plane + (size_t)yy * W + xx;
-                va[u] = in ? adjA[o] : 0.f;
-                vb[u] = in ? adjB[o] : 0.f;
-                vc[u] = in ? adjC[o] : 0.f;
+                // unconditional loads from a clamped address, then a select (a load under `in ? *p : 0` is a branch around each load)
+                const size_t o = plane + (in ? (size_t)yy * W + xx : 0);
+                const float ta = adjA[o], tb = adjB[o], tc = adjC[o];
+                va[u] = in ? ta : 0.f;
+                vb[u] = in ? tb : 0.f;
+                vc[u] = in ? tc : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
