@@ -2847,8 +2847,14 @@ static int wgrad_group_impl(int G, const long* a, const long* x, const long* gw,
     const long P = (long)B * AH * AW;
     const int bm = pick_bm(M);
     const long tiles = ((Ntot + BN - 1) / BN) * ((M + bm - 1) / bm) * G;
-    long nsplit = (env_int_early("CC_WGRAD_SPLIT_TARGET", 512) + tiles - 1) / tiles;
-    const long mr = env_int_early("CC_WGRAD_MINRANGE", 32);
+    // a problem that will share a launch with others (cc_conv2d_wgrad_list) does not have to fill the chip alone: fewer, longer
+    // pixel ranges -- fewer 64 KB partial tiles written, reduced and paid for in epilogues (never more splits than stand-alone:
+    // the workspace is sized for that).  Measured (profiles/r04_ab_round4.txt): target 256 / ranges >= 64 pixels -0.13 ms against
+    // the stand-alone plan; much longer chains lose again (target 64: +0.5 ms, 32: +1.6 ms -- the kernel is slow per k-step)
+    const bool parked = park && park->n < park->cap;
+    const long target = parked ? env_int_early("CC_WGRAD_PARK_TARGET", 256) : env_int_early("CC_WGRAD_SPLIT_TARGET", 512);
+    long nsplit = (target + tiles - 1) / tiles;
+    const long mr = parked ? env_int_early("CC_WGRAD_PARK_MINRANGE", 64) : env_int_early("CC_WGRAD_MINRANGE", 32);
     const long maxsplit = (P + mr - 1) / mr;  // small maps still need >= 256 workgroups: split down to 32-pixel ranges (-0.16 ms/step against 64, r3s3)
     if (nsplit > maxsplit) nsplit = maxsplit;
     if (nsplit < 1) nsplit = 1;
