@@ -463,6 +463,9 @@ def main():
     batch = (batch_cpu[0].to(dev), [r.to(dev) for r in batch_cpu[1]], batch_cpu[2].to(dev), batch_cpu[3].to(dev))
     # measurement switches of the data-parallel step (tools/gpu_r3y.sh, gpu_r3z.sh): read HERE, by the measuring script -- the
     # product step (cc_amd/trainer.py) reads no environment variable
+    if os.environ.get("CC_NO_HEAD_ACC", "0") == "1":                    # A/B: the loss terms return separate gradients, the engine adds them
+        from cc_amd import loss_functions as _LF
+        _LF.head_grads.enabled = False
     comm_debug = {"events": os.environ.get("CC_NO_COMM_EVENTS", "0") != "1"}
     if os.environ.get("CC_COMM_JOIN"):
         comm_debug["join"] = os.environ["CC_COMM_JOIN"]

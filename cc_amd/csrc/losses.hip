@@ -322,6 +322,34 @@ __global__ __launch_bounds__(256) void k_scale_by_scalar(const float* __restrict
     if (i < n) out[i] = a[i] * s[0];
 }
 
+// dst_k (=, +=) src_k * s[0] for up to SA_MAX spans in one launch (cc_scale_acc_jobs): the `* grad_output` of a fused loss written
+// straight into the step's per-tensor gradient accumulators -- float4 where both spans are 16-byte aligned
+constexpr int SA_MAX = 32;
+struct ScaleAccTab { const float* src[SA_MAX]; float* dst[SA_MAX]; int n[SA_MAX]; int acc[SA_MAX]; int blk_end[SA_MAX]; int njobs; };
+__global__ __launch_bounds__(256) void k_scale_acc_jobs(ScaleAccTab t, const float* __restrict__ s) {
+    int j = 0, first = 0;
+#pragma unroll 1
+    for (int q = 0; q + 1 < t.njobs; q++)
+        if ((int)blockIdx.x >= t.blk_end[q]) { j = q + 1; first = t.blk_end[q]; }
+    const float sc = s[0];
+    const float* __restrict__ src = t.src[j];
+    float* __restrict__ dst = t.dst[j];
+    const int n = t.n[j], acc = t.acc[j];
+    const int i4 = (((int)blockIdx.x - first) * 256 + (int)threadIdx.x) * 4;
+    if (i4 >= n) return;
+    if (i4 + 3 < n && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const float4 v = *reinterpret_cast<const float4*>(src + i4);
+        float4 o = make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc);
+        if (acc) { const float4 d = *reinterpret_cast<const float4*>(dst + i4); o.x = d.x + o.x; o.y = d.y + o.y; o.z = d.z + o.z; o.w = d.w + o.w; }
+        *reinterpret_cast<float4*>(dst + i4) = o;
+        return;
+    }
+    for (int i = i4; i < n && i < i4 + 4; i++) {
+        const float o = src[i] * sc;
+        dst[i] = acc ? dst[i] + o : o;
+    }
+}
+
 // ------------------------------------------------------------------ job-table forms (all pyramid levels in one launch, jobs.h)
 #define CC_JOB_PIXEL(t, j, b, p, HW)                                        \
     int first__;                                                            \
@@ -636,6 +664,27 @@ int cc_sum_strided(int n, const long* src, const long* src_bs, float* out, long 
 int cc_scale_by_scalar(const float* a, const float* scalar_dev, float* out, int n, void* stream) {
     if (n <= 0) return CC_ERR_ARG;
     hipLaunchKernelGGL(k_scale_by_scalar, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, scalar_dev, out, n);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_scale_acc_jobs(const long* jobs_host, int njobs, const float* scalar_dev, void* stream) {
+    if (!jobs_host || njobs <= 0 || !scalar_dev) return CC_ERR_ARG;
+    for (int j0 = 0; j0 < njobs; j0 += SA_MAX) {
+        ScaleAccTab t = {};
+        long blk = 0;
+        const int nj = njobs - j0 < SA_MAX ? njobs - j0 : SA_MAX;
+        for (int k = 0; k < nj; k++) {
+            const long* d = jobs_host + 4l * (j0 + k);
+            if (!d[0] || !d[1] || d[2] <= 0 || d[2] >= (1l << 31)) return CC_ERR_ARG;
+            t.src[k] = (const float*)d[0]; t.dst[k] = (float*)d[1]; t.n[k] = (int)d[2]; t.acc[k] = d[3] ? 1 : 0;
+            blk += (d[2] + 1023) / 1024;
+            if (blk >= (1l << 31)) return CC_ERR_ARG;
+            t.blk_end[k] = (int)blk;
+        }
+        t.njobs = nj;
+        hipLaunchKernelGGL(k_scale_acc_jobs, dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, t, scalar_dev);
+    }
     CC_CHECK_LAUNCH();
     return CC_OK;
 }

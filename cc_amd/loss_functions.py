@@ -194,6 +194,37 @@ def _scaled_intrinsics(intrinsics, intrinsics_inv, downscale):
     return K_s, Kinv_s
 
 
+class _HeadGrads:
+    """Per-step gradient accumulators of the network outputs the loss terms share (train.py:509,567: a disparity / flow / mask
+    level feeds two to four loss terms and the autograd engine adds their gradients pairwise -- ~44 launches per step).  While
+    the trainer has this active (CCTrainer._stage_a: ONE backward pass per forward pass), every fused loss scales its stashed
+    gradients straight INTO the tensor's accumulator (cc_scale_acc_jobs: first writer =, later writers +=, in the engine's own
+    execution order); the term that registered the tensor first hands the accumulator to autograd, the others return None.  The
+    engine runs a tensor's consumer only after every term that has an edge to it has executed, so the sum is complete by then.
+    Inactive (stand-alone use of the loss functions, double backward): every term returns its own scaled copy, as before."""
+
+    def __init__(self):
+        self.enabled = True          # (bench.py A/B: CC_NO_HEAD_ACC=1 clears it)
+        self.active = False
+        self.acc = {}
+
+    def begin(self):
+        self.active, self.acc = self.enabled, {}
+
+    def end(self):
+        self.active, self.acc = False, {}
+
+    def register(self, t, owner):
+        key = (t.data_ptr(), t.numel())
+        ent = self.acc.get(key)
+        if ent is None:
+            ent = self.acc[key] = [torch.empty(t.numel(), device=t.device, dtype=torch.float32), owner, False]
+        return ent
+
+
+head_grads = _HeadGrads()
+
+
 class _GradArena:
     """The gradients a fused loss stashes in forward live in ONE flat buffer (one view per differentiable input, same
     shape), so that backward is ONE `* grad_output` launch for the whole loss instead of one per tensor."""
@@ -206,6 +237,9 @@ class _GradArena:
         for t, n in zip(inputs, sizes):
             self.spans.append((off, n, tuple(t.shape)) if n else None)
             off += n
+        # shared per-tensor accumulators of the step (see _HeadGrads): one entry per span, or None
+        self.heads = [head_grads.register(t, id(self)) if sp is not None else None
+                      for t, sp in zip(inputs, self.spans)] if head_grads.active else None
 
     def view(self, i, flat=None):
         sp = self.spans[i]
@@ -215,6 +249,23 @@ class _GradArena:
 
     def scaled(self, gout):
         """-> [grad_i * gout or None] (fresh storage: the arena itself stays valid for a second backward)."""
+        if self.heads is not None:
+            import ctypes
+            jobs, res, handed = [], [], set()
+            for sp, ent in zip(self.spans, self.heads):
+                if sp is None:
+                    res.append(None)
+                    continue
+                jobs += [self.flat.data_ptr() + 4 * sp[0], ent[0].data_ptr(), sp[1], 1 if ent[2] else 0]
+                ent[2] = True
+                # the accumulator goes to autograd once: from the term that registered the tensor first, at its first position
+                mine = ent[1] == id(self) and id(ent) not in handed
+                handed.add(id(ent))
+                res.append(ent[0].view(sp[2]) if mine else None)
+            if jobs:
+                arr = (ctypes.c_long * len(jobs))(*jobs)
+                engine().call("cc_scale_acc_jobs", ctypes.addressof(arr), len(jobs) // 4, _f32c(gout).reshape(1), STREAM)
+            return res
         out = torch.empty_like(self.flat)
         engine().call("cc_scale_by_scalar", self.flat, _f32c(gout).reshape(1), out, self.flat.numel(), STREAM)
         return [self.view(i, out) for i in range(len(self.spans))]

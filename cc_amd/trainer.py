@@ -304,10 +304,14 @@ class CCTrainer:
         ops.grad_sinks = self.opt.sinks
         LF.scalar_pool.begin(batch[0].device)
         cut = {}
-        out = cc_forward(self.nets, batch, self.cfg, cut=cut)
-        self.bn_counters.commit()
-        pairs = cut.get("dp", []) + cut.get("mf", [])
-        g = torch.autograd.grad(out["loss"], [d for _, d in pairs], allow_unused=True) if pairs else ()   # :567, losses only
+        LF.head_grads.begin()              # the loss terms' gradients of a shared network output meet in one accumulator
+        try:
+            out = cc_forward(self.nets, batch, self.cfg, cut=cut)
+            self.bn_counters.commit()
+            pairs = cut.get("dp", []) + cut.get("mf", [])
+            g = torch.autograd.grad(out["loss"], [d for _, d in pairs], allow_unused=True) if pairs else ()   # :567, losses only
+        finally:
+            LF.head_grads.end()
         ndp = len(cut.get("dp", []))
         dp = [(t, gt) for (t, _), gt in zip(pairs[:ndp], g[:ndp]) if gt is not None]
         mf = [(t, gt) for (t, _), gt in zip(pairs[ndp:], g[ndp:]) if gt is not None]

@@ -184,6 +184,11 @@ int cc_sum_strided(int n, const long* src, const long* src_bs, float* out, long 
                    void* stream);
 /* out = a * scalar_dev[0] */
 int cc_scale_by_scalar(const float* a, const float* scalar_dev, float* out, int n, void* stream);
+/* dst_k (=, +=) src_k * scalar_dev[0] for njobs spans in one launch per 32; jobs_host: njobs x 4 longs {src, dst, n floats,
+ * accumulate}.  Replaces: the `* grad_output` of a loss term's backward AND the autograd engine's pairwise accumulation of the
+ * gradients several loss terms send to one network output (train.py:509,567): every term scales its stashed gradients straight
+ * into the step's per-tensor accumulator (first writer =, later writers +=, in the engine's own fixed order). */
+int cc_scale_acc_jobs(const long* jobs_host, int njobs, const float* scalar_dev, void* stream);
 
 /* ---------------------------------------------------------------- cost volume (models/back2future.py:15-25)
  * vol[b, ch(d), y, x] = (1/C) sum_c f1[b,c,y,x] * f2[b,c,y+dy-4,x+dx-4], d = dy*9+dx: the spatial_correlation_sampler
