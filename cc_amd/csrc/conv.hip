@@ -2592,7 +2592,11 @@ inline WinoPadPlan wino_pad_plan(int B, int M, int AH, int AW, int Cin, int G) {
 
 size_t cc_conv2d_wgrad_ws_bytes(int B, int M, int AH, int AW, int Cin, int R, int S, int si) {
     // the thin path is confirmed at launch (pad, input width): size for it AND for the path it would fall back to
-    const size_t thin = ccint::wgrad_thin_ws_floats(B, M, AH, AW, Cin, R, S, si) * sizeof(float);
+    size_t thin = ccint::wgrad_thin_ws_floats(B, M, AH, AW, Cin, R, S, si) * sizeof(float);
+    if (R == 3 && S == 3 && si == 1 && M <= 2) {          // a head's weight gradient (conv_heads.hip)
+        const ccint::HeadWgradPlan hp = ccint::head_wgrad_plan(B, M, AH, AW, Cin);
+        if (hp.ok && hp.ws_floats * sizeof(float) > thin) thin = hp.ws_floats * sizeof(float);
+    }
     const size_t base = wgrad_ws_bytes_base(B, M, AH, AW, Cin, R, S, si);
     return ((thin > base ? thin : base) + 15) & ~(size_t)15;        // (the areas of a group's problems follow each other: keep them 16-byte aligned)
 }
@@ -2749,6 +2753,33 @@ static int wgrad_group_impl(int G, const long* a, const long* x, const long* gw,
             if (ok) {
                 for (int k = 0; k < G; k++) {
                     const long d[ccint::RD_LONGS] = {1, (long)wsp[k], (long)gw[k], pp.wp.nsplit, accumulate, o_sm, o_sc, 9, M, Cin, pp.wp.Cp};
+                    for (int i = 0; i < ccint::RD_LONGS; i++) rd[k][i] = d[i];
+                }
+                if (ccint::wgrad_reduce_emit(sink, &rd[0][0], G, s) != CC_OK) return CC_ERR_ARG;
+                CC_CHECK_LAUNCH();
+                return CC_OK;
+            }
+        }
+    }
+    if (R == 3 && S == 3 && si == 1 && pad == 1 && IH == AH && IW == AW && M <= 2) {
+        // weight gradient of a prediction head: HBM-bound VALU kernel (conv_heads.hip), one launch per problem
+        const ccint::HeadWgradPlan hp = ccint::head_wgrad_plan(B, M, AH, AW, Cin);
+        if (hp.ok && hp.ws_floats <= stride_f) {
+            bool ok = true;
+            char nm[128];
+            int nl = snprintf(nm, sizeof nm, "k_wgrad_thinm<%d>", M);
+            if (cctools::env_flag("CC_TIMING_DETAIL"))
+                snprintf(nm + nl, sizeof nm - nl, " G%d B%d M%d C%d %dx%d r3 s1 k%d", G, B, M, Cin, AH, AW, hp.nblk);
+            {
+                cctiming::Scope tsc(nm, 2e-9 * G * B * AH * AW * (double)M * Cin * 9, s);
+                for (int k = 0; k < G && ok; k++)
+                    ok = ccint::head_wgrad_launch(hp, (const float*)a[k], (const float*)x[k], ws + k * stride_f, B, M, AH, AW, a_bs, Cin, x_bs, s);
+            }
+            if (ok && cctools::env_flag("CC_HEAD_TRACE"))
+                fprintf(stderr, "head wgrad: G%d B%d M%d C%d %dx%d R%d nblk %d\n", G, B, M, Cin, AH, AW, hp.R, hp.nblk);
+            if (ok) {
+                for (int k = 0; k < G; k++) {
+                    const long d[ccint::RD_LONGS] = {0, (long)(ws + k * stride_f), (long)gw[k], hp.nblk, accumulate, o_sm, o_sc, M, (long)Cin * 9, 9, 3, 3, 1};
                     for (int i = 0; i < ccint::RD_LONGS; i++) rd[k][i] = d[i];
                 }
                 if (ccint::wgrad_reduce_emit(sink, &rd[0][0], G, s) != CC_OK) return CC_ERR_ARG;

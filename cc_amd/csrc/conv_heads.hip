@@ -15,6 +15,12 @@
 //       consecutive pixels x one share of the input channels (CS shares per workgroup, one per wave group); per channel nine loads
 //       (three rows: one 16-byte piece + the two halo columns) and 36 M FMAs against LDS-resident weights; the shares' partial
 //       sums meet in LDS, the first share applies the epilogue.  Algorithmic traffic: (C + M) x B H W floats (the input once).
+//   k_wgrad_thinm<M, CB>       weight gradient of a head (M <= 2 gradient channels; 4 channels measured slower than wgrad_thin.hip): dW[m][c][i][j] = sum_p dY[m][p - (i-1, j-1)] x[c][p].
+//       work-item = 4 consecutive pixels x a strip of R rows x CB input channels; the 3 x 6 x M neighbourhood of dY slides down the
+//       strip in registers (one new row per step), every input row is ONE 16-byte load per channel (no halo: the taps shift dY, not
+//       x); 9 M CB accumulators per work-item, summed over the workgroup at the end of the strip and written as one partial slab
+//       per workgroup in the layout of the generic weight-gradient kernel (wgrad_reduce.hip kind 0).
+//       Algorithmic traffic: (C + M) x B H W floats; dY is re-read once per channel block.
 #include "cc_common.h"
 #include "conv_internal.h"
 #include "conv_tail.h"
@@ -283,6 +289,108 @@ __global__ __launch_bounds__(64 * TM_MAXCS) void k_conv_thinm(HeadConv g, int Wg
     }
 }
 
+struct HeadWgrad {
+    const float* dy; const float* x; float* ws;
+    int B, M, C, H, W;
+    long dy_bs, x_bs;
+    int R, nstrips, Wg;          // rows per strip, strips per image, 4-pixel groups per row
+    long ngroups;                // B * nstrips * Wg work-items per channel block
+};
+
+template <int M, int CB>
+__global__ __launch_bounds__(256) void k_wgrad_thinm(HeadWgrad g) {
+    constexpr int NA = CB * M * 9;
+    __shared__ float red[4 * NA];
+    const int tid = threadIdx.x;
+    const long gid = (long)blockIdx.x * 256 + tid;
+    const bool live = gid < g.ngroups;
+    const long gq = live ? gid : 0;
+    const int xg = (int)(gq % g.Wg);
+    const long rr = gq / g.Wg;
+    const int ys = (int)(rr % g.nstrips), n = (int)(rr / g.nstrips);
+    const int x0 = xg * 4, y0 = ys * g.R;
+    int y1 = y0 + g.R;
+    if (y1 > g.H) y1 = g.H;
+    const int c0 = (int)blockIdx.y * CB;
+    const int HW = g.H * g.W;
+    const bool lin = x0 > 0, rin = x0 + 4 < g.W;
+    const int lo = lin ? -1 : 0, ro = rin ? 4 : 3;
+
+    float acc[NA];
+#pragma unroll
+    for (int k = 0; k < NA; k++) acc[k] = 0.f;
+    // dY neighbourhood: nb[m][r][u], r = 0, 1, 2 <-> rows y - 1, y, y + 1, u <-> columns x0 - 1 .. x0 + 4 (zero outside the image)
+    float nb[M][3][6];
+    const float* dyn = g.dy + (long)n * g.dy_bs + x0;
+    auto load_row = [&](int yy, float (&o)[M][6]) {
+        const bool in = live && (unsigned)yy < (unsigned)g.H;
+        const float* row = dyn + (long)(in ? yy : 0) * g.W;
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const float* rm = row + (long)m * HW;
+            const float4 c = *reinterpret_cast<const float4*>(rm);
+            const float l = rm[lo], r = rm[ro];
+            o[m][0] = (in && lin) ? l : 0.f;
+            o[m][1] = in ? c.x : 0.f; o[m][2] = in ? c.y : 0.f; o[m][3] = in ? c.z : 0.f; o[m][4] = in ? c.w : 0.f;
+            o[m][5] = (in && rin) ? r : 0.f;
+        }
+    };
+    {
+        float t0[M][6], t1[M][6];
+        load_row(y0 - 1, t0);
+        load_row(y0, t1);
+#pragma unroll
+        for (int m = 0; m < M; m++)
+#pragma unroll
+            for (int u = 0; u < 6; u++) { nb[m][0][u] = t0[m][u]; nb[m][1][u] = t1[m][u]; }
+    }
+    // input channels of this block (channels past the layer's last are clamped and their sums dropped at the end)
+    const float* xb[CB];
+#pragma unroll
+    for (int c = 0; c < CB; c++) xb[c] = g.x + (long)n * g.x_bs + (long)(c0 + c < g.C ? c0 + c : g.C - 1) * HW + x0;
+    for (int y = y0; y < y1; y++) {
+        float t2[M][6];
+        load_row(y + 1, t2);
+        float4 xv[CB];
+#pragma unroll
+        for (int c = 0; c < CB; c++) xv[c] = *reinterpret_cast<const float4*>(xb[c] + (long)y * g.W);
+#pragma unroll
+        for (int m = 0; m < M; m++)
+#pragma unroll
+            for (int u = 0; u < 6; u++) nb[m][2][u] = t2[m][u];
+#pragma unroll
+        for (int c = 0; c < CB; c++) {
+            const float xs[4] = {live ? xv[c].x : 0.f, live ? xv[c].y : 0.f, live ? xv[c].z : 0.f, live ? xv[c].w : 0.f};
+#pragma unroll
+            for (int m = 0; m < M; m++)
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        float a = acc[(c * M + m) * 9 + 3 * i + j];
+#pragma unroll
+                        for (int v = 0; v < 4; v++) a = fmaf(xs[v], nb[m][2 - i][v + 2 - j], a);
+                        acc[(c * M + m) * 9 + 3 * i + j] = a;
+                    }
+        }
+#pragma unroll
+        for (int m = 0; m < M; m++)
+#pragma unroll
+            for (int u = 0; u < 6; u++) { nb[m][0][u] = nb[m][1][u]; nb[m][1][u] = nb[m][2][u]; }
+    }
+    cc::block_sum_256<NA>(acc, red);
+    if (tid == 0) {
+        float* w = g.ws + (long)blockIdx.x * g.M * ((long)g.C * 9);
+#pragma unroll
+        for (int c = 0; c < CB; c++)
+            if (c0 + c < g.C)
+#pragma unroll
+                for (int m = 0; m < M; m++)
+#pragma unroll
+                    for (int t = 0; t < 9; t++) w[(long)m * g.C * 9 + (long)(c0 + c) * 9 + t] = acc[(c * M + m) * 9 + t];
+    }
+}
+
 template <int M>
 void launch_thinm(const HeadConv& g, int Wg, long ngroups, int cpw, int nshare, dim3 grid, int threads, hipStream_t s) {
     if (g.dstep > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_thinm<M, 1>), grid, dim3(threads), 0, s, g, Wg, ngroups, cpw, nshare);
@@ -376,6 +484,40 @@ bool head_conv_thinm_launch(const HeadConv& g, hipStream_t s) {
         case 2: launch_thinm<2>(g, Wg, ngroups, cpw, nshare, grid, 64 * nwaves, s); break;
         case 3: launch_thinm<3>(g, Wg, ngroups, cpw, nshare, grid, 64 * nwaves, s); break;
         default: launch_thinm<4>(g, Wg, ngroups, cpw, nshare, grid, 64 * nwaves, s); break;
+    }
+    return true;
+}
+
+// ---- weight gradient of a head.  Plan: rows per strip so that >= ~1024 waves are in flight (2 <= R <= 8); channels per block by M.
+static inline int hw_cb(int M) { return M == 1 ? 8 : 4; }      // (M = 3, 4 measured slower than wgrad_thin.hip at any block: not taken)
+HeadWgradPlan head_wgrad_plan(int B, int M, int H, int W, int Cin) {
+    HeadWgradPlan p = {};
+    if (cctools::env_int("CC_NO_HEAD_KERNELS", 0) == 1 || cctools::env_int("CC_NO_HEAD_KERNELS", 0) == 4) return p;
+    if (M < 1 || M > 2 || Cin < 1 || B < 1 || H < 2 || (W % 4) != 0) return p;
+    if ((long)B * H * W < cctools::env_int("CC_HEAD_WGRAD_MINPIX", 16384)) return p;
+    const int cb = hw_cb(M);
+    const long ncb = (Cin + cb - 1) / cb;
+    const int Wg = W / 4;
+    int R = 8;
+    while (R > 2 && ((long)B * ((H + R - 1) / R) * Wg + 63) / 64 * ncb < cctools::env_int("CC_HEAD_WGRAD_WAVES", 1024)) R >>= 1;
+    p.ok = 1;
+    p.R = R;
+    p.nstrips = (H + R - 1) / R;
+    p.nblk = (int)(((long)B * p.nstrips * Wg + 255) / 256);
+    p.ws_floats = (size_t)p.nblk * M * Cin * 9;
+    return p;
+}
+
+bool head_wgrad_launch(const HeadWgradPlan& p, const float* dy, const float* x, float* ws, int B, int M, int H, int W, long dy_bs,
+                       int Cin, long x_bs, hipStream_t s) {
+    if (!p.ok || !aligned_to(dy, 16) || !aligned_to(x, 16) || (dy_bs % 4) != 0 || (x_bs % 4) != 0) return false;
+    HeadWgrad g = {dy, x, ws, B, M, Cin, H, W, dy_bs, x_bs, p.R, p.nstrips, W / 4, (long)B * p.nstrips * (W / 4)};
+    const int cb = hw_cb(M);
+    dim3 grid((unsigned)p.nblk, (unsigned)((Cin + cb - 1) / cb));
+    switch (M) {
+        case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad_thinm<1, 8>), grid, dim3(256), 0, s, g); break;
+        case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad_thinm<2, 4>), grid, dim3(256), 0, s, g); break;
+        default: return false;
     }
     return true;
 }

@@ -96,5 +96,11 @@ bool head_conv_thinc_launch(const HeadConv& g, hipStream_t s);      // -> false:
 // few OUTPUT channels (M <= 4) from <= 64 input channels on large maps (the heads' forward pass)
 bool head_conv_thinm_ok(const HeadConv& g);
 bool head_conv_thinm_launch(const HeadConv& g, hipStream_t s);      // -> false: not eligible, nothing launched
+// weight gradient of a head (M <= 4 channels of dY [B, M, H, W], x [B, Cin, H, W], 3x3 / stride 1 / pad 1): partial slabs
+// ws[nblk][M][Cin * 9] (the generic kernel's layout: wgrad_reduce.hip kind 0 with nsplit = nblk)
+struct HeadWgradPlan { int ok, R, nstrips, nblk; size_t ws_floats; };
+HeadWgradPlan head_wgrad_plan(int B, int M, int H, int W, int Cin);
+bool head_wgrad_launch(const HeadWgradPlan& p, const float* dy, const float* x, float* ws, int B, int M, int H, int W, long dy_bs,
+                       int Cin, long x_bs, hipStream_t s);      // -> false: tensors not 16-byte aligned, nothing launched
 
 }  // namespace ccint

@@ -104,6 +104,9 @@ def test_convs_thin_wgrad(monkeypatch):
 
 def test_convs_head_kernels(monkeypatch):
     monkeypatch.setenv("CC_HEAD_MINPIX", "1")            # the heads' forward pass on k_conv_thinm (conv_heads.hip)
+    monkeypatch.setenv("CC_HEAD_WGRAD_MINPIX", "1")      # ... and their weight gradients on k_wgrad_thinm
+    parity.check_convs("cpu", cases=parity.CONV_CASES_HEADS, tcases=[])
+    monkeypatch.setenv("CC_HEAD_WGRAD_WAVES", "1")       # strips of 8 rows (the plan of the large maps)
     parity.check_convs("cpu", cases=parity.CONV_CASES_HEADS, tcases=[])
 
 

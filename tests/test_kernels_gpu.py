@@ -123,6 +123,7 @@ def test_convs_head_kernels(monkeypatch):
     # small maps steered onto the heads' VALU forward kernel (tools build); the product thresholds: test_convs_full_size_thin_layers
     from cc_amd import _lib, build
     monkeypatch.setenv("CC_HEAD_MINPIX", "1")
+    monkeypatch.setenv("CC_HEAD_WGRAD_MINPIX", "1")
     with _lib.use_library(build.build_tools()) as e:
         assert e.fn["cc_is_tools_build"]() == 1
         parity.check_convs("cuda", cases=parity.CONV_CASES_HEADS, tcases=[])
