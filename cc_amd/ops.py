@@ -172,8 +172,10 @@ class _WgradQueue:
             if not q:
                 continue
             B, M, AH, AW, Cin, IH, IW, R, S, si, pad, o_sm, o_sc, a_bs, x_bs = key
-            items.append(([t[0] for t in q], [t[1] for t in q], [t[2] for t in q],
-                          (B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc)))
+            for g0 in range(0, len(q), self.GROUP):
+                qq = q[g0:g0 + self.GROUP]
+                items.append(([t[0] for t in qq], [t[1] for t in qq], [t[2] for t in qq],
+                              (B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc)))
         if items:
             _wgrad_list(items)
         wgrad_reduces.flush()
