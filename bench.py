@@ -139,33 +139,12 @@ def job_pixels(d):
     return float(sum(arr[10 * j + 8] * arr[10 * j + 9] for j in range(n)))
 
 
-def kernel_of(eng, name, d):
-    """Device kernel a conv entry point dispatches to for this geometry (C-ABI introspection, host only)."""
-    import ctypes
-    buf = ctypes.create_string_buffer(96)
-    a = ctypes.addressof(buf)
-    if name.endswith("_group"):
-        base = kernel_of(eng, name[:-6], dict(d, prepacked_or_null=d.get("prepacked")))
-        if not base or d["G"] == 1:
-            return base
-        if name == "cc_conv2d_wgrad_group":
-            return base + " xG"
-        if base.startswith("k_conv_thin"):          # few-channel layers: the VALU kernels take single problems only, groups run merged
-            return "k_conv_patch_multi<few-channel group> xG"
-        # merged launch of the G problems (x their parity classes) on the multi-problem kernel
-        return base.replace("k_conv_patch<", "k_conv_patch_multi<").replace(", 1>+", ">+").replace(", 0>", ">") + " xG"
-    if name == "cc_conv2d_fwd":
-        eng.fn["cc_conv2d_fwd_kernel"](d["B"], d["Cin"], d["IH"], d["IW"], d["Cout"], d["R"], d["S"], d["stride"], d["pad"],
-                                       d["OH"], d["OW"], a, 96)
-    elif name == "cc_conv2d_dgrad":
-        eng.fn["cc_conv2d_dgrad_kernel"](d["B"], d["K"], d["OH"], d["OW"], d["C"], d["R"], d["S"], d["stride"], d["pad"],
-                                         d["IH"], d["IW"], int(d["prepacked_or_null"] is not None), a, 96)
-    elif name == "cc_conv2d_wgrad":
-        eng.fn["cc_conv2d_wgrad_kernel"](d["B"], d["M"], d["AH"], d["AW"], d["Cin"], d["IH"], d["IW"], d["R"], d["S"], d["si"],
-                                         d["pad"], a, 96)
-    else:
-        return None
-    return buf.value.decode()
+def call_group_of(name, d):
+    """Label of a conv call group: the C-ABI entry point + the layer class (taps, stride, group size).  The device kernels behind
+    a group are named by the library itself (tools build: cc_timing_collect -> `by_kernel`); nothing is inferred here."""
+    r, s_, st = d.get("R"), d.get("S"), d.get("stride", d.get("si"))
+    g = d.get("G", 1)
+    return "%s %sx%s s%s%s" % (name, r, s_, st, " xG" if (g or 1) > 1 else "")
 
 
 def algorithmic_bytes(name, d):
@@ -203,9 +182,8 @@ class CallTimer:
                 r = self._orig(real, *args)
                 e.record()
                 d = dict(zip(self.eng.sigs[real][2], args))
-                kn = kernel_of(self.eng, name, d)
-                if kn is not None:
-                    self.by_kernel.append((kn, WORK[name][1](d), algorithmic_bytes(name, d), s, e))
+                if name.startswith("cc_conv2d_"):
+                    self.by_kernel.append((call_group_of(name, d), WORK[name][1](d), algorithmic_bytes(name, d), s, e))
                 self.records.append((name, WORK[name][1](d), s, e, {k: v for k, v in d.items() if isinstance(v, int) and k not in ("x_bs", "y_bs", "res_bs", "a_bs", "gy_bs", "gx_bs")}))
                 return r
             return self._orig(name, *args)
@@ -216,8 +194,8 @@ class CallTimer:
         self.eng.call = self._orig
 
     def kernel_groups(self):
-        """-> {device kernel: {launches, ms, gflop, bytes}} over the conv calls (one call = one launch of that kernel,
-        plus its split-K epilogue where the name says so)."""
+        """-> {call group: {launches, ms, gflop, bytes}} over the conv calls (one call = its main kernel launch(es) plus the
+        epilogue / reduction launches it issues)."""
         torch.cuda.synchronize()
         g = {}
         for kn, fl, by, s, e in self.by_kernel:

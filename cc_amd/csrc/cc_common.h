@@ -39,6 +39,23 @@ __device__ __forceinline__ float2 cc_buf_load_f32x2(cc_buf_t rsrc, unsigned voff
 #endif
 #define CC_BUF_OOB 0x80000000u
 
+// One-instruction reciprocal / square root (v_rcp_f32, v_sqrt_f32: 1 ulp) for arguments known to be normal numbers -- the IEEE
+// division and sqrtf sequences cost ~10 VALU instructions each (scaling, Newton steps, fix-up of denormals and specials).
+__device__ __forceinline__ float cc_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CC_HIPEMU)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+__device__ __forceinline__ float cc_sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CC_HIPEMU)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
+
 // Four 16-byte LDS-DMA transfers per lane (1 KB per wave each), rows 1 KB apart in BOTH global memory and LDS (the immediate
 // offset of global_load_lds applies to both addresses), issued from inline assembly: hipcc waits vmcnt(0) before the next ds_read
 // whenever a compiler-visible LDS-DMA is in flight (it cannot tell which LDS bytes the DMA writes), which serialises a

@@ -56,8 +56,8 @@ struct PhotoArgs {
 };
 
 __device__ __forceinline__ float robust_pow(float v, float q) {
-    // (x^2 + 0.01)^q  (loss_functions.py:18-25); q = 0.5 is the only value the reference trains with
-    return (q == 0.5f) ? sqrtf(v) : powf(v, q);
+    // (x^2 + 0.01)^q  (loss_functions.py:18-25); q = 0.5 is the only value the reference trains with (v >= 0.01: cc_sqrt)
+    return (q == 0.5f) ? cc_sqrt(v) : powf(v, q);
 }
 
 // one 32x32 tile of image b: (tile_x, tile_y) -> outputs; `blk` = index of this tile's partial sums (MODE_PHOTO)
@@ -211,7 +211,10 @@ __device__ __forceinline__ void ssim_tile_body(const PhotoArgs& a, const Gauss13
             const float s12 = mo[3][j] - mu12;
             const float num1 = 2.f * mu12 + C1, num2 = 2.f * s12 + C2;
             const float den1 = mu1_sq + mu2_sq + C1, den2 = ((mo[2][j] - mu1_sq) - mu2_sq) + C2;       // sigma1_sq + sigma2_sq + C2
-            const float S = (num1 * num2) / (den1 * den2);
+            // ONE reciprocal per pixel and channel (den1 >= C1, den2 ~ C2: a normal number; v_rcp_f32, 1 ulp) shared by the SSIM value
+            // and its adjoints: the IEEE divisions and sqrtf of this block were ~40 of its ~150 VALU instructions per pixel
+            const float iD = cc_rcp(den1 * den2);
+            const float S = (num1 * num2) * iD;
             if (MODE == MODE_MAP) {
                 a.out_map[((size_t)b * 3 + c) * HW + p] = S;
                 continue;
@@ -220,8 +223,8 @@ __device__ __forceinline__ void ssim_tile_body(const PhotoArgs& a, const Gauss13
                 // adjoint maps of the SSIM map w.r.t. the SECOND image (call with swapped roles for the first)
                 const size_t o = ((size_t)b * 3 + c) * HW + p;
                 const float gS = a.upstream[o];
-                // one reciprocal: 1 / den2 = den1 / D, 1 / den1 = den2 / D
-                const float iD = 1.f / (den1 * den2), id1 = den2 * iD, id2 = den1 * iD;
+                // 1 / den2 = den1 / D, 1 / den1 = den2 / D
+                const float id1 = den2 * iD, id2 = den1 * iD;
                 a.adjC[o] = gS * (2.f * num1 * iD);
                 a.adjB[o] = gS * (-S * id2);
                 a.adjA[o] = gS * (2.f * mu1 * (num2 - num1) * iD - 2.f * mu2 * S * (id1 - id2));
@@ -231,7 +234,7 @@ __device__ __forceinline__ void ssim_tile_body(const PhotoArgs& a, const Gauss13
             if (MODE == MODE_ERR) {
                 // loss_functions.py:181-188: robust_l1_per_pix(tgt - warped) and (1 - ssim), channel means
                 const float d = xc - yc;
-                err_rob[j] += sqrtf(d * d + 0.01f);
+                err_rob[j] += cc_sqrt(d * d + 0.01f);
                 err_ss[j] += 1.f - S;
                 continue;
             }
@@ -245,10 +248,10 @@ __device__ __forceinline__ void ssim_tile_body(const PhotoArgs& a, const Gauss13
             s_sl += sl;
             if (a.want_grad) {
                 // d rob / d d = q * base^(q-1) * 2 d
-                const float drob = (a.q == 0.5f) ? (d / rob) : (a.q * powf(base, a.q - 1.f) * 2.f * d);
+                const float drob = (a.q == 0.5f) ? (d * cc_rcp(rob)) : (a.q * powf(base, a.q - 1.f) * 2.f * d);
                 const size_t o = ((size_t)b * 3 + c) * HW + p;
                 a.g0[o] = -drob * vm;                           // d/dy through diff
-                const float iD = 1.f / (den1 * den2), id1 = den2 * iD, id2 = den1 * iD;        // (one reciprocal, see MODE_GRAD)
+                const float id1 = den2 * iD, id2 = den1 * iD;
                 const float gS = -vm * a.wssim;                 // d(wssim * sl)/dS
                 a.adjC[o] = gS * (2.f * num1 * iD);             // dS/dE[xy]
                 a.adjB[o] = gS * (-S * id2);                    // dS/dE[yy]
@@ -321,7 +324,7 @@ __device__ __forceinline__ void tile_of(const JobTab& t, int& j, int& b, int& ti
 //              6 partials [B*tiles][4], 7 batch strides of mask_a / mask_b / gmask in units of H*W (8 bits each)
 struct PhotoCommon { int b_complement, want_grad; float wssim, q; };
 
-__global__ __launch_bounds__(256) void k_ssim_photo_jobs(JobTab t, PhotoCommon c, Gauss13 gw) {
+__global__ __launch_bounds__(256, 4) void k_ssim_photo_jobs(JobTab t, PhotoCommon c, Gauss13 gw) {
     int j, b, tile_x, tile_y, local;
     tile_of(t, j, b, tile_x, tile_y, local);
     PhotoArgs a = {};
