@@ -107,6 +107,8 @@ WORK = {   # entry point -> (kind, fn(args dict) -> algorithmic flops or bytes)
     "cc_conv2d_fwd_group": ("flop", lambda d: 2.0 * d["G"] * d["B"] * d["OH"] * d["OW"] * d["Cout"] * d["Cin"] * d["R"] * d["S"]),
     "cc_conv2d_dgrad_group": ("flop", lambda d: 2.0 * d["G"] * d["B"] * d["OH"] * d["OW"] * d["K"] * d["C"] * d["R"] * d["S"]),
     "cc_conv2d_wgrad_group": ("flop", lambda d: 2.0 * d["G"] * d["B"] * d["AH"] * d["AW"] * d["M"] * d["Cin"] * d["R"] * d["S"]),
+    # n groups of different shapes in one call (the end-of-stage flush of the weight-gradient queue): desc_host = n x 32 longs
+    "cc_conv2d_wgrad_list": ("flop", lambda d: wgrad_list_flops(d)),
     # algorithmic bytes per pixel (SURVEY.md 8d conventions: each distinct tensor argument once, fp32)
     "cc_inverse_warp_fwd": ("byte", lambda d: 28.0 * d["B"] * d["H"] * d["W"]),
     "cc_inverse_warp_bwd": ("byte", lambda d: 32.0 * d["B"] * d["H"] * d["W"]),
@@ -131,6 +133,19 @@ WORK = {   # entry point -> (kind, fn(args dict) -> algorithmic flops or bytes)
 }
 
 
+def wgrad_list_flops(d):
+    """2 * MACs over the groups of a cc_conv2d_wgrad_list call (host records {G, a[4], x[4], gw[4], ws, B, M, AH, AW, a_bs, Cin,
+    IH, IW, x_bs, R, S, ...} of 32 longs each, include/ccengine.h)."""
+    import ctypes
+    n = d["n"]
+    arr = (ctypes.c_long * (32 * n)).from_address(d["desc_host"])
+    tot = 0.0
+    for i in range(n):
+        r = arr[32 * i:32 * i + 32]
+        tot += 2.0 * r[0] * r[14] * r[16] * r[17] * r[15] * r[19] * r[23] * r[24]
+    return tot
+
+
 def job_pixels(d):
     """sum of H*W over the jobs of a *_jobs call (the host job table: njobs x {8 slots, H, W} longs)."""
     import ctypes
@@ -142,6 +157,8 @@ def job_pixels(d):
 def call_group_of(name, d):
     """Label of a conv call group: the C-ABI entry point + the layer class (taps, stride, group size).  The device kernels behind
     a group are named by the library itself (tools build: cc_timing_collect -> `by_kernel`); nothing is inferred here."""
+    if "R" not in d:
+        return name
     r, s_, st = d.get("R"), d.get("S"), d.get("stride", d.get("si"))
     g = d.get("G", 1)
     return "%s %sx%s s%s%s" % (name, r, s_, st, " xG" if (g or 1) > 1 else "")
@@ -149,6 +166,8 @@ def call_group_of(name, d):
 
 def algorithmic_bytes(name, d):
     """fp32 bytes of each distinct tensor argument once (input, weights, output) for one conv call."""
+    if name == "cc_conv2d_wgrad_list":
+        return 0.0
     if name.endswith("_group"):
         return d["G"] * algorithmic_bytes(name[:-6], d)
     if name == "cc_conv2d_fwd":
