@@ -141,13 +141,18 @@ __global__ __launch_bounds__(256) void k_conv_thinc(HeadConv g, int Wg, long ngr
 constexpr int TM_MAXC = 64;         // input channels, at most (weights stay in LDS: 64 x 4 x 9 floats)
 constexpr int TM_MAXCS = 8;         // channel shares per workgroup, at most
 
-// y[m][p] = tail( sum_{c,i,j} w[m][c][i][j] x[c][p + DS (i - 1, j - 1)] ),  M <= 4.  Workgroup = NW waves = (NW / nshare) pixel
-// waves x nshare channel shares: wave w accumulates channels [cs * cpw, (cs + 1) * cpw), cs = w % nshare, for the 4-pixel groups
-// (blockIdx.x * (NW / nshare) + w / nshare) * 64 + lane.  Four channels per batch: all 36 loads are issued before the first FMA.
-template <int M, int DS>
-__global__ __launch_bounds__(64 * TM_MAXCS) void k_conv_thinm(HeadConv g, int Wg, long ngroups, int cpw, int nshare) {
+// y[m][p] = tail( sum_{c,i,j} w[m][c][i][j] x[c][p + DS (i - 1, j - 1)] ),  M <= 4.  Work-item = 4 consecutive pixels x R rows
+// (R = 4 for M <= 2, 2 above: the R + 2 input rows of a channel serve R output rows -- 1.5x / 2x row traffic through the L1 instead
+// of 3x, and 3 (R + 2) load instructions per 4 R outputs).  Workgroup = NW waves = (NW / nshare) pixel waves x nshare channel shares:
+// wave w accumulates channels [cs * cpw, (cs + 1) * cpw), cs = w % nshare, for the groups (blockIdx.x * (NW / nshare) + w / nshare)
+// * 64 + lane.  NB channels per batch: all 3 NB (R + 2) loads are issued before the first FMA.
+template <int M, int DS, int R>
+__global__ __launch_bounds__(64 * TM_MAXCS) void k_conv_thinm(HeadConv g, int Wg, long ngroups, int cpw, int nshare, int nstrips) {
+    constexpr int NB = (R >= 4) ? 1 : (R == 2 ? 2 : 4);
+    constexpr int NR = R + 2;
     __shared__ __attribute__((aligned(16))) float wsm[TM_MAXC * M * 9];       // [c][m][9]
-    __shared__ float red[TM_MAXCS * M * 4 * 64];                              // [wave][m][v][lane] (share 0's slots stay unused)
+    constexpr int MAXW = (M * R >= 8) ? 4 : TM_MAXCS;                         // waves per workgroup, at most (32 KB of partial sums)
+    __shared__ float red[MAXW * M * 4 * R * 64];                              // [wave][m][r][v][lane] (share 0's slots stay unused)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cs = wid % nshare, pw = wid / nshare;
@@ -157,57 +162,58 @@ __global__ __launch_bounds__(64 * TM_MAXCS) void k_conv_thinm(HeadConv g, int Wg
     const long gq = live ? gid : 0;
     const int xg = (int)(gq % Wg);
     const long rr = gq / Wg;
-    const int y = (int)(rr % g.H), n = (int)(rr / g.H);
-    const int x0 = xg * 4;
+    const int ys = (int)(rr % nstrips), n = (int)(rr / nstrips);
+    const int x0 = xg * 4, y0 = ys * R;
     const int HW = g.H * g.W;
     const int c_beg = cs * cpw;
     int c_end = c_beg + cpw;
     if (c_end > g.Cin) c_end = g.Cin;
 
-    float acc[M][4];
+    float acc[M][R][4];
 #pragma unroll
     for (int m = 0; m < M; m++)
 #pragma unroll
-        for (int v = 0; v < 4; v++) acc[m][v] = 0.f;
-    // rows y - DS, y, y + DS (tap rows 0, 1, 2); rows / halo columns outside the image contribute zero (their loads are redirected
-    // to the centre piece and the value masked)
-    bool rowin[3];
-    long roff[3];
+        for (int r = 0; r < R; r++)
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const int iy = y + (i - 1) * DS;
-        rowin[i] = live && (unsigned)iy < (unsigned)g.H;
-        roff[i] = (long)(rowin[i] ? iy : y) * g.W + x0;
+            for (int v = 0; v < 4; v++) acc[m][r][v] = 0.f;
+    // input rows y0 - 1 .. y0 + R (window row q); rows / halo columns outside the image contribute zero (their loads are redirected to
+    // an image row / the centre piece and the value masked)
+    bool rowin[NR];
+    long roff[NR];
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        const int iy = y0 - 1 + q;
+        rowin[q] = live && (unsigned)iy < (unsigned)g.H;
+        roff[q] = (long)(rowin[q] ? iy : y0) * g.W + x0;
     }
     const bool lin = x0 > 0, rin = x0 + 4 < g.W;
     const int lo = lin ? -1 : 0, ro = rin ? 4 : 3;
     const float* xc = g.x + (long)n * g.x_bs + (long)(c_beg < g.Cin ? c_beg : 0) * HW;      // (an empty share reads channel 0 and uses nothing)
-    // one batch = up to 4 channels: 36 loads in flight (channels past the share's end re-read its last channel and are not used)
-    struct Batch { float4 ctr[4][3]; float lft[4][3], rgt[4][3]; };
+    struct Batch { float4 ctr[NB][NR]; float lft[NB][NR], rgt[NB][NR]; };
     auto load = [&](const float* xp, int nch, Batch& bt) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < NB; u++) {
             const float* xu = xp + (long)(u < nch ? u : (nch > 0 ? nch - 1 : 0)) * HW;
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const float* row = xu + roff[i];
-                bt.ctr[u][i] = *reinterpret_cast<const float4*>(row);
-                bt.lft[u][i] = row[lo];
-                bt.rgt[u][i] = row[ro];
+            for (int q = 0; q < NR; q++) {
+                const float* row = xu + roff[q];
+                bt.ctr[u][q] = *reinterpret_cast<const float4*>(row);
+                bt.lft[u][q] = row[lo];
+                bt.rgt[u][q] = row[ro];
             }
         }
     };
     auto fma_batch = [&](int c0, int nch, const Batch& bt) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < NB; u++) {
             if (u >= nch) break;
-            float nb[3][6];
+            float nb[NR][6];
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
-                nb[i][0] = (rowin[i] && lin) ? bt.lft[u][i] : 0.f;
-                nb[i][1] = rowin[i] ? bt.ctr[u][i].x : 0.f; nb[i][2] = rowin[i] ? bt.ctr[u][i].y : 0.f;
-                nb[i][3] = rowin[i] ? bt.ctr[u][i].z : 0.f; nb[i][4] = rowin[i] ? bt.ctr[u][i].w : 0.f;
-                nb[i][5] = (rowin[i] && rin) ? bt.rgt[u][i] : 0.f;
+            for (int q = 0; q < NR; q++) {
+                nb[q][0] = (rowin[q] && lin) ? bt.lft[u][q] : 0.f;
+                nb[q][1] = rowin[q] ? bt.ctr[u][q].x : 0.f; nb[q][2] = rowin[q] ? bt.ctr[u][q].y : 0.f;
+                nb[q][3] = rowin[q] ? bt.ctr[u][q].z : 0.f; nb[q][4] = rowin[q] ? bt.ctr[u][q].w : 0.f;
+                nb[q][5] = (rowin[q] && rin) ? bt.rgt[u][q] : 0.f;
             }
             const float* wc = wsm + (c0 + u) * (M * 9);
 #pragma unroll
@@ -218,7 +224,10 @@ __global__ __launch_bounds__(64 * TM_MAXCS) void k_conv_thinm(HeadConv g, int Wg
                     for (int j = 0; j < 3; j++) {
                         const float wv = wc[m * 9 + 3 * i + j];
 #pragma unroll
-                        for (int v = 0; v < 4; v++) acc[m][v] = fmaf(wv, nb[i][v + (DS > 0 ? j : 2 - j)], acc[m][v]);
+                        for (int r = 0; r < R; r++)
+#pragma unroll
+                            for (int v = 0; v < 4; v++)      // output row y0 + r reads input row y0 + r + DS (i - 1) = window row r + 1 + DS (i - 1)
+                                acc[m][r][v] = fmaf(wv, nb[r + (DS > 0 ? i : 2 - i)][v + (DS > 0 ? j : 2 - j)], acc[m][r][v]);
                     }
         }
     };
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(64 * TM_MAXCS) void k_conv_thinm(HeadConv g, int Wg
             }
             if (first) {
                 const int nch = c_end - c_beg;
-                load(xc, nch < 4 ? nch : 4, bt);
+                load(xc, nch < NB ? nch : NB, bt);
                 first = false;
             }
 #pragma unroll
@@ -251,20 +260,22 @@ __global__ __launch_bounds__(64 * TM_MAXCS) void k_conv_thinm(HeadConv g, int Wg
         }
     }
     __syncthreads();
-    for (int c = c_beg; c < c_end; c += 4) {
-        const int nch = c_end - c < 4 ? c_end - c : 4;
+    for (int c = c_beg; c < c_end; c += NB) {
+        const int nch = c_end - c < NB ? c_end - c : NB;
         fma_batch(c, nch, bt);
-        const int left = c_end - c - 4;
+        const int left = c_end - c - NB;
         if (left > 0) {
-            xc += 4 * (long)HW;
-            load(xc, left < 4 ? left : 4, bt);
+            xc += NB * (long)HW;
+            load(xc, left < NB ? left : NB, bt);
         }
     }
     if (cs > 0) {
 #pragma unroll
         for (int m = 0; m < M; m++)
 #pragma unroll
-            for (int v = 0; v < 4; v++) red[((wid * M + m) * 4 + v) * 64 + lane] = acc[m][v];
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) red[(((wid * M + m) * R + r) * 4 + v) * 64 + lane] = acc[m][r][v];
     }
     __syncthreads();
     if (cs > 0 || !live) return;
@@ -272,20 +283,30 @@ __global__ __launch_bounds__(64 * TM_MAXCS) void k_conv_thinm(HeadConv g, int Wg
 #pragma unroll
         for (int m = 0; m < M; m++)
 #pragma unroll
-            for (int v = 0; v < 4; v++) acc[m][v] += red[(((wid + k) * M + m) * 4 + v) * 64 + lane];
-    const long pix = (long)y * g.W + x0;
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) acc[m][r][v] += red[((((wid + k) * M + m) * R + r) * 4 + v) * 64 + lane];
     const bool hr = g.res != nullptr, ha = g.add != nullptr;
 #pragma unroll
-    for (int m = 0; m < M; m++) {
-        const long o = (long)m * HW + pix;
-        const float bias = g.bias ? g.bias[m] : 0.f;
-        float rv[4], av[4], out[4];
-        if (hr) vload<4>(g.res + (long)n * g.res_bs + o, rv);
-        if (ha) vload<4>(g.add + (long)n * g.add_bs + o, av);
+    for (int r = 0; r < R; r++) {
+        if (y0 + r >= g.H) break;
+        const long pix = (long)(y0 + r) * g.W + x0;
+        float rv[M][4], av[M][4];
 #pragma unroll
-        for (int v = 0; v < 4; v++)
-            out[v] = cctail::conv_tail(acc[m][v] + bias, hr, hr ? rv[v] : 0.f, g.res_mul, g.act, g.act_a, g.act_b, ha ? av[v] : 0.f);
-        vstore<4>(g.y + (long)n * g.y_bs + o, out);
+        for (int m = 0; m < M; m++) {
+            const long o = (long)m * HW + pix;
+            if (hr) vload<4>(g.res + (long)n * g.res_bs + o, rv[m]);
+            if (ha) vload<4>(g.add + (long)n * g.add_bs + o, av[m]);
+        }
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const float bias = g.bias ? g.bias[m] : 0.f;
+            float out[4];
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+                out[v] = cctail::conv_tail(acc[m][r][v] + bias, hr, hr ? rv[m][v] : 0.f, g.res_mul, g.act, g.act_a, g.act_b, ha ? av[m][v] : 0.f);
+            vstore<4>(g.y + (long)n * g.y_bs + (long)m * HW + pix, out);
+        }
     }
 }
 
@@ -391,10 +412,10 @@ __global__ __launch_bounds__(256) void k_wgrad_thinm(HeadWgrad g) {
     }
 }
 
-template <int M>
-void launch_thinm(const HeadConv& g, int Wg, long ngroups, int cpw, int nshare, dim3 grid, int threads, hipStream_t s) {
-    if (g.dstep > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_thinm<M, 1>), grid, dim3(threads), 0, s, g, Wg, ngroups, cpw, nshare);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_thinm<M, -1>), grid, dim3(threads), 0, s, g, Wg, ngroups, cpw, nshare);
+template <int M, int R>
+void launch_thinm(const HeadConv& g, int Wg, long ngroups, int cpw, int nshare, int nstrips, dim3 grid, int threads, hipStream_t s) {
+    if (g.dstep > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_thinm<M, 1, R>), grid, dim3(threads), 0, s, g, Wg, ngroups, cpw, nshare, nstrips);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv_thinm<M, -1, R>), grid, dim3(threads), 0, s, g, Wg, ngroups, cpw, nshare, nstrips);
 }
 
 template <int K, int VEC>
@@ -467,24 +488,36 @@ bool head_conv_thinm_ok(const HeadConv& g) {
 bool head_conv_thinm_launch(const HeadConv& g, hipStream_t s) {
     if (!head_conv_thinm_ok(g)) return false;
     const int Wg = g.W / 4;
-    const long ngroups = (long)g.B * g.H * Wg;
+    // rows per work-item: 4 (M <= 2) / 2 on maps of >= 200 k pixels, where enough waves remain (measured per map size, us:
+    // M1 256x832 34 -> 25, 128x416 24 -> 17, but 64x208 15 -> 24; M4 128x416 36 -> 26, 64x208 20 -> 31), else 1
+    const bool big = (long)g.B * g.H * g.W >= cctools::env_int("CC_HEAD_ROWS_MINPIX", 200000);
+    const int R = big ? (g.M <= 2 ? 4 : 2) : 1;
+    const int nstrips = (g.H + R - 1) / R;
+    const long ngroups = (long)g.B * nstrips * Wg;
     const long npw = (ngroups + 63) / 64;                      // pixel waves
     // channel shares: the kernel is a chain of memory round trips per wave (weights + first batch, further batches, epilogue), so
-    // short chains in many waves: >= ~8000 waves, >= 4 channels (one batch) per share; workgroup = 4 waves (8 with 8 shares)
+    // short chains in many waves: >= ~8000 waves, >= 4 channels per share; workgroup = 4 waves (8 with 8 shares)
+    const int maxshare = g.M * R >= 8 ? 4 : TM_MAXCS;         // (the kernel's LDS for the shares' partial sums: MAXW)
     int nshare = 1;
-    while (nshare < TM_MAXCS && npw * nshare < cctools::env_int("CC_HEAD_WAVES", 8000) && g.Cin / (nshare * 2) >= 4) nshare *= 2;
+    while (nshare < maxshare && npw * nshare < cctools::env_int("CC_HEAD_WAVES", 8000) && g.Cin / (nshare * 2) >= 4) nshare *= 2;
     const int cpw = (g.Cin + nshare - 1) / nshare;
     const int nwaves = nshare > 4 ? nshare : 4;
     const int pwpb = nwaves / nshare;
     const long nbx = (npw + pwpb - 1) / pwpb;
     if (nbx >= (1l << 31)) return false;
     dim3 grid((unsigned)nbx);
+    const int th = 64 * nwaves;
+#define CC_THINM(M_)                                                                                          \
+    if (R == 4) launch_thinm<M_, (M_ <= 2 ? 4 : 2)>(g, Wg, ngroups, cpw, nshare, nstrips, grid, th, s);       \
+    else if (R == 2) launch_thinm<M_, 2>(g, Wg, ngroups, cpw, nshare, nstrips, grid, th, s);                  \
+    else launch_thinm<M_, 1>(g, Wg, ngroups, cpw, nshare, nstrips, grid, th, s);
     switch (g.M) {
-        case 1: launch_thinm<1>(g, Wg, ngroups, cpw, nshare, grid, 64 * nwaves, s); break;
-        case 2: launch_thinm<2>(g, Wg, ngroups, cpw, nshare, grid, 64 * nwaves, s); break;
-        case 3: launch_thinm<3>(g, Wg, ngroups, cpw, nshare, grid, 64 * nwaves, s); break;
-        default: launch_thinm<4>(g, Wg, ngroups, cpw, nshare, grid, 64 * nwaves, s); break;
+        case 1: CC_THINM(1) break;
+        case 2: CC_THINM(2) break;
+        case 3: CC_THINM(3) break;
+        default: CC_THINM(4) break;
     }
+#undef CC_THINM
     return true;
 }
 

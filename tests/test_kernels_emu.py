@@ -107,6 +107,7 @@ def test_convs_head_kernels(monkeypatch):
     monkeypatch.setenv("CC_HEAD_WGRAD_MINPIX", "1")      # ... and their weight gradients on k_wgrad_thinm
     parity.check_convs("cpu", cases=parity.CONV_CASES_HEADS, tcases=[])
     monkeypatch.setenv("CC_HEAD_WGRAD_WAVES", "1")       # strips of 8 rows (the plan of the large maps)
+    monkeypatch.setenv("CC_HEAD_ROWS_MINPIX", "1")       # forward: 4 / 2 rows per work-item (the plan of the large maps)
     parity.check_convs("cpu", cases=parity.CONV_CASES_HEADS, tcases=[])
 
 

@@ -127,6 +127,8 @@ def test_convs_head_kernels(monkeypatch):
     with _lib.use_library(build.build_tools()) as e:
         assert e.fn["cc_is_tools_build"]() == 1
         parity.check_convs("cuda", cases=parity.CONV_CASES_HEADS, tcases=[])
+        monkeypatch.setenv("CC_HEAD_ROWS_MINPIX", "1")       # 4 / 2 rows per work-item on the small test maps too
+        parity.check_convs("cuda", cases=parity.CONV_CASES_HEADS, tcases=[])
 
 
 def test_convs_full_size_thin_layers():
