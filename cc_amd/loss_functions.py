@@ -218,7 +218,8 @@ class _HeadGrads:
         key = (t.data_ptr(), t.numel())
         ent = self.acc.get(key)
         if ent is None:
-            ent = self.acc[key] = [torch.empty(t.numel(), device=t.device, dtype=torch.float32), owner, False]
+            # (the tensor itself is kept until end(): its address is the key, so it must not be reused by another tensor of the step)
+            ent = self.acc[key] = [torch.empty(t.numel(), device=t.device, dtype=torch.float32), owner, False, t]
         return ent
 
 

@@ -111,6 +111,32 @@ def test_convs_head_kernels(monkeypatch):
     parity.check_convs("cpu", cases=parity.CONV_CASES_HEADS, tcases=[])
 
 
+def test_head_gradient_accumulators_match_the_engine_sums():
+    # several loss terms on the same network outputs: with LF.head_grads active (the trainer's step) every term scales its gradients
+    # into the per-tensor accumulator (cc_scale_acc_jobs) and ONE term hands it to autograd; the result must be what the autograd
+    # engine sums up from the terms' separate tensors
+    import torch
+    from cc_amd import loss_functions as LF
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(2, 3, 24, 40, generator=g) * 2 - 1
+    masks = [torch.sigmoid(torch.randn(2, 4, 24 >> s, 40 >> s, generator=g)).requires_grad_(True) for s in range(3)]
+
+    def total():
+        LF.pyramid_cache.clear()
+        return 0.3 * LF.explainability_loss(masks) + 0.7 * LF.smooth_loss(masks) + 0.2 * LF.edge_aware_smoothness_loss(img, masks) \
+            + 0.1 * LF.smooth_loss([masks[1], masks[1]])          # (the same tensor at two positions of one term)
+
+    want = torch.autograd.grad(total(), masks)
+    LF.head_grads.begin()
+    try:
+        assert LF.head_grads.active
+        got = torch.autograd.grad(total(), masks)
+    finally:
+        LF.head_grads.end()
+    for a, b in zip(got, want):
+        assert float((a - b).abs().max()) <= 1e-6 * max(float(b.abs().max()), 1e-30), float((a - b).abs().max())
+
+
 def test_cost_volume():
     parity.check_corr("cpu")
     parity.check_corr_patch("cpu")
