@@ -887,6 +887,8 @@ struct ConvPlan {
     int ipt, phi;              // stacked tiny maps (CP::ipt)
     int bm, ck, tps, Mpad, Cpad, PH, PWr, PS, ymin, xmin, tiles_x, tiles_y, nsplit, cps, aligned, shift;
     size_t smem, wp_floats, part_floats;
+    int wpad;                  // Winograd over a zero-padded copy of the input (maps whose width is not a multiple of 4): its row pitch
+    size_t pad_floats;         // ... and size (behind the partial slabs in the workspace)
 };
 
 static int env_int_early(const char* name, int dflt) { return cctools::env_int(name, dflt); }
@@ -919,6 +921,41 @@ inline ConvPlan plan_conv(const GG& g, int mult = 1) {
             p.wp_floats = w.u_floats;
             p.part_floats = w.part_floats;
             return p;
+        }
+        // Maps whose width is not a multiple of 4 (the 8x26 level of DispResNet6: 512- / 1024-channel layers, 4 GFLOP each on the direct
+        // kernel + a split-K epilogue): the Winograd kernel stages aligned 16-byte row pieces, so the input is first copied into rows
+        // padded with zeros to the next width it takes (k_pad_rows; zero columns ARE the convolution's padding) and the launch is
+        // always split-K: the partial slabs have the padded pitch, and the deterministic epilogue kernel that sums them writes the
+        // real output.  Large layers only (the copy, 23 % empty tile columns and the forced second pass have to pay), never for the
+        // grouped launches of parallel branches (they share one direct launch today).
+        if (!dbg_flag_early("CC_NO_WINO_PAD") && (g.IW % 4) != 0 && g.IH >= 2 && g.M >= env_int_early("CC_WINOP_MINM", 256) &&
+            g.Cin >= env_int_early("CC_WINOP_MINC", 256)) {
+            int wp = (g.IW + 3) & ~3;
+            while (!(wp / 2 >= 16 || wp / 2 == 8)) wp += 4;
+            if (4 * (wp - g.IW) <= wp && (long)g.B * ((g.IH + 1) / 2) * (wp / 2) >= env_int_early("CC_WINOP_MINQ", 128)) {
+                ccint::WinoPlan wq = ccint::wino_plan(g.B, g.Cin, g.IH, wp, g.M, mult);
+                if (wq.ok) {
+                    if (wq.nsplit < 2) {                    // the epilogue pass is what un-pads the output
+                        wq.cps = (wq.nchunk + 1) / 2;
+                        wq.nsplit = (wq.nchunk + wq.cps - 1) / wq.cps;
+                        wq.part_floats = (size_t)wq.nsplit * g.B * g.M * wq.Hp * wq.Wp;
+                    }
+                    if (wq.nsplit >= 2) {
+                        p.wino = 1;
+                        p.wn = wq;
+                        p.use_patch = true;
+                        p.bm = ccwino::WBM; p.ck = ccwino::WCK; p.tps = 1;
+                        p.Mpad = wq.Mpad; p.Cpad = wq.Cpad;
+                        p.nsplit = wq.nsplit; p.cps = wq.cps;
+                        p.Hp = wq.Hp; p.Wp = wq.Wp;
+                        p.wp_floats = wq.u_floats;
+                        p.part_floats = wq.part_floats;
+                        p.wpad = wp;
+                        p.pad_floats = ((size_t)g.B * g.Cin * g.IH * wp + 3) & ~(size_t)3;
+                        return p;
+                    }
+                }
+            }
         }
     }
     p.bm = pick_bm_fwd(g.M);
@@ -1040,7 +1077,7 @@ inline ConvPlan plan_conv(const GG& g, int mult = 1) {
     return p;
 }
 
-inline size_t conv_ws_floats(const ConvPlan& p) { return 64 + p.wp_floats + p.part_floats; }
+inline size_t conv_ws_floats(const ConvPlan& p) { return 64 + p.wp_floats + p.part_floats + p.pad_floats; }
 
 // ------------------------------------------------------------------ weight gradient
 constexpr int MAXGRP = 4;       // same-shaped weight-gradient problems per launch (parallel branches of a network)
@@ -1811,7 +1848,7 @@ inline ccint::WinoGeom wino_geom(const GG& g) {
 inline void wino_scope_name(const GG& g, const ConvPlan& p, int nprob, char* nm, int cap) {
     int nl = snprintf(nm, cap, "k_wino_f2x3<%d>", p.nsplit > 1 ? 1 : 0);
     if (cctools::env_flag("CC_TIMING_DETAIL"))
-        snprintf(nm + nl, cap - nl, " %dx[B%d M%d C%d %dx%d t9 k%d] wg%d", nprob, g.B, g.M, g.Cin, g.OH, g.OW, p.nsplit,
+        snprintf(nm + nl, cap - nl, " %dx[B%d M%d C%d %dx%d%s t9 k%d] wg%d", nprob, g.B, g.M, g.Cin, g.OH, g.OW, p.wpad ? "(pad)" : "", p.nsplit,
                  nprob * p.wn.nqb * p.wn.nmb * p.nsplit);
 }
 
@@ -1819,6 +1856,53 @@ inline void wino_scope_name(const GG& g, const ConvPlan& p, int nprob, char* nm,
 inline double wino_gflop(const GG& g, const ConvPlan& p) { return 2e-9 * 16.0 * g.B * p.wn.TY * p.wn.TX * (double)g.M * g.Cin; }
 
 inline int wino_flip(const GG& g) { return g.dstep < 0 ? 1 : 0; }
+
+// ---- 3x3 / stride-1 layers on maps whose width is not a multiple of 4 (8x26, 4x13: the deep levels): the Winograd weight-gradient
+// kernel moves rows as 16-byte pieces, so dY and the input are first copied into rows padded with zeros to a multiple of 4 (zero
+// dY columns add nothing, zero input columns are the convolution's own padding) -- two 1-2 MB copies in one launch against half
+// the time of the im2col kernel on these 512-channel layers (profiles/r04_ab_round4.txt).
+struct PadJob { const float* src; float* dst; long bs; int rows_per_image; };        // rows of image n start at src + n * bs
+struct PadTab { PadJob j[2 * MAXGRP]; int n, B, W, Wp; long row_end[2 * MAXGRP]; };     // row_end: cumulative B * rows_per_image
+__global__ __launch_bounds__(256) void k_pad_rows(PadTab t) {
+    const int q4 = t.Wp >> 2;                                  // float4s per padded row
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;       // one float4 of one padded row
+    const long row = e / q4;
+    const int c4 = (int)(e - row * q4) * 4;
+    int k = 0;
+    long first = 0;
+#pragma unroll
+    for (int q = 0; q < 2 * MAXGRP - 1; q++)
+        if (q + 1 < t.n && row >= t.row_end[q]) { k = q + 1; first = t.row_end[q]; }
+    if (row >= t.row_end[t.n - 1]) return;
+    const PadJob& j = t.j[k];
+    const long r = row - first;
+    const int n = (int)(r / j.rows_per_image);
+    const long rr = r - (long)n * j.rows_per_image;
+    const float* s = j.src + (long)n * j.bs + rr * t.W;
+    float4 v;
+    v.x = c4 + 0 < t.W ? s[c4 + 0] : 0.f;
+    v.y = c4 + 1 < t.W ? s[c4 + 1] : 0.f;
+    v.z = c4 + 2 < t.W ? s[c4 + 2] : 0.f;
+    v.w = c4 + 3 < t.W ? s[c4 + 3] : 0.f;
+    *reinterpret_cast<float4*>(j.dst + (r * t.Wp + c4)) = v;
+}
+
+// Winograd over a zero-padded copy of the input (ConvPlan::wpad): the copy goes behind the problem's partial slabs; pr / wg are
+// re-pointed at it (rows of wpad floats, dense [B][Cin][H][wpad])
+inline void wino_pad_input(const GG& g, const ConvPlan& p, float* part, hipStream_t s, ccint::WinoProb& pr, ccint::WinoGeom& wg) {
+    float* xpad = part + p.part_floats;
+    PadTab t = {};
+    t.B = g.B; t.W = g.IW; t.Wp = p.wpad; t.n = 1;
+    t.j[0] = PadJob{g.x, xpad, g.x_bs, g.Cin * g.IH};
+    t.row_end[0] = (long)g.B * g.Cin * g.IH;
+    const long nf4 = t.row_end[0] * (p.wpad >> 2);
+    hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)((nf4 + 255) / 256)), dim3(256), 0, s, t);
+    if (cctools::env_flag("CC_WINO_TRACE"))
+        fprintf(stderr, "wino padded input: B%d M%d C%d %dx%d -> pitch %d, nsplit %d dstep %d\n", g.B, g.M, g.Cin, g.IH, g.IW, p.wpad, p.nsplit, g.dstep);
+    pr.x = xpad;
+    wg.W = p.wpad;
+    wg.x_bs = (long)g.Cin * g.IH * p.wpad;
+}
 
 // ws: [64 zeros][repacked weights][split-K partial slabs]; sized by conv_ws_floats(plan_conv(g))
 // prepacked (optional): {64 zeros, wp} produced earlier by k_repack_table -> no repack launch here
@@ -1861,13 +1945,15 @@ inline void launch_gg(const GG& g, float* ws, hipStream_t s, const float* prepac
     if (p.wino) {
         if (!prepacked)
             ccint::wino_weights_launch(g.w, ws + 64, g.M, g.Cin, p.Cpad, p.Mpad, g.w_sm, g.w_sc, g.w0, g.w_ri, g.w_sj, wino_flip(g), s);
-        const ccint::WinoProb pr = {g.x, prepacked ? prepacked : wp, g.bias, g.res, g.add, g.y, part};
+        ccint::WinoProb pr = {g.x, prepacked ? prepacked : wp, g.bias, g.res, g.add, g.y, part};
+        ccint::WinoGeom wg = wino_geom(g);
+        if (p.wpad) wino_pad_input(g, p, part, s, pr, wg);
         bool ok;
         {
             char nm[128];
             wino_scope_name(g, p, 1, nm, sizeof nm);
             cctiming::Scope tsc(nm, wino_gflop(g, p), s);
-            ok = ccint::wino_launch(wino_geom(g), p.wn, &pr, 1, s);
+            ok = ccint::wino_launch(wg, p.wn, &pr, 1, s);
         }
         if (!ok) { launch_gg_flat(g, s); return; }      // x not 16-byte aligned (an odd view): the gather kernel reads the weights as they lie
         if (p.nsplit > 1) {
@@ -1930,6 +2016,8 @@ inline bool launch_classes(const ClsIn* cs, int n, hipStream_t s, bool idle_taps
     {   // Winograd problems: all of the launch or none (a mixed list goes back to the caller, which launches one by one)
         int nw = 0;
         for (int k = 0; k < n; k++) nw += cs[k].p.wino ? 1 : 0;
+        for (int k = 0; k < n; k++)
+            if (cs[k].p.wpad && n > 1) return false;   // (padded-input Winograd problems run one by one)
         if (nw) {
             if (nw != n) return false;
             ccint::WinoProb pr[MAXCLS];
@@ -1953,11 +2041,13 @@ inline bool launch_classes(const ClsIn* cs, int n, hipStream_t s, bool idle_taps
                 ebx += (int)((c.total + 255) / 256);
                 e.bx_end[k] = ebx;
             }
+            ccint::WinoGeom wg = wino_geom(cs[0].g);
+            if (p.wpad) wino_pad_input(cs[0].g, p, cs[0].part, s, pr[0], wg);       // (n == 1)
             {
                 char nm[128];
                 wino_scope_name(cs[0].g, p, n, nm, sizeof nm);
                 cctiming::Scope tsc(nm, n * wino_gflop(cs[0].g, p), s);
-                if (!ccint::wino_launch(wino_geom(cs[0].g), p.wn, pr, n, s)) return false;
+                if (!ccint::wino_launch(wg, p.wn, pr, n, s)) return false;
             }
             if (p.nsplit > 1) hipLaunchKernelGGL(k_splitk_epilogue_multi, dim3((unsigned)ebx), dim3(256), 0, s, e);
             return true;
@@ -2256,7 +2346,7 @@ size_t cc_conv2d_dgrad_group_ws_bytes(int G, int B, int K, int OH, int OW, int C
                     continue;
                 const ConvPlan p = plan_conv(g, mult);
                 if (p.wp_floats > wmax) wmax = p.wp_floats;
-                psum += p.part_floats;
+                psum += p.part_floats + p.pad_floats;
             }
         const size_t t = 64 + wmax + psum;
         if (t > best) best = t;
@@ -2477,7 +2567,7 @@ static long list_run(int n, const long* d, float* ws, int target, bool launch, h
         if (all[i].c.p.wino) {       // Winograd problems keep the plan of their own geometry: one launch each
             done[i] = 1;
             all[i].c.part = ws ? ws + off : nullptr;
-            off += (long)all[i].c.p.part_floats;
+            off += (long)(all[i].c.p.part_floats + all[i].c.p.pad_floats);
             if (launch && !launch_classes(&all[i].c, 1, s)) return -1;
             continue;
         }
@@ -2546,36 +2636,6 @@ inline W3Plan plan_w3(int B, int M, int AH, int AW, int Cin, int R, int S, int s
 
 static size_t wgrad_ws_bytes_base(int B, int M, int AH, int AW, int Cin, int R, int S, int si);
 static size_t wgrad_ws_bytes_rest(int B, int M, int AH, int AW, int Cin, int R, int S, int si);
-
-// ---- 3x3 / stride-1 layers on maps whose width is not a multiple of 4 (8x26, 4x13: the deep levels): the Winograd weight-gradient
-// kernel moves rows as 16-byte pieces, so dY and the input are first copied into rows padded with zeros to a multiple of 4 (zero
-// dY columns add nothing, zero input columns are the convolution's own padding) -- two 1-2 MB copies in one launch against half
-// the time of the im2col kernel on these 512-channel layers (profiles/r04_ab_round4.txt).
-struct PadJob { const float* src; float* dst; long bs; int rows_per_image; };        // rows of image n start at src + n * bs
-struct PadTab { PadJob j[2 * MAXGRP]; int n, B, W, Wp; long row_end[2 * MAXGRP]; };     // row_end: cumulative B * rows_per_image
-__global__ __launch_bounds__(256) void k_pad_rows(PadTab t) {
-    const int q4 = t.Wp >> 2;                                  // float4s per padded row
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;       // one float4 of one padded row
-    const long row = e / q4;
-    const int c4 = (int)(e - row * q4) * 4;
-    int k = 0;
-    long first = 0;
-#pragma unroll
-    for (int q = 0; q < 2 * MAXGRP - 1; q++)
-        if (q + 1 < t.n && row >= t.row_end[q]) { k = q + 1; first = t.row_end[q]; }
-    if (row >= t.row_end[t.n - 1]) return;
-    const PadJob& j = t.j[k];
-    const long r = row - first;
-    const int n = (int)(r / j.rows_per_image);
-    const long rr = r - (long)n * j.rows_per_image;
-    const float* s = j.src + (long)n * j.bs + rr * t.W;
-    float4 v;
-    v.x = c4 + 0 < t.W ? s[c4 + 0] : 0.f;
-    v.y = c4 + 1 < t.W ? s[c4 + 1] : 0.f;
-    v.z = c4 + 2 < t.W ? s[c4 + 2] : 0.f;
-    v.w = c4 + 3 < t.W ? s[c4 + 3] : 0.f;
-    *reinterpret_cast<float4*>(j.dst + (r * t.Wp + c4)) = v;
-}
 
 struct WinoPadPlan { bool ok; int Wp; ccint::WinoWgradPlan wp; size_t pad_floats; };     // pad_floats: padded x + dY of ONE problem
 inline WinoPadPlan wino_pad_plan(int B, int M, int AH, int AW, int Cin, int G) {

@@ -489,6 +489,18 @@ CONV_CASES_WINO_PADW = [          # product thresholds (>= 96 channels on both s
     (4, 100, 4, 13, 96, 3, 1, 1, "sigmoid", True, False),
     (3, 128, 5, 10, 97, 3, 1, 1, None, False, False),
 ]
+# ... and their forward / data-gradient arithmetic on the Winograd kernel over a zero-padded copy of the INPUT (conv.hip plan_conv
+# ConvPlan::wpad: always split-K, the epilogue kernel writes the real output): product thresholds (>= 256 channels on both sides)
+CONV_CASES_WINO_PADIN = [
+    (4, 256, 8, 26, 256, 3, 1, 1, None, True, True),
+    (2, 256, 9, 30, 260, 3, 1, 1, "sigmoid", True, False),
+]
+CONV_CASES_WINO_PADIN_SMALL = [   # emulator sizes (thresholds lowered through the tools switches); 13 -> 16 columns (8 tile columns)
+    (2, 20, 6, 26, 24, 3, 1, 1, None, True, False),
+    (1, 16, 5, 13, 24, 3, 1, 1, "sigmoid", True, True),
+    (3, 24, 4, 30, 40, 3, 1, 1, "relu", True, False),
+    (2, 9, 3, 26, 33, 3, 1, 1, "lrelu", False, False),
+]
 CONV_CASES_WINO_PADW_SMALL = [    # emulator sizes (thresholds lowered through the tools switches)
     (2, 20, 4, 10, 24, 3, 1, 1, None, True, False),
     (2, 33, 5, 13, 40, 3, 1, 1, "sigmoid", True, True),

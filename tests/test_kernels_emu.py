@@ -85,6 +85,14 @@ def test_convs_winograd_weight_gradient_padded_rows(monkeypatch):
     parity.check_conv_groups("cpu", cases=((2, 12, 5, 10, 40, 16, 1),))
 
 
+def test_convs_winograd_padded_input(monkeypatch):
+    # widths that are not multiples of 4: forward and data-gradient on the Winograd kernel over a zero-padded copy of the input
+    for k in ("CC_WINOP_MINM", "CC_WINOP_MINC", "CC_WINOP_MINQ", "CC_WINO_MINM", "CC_WINO_MINC", "CC_WINO_MINQ"):
+        monkeypatch.setenv(k, "1")
+    monkeypatch.setenv("CC_WINO_TRACE", "1")
+    parity.check_convs("cpu", cases=parity.CONV_CASES_WINO_PADIN_SMALL, tcases=[], prepack=True)
+
+
 def test_weight_gradient_list():
     parity.check_wgrad_list("cpu")
 

@@ -82,6 +82,18 @@ def test_convs_winograd():
     parity.check_conv_groups("cuda", cases=((4, 96, 8, 26, 128, 96, 1),))
 
 
+def test_convs_winograd_padded_input(monkeypatch):
+    # 8x26-style maps: forward / data-gradient on the Winograd kernel over a zero-padded copy of the input (product thresholds),
+    # then small shapes steered there through the tools build
+    from cc_amd import _lib, build
+    parity.check_convs("cuda", cases=parity.CONV_CASES_WINO_PADIN, tcases=[], prepack=True)
+    for k in ("CC_WINOP_MINM", "CC_WINOP_MINC", "CC_WINOP_MINQ", "CC_WINO_MINM", "CC_WINO_MINC", "CC_WINO_MINQ"):
+        monkeypatch.setenv(k, "1")
+    with _lib.use_library(build.build_tools()) as e:
+        assert e.fn["cc_is_tools_build"]() == 1
+        parity.check_convs("cuda", cases=parity.CONV_CASES_WINO_PADIN_SMALL, tcases=[], prepack=True)
+
+
 def test_weight_gradient_list():
     # the end-of-stage flush of the weight-gradient queue: groups of different shapes in one cc_conv2d_wgrad_list call
     parity.check_wgrad_list("cuda")
