@@ -932,7 +932,7 @@ inline ConvPlan plan_conv(const GG& g, int mult = 1) {
             g.Cin >= env_int_early("CC_WINOP_MINC", 256)) {
             int wp = (g.IW + 3) & ~3;
             while (!(wp / 2 >= 16 || wp / 2 == 8)) wp += 4;
-            if (4 * (wp - g.IW) <= wp && (long)g.B * ((g.IH + 1) / 2) * (wp / 2) >= env_int_early("CC_WINOP_MINQ", 128)) {
+            if (4 * (wp - g.IW) <= wp && (long)g.B * ((g.IH + 1) / 2) * (wp / 2) >= env_int_early("CC_WINOP_MINQ", 64)) {
                 ccint::WinoPlan wq = ccint::wino_plan(g.B, g.Cin, g.IH, wp, g.M, mult);
                 if (wq.ok) {
                     if (wq.nsplit < 2) {                    // the epilogue pass is what un-pads the output
