@@ -2016,8 +2016,7 @@ inline bool launch_classes(const ClsIn* cs, int n, hipStream_t s, bool idle_taps
     {   // Winograd problems: all of the launch or none (a mixed list goes back to the caller, which launches one by one)
         int nw = 0;
         for (int k = 0; k < n; k++) nw += cs[k].p.wino ? 1 : 0;
-        for (int k = 0; k < n; k++)
-            if (cs[k].p.wpad && n > 1) return false;   // (padded-input Winograd problems run one by one)
+
         if (nw) {
             if (nw != n) return false;
             ccint::WinoProb pr[MAXCLS];
@@ -2027,7 +2026,12 @@ inline bool launch_classes(const ClsIn* cs, int n, hipStream_t s, bool idle_taps
             const ConvPlan& p = cs[0].p;
             for (int k = 0; k < n; k++) {
                 const GG& g = cs[k].g;
-                if (!cs[k].wp || !same_problem_shape(g, cs[0].g) || cs[k].p.nsplit != p.nsplit || cs[k].p.cps != p.cps) return false;
+                if (!cs[k].wp || !same_problem_shape(g, cs[0].g) || cs[k].p.nsplit != p.nsplit || cs[k].p.cps != p.cps) {
+                    if (cctools::env_flag("CC_WINO_TRACE"))
+                        fprintf(stderr, "wino classes declined: k %d wp %p same %d nsplit %d/%d cps %d/%d\n", k, (const void*)cs[k].wp,
+                                (int)same_problem_shape(g, cs[0].g), cs[k].p.nsplit, p.nsplit, cs[k].p.cps, p.cps);
+                    return false;
+                }
                 pr[k] = ccint::WinoProb{g.x, cs[k].wp, g.bias, g.res, g.add, g.y, cs[k].part};
                 EPC& c = e.c[k];
                 c.part = cs[k].part; c.bias = g.bias; c.res = g.res; c.add = g.add; c.y = g.y;
@@ -2042,7 +2046,32 @@ inline bool launch_classes(const ClsIn* cs, int n, hipStream_t s, bool idle_taps
                 e.bx_end[k] = ebx;
             }
             ccint::WinoGeom wg = wino_geom(cs[0].g);
-            if (p.wpad) wino_pad_input(cs[0].g, p, cs[0].part, s, pr[0], wg);       // (n == 1)
+            if (p.wpad) {
+                // zero-padded input copies of all n problems (same shape: same plan), 2 * MAXGRP jobs per copy launch
+                for (int k = 0; k < n; k++)
+                    if (cs[k].p.wpad != p.wpad || cs[k].p.part_floats != p.part_floats || !cs[k].part) return false;
+                for (int k0 = 0; k0 < n; k0 += 2 * MAXGRP) {
+                    PadTab t = {};
+                    t.B = cs[0].g.B; t.W = cs[0].g.IW; t.Wp = p.wpad;
+                    long rows = 0;
+                    for (int k = k0; k < n && k < k0 + 2 * MAXGRP; k++) {
+                        const GG& g = cs[k].g;
+                        float* xpad = cs[k].part + p.part_floats;
+                        t.j[t.n] = PadJob{g.x, xpad, g.x_bs, g.Cin * g.IH};
+                        rows += (long)g.B * g.Cin * g.IH;
+                        t.row_end[t.n] = rows;
+                        t.n++;
+                        pr[k].x = xpad;
+                    }
+                    const long nf4 = rows * (p.wpad >> 2);
+                    hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)((nf4 + 255) / 256)), dim3(256), 0, s, t);
+                }
+                wg.W = p.wpad;
+                wg.x_bs = (long)cs[0].g.Cin * cs[0].g.IH * p.wpad;
+                if (cctools::env_flag("CC_WINO_TRACE"))
+                    fprintf(stderr, "wino padded input, %d problems: B%d M%d C%d %dx%d -> pitch %d, nsplit %d\n", n, cs[0].g.B, cs[0].g.M,
+                            cs[0].g.Cin, cs[0].g.IH, cs[0].g.IW, p.wpad, p.nsplit);
+            }
             {
                 char nm[128];
                 wino_scope_name(cs[0].g, p, n, nm, sizeof nm);

@@ -91,6 +91,8 @@ def test_convs_winograd_padded_input(monkeypatch):
         monkeypatch.setenv(k, "1")
     monkeypatch.setenv("CC_WINO_TRACE", "1")
     parity.check_convs("cpu", cases=parity.CONV_CASES_WINO_PADIN_SMALL, tcases=[], prepack=True)
+    # the same for G = 3 parallel branches in one launch (one copy launch pads all three inputs)
+    parity.check_conv_groups("cpu", cases=((2, 12, 5, 26, 40, 16, 1), (1, 16, 4, 13, 24, 24, 1)))
 
 
 def test_weight_gradient_list():

@@ -92,6 +92,7 @@ def test_convs_winograd_padded_input(monkeypatch):
     with _lib.use_library(build.build_tools()) as e:
         assert e.fn["cc_is_tools_build"]() == 1
         parity.check_convs("cuda", cases=parity.CONV_CASES_WINO_PADIN_SMALL, tcases=[], prepack=True)
+        parity.check_conv_groups("cuda", cases=((2, 12, 5, 26, 40, 16, 1), (1, 16, 4, 13, 24, 24, 1)))      # G = 3 branches per launch
 
 
 def test_weight_gradient_list():
