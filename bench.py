@@ -460,6 +460,8 @@ def main():
     batch = (batch_cpu[0].to(dev), [r.to(dev) for r in batch_cpu[1]], batch_cpu[2].to(dev), batch_cpu[3].to(dev))
     # measurement switches of the data-parallel step (tools/gpu_r3y.sh, gpu_r3z.sh): read HERE, by the measuring script -- the
     # product step (cc_amd/trainer.py) reads no environment variable
+    from tools import ab_env
+    ab_switches = ab_env.apply()            # CC_* A/B variables -> cc_amd.config.debug (explicit: the package reads no environment)
     if os.environ.get("CC_NO_HEAD_ACC", "0") == "1":                    # A/B: the loss terms return separate gradients, the engine adds them
         from cc_amd import loss_functions as _LF
         _LF.head_grads.enabled = False
@@ -583,7 +585,9 @@ def main():
                 return r
             mfma_k = {k: v for k, v in dev_k.items() if v["gflop"] > 0}
             ex_ms, ex_gf = sum(v["ms"] for v in mfma_k.values()), sum(v["gflop"] for v in mfma_k.values())
-            roof = {"bound": "mfma", "kernel": kn, "achieved": round(ach, 2), "peak": PEAK_MFMA_F32, "unit": "TFLOP/s",
+            # "library": the per-kernel durations come from the TOOLS build of the same sources (timing registry compiled in, default
+            # thresholds); the timed region above ran on the product library
+            roof = {"library": "tools", "bound": "mfma", "kernel": kn, "achieved": round(ach, 2), "peak": PEAK_MFMA_F32, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_MFMA_F32, 4), "traffic": traffic, "traffic_source": src,
                     "launches": a["launches"], "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2),
                     "timing": "HIP events around the kernel launch on its stream (cc_timing_enable / cc_timing_collect), one "
@@ -621,7 +625,7 @@ def main():
                        "loss": round(loss_val, 6), "rccl_ranks": dist.get_world_size() if use_dist else 1,
                        "rank_losses": rank_losses,
                        "hip_runtime": {"AMD_DIRECT_DISPATCH": os.environ.get("AMD_DIRECT_DISPATCH", "default (1)")},
-                       "dead_occlusion_decoders_elided": bool(args.elide_occ)},
+                       "dead_occlusion_decoders_elided": bool(args.elide_occ), "ab_switches": ab_switches or None},
             "step_ms": step_ms, "comm": comm,
             "roofline": roof, "kernels": kernels,
         }

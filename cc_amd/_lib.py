@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "ccengine.h")
-LIB_PATH = os.environ.get("CC_LIB_PATH") or os.path.join(_HERE, "libccengine.so")      # CC_LIB_PATH: A/B builds (tools/)
+LIB_PATH = os.path.join(_HERE, "libccengine.so")
 
 _CT = {"long": ctypes.c_long, "int": ctypes.c_int, "float": ctypes.c_float, "size_t": ctypes.c_size_t, "double": ctypes.c_double}
 
@@ -52,7 +52,8 @@ def image_dense(t):
 
 
 class Engine:
-    def __init__(self, path=LIB_PATH, require_device=True):
+    def __init__(self, path=None, require_device=True):
+        path = path or LIB_PATH
         if not os.path.isfile(path):
             raise RuntimeError(
                 "ccengine: %s not found -- build it with `python -m cc_amd.build` (hipcc, gfx950). "
@@ -118,7 +119,8 @@ _engine = None
 def engine():
     global _engine
     if _engine is None:
-        _engine = Engine()
+        from . import config
+        _engine = Engine(config.debug.library_path)       # None -> the product library next to this file
     return _engine
 
 

@@ -14,3 +14,21 @@ strict_nan_checks = False
 # scatter of Back2Future's warps (float atomics, as in the reference's grid_sample backward) -- then accumulates 64-bit
 # fixed-point integers instead (cc_feature_warp_bwd_det: four launches per warp instead of two, ~+0.3 ms per step).
 deterministic = False
+
+
+class _Debug:
+    """A/B and diagnosis switches of the host glue.  The product reads nothing from the process environment: these are plain attributes that
+    tools/ab_env.py (bench.py, the A/B scripts, tests/conftest.py) sets from CC_* variables explicitly.  All False / None = the
+    shipped step."""
+    no_slice_gy = False          # copy a concat gradient's channel slice instead of reading it in place
+    no_wgrad_defer = False       # reduce every weight gradient right behind its kernel instead of once per backward stage
+    no_sum_n = False             # pairwise adds for multi-consumer gradients instead of one n-ary sum
+    no_bias_table = False        # one bias-gradient pass per layer instead of the per-stage table launch
+    no_wgrad_list = False        # the stage's last parked weight-gradient groups one by one
+    no_wgrad_queue = False       # no parking of same-shaped weight gradients at all
+    force_comm = False           # issue the gradient collectives on a one-rank process group too (tests, tools)
+    capture_mode = "thread_local"    # hipGraph capture error mode of CCTrainer
+    library_path = None          # another build of libccengine.so (the tools build): picked up by _lib.engine() on first use
+
+
+debug = _Debug()

@@ -80,6 +80,35 @@ __device__ __forceinline__ void cc_glds16x4(const void* gsrc, unsigned lds_dst) 
 #define CC_GLDS16X4(gsrc, lds_ptr) cc_glds16x4((gsrc), __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)CC_LDS_PTR(lds_ptr)))
 #endif
 
+// The same four transfers with a wave-uniform 64-bit base (SGPR pair) + a per-lane 32-bit byte offset PER ROW: the rows still land
+// 1 KB apart in LDS (the immediate offset applies to both sides), but their global sources are voff[k] + 1024 k bytes behind the
+// base, i.e. wherever the caller points them (wino.hip small-tile kernel: 512-byte halves of the 1 KB rows of a 64-row weight block).
+#ifndef CC_GLDS16X4_S
+__device__ __forceinline__ void cc_glds16x4_s(const void* sbase, unsigned v0, unsigned v1, unsigned v2, unsigned v3, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %6\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %5\n\t"
+        "global_load_lds_dwordx4 %2, %5 offset:1024\n\t"
+        "global_load_lds_dwordx4 %3, %5 offset:2048\n\t"
+        "global_load_lds_dwordx4 %4, %5 offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+__device__ __forceinline__ const void* cc_uniform_ptr(const void* p) {      // a pointer the compiler can keep in an SGPR pair
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (const void*)(((unsigned long long)hi << 32) | lo);
+}
+#define CC_GLDS16X4_S(sbase, voff, lds_ptr)                                                         \
+    cc_glds16x4_s(cc_uniform_ptr(sbase), (voff)[0], (voff)[1], (voff)[2], (voff)[3],                \
+                  __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)CC_LDS_PTR(lds_ptr)))
+#endif
+
 // One 16-byte LDS-DMA transfer per lane through a buffer resource (bounds-checked: lanes whose offset lies at or beyond the
 // resource's size move zeros), from inline assembly for the same reason as CC_GLDS16X4.  lds_ptr: wave-uniform destination (lane l
 // lands at lds_ptr + 16 l bytes); voff: per-lane byte offset; soff: wave-uniform byte offset (not range-checked).

@@ -936,6 +936,7 @@ inline ConvPlan plan_conv(const GG& g, int mult = 1) {
                 ccint::WinoPlan wq = ccint::wino_plan(g.B, g.Cin, g.IH, wp, g.M, mult);
                 if (wq.ok) {
                     if (wq.nsplit < 2) {                    // the epilogue pass is what un-pads the output
+                        if (wq.tile == 2) wq.tile = 1;      // (the eight-wave instance halves the reduction itself: no slices across workgroups)
                         wq.cps = (wq.nchunk + 1) / 2;
                         wq.nsplit = (wq.nchunk + wq.cps - 1) / wq.cps;
                         wq.part_floats = (size_t)wq.nsplit * g.B * g.M * wq.Hp * wq.Wp;
@@ -1846,7 +1847,8 @@ inline ccint::WinoGeom wino_geom(const GG& g) {
 }
 
 inline void wino_scope_name(const GG& g, const ConvPlan& p, int nprob, char* nm, int cap) {
-    int nl = snprintf(nm, cap, "k_wino_f2x3<%d>", p.nsplit > 1 ? 1 : 0);
+    int nl = p.wn.tile ? snprintf(nm, cap, "k_wino_f2x3_s<%d, %d>", p.wn.tile, p.nsplit > 1 ? 1 : 0)
+                       : snprintf(nm, cap, "k_wino_f2x3<%d>", p.nsplit > 1 ? 1 : 0);
     if (cctools::env_flag("CC_TIMING_DETAIL"))
         snprintf(nm + nl, cap - nl, " %dx[B%d M%d C%d %dx%d%s t9 k%d] wg%d", nprob, g.B, g.M, g.Cin, g.OH, g.OW, p.wpad ? "(pad)" : "", p.nsplit,
                  nprob * p.wn.nqb * p.wn.nmb * p.nsplit);
@@ -2693,7 +2695,7 @@ size_t cc_conv2d_wgrad_ws_bytes(int B, int M, int AH, int AW, int Cin, int R, in
 static size_t wgrad_ws_bytes_base(int B, int M, int AH, int AW, int Cin, int R, int S, int si) {
     size_t wino = 0;
     if (R == 3 && S == 3 && si == 1) {       // Winograd path (pad / input size are implied by "same" convolutions: checked again at launch)
-        for (int G = 1; G <= MAXGRP; G += MAXGRP - 1) {
+        for (int G = 1; G <= MAXGRP; G++) {       // every group size: the split search is not monotonic in G
             const ccint::WinoWgradPlan wp = ccint::wino_wgrad_plan(B, M, AH, AW, Cin, G);
             if (wp.ok && wp.ws_floats * sizeof(float) > wino) wino = wp.ws_floats * sizeof(float);
             const WinoPadPlan pp = wino_pad_plan(B, M, AH, AW, Cin, G);
@@ -2743,7 +2745,7 @@ static void launch_wgrad_parked(const WgradCollector& c, hipStream_t s) {
                 if (c.p[i].bm != bm) continue;
                 const dim3& gr = c.p[i].grid;
                 const long nb = (long)gr.x * gr.y * gr.z;
-                if (blk + nb >= (1l << 31)) break;
+                if (m.n && blk + nb >= (1l << 31)) break;          // (a problem that large goes into a launch of its own: never dropped)
                 m.c[m.n] = c.p[i].g;
                 m.gx[m.n] = (int)gr.x; m.gy[m.n] = (int)gr.y;
                 blk += nb;
@@ -3059,12 +3061,20 @@ int cc_conv2d_wgrad_list(int n, const long* desc_host, const float* zeros64_or_n
     for (int i = 0; i < n; i++) {
         const long* d = desc_host + 32l * i;
         const int G = (int)d[0];
-        if (G <= 0 || G > MAXGRP || sink.n + G > red_cap) return CC_ERR_ARG;
+        // on an error in the middle of the list: what was collected is launched (its reduce descriptors describe slabs that are then
+        // really written) and the descriptors emitted so far are handed back, so that the caller's state stays consistent
+        auto bail = [&](int code) {
+            launch_wgrad_parked(col, s);
+            if (wino_parked.n > 0) ccint::wino_wgrad_launch_parked(&wino_parked, s);
+            *nred_host = sink.n;
+            return code;
+        };
+        if (G <= 0 || G > MAXGRP || sink.n + G > red_cap) return bail(CC_ERR_ARG);
         const int before = col.n;
         const int r = wgrad_group_impl(G, d + 1, d + 5, d + 9, (float*)d[13], (int)d[14], (int)d[15], (int)d[16], (int)d[17], d[18],
                                        (int)d[19], (int)d[20], (int)d[21], d[22], (int)d[23], (int)d[24], (int)d[25], (int)d[26], d[27],
                                        d[28], (int)d[29], stream, &sink, zeros64_or_null, &col);
-        if (r != CC_OK) return r;
+        if (r != CC_OK) return bail(r);
         if (col.n > before && col.p[before].g.direct) {
             // a problem that writes its gradient itself (no split): it must not share a launch with an earlier one of the same target
             bool dup = false;
@@ -3157,6 +3167,7 @@ int cc_is_tools_build(void) {
 
 /* ---- introspection (bench.py groups its per-call timings by the kernel a call dispatches to) */
 static void patch_name(const ConvPlan& p, bool multi, char* out, int cap) {
+    if (p.wino && p.wn.tile) { snprintf(out, cap, "k_wino_f2x3_s<%d, %d>%s", p.wn.tile, p.nsplit > 1 ? 1 : 0, p.nsplit > 1 ? "+splitk" : ""); return; }
     if (p.wino) { snprintf(out, cap, "k_wino_f2x3<%d>%s", p.nsplit > 1 ? 1 : 0, p.nsplit > 1 ? "+splitk" : ""); return; }
     if (!p.use_patch) { snprintf(out, cap, "k_gather_gemm<%d>", pick_bm(p.Mpad ? p.Mpad : 32)); return; }
     const char* sk = p.nsplit > 1 ? "+splitk" : "";

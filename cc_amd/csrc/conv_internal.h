@@ -38,6 +38,8 @@ struct WinoPlan {
     int nsplit, cps;            // split-K over channel chunks (deterministic second pass: conv.hip k_splitk_epilogue*)
     int Hp, Wp;                 // partial slab rows / pitch: [split][n][m][Hp][Wp]
     size_t u_floats, part_floats;
+    int tile;                   // kernel instance: 0 = 64 rows x 64 tiles (nqb / nmb count those blocks); 1 = 32 x 32, four waves, two
+                                // workgroups per CU; 2 = 32 x 32, eight waves: the channel chunks halved INSIDE the workgroup
 };
 constexpr int WINO_MAXP = 12;   // problems per launch (= conv.hip MAXCLS)
 // eligibility (geometry only: the weight image is laid out for the algorithm the plan names) + split-K for `mult` problems per launch

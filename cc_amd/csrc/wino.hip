@@ -486,6 +486,367 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_wino_f2x3(WN g) {
     }
 }
 
+// ---- Small-tile instance: 32 output channels x 32 tiles (128 output pixels) x 16 frequencies per workgroup, for launches whose 64 x 64
+// blocks cannot fill the chip (the <= 32x104 levels: 52-208 blocks on 256 CUs, which used to go split-K -> partial slabs -> a separate
+// epilogue launch).  A quarter of the block area = 4x the workgroups at FULL reduction depth, bias / residual / activation fused, no
+// slabs.  KS = 1: four waves, one per SIMD; wave fr owns frequency ROW fr (f = 4 fr + j: four accumulator tiles = 64 registers), 76 KB
+// of LDS -> two workgroups per CU: one's prologue / output transform runs under the other's MFMAs, and the two waves of a SIMD are in
+// unrelated phases of their stages.  KS = 2 (in-workgroup split of the reduction): eight waves = frequency row x HALF of the channel
+// chunks, each half with its own U / V / patch buffers (152 KB, one workgroup per CU, two waves per SIMD); the halves meet in the
+// output transform's LDS exchange -- for problems that have <= 256 blocks even at this tile size (16x52 with 256 channels: 208).
+// Same stage structure as the 64 x 64 kernel (U by LDS-DMA, wave-private raw patches by bounds-checked buffer LDS-DMA one stage ahead,
+// input transform between the MFMAs); U comes from the SAME weight image: the 512-byte halves of the 1 KB [f][quad] rows of a 64-row
+// block (CC_GLDS16X4_S).  Output transform: columns inside the wave (M[fr][:] A), rows across the waves through LDS.
+constexpr int SBM = 32, SBT = 32;
+constexpr int UBLK_S = 16 * WCK * SBM;        // floats of one U chunk of a 32-row block (16 KB)
+constexpr int VBLK_S = 16 * WCK * SBT;
+constexpr int SHALF = 2 * UBLK_S + 2 * VBLK_S + 4 * RWAVE;      // LDS floats of one reduction half: U / V double-buffered + four patches
+
+template <int KS, int SPLIT, int EPI>
+__global__ __launch_bounds__(256 * KS, 2) void k_wino_f2x3_s(WN g) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = wid & 3, kh = wid >> 2;           // frequency row of this wave's MFMAs; reduction half (KS = 2)
+    const int l31 = lane & 31, lk = lane >> 5;
+    float* Us = smem + kh * SHALF;                   // [2][UBLK_S]
+    float* Vs = Us + 2 * UBLK_S;                     // [2][VBLK_S]
+    float* Rs = Vs + 2 * VBLK_S;                     // [4 waves][RWAVE]
+
+    const int cnt = (int)gridDim.x >> 3;
+    const int w = ((int)blockIdx.x & 7) * cnt + ((int)blockIdx.x >> 3);
+    if (w >= g.total) return;
+    const int prob = w / g.per_prob;
+    const int wr = w - prob * g.per_prob;
+    const int qb = wr / g.nmb, mb = wr - qb * g.nmb;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CC_HIPEMU)
+    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    const ccint::WinoProb& P = *(reinterpret_cast<const ccint::WinoProb*>(ka + offsetof(WN, p)) + prob);
+#else
+    const ccint::WinoProb& P = g.p[prob];
+#endif
+    // chunk range of this launch slice (blockIdx.z: split-K across workgroups), then of this wave's half of it
+    int c_beg = (int)blockIdx.z * g.cps;
+    int c_end = c_beg + g.cps;
+    if (c_end > g.nchunk) c_end = g.nchunk;
+    if constexpr (KS == 2) {       // (the host gives KS = 2 launches an even number of chunks per slice: both halves run the same number of barriers)
+        const int half = (c_end - c_beg) >> 1;
+        c_beg += kh * half;
+        c_end = c_beg + half;
+    }
+    const int odd = (c_end - c_beg) & 1;
+    // U: rows f = 4 fr + k of the block, both channel quads (lanes 0-31 / 32-63), this block's 32-row half of the 64-row weight block
+    unsigned uoff[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) uoff[k] = (unsigned)(fr * 8192 + k * 1024 + lk * 1024 + (mb & 1) * 512 + l31 * 16);
+    auto dma_U = [&](int kc, int buf) {
+        const float* src = P.U + ((long)(mb >> 1) * g.nchunk + kc) * UBLK;
+        CC_GLDS16X4_S(src, uoff, Us + buf * UBLK_S + fr * 1024);
+    };
+    if (c_beg < c_end) dma_U(c_beg, odd);
+    float bias_w = 0.f;
+    if constexpr (!SPLIT) {
+        const int mr = mb * SBM + l31;
+        if (P.bias) bias_w = P.bias[mr < g.M ? mr : g.M - 1];
+    }
+
+    // ---- input path (as in the 64 x 64 kernel): transform role of wave fr = the 16 consecutive tiles tg = fr & 1 of the block x the
+    // channel quad qd = fr >> 1 of the chunk
+    const int tg = fr & 1, qd = fr >> 1;
+    float* Rw = Rs + fr * RWAVE;
+    const int q0 = qb * SBT + 16 * tg;
+    int rn[2], riy[2], rxal[2], rlen[2], rjb[2], rxs[2];
+    {
+        int q = q0;
+        int jb = 0;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const bool v = q < g.Q;
+            const int qq = v ? q : 0;
+            const int n = qq / g.TPI;
+            const int rem = qq - n * g.TPI;
+            const int ty = rem / g.TX, tx = rem - ty * g.TX;
+            int len = g.TX - tx;
+            const int left = 16 - (q - q0);
+            if (len > left) len = left;
+            if (len > g.Q - q) len = g.Q - q;
+            if (!v || len < 0) len = 0;
+            const int xs = 2 * tx - 1;
+            const int xal = xs & ~3;
+            rn[r] = n; riy[r] = 2 * ty - 1; rxal[r] = xal; rlen[r] = len; rjb[r] = jb; rxs[r] = xs;
+            jb += len > 0 ? (xs + 2 * len + 2 - xal + 3) >> 2 : 0;
+            q += len;
+        }
+    }
+    unsigned doff[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int piece = i * 64 + lane;
+        const int cl = piece / 48, rem = piece - cl * 48;
+        const int a = rem / 12, j = rem - a * 12;
+        const int r = (rlen[1] > 0 && j >= rjb[1]) ? 1 : 0;
+        const int n = r ? rn[1] : rn[0], iy = (r ? riy[1] : riy[0]) + a, xal = r ? rxal[1] : rxal[0];
+        const int len = r ? rlen[1] : rlen[0], xs = r ? rxs[1] : rxs[0], jb = r ? rjb[1] : rjb[0];
+        const int x = xal + 4 * (j - jb);
+        const bool ok = len > 0 && x < xs + 2 * len + 2 && (unsigned)iy < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
+        doff[i] = ok ? (unsigned)(((long)n * g.x_bs + (long)cl * g.HW + (long)iy * g.W + x) * 4) : CC_BUF_OOB;
+    }
+    const cc_buf_t xr = CC_BUF_RSRC(P.x, g.x_bytes);
+    auto dma_raw = [&](int kc, int i) {
+        const int cl = (i * 64 + lane) / 48;
+        const int cb = kc * WCK + qd * 4;
+        // (chunks past this wave's range are never consumed: their requests move zeros / garbage into a patch nobody reads)
+        const unsigned inv = (cb + cl < g.Cin) ? 0u : CC_BUF_OOB;
+        CC_BUF_GLDS16(xr, doff[i] | inv, (unsigned)cb * (unsigned)g.HW * 4u, Rw + i * 256);
+    };
+    const int tl16 = lane & 15, c3 = lane >> 4;
+    const int tl = tg * 16 + tl16;
+    int roff;
+    {
+        const int r = tl16 < rlen[0] ? 0 : 1;
+        const int tt = tl16 - (r ? rlen[0] : 0);
+        roff = (r ? rjb[1] : rjb[0]) * 4 + (r ? rxs[1] : rxs[0]) + 2 * tt - (r ? rxal[1] : rxal[0]);
+        if (tt >= (r ? rlen[1] : rlen[0])) roff = 0;
+    }
+    float raw[16];
+    auto read_raw = [&]() {
+        const float* src = Rw + c3 * RCH + roff;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) raw[4 * a + b] = src[a * RROW + b];
+    };
+    float tt[4][4];
+    auto col_step = [&](int b) {
+        const float d0 = raw[b], d1 = raw[4 + b], d2 = raw[8 + b], d3 = raw[12 + b];
+        tt[0][b] = d0 - d2;
+        tt[1][b] = d1 + d2;
+        tt[2][b] = d2 - d1;
+        tt[3][b] = d1 - d3;
+    };
+    auto row_step = [&](int i, int buf) {
+        float* o = Vs + buf * VBLK_S + qd * 128 + tl * 4 + c3;
+        o[(4 * i + 0) * 256] = tt[i][0] - tt[i][2];
+        o[(4 * i + 1) * 256] = tt[i][1] + tt[i][2];
+        o[(4 * i + 2) * 256] = tt[i][2] - tt[i][1];
+        o[(4 * i + 3) * 256] = tt[i][1] - tt[i][3];
+    };
+#pragma unroll
+    for (int i = 0; i < 3; i++) *reinterpret_cast<float4*>(Rw + i * 256 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): before the first DMA into the patch
+    __builtin_amdgcn_wave_barrier();
+    if (c_beg < c_end) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) dma_raw(c_beg, i);
+    }
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int f = 0; f < 4; f++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[f][r] = 0.f;
+
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+
+    // One stage = one 8-channel chunk = 4 frequencies x 4 k-steps = 16 MFMAs per wave; the next chunk's preparation sits in their gaps:
+    //   gap 0       this wave's quarter of the next U block (4 LDS-DMA rows)
+    //   gap 3       the next chunk's raw patch (requested a stage ago) has landed (counted wait); read this thread's 4 x 4 block
+    //   gaps 4-11   the input transform -> the other V buffer
+    //   gap 13      request the patch of the chunk after the next
+    auto stage = [&](auto PAR, int kc) {
+        constexpr int buf = decltype(PAR)::value;
+        const int kd = kc + 1 < g.nchunk ? kc + 1 : g.nchunk - 1;
+        const float4* Ua = reinterpret_cast<const float4*>(Us + buf * UBLK_S) + fr * 256 + lane;
+        const float4* Vb = reinterpret_cast<const float4*>(Vs + buf * VBLK_S) + fr * 256 + lane;
+        float4 a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { a[j] = Ua[j * 64]; b[j] = Vb[j * 64]; }
+        __builtin_amdgcn_sched_barrier(0);
+        const float av[4][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}, {a[2].x, a[2].y, a[2].z, a[2].w}, {a[3].x, a[3].y, a[3].z, a[3].w}};
+        const float bv[4][4] = {{b[0].x, b[0].y, b[0].z, b[0].w}, {b[1].x, b[1].y, b[1].z, b[1].w}, {b[2].x, b[2].y, b[2].z, b[2].w}, {b[3].x, b[3].y, b[3].z, b[3].w}};
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int j = i & 3, ks = i >> 2;           // frequencies alternate: two MFMAs on one accumulator are four apart
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][ks], bv[j][ks], acc[j], 0, 0, 0);
+            if (i == 0) dma_U(kd, buf ^ 1);
+            else if (i == 3) { CC_WAIT_VMCNT_FENCE(4); read_raw(); }
+            else if (i >= 4 && i < 12) {
+                const int s8 = i - 4;
+                if (s8 < 4) col_step(s8);
+                else row_step(s8 - 4, buf ^ 1);
+            }
+            else if (i == 13) { dma_raw(kc + 2, 0); dma_raw(kc + 2, 1); dma_raw(kc + 2, 2); }
+            if (i == 0 || (i >= 3 && i < 14)) __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        CC_WAIT_VMCNT_FENCE(3);                  // this wave's part of the next U block has landed (the three patch requests stay in flight)
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+    };
+
+    if (c_beg < c_end) {
+        CC_WAIT_VMCNT0_FENCE();
+        read_raw();
+#pragma unroll
+        for (int b = 0; b < 4; b++) col_step(b);
+#pragma unroll
+        for (int i = 0; i < 4; i++) row_step(i, odd);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 3; i++) dma_raw(c_beg + 1, i);
+        __builtin_amdgcn_s_barrier();
+        int kc = c_beg;
+        if (odd) {
+            stage(I1(), kc);
+            kc++;
+        }
+        for (; kc < c_end; kc += 2) {
+            stage(I0(), kc);
+            stage(I1(), kc + 1);
+        }
+    }
+    CC_WAIT_VMCNT0_FENCE();                      // the last stage's look-ahead patch requests: landed before the patch area can be reused
+
+    // ---- output transform Y = A^T M A.  This lane holds tile t = l31 and rows m = (r & 3) + 8 (r >> 2) + 4 lk (r = 0 .. 15) of frequency
+    // row fr.  Columns first, inside the wave: P[fr][0] = M0 + M1 + M2, P[fr][1] = M1 - M2 - M3; every wave publishes its two column
+    // values of all 16 rows in LDS (lane-linear: conflict-free), then wave (fr, kh) finishes rows r0 .. r0 + RPW - 1: Y[0][b] = P0 + P1 + P2,
+    // Y[1][b] = P1 - P2 - P3 (summed over the reduction halves first).  No register is indexed by a wave id that way.
+    constexpr int RPW = 4 / KS;                  // rows of the 16 finished per wave
+    const int rbase = 4 * fr + RPW * kh;         // r = rbase + rr:  r >> 2 = fr,  r & 3 = RPW kh + rr
+    const int q = qb * SBT + l31;
+    const bool qv = q < g.Q;
+    const int qq = qv ? q : 0;
+    const int n = qq / g.TPI;
+    const int qr = qq - n * g.TPI;
+    const int ty = qr / g.TX, tx = qr - ty * g.TX;
+    const int oy = 2 * ty, ox = 2 * tx;
+    const int m_base = mb * SBM + 4 * lk + 8 * fr + RPW * kh;        // + rr
+    const bool hr = P.res != nullptr, ha = P.add != nullptr;
+    const bool row1 = oy + 1 < g.H;
+    const long o0 = (long)oy * g.W + ox;
+    const int odd_lane = lane & 1;
+    const long o4 = (long)(oy + odd_lane) * g.W + (ox - 2 * odd_lane);
+    const bool row_ok = odd_lane ? row1 : true;
+    float4 res_r[RPW], add_r[RPW];
+    if constexpr (!SPLIT) {
+#pragma unroll
+        for (int rr = 0; rr < RPW; rr++) res_r[rr] = add_r[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.vec2 && qv && row_ok) {
+            if (hr) {
+                const float* rb = P.res + (long)n * g.res_bs + o4;
+#pragma unroll
+                for (int rr = 0; rr < RPW; rr++) {
+                    const int m = m_base + rr;
+                    res_r[rr] = *reinterpret_cast<const float4*>(rb + (long)(m < g.M ? m : g.M - 1) * g.HW);
+                }
+            }
+            if (ha) {
+                const float* ab = P.add + (long)n * g.add_bs + o4;
+#pragma unroll
+                for (int rr = 0; rr < RPW; rr++) {
+                    const int m = m_base + rr;
+                    add_r[rr] = *reinterpret_cast<const float4*>(ab + (long)(m < g.M ? m : g.M - 1) * g.HW);
+                }
+            }
+        }
+    }
+    float* Xs = smem;                            // [half KS][frequency row 4][column value 2][row 16][lane 64]: 32 KB per half, over the U / V buffers
+    __syncthreads();                             // (KS = 2: the other half may still be reading its last fragments out of the area)
+    {
+        float* xo = Xs + ((kh * 4 + fr) * 32) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            xo[r * 64] = (acc[0][r] + acc[1][r]) + acc[2][r];
+            xo[(16 + r) * 64] = (acc[1][r] - acc[2][r]) - acc[3][r];
+        }
+    }
+    __syncthreads();
+    auto out_tile = [&](int rr, float& y00, float& y01, float& y10, float& y11) {
+        float pv[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                float v = Xs[((i * 2 + b) * 16 + rbase + rr) * 64 + lane];
+                if constexpr (KS == 2) v += Xs[(((4 + i) * 2 + b) * 16 + rbase + rr) * 64 + lane];
+                pv[i][b] = v;
+            }
+        y00 = (pv[0][0] + pv[1][0]) + pv[2][0];
+        y01 = (pv[0][1] + pv[1][1]) + pv[2][1];
+        y10 = (pv[1][0] - pv[2][0]) - pv[3][0];
+        y11 = (pv[1][1] - pv[2][1]) - pv[3][1];
+    };
+    auto pair4 = [&](float y00, float y01, float y10, float y11) -> float4 {
+        const float sx = odd_lane ? y00 : y10, sy = odd_lane ? y01 : y11;
+        const float rx = __shfl_xor(sx, 1), ry = __shfl_xor(sy, 1);
+        return odd_lane ? make_float4(rx, ry, y10, y11) : make_float4(y00, y01, rx, ry);
+    };
+    if constexpr (SPLIT) {
+        float* pb0 = P.part + (long)blockIdx.z * g.part_stride + (((long)n * g.M) * g.Hp + oy + odd_lane) * g.Wp + (ox - 2 * odd_lane);
+        const long mstride = (long)g.Hp * g.Wp;
+#pragma unroll
+        for (int rr = 0; rr < RPW; rr++) {
+            const int m = m_base + rr;
+            float y00, y01, y10, y11;
+            out_tile(rr, y00, y01, y10, y11);
+            const float4 v = pair4(y00, y01, y10, y11);
+            if (qv && m < g.M) *reinterpret_cast<float4*>(pb0 + (long)m * mstride) = v;
+        }
+        return;
+    }
+    const float slope = g.act == ACT_RELU ? 0.f : (g.act == ACT_LRELU ? (g.act_b != 0.f ? g.act_b : 0.2f) : 1.f);
+    auto tail = [&](float v, float r, float ad) -> float {
+        if constexpr (EPI == EPI_LIN) {
+            const float t = v + r;
+            return t > 0.f ? t : slope * t + 0.f;
+        } else if constexpr (EPI == EPI_GRAD) {
+            const float t = v + ad;
+            return r > 0.f ? t : slope * t;
+        } else {
+            return conv_tail(v, hr, r, g.res_mul, g.act, g.act_a, g.act_b, ad);
+        }
+    };
+    if (g.vec2) {
+        float* yb = P.y + (long)n * g.y_bs + o4;
+#pragma unroll
+        for (int rr = 0; rr < RPW; rr++) {
+            const int m = m_base + rr;
+            float y00, y01, y10, y11;
+            out_tile(rr, y00, y01, y10, y11);
+            const float bv = __shfl(bias_w, 4 * lk + 8 * fr + RPW * kh + rr);      // row m of this lane: lane m - mb*32 of the wave's load
+            float4 v = pair4(y00, y01, y10, y11);
+            v.x = tail(v.x + bv, res_r[rr].x, add_r[rr].x);
+            v.y = tail(v.y + bv, res_r[rr].y, add_r[rr].y);
+            v.z = tail(v.z + bv, res_r[rr].z, add_r[rr].z);
+            v.w = tail(v.w + bv, res_r[rr].w, add_r[rr].w);
+            if (qv && row_ok && m < g.M) *reinterpret_cast<float4*>(yb + (long)m * g.HW) = v;
+        }
+        return;
+    }
+    if (!qv) return;
+    const bool col1 = ox + 1 < g.W;
+#pragma unroll
+    for (int rr = 0; rr < RPW; rr++) {
+        float y00, y01, y10, y11;
+        out_tile(rr, y00, y01, y10, y11);
+        const int m = m_base + rr;
+        if (m >= g.M) continue;
+        const float bv = P.bias ? P.bias[m] : 0.f;
+        const long o = (long)m * g.HW + o0;
+        float* yo = P.y + (long)n * g.y_bs + o;
+        const float* ro = hr ? P.res + (long)n * g.res_bs + o : nullptr;
+        const float* ao = ha ? P.add + (long)n * g.add_bs + o : nullptr;
+        yo[0] = tail(y00 + bv, hr ? ro[0] : 0.f, ha ? ao[0] : 0.f);
+        if (col1) yo[1] = tail(y01 + bv, hr ? ro[1] : 0.f, ha ? ao[1] : 0.f);
+        if (row1) {
+            yo[g.W] = tail(y10 + bv, hr ? ro[g.W] : 0.f, ha ? ao[g.W] : 0.f);
+            if (col1) yo[g.W + 1] = tail(y11 + bv, hr ? ro[g.W + 1] : 0.f, ha ? ao[g.W + 1] : 0.f);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_wino_weights(const float* __restrict__ w, float* __restrict__ U, int M, int Cin, int Cpad,
                                                       long w_sm, long w_sc, long w0, long w_ri, long w_sj, int flip) {
     wino_weight_body(w, U, M, Cin, Cpad, w_sm, w_sc, w0, w_ri, w_sj, flip, (int)blockIdx.x);
@@ -515,26 +876,59 @@ WinoPlan wino_plan(int B, int Cin, int H, int W, int M, int mult) {
     p.nmb = p.Mpad / WBM;
     p.Hp = 2 * TY; p.Wp = 2 * TX;
     p.u_floats = (size_t)16 * p.Cpad * p.Mpad;
-    // split-K: one workgroup per CU (256 registers of accumulators per lane), so a launch runs in ceil(workgroups / 256) rounds of
-    // `chunks per workgroup` stages; pick the split that minimises rounds * (stages + fixed per-workgroup cost), the partial slabs
-    // and the epilogue launch charged as a few stages
-    const long blocks = (long)p.nqb * p.nmb * (mult > 1 ? mult : 1);
+    // Which instance, and how many slices of the reduction.  Cost model in units of one 8-channel stage of the 64 x 64 kernel
+    // (~5 800 cycles, profiles/r04_wino_probe_b.txt); per candidate: rounds x (stages per workgroup x stage cost + fixed), the
+    // partial slabs and the epilogue launch of a split charged as a few stages.
+    //   64 x 64: one workgroup per CU (152 KB of LDS), stage 1.0, fixed 1.5
+    //   32 x 32, four waves: two per CU; a stage costs `sst` when the CU is shared and `sal` when the workgroup has it alone
+    //   32 x 32, eight waves (the reduction halved inside the workgroup): one per CU, stages / 2 at `sst` each, a longer exchange
+    const long mu = mult > 1 ? mult : 1;
+    const long blocks = (long)p.nqb * p.nmb * mu;
     p.nsplit = 1;
     p.cps = p.nchunk;
-    if (blocks < cctools::env_int("CC_WINO_SPLIT_BELOW", 224) && p.nchunk >= 4) {
-        const double fixed = 1.5;       // prologue + output transform, in stages
-        double best = 1e30;
-        int best_ns = 1;
-        const int cap = p.nchunk / 2 < 16 ? p.nchunk / 2 : 16;
+    p.tile = 0;
+    const int small_mode = cctools::env_int("CC_WINO_SMALL", 1);        // tools: 0 = never, 2 = wherever the geometry allows
+    const int nqb_s = (int)((Q + SBT - 1) / SBT), nmb_s = (M + SBM - 1) / SBM;
+    const long blocks_s = (long)nqb_s * nmb_s * mu;
+    double best = 1e30;
+    auto split_cost = [](int real) { return real > 1 ? 1.0 + 0.25 * real : 0.0; };
+    if (small_mode != 2 || blocks_s > (1l << 20)) {
+        // 64 x 64 candidates (the model of round 4)
+        best = (double)((blocks + 255) / 256) * (p.nchunk + 1.5);
+        if (blocks < cctools::env_int("CC_WINO_SPLIT_BELOW", 224) && p.nchunk >= 4) {
+            const int cap = p.nchunk / 2 < 16 ? p.nchunk / 2 : 16;
+            for (int ns = 2; ns <= cap; ns++) {
+                const int cps = (p.nchunk + ns - 1) / ns;
+                const int real = (p.nchunk + cps - 1) / cps;
+                const double rounds = (double)((blocks * real + 255) / 256);
+                const double t = rounds * (cps + 1.5) + split_cost(real);
+                if (t < best - 1e-9) { best = t; p.nsplit = real; p.cps = cps; }
+            }
+        }
+    }
+    if (small_mode && blocks < cctools::env_int("CC_WINO_SMALL_BELOW", 400) && blocks_s <= (1l << 20)) {
+        const double sst = 0.01 * cctools::env_int("CC_WINO_S_STAGE", 31);      // shared CU: two workgroups advance one stage each per ~3 600 cycles
+        const double sal = 0.01 * cctools::env_int("CC_WINO_S_ALONE", 42);
+        const double sfx = 0.01 * cctools::env_int("CC_WINO_S_FIXED", 100);
+        const int only_tile = cctools::env_int("CC_WINO_S_TILE", 0);           // tools / tests: 1 = four-wave form only, 2 = eight-wave form wherever it can run
+        int t_tile = 0, t_ns = 1, t_cps = p.nchunk;
+        double t_best = 1e30;
+        const int cap = p.nchunk >= 4 ? (p.nchunk / 2 < 16 ? p.nchunk / 2 : 16) : 1;
         for (int ns = 1; ns <= cap; ns++) {
             const int cps = (p.nchunk + ns - 1) / ns;
             const int real = (p.nchunk + cps - 1) / cps;
-            const double rounds = (double)((blocks * real + 255) / 256);
-            const double t = rounds * (cps + fixed) + (real > 1 ? 1.0 + 0.25 * real : 0.0);
-            if (t < best - 1e-9) { best = t; best_ns = real; p.cps = cps; }
+            const long wgs = blocks_s * real;
+            // four waves: 512 slots; a launch that leaves every CU one workgroup runs the stages alone
+            const double t4 = wgs <= 256 ? cps * sal + sfx : (double)((wgs + 511) / 512) * (cps * 2.0 * sst + sfx);
+            if (t4 + split_cost(real) < t_best - 1e-9) { t_best = t4 + split_cost(real); t_tile = 1; t_ns = real; t_cps = cps; }
+            if (real == 1 && (p.nchunk & 1) == 0 && p.nchunk >= 4 && only_tile != 1) {
+                const double t8 = only_tile == 2 ? -1.0 : (double)((wgs + 255) / 256) * ((cps / 2) * 2.0 * sst + sfx + 0.3);
+                if (t8 < t_best - 1e-9) { t_best = t8; t_tile = 2; t_ns = 1; t_cps = cps; }
+            }
         }
-        p.nsplit = best_ns;
+        if (t_best < best || small_mode == 2) { best = t_best; p.tile = t_tile; p.nsplit = t_ns; p.cps = t_cps; }
     }
+    if (p.tile) { p.nqb = nqb_s; p.nmb = nmb_s; }
     p.part_floats = p.nsplit > 1 ? (size_t)p.nsplit * B * M * p.Hp * p.Wp : 0;
     return p;
 }
@@ -571,9 +965,9 @@ bool wino_launch(const WinoGeom& gg, const WinoPlan& p, const WinoProb* probs, i
         v2 = v2 && ((((uintptr_t)probs[k].y) | (uintptr_t)probs[k].res | (uintptr_t)probs[k].add | (uintptr_t)probs[k].part) % 16 == 0);
     a.vec2 = v2 ? 1 : 0;
     if (cctools::env_flag("CC_WINO_TRACE"))
-        fprintf(stderr, "wino: %dx[B%d M%d C%d %dx%d] nqb %d nmb %d nsplit %d cps %d act %d res_mul %d vec2 %d\n", nprob, gg.B, gg.M, gg.Cin,
-                gg.H, gg.W, p.nqb, p.nmb, p.nsplit, p.cps, gg.act, gg.res_mul, a.vec2);
-    const size_t smem = (size_t)(2 * UBLK + 2 * VBLK + 8 * RWAVE) * sizeof(float);
+        fprintf(stderr, "wino: %dx[B%d M%d C%d %dx%d] tile %d nqb %d nmb %d nsplit %d cps %d act %d res_mul %d vec2 %d\n", nprob, gg.B, gg.M,
+                gg.Cin, gg.H, gg.W, p.tile, p.nqb, p.nmb, p.nsplit, p.cps, gg.act, gg.res_mul, a.vec2);
+    const size_t smem = p.tile ? (size_t)SHALF * p.tile * sizeof(float) : (size_t)(2 * UBLK + 2 * VBLK + 8 * RWAVE) * sizeof(float);
     dim3 grid((unsigned)(((a.total + 7) / 8) * 8), 1, (unsigned)p.nsplit);
     const bool grad = gg.res_mul != 0;          // (every problem of a launch has the multiplier or none has: conv.hip same_problem_shape)
     const int epi = (!grad && (gg.act == ACT_NONE || gg.act == ACT_RELU || gg.act == ACT_LRELU)) ? EPI_LIN
@@ -586,6 +980,29 @@ bool wino_launch(const WinoGeom& gg, const WinoPlan& p, const WinoProb* probs, i
         hipLaunchKernelGGL(kern, grid, dim3(WTHREADS), smem, s, a);
     };
     static bool attr_set[4] = {false, false, false, false};
+    if (p.tile) {        // 32 x 32 instance: four waves (p.tile 1) or eight with the reduction halved inside the workgroup (2)
+        static bool attr_s[2][4] = {};
+        const unsigned nth = 256u * (unsigned)p.tile;
+        auto gos = [&](auto kern, bool& attr) {
+            if (!attr) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr = true;
+            }
+            hipLaunchKernelGGL(kern, grid, dim3(nth), smem, s, a);
+        };
+        if (p.tile == 2) {
+            if (p.nsplit > 1 || (p.nchunk & 1)) return false;
+            if (epi == EPI_LIN) gos(k_wino_f2x3_s<2, 0, EPI_LIN>, attr_s[1][0]);
+            else if (epi == EPI_GRAD) gos(k_wino_f2x3_s<2, 0, EPI_GRAD>, attr_s[1][1]);
+            else gos(k_wino_f2x3_s<2, 0, EPI_GEN>, attr_s[1][2]);
+        } else {
+            if (p.nsplit > 1) gos(k_wino_f2x3_s<1, 1, 0>, attr_s[0][3]);
+            else if (epi == EPI_LIN) gos(k_wino_f2x3_s<1, 0, EPI_LIN>, attr_s[0][0]);
+            else if (epi == EPI_GRAD) gos(k_wino_f2x3_s<1, 0, EPI_GRAD>, attr_s[0][1]);
+            else gos(k_wino_f2x3_s<1, 0, EPI_GEN>, attr_s[0][2]);
+        }
+        return true;
+    }
 #ifdef CC_TOOLS
     const int abl = cctools::env_int("CC_WINO_ABL", 0);
     static bool attr_abl[16] = {};

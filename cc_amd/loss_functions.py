@@ -215,10 +215,11 @@ class _HeadGrads:
         self.active, self.acc = False, {}
 
     def register(self, t, owner):
-        key = (t.data_ptr(), t.numel())
+        # keyed on the autograd tensor itself (kept alive until end(), so its id is not reused): two distinct tensors that alias
+        # one storage get one accumulator each and autograd adds them -- correct whichever producers they feed
+        key = id(t)
         ent = self.acc.get(key)
         if ent is None:
-            # (the tensor itself is kept until end(): its address is the key, so it must not be reused by another tensor of the step)
             ent = self.acc[key] = [torch.empty(t.numel(), device=t.device, dtype=torch.float32), owner, False, t]
         return ent
 
@@ -241,6 +242,7 @@ class _GradArena:
         # shared per-tensor accumulators of the step (see _HeadGrads): one entry per span, or None
         self.heads = [head_grads.register(t, id(self)) if sp is not None else None
                       for t, sp in zip(inputs, self.spans)] if head_grads.active else None
+        self.spent = False
 
     def view(self, i, flat=None):
         sp = self.spans[i]
@@ -252,20 +254,30 @@ class _GradArena:
         """-> [grad_i * gout or None] (fresh storage: the arena itself stays valid for a second backward)."""
         if self.heads is not None:
             import ctypes
-            jobs, res, handed = [], [], set()
+            if self.spent:
+                raise RuntimeError("second backward through a loss term while the step's gradient accumulators are active "
+                                   "(head_grads): the accumulators would be added into twice")
+            self.spent = True
+            # rounds[r] = the r-th occurrence of every accumulator in THIS term.  Jobs of one launch are unordered, so a tensor that
+            # sits at two positions of a term (smooth_loss([m, m])) must not have its '=' and its '+=' in the same launch.
+            rounds, res, seen = [[]], [], {}
             for sp, ent in zip(self.spans, self.heads):
                 if sp is None:
                     res.append(None)
                     continue
-                jobs += [self.flat.data_ptr() + 4 * sp[0], ent[0].data_ptr(), sp[1], 1 if ent[2] else 0]
+                r = seen.get(id(ent), 0)
+                seen[id(ent)] = r + 1
+                while len(rounds) <= r:
+                    rounds.append([])
+                rounds[r] += [self.flat.data_ptr() + 4 * sp[0], ent[0].data_ptr(), sp[1], 1 if ent[2] else 0]
                 ent[2] = True
                 # the accumulator goes to autograd once: from the term that registered the tensor first, at its first position
-                mine = ent[1] == id(self) and id(ent) not in handed
-                handed.add(id(ent))
-                res.append(ent[0].view(sp[2]) if mine else None)
-            if jobs:
-                arr = (ctypes.c_long * len(jobs))(*jobs)
-                engine().call("cc_scale_acc_jobs", ctypes.addressof(arr), len(jobs) // 4, _f32c(gout).reshape(1), STREAM)
+                res.append(ent[0].view(sp[2]) if (ent[1] == id(self) and r == 0) else None)
+            g1 = _f32c(gout).reshape(1)
+            for jobs in rounds:
+                if jobs:
+                    arr = (ctypes.c_long * len(jobs))(*jobs)
+                    engine().call("cc_scale_acc_jobs", ctypes.addressof(arr), len(jobs) // 4, g1, STREAM)
             return res
         out = torch.empty_like(self.flat)
         engine().call("cc_scale_by_scalar", self.flat, _f32c(gout).reshape(1), out, self.flat.numel(), STREAM)

@@ -4,12 +4,11 @@
 Everything heavy is a HIP kernel.  What is still stock ATen (tiny tensors, listed in DESIGN.md as "torch
 plumbing"): nearest upsampling + channel softmax of the (unused-by-training) occlusion head, torch.cat.
 """
-import os
-
 import torch
 import torch.nn.functional as F
 
 from ._lib import engine, image_dense, STREAM
+from .config import debug as _dbg
 
 ACT = {None: 0, "relu": 1, "lrelu": 2, "sigmoid": 3}
 
@@ -18,14 +17,11 @@ def _c(t):
     return t.contiguous().float()
 
 
-_NO_SLICE = __import__("os").environ.get("CC_NO_SLICE_GY", "0") == "1"       # A/B switch (tools/)
-
-
 def _slice_or_c(t):
     """-> (tensor, batch stride in floats): a per-image dense channel slice (the narrow() views autograd hands to the producers
     of a torch.cat) is read in place through the kernels' batch-stride arguments instead of being copied."""
     if (t.dtype == torch.float32 and not t.is_contiguous() and image_dense(t) and t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0
-            and not _NO_SLICE):
+            and not _dbg.no_slice_gy):
         return t, t.stride(0)
     t = _c(t)
     return t, t.shape[1] * t.shape[2] * t.shape[3]
@@ -221,10 +217,6 @@ class _WgradReduces:
 
 wgrad_queue = _WgradQueue()
 wgrad_reduces = _WgradReduces()
-_NO_DEFER = __import__("os").environ.get("CC_NO_WGRAD_DEFER", "0") == "1"       # A/B switch (tools/)
-_NO_SUM_N = __import__("os").environ.get("CC_NO_SUM_N", "0") == "1"             # A/B switch: pairwise adds for multi-consumer gradients
-_NO_BIAS_TABLE = __import__("os").environ.get("CC_NO_BIAS_TABLE", "0") == "1"   # A/B switch: one bias-gradient pass per layer
-_NO_WGRAD_LIST = __import__("os").environ.get("CC_NO_WGRAD_LIST", "0") == "1"   # A/B switch: the stage's last parked groups one by one
 
 
 def _act_bwd_bias(gys, ys, geffs, gbs, ref, B, C, H, W, gy_bs, act, act_a, act_b, accumulate):
@@ -239,7 +231,7 @@ def _act_bwd_bias(gys, ys, geffs, gbs, ref, B, C, H, W, gy_bs, act, act_a, act_b
     ws = _ws(E.call("cc_act_bwd_ws_bytes", C) * G, ref)
     args = (G, _addr(a1), _addr(a2) if has_y else 0, _addr(a3) if has_ge else 0, _addr(a4) if has_gb else 0, ws, B, C, H, W,
             gy_bs, C * H * W, C * H * W, act, act_a, act_b, int(accumulate))
-    if has_gb and accumulate and wgrad_queue.enabled and not _NO_DEFER:
+    if has_gb and accumulate and wgrad_queue.enabled and not _dbg.no_wgrad_defer:
         ptrs = [t.data_ptr() for t in gbs]
         if wgrad_reduces.targets.intersection(ptrs):
             wgrad_reduces.flush()
@@ -273,7 +265,7 @@ def _wgrad_group(a_list, x_list, gw_list, ref, B, M, AH, AW, a_bs, Cin, IH, IW, 
     G = len(a_list)
     per = E.call("cc_conv2d_wgrad_ws_bytes", B, M, AH, AW, Cin, R, S, si)
     a1, a2, a3 = _parr(a_list), _parr(x_list), _parr(gw_list)
-    if accumulate and wgrad_queue.enabled and not _NO_DEFER:
+    if accumulate and wgrad_queue.enabled and not _dbg.no_wgrad_defer:
         ptrs = [t.data_ptr() for t in gw_list]
         if len(set(ptrs)) != len(ptrs):                    # one weight twice in ONE launch: its two `gw +=` would race -> one by one
             for a, x, gw in zip(a_list, x_list, gw_list):
@@ -301,7 +293,7 @@ def _wgrad_list(items):
     the optimizer's bucket, reductions parked (the queue is enabled): one cc_conv2d_wgrad_list call."""
     import ctypes
     E = engine()
-    if _NO_DEFER or not wgrad_queue.enabled or _NO_WGRAD_LIST:
+    if _dbg.no_wgrad_defer or not wgrad_queue.enabled or _dbg.no_wgrad_list:
         for a_list, x_list, gw_list, geo in items:
             B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc = geo
             _wgrad_group(a_list, x_list, gw_list, a_list[0], B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, 1)

@@ -117,7 +117,7 @@ class TT:
         parts = self.pend
         self.pend = []
         if self.t.dim() == 4 and all(p.dim() == 4 and p.dtype == torch.float32 and _dense(p) and p.shape == self.t.shape for p in parts) \
-                and (self.grad is None or _dense(self.grad)) and not ops._NO_SUM_N:
+                and (self.grad is None or _dense(self.grad)) and not ops._dbg.no_sum_n:
             acc = self.grad is not None
             if not acc:
                 self.grad = _new(self.t.shape, self.t)
@@ -286,7 +286,7 @@ class Tape:
                 return out
             gbs = [t for t, _ in tgt]
         geffs = [_new((B, C, H, W), ref) for _ in range(G)] if act != 0 else [None] * G
-        if act == 0 and acc and ops.wgrad_queue.enabled and not ops._NO_DEFER and not ops._NO_BIAS_TABLE:
+        if act == 0 and acc and ops.wgrad_queue.enabled and not ops._dbg.no_wgrad_defer and not ops._dbg.no_bias_table:
             # pure bias sums inside a trainer stage: parked, all layers of the stage in one launch (cc_bias_grad_table)
             for g, gb in zip(gs, gbs):
                 ops.wgrad_reduces.park_bias(g, gb, B, C, H, W, _bs(g))
@@ -308,7 +308,7 @@ class Tape:
             args = (n, ops._addr(a1), ops._addr(a2) if act != 0 else 0, ops._addr(a3) if act != 0 else 0,
                     ops._addr(a4) if want_b else 0, ws, B, C, H, W, gy_bs, _bs(ops_ys[0]) if act != 0 else C * H * W, C * H * W,
                     act, act_a, act_b, int(acc))
-            if want_b and acc and ops.wgrad_queue.enabled and not ops._NO_DEFER:
+            if want_b and acc and ops.wgrad_queue.enabled and not ops._dbg.no_wgrad_defer:
                 ptrs = [t.data_ptr() for t in ops_gb]
                 if ops.wgrad_reduces.targets.intersection(ptrs) or len(set(ptrs)) != len(ptrs):
                     ops.wgrad_reduces.flush()

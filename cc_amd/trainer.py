@@ -10,8 +10,6 @@ MI355X-first structure around that body:
   * forward + backward of a step are captured once into a hipGraph (static shapes, no host syncs on the path)
     and replayed, which removes the ~1.5 k kernel-launch and Python/autograd dispatch costs from the step.
 """
-import os
-
 import torch
 import torch.distributed as dist
 
@@ -181,11 +179,11 @@ class FlatAdam:
 
     @staticmethod
     def comm_active():
-        """collectives are issued when there is more than one rank -- or when CC_FORCE_COMM=1 asks for them on a one-rank
+        """collectives are issued when there is more than one rank -- or when config.debug.force_comm asks for them on a one-rank
         process group (exercises the RCCL / two-graph path on a single GPU: tests, tools)"""
         if not (dist.is_available() and dist.is_initialized()):
             return False
-        return dist.get_world_size() > 1 or os.environ.get("CC_FORCE_COMM", "0") == "1"
+        return dist.get_world_size() > 1 or config.debug.force_comm
 
     def all_reduce(self, lo=0, hi=None, async_op=False):
         """SUM-all-reduce flat_g[lo:hi] over the ranks (RCCL over xGMI; gloo in the CPU tests).  -> work handle or None."""
@@ -315,7 +313,7 @@ class CCTrainer:
         ndp = len(cut.get("dp", []))
         dp = [(t, gt) for (t, _), gt in zip(pairs[:ndp], g[:ndp]) if gt is not None]
         mf = [(t, gt) for (t, _), gt in zip(pairs[ndp:], g[ndp:]) if gt is not None]
-        ops.wgrad_queue.enabled = os.environ.get("CC_NO_WGRAD_QUEUE", "0") != "1"        # A/B switch (tools/)
+        ops.wgrad_queue.enabled = not config.debug.no_wgrad_queue
         if dp:
             torch.autograd.backward([t for t, _ in dp], [gt for _, gt in dp])
         ops.wgrad_queue.flush()              # the segment's gradients are complete before its all-reduce is issued
@@ -380,7 +378,7 @@ class CCTrainer:
         LF.check_finite()                   # the warm-up's own flags (and drop them: the captured step registers its own)
         # thread_local: only the capturing thread's calls are policed -- a process-group watchdog thread (multi-GPU runs)
         # polling its events must not invalidate the capture
-        mode = os.environ.get("CC_CAPTURE_MODE", "thread_local")
+        mode = config.debug.capture_mode
         self.graph = torch.cuda.CUDAGraph()
         if self.split_graphs:
             # two graphs sharing one memory pool: the collective of the first gradient segment is issued between them

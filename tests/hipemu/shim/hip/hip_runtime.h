@@ -390,6 +390,12 @@ static inline void hipemu_glds16x4(const void* src, void* dst) {
         memcpy(static_cast<char*>(dst) + 1024 * i + (size_t)hipemu::lane_id() * 16, static_cast<const char*>(src) + 1024 * i, 16);
 }
 #define CC_GLDS16X4(gsrc, lds_ptr) hipemu_glds16x4((gsrc), (lds_ptr))
+// ... with a uniform base and one per-lane byte offset per row (cc_common.h CC_GLDS16X4_S): row k reads base + voff[k] + 1024 k
+static inline void hipemu_glds16x4_s(const void* base, const unsigned* voff, void* dst) {
+    for (int i = 0; i < 4; i++)
+        memcpy(static_cast<char*>(dst) + 1024 * i + (size_t)hipemu::lane_id() * 16, static_cast<const char*>(base) + voff[i] + 1024 * i, 16);
+}
+#define CC_GLDS16X4_S(sbase, voff, lds_ptr) hipemu_glds16x4_s((sbase), (voff), (lds_ptr))
 // bounds-checked 16-byte LDS-DMA (cc_common.h CC_BUF_GLDS16): out-of-range lanes move zeros
 static inline void hipemu_buf_glds16(cc_buf_t r, unsigned voff, unsigned soff, void* dst) {
     char* d = static_cast<char*>(dst) + (size_t)hipemu::lane_id() * 16;

@@ -675,7 +675,8 @@ def check_conv_list(dev, tol=2e-5):
     a plain forward on another map size, a stride-2 data-gradient with the fused (sum + add) * relu'(mul) epilogue and a
     stride-1 data-gradient accumulating in place under LeakyReLU' -- against torch's convolutions."""
     import torch.nn.functional as F
-    from cc_amd import ops, launchlist as LL
+    from cc_amd import ops
+    from tools import launchlist as LL
     g = torch.Generator().manual_seed(5)
 
     def rn(*s):

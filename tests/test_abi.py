@@ -62,3 +62,26 @@ def test_product_library_reads_no_environment_and_keeps_no_timing_state():
     tools = build.build_tools()
     assert "getenv" in subprocess.run(["nm", "-D", tools], capture_output=True, text=True, check=True).stdout
     assert ctypes.CDLL(tools).cc_is_tools_build() == 1
+
+
+def test_product_package_reads_no_environment():
+    """The host glue takes its A/B switches from cc_amd.config.debug (set explicitly by tools/ab_env.py); the only environment
+    variable the package looks at is HIPCC, in the build helper."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "cc_amd")):
+        for f in files:
+            if f.endswith(".py") and f != "build.py":
+                src = open(os.path.join(dirpath, f)).read()
+                assert "os.environ" not in src and "getenv" not in src, f
+    from cc_amd import config
+    from tools import ab_env
+    saved = dict(vars(config.debug))
+    try:
+        got = ab_env.apply({"CC_NO_SUM_N": "1", "CC_FORCE_COMM": "1", "CC_CAPTURE_MODE": "relaxed", "CC_NO_WGRAD_LIST": "0"})
+        assert got == {"no_sum_n": True, "force_comm": True, "capture_mode": "relaxed"}
+        assert config.debug.no_sum_n and config.debug.force_comm and not config.debug.no_wgrad_list
+    finally:
+        for k in list(vars(config.debug)):
+            delattr(config.debug, k)
+        for k, v in saved.items():
+            setattr(config.debug, k, v)

@@ -65,6 +65,18 @@ def test_convs_winograd_fused_epilogue(monkeypatch):
     parity.check_convs("cpu", cases=parity.CONV_CASES_WINO, tcases=[], prepack=True)
 
 
+@pytest.mark.parametrize("tile", [1, 2])
+def test_convs_winograd_small_tile(monkeypatch, tile):
+    # the 32 x 32 instances of the Winograd kernel (wino.hip k_wino_f2x3_s): four waves (two workgroups per CU) / eight waves with the
+    # reduction halved inside the workgroup; every case with the whole reduction in the launch (fused epilogue), then sliced (split-K)
+    monkeypatch.setenv("CC_WINO_MINQ", "1")
+    monkeypatch.setenv("CC_WINO_SMALL", "2")
+    monkeypatch.setenv("CC_WINO_S_TILE", str(tile))
+    monkeypatch.setenv("CC_WINO_TRACE", "1")
+    parity.check_convs("cpu", cases=parity.CONV_CASES_WINO, tcases=[], prepack=True)
+    parity.check_conv_groups("cpu", cases=((2, 48, 16, 32, 64, 48, 1),))
+
+
 def test_convs_winograd_weight_gradient(monkeypatch):
     # the small test maps on the Winograd F(3x3, 2x2) weight-gradient kernel (wino_wgrad.hip): odd heights, channel counts that are
     # not multiples of 64, tile rows that are not multiples of the 8-tile chunks, several splits
@@ -137,14 +149,27 @@ def test_head_gradient_accumulators_match_the_engine_sums():
             + 0.1 * LF.smooth_loss([masks[1], masks[1]])          # (the same tensor at two positions of one term)
 
     want = torch.autograd.grad(total(), masks)
+    # repeated: the duplicate position used to share ONE launch with the first one ('=' and '+=' of unordered jobs: a race that lost
+    # a contribution in most, not all, runs); now it goes into a launch of its own
+    for _ in range(12):
+        LF.head_grads.begin()
+        try:
+            assert LF.head_grads.active
+            got = torch.autograd.grad(total(), masks)
+        finally:
+            LF.head_grads.end()
+        for a, b in zip(got, want):
+            assert float((a - b).abs().max()) <= 1e-6 * max(float(b.abs().max()), 1e-30), float((a - b).abs().max())
+    # a second backward through the same term would add into the accumulators twice: refused, not silently doubled
     LF.head_grads.begin()
     try:
-        assert LF.head_grads.active
-        got = torch.autograd.grad(total(), masks)
+        t = total()
+        torch.autograd.grad(t, masks, retain_graph=True)
+        import pytest
+        with pytest.raises(RuntimeError):
+            torch.autograd.grad(t, masks)
     finally:
         LF.head_grads.end()
-    for a, b in zip(got, want):
-        assert float((a - b).abs().max()) <= 1e-6 * max(float(b.abs().max()), 1e-30), float((a - b).abs().max())
 
 
 def test_cost_volume():

@@ -194,7 +194,7 @@ def test_step_is_bit_reproducible_in_deterministic_mode(use_graph, monkeypatch):
 
 def test_step_with_rccl_process_group_of_one(monkeypatch):
     """The multi-GPU code path on the one GPU a test box has: a 1-rank RCCL (backend 'nccl') process group with
-    CC_FORCE_COMM=1 -- parameter broadcast, the two hipGraphs with the asynchronous segment all-reduce between the replays,
+    config.debug.force_comm -- parameter broadcast, the two hipGraphs with the asynchronous segment all-reduce between the replays,
     the second all-reduce, Adam -- must reproduce the plain single-process step."""
     import socket
     import torch.distributed as dist
@@ -218,7 +218,8 @@ def test_step_with_rccl_process_group_of_one(monkeypatch):
         port = sk.getsockname()[1]
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
     monkeypatch.setenv("MASTER_PORT", str(port))
-    monkeypatch.setenv("CC_FORCE_COMM", "1")
+    from cc_amd import config as _cfg
+    monkeypatch.setattr(_cfg.debug, "force_comm", True)
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         tr, b1, b2, b3 = run()

@@ -1,0 +1,30 @@
+"""CC_* environment variables -> cc_amd.config.debug (the product package itself reads no environment variable).
+
+    import tools.ab_env; tools.ab_env.apply()
+
+Used by bench.py, tests/conftest.py and the A/B scripts (tools/gpu.sh ab ...).  Host-glue switches are listed here; the
+kernel-selection switches of the TOOLS build of the library (tools/README.md) are read by that library itself and only take
+effect when CC_LIB_PATH points at tools/_bin/libccengine_tools.so."""
+import os
+
+_FLAGS = {
+    "CC_NO_SLICE_GY": "no_slice_gy", "CC_NO_WGRAD_DEFER": "no_wgrad_defer", "CC_NO_SUM_N": "no_sum_n",
+    "CC_NO_BIAS_TABLE": "no_bias_table", "CC_NO_WGRAD_LIST": "no_wgrad_list", "CC_NO_WGRAD_QUEUE": "no_wgrad_queue",
+    "CC_FORCE_COMM": "force_comm",
+}
+
+
+def apply(env=None):
+    """-> dict of the switches that were set (for the bench line)."""
+    from cc_amd import config
+    env = os.environ if env is None else env
+    got = {}
+    for var, attr in _FLAGS.items():
+        if env.get(var, "0") == "1":
+            setattr(config.debug, attr, True)
+            got[attr] = True
+    if env.get("CC_CAPTURE_MODE"):
+        config.debug.capture_mode = got["capture_mode"] = env["CC_CAPTURE_MODE"]
+    if env.get("CC_LIB_PATH"):
+        config.debug.library_path = got["library_path"] = env["CC_LIB_PATH"]
+    return got

@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from cc_amd import synthetic as syn, trainer as T      # noqa: E402
 
-comm = os.environ.get("CC_FORCE_COMM", "0") == "1"
+from tools import ab_env                                # noqa: E402
+comm = bool(ab_env.apply().get("force_comm"))
 if comm:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29545")

@@ -4,14 +4,17 @@ different layers / networks packed into as few kernel launches as their tile con
 A problem is described once (static shapes, static buffers) as a 32-long record; a list of records is one C-ABI call.
 The reference runs its four networks one after the other (train.py:454-463) although they only share their input; on a
 256-CU device the deep, small-map layers of one network cannot fill the chip alone, the same layers next to another
-network's large-map layers can."""
+network's large-map layers can.
+
+Probe code (tools/merge_probe.py, one parity test): the measurement said packing does NOT pay on this chip
+(profiles/r03_merge_probe.txt), so the training step does not use it and the module lives here, not in the package."""
 import ctypes
 import struct
 
 import torch
 
-from ._lib import engine, STREAM
-from . import ops
+from cc_amd._lib import engine, STREAM
+from cc_amd import ops
 
 CL_LONGS = 32
 

@@ -12,7 +12,8 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from cc_amd import trainer as T, synthetic as syn, ops, launchlist as LL
+from cc_amd import trainer as T, synthetic as syn, ops
+from tools import launchlist as LL
 from cc_amd._lib import engine
 
 
