@@ -439,6 +439,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)     # nccl == RCCL on ROCm
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
+    from tools import ab_env
+    ab_switches = ab_env.apply()            # CC_* A/B variables -> cc_amd.config.debug, BEFORE the first engine() call (library path);
+    #                                         explicit: the package itself reads no environment variable
     from cc_amd import synthetic as syn, trainer as T, _lib
     eng = _lib.engine()
 
@@ -460,8 +463,6 @@ def main():
     batch = (batch_cpu[0].to(dev), [r.to(dev) for r in batch_cpu[1]], batch_cpu[2].to(dev), batch_cpu[3].to(dev))
     # measurement switches of the data-parallel step (tools/gpu_r3y.sh, gpu_r3z.sh): read HERE, by the measuring script -- the
     # product step (cc_amd/trainer.py) reads no environment variable
-    from tools import ab_env
-    ab_switches = ab_env.apply()            # CC_* A/B variables -> cc_amd.config.debug (explicit: the package reads no environment)
     if os.environ.get("CC_NO_HEAD_ACC", "0") == "1":                    # A/B: the loss terms return separate gradients, the engine adds them
         from cc_amd import loss_functions as _LF
         _LF.head_grads.enabled = False
@@ -470,6 +471,7 @@ def main():
         comm_debug["join"] = os.environ["CC_COMM_JOIN"]
     if os.environ.get("CC_COMM_PROBE"):
         comm_debug["probe"] = os.environ["CC_COMM_PROBE"]
+    ab_env.assert_applied()
     tr = T.CCTrainer(nets, cfg, use_graph=not args.no_graph,
                      split_graphs=None if args.split_graphs == "auto" else args.split_graphs == "1", comm_debug=comm_debug)
 

@@ -863,7 +863,7 @@ WinoPlan wino_plan(int B, int Cin, int H, int W, int M, int mult) {
     // reduction channels to amortise the workgroup's prologue / output transform, enough tiles to fill a 64-tile block
     const int TY = (H + 1) / 2, TX = (W + 1) / 2;
     const long Q = (long)B * TY * TX;
-    if (M < cctools::env_int("CC_WINO_MINM", 33) || Cin < cctools::env_int("CC_WINO_MINC", 24) || Q < cctools::env_int("CC_WINO_MINQ", 48)) return p;
+    if (M < cctools::env_int("CC_WINO_MINM", 32) || Cin < cctools::env_int("CC_WINO_MINC", 24) || Q < cctools::env_int("CC_WINO_MINQ", 48)) return p;
     // the raw-input path stages 16-byte pieces of aligned rows, one or two tile-row runs per wave (16 tiles)
     if (H < 2 || (W % 4) != 0 || !(TX >= 16 || TX == 8)) return p;
     if (Q > (1l << 30)) return p;
@@ -906,8 +906,8 @@ WinoPlan wino_plan(int B, int Cin, int H, int W, int M, int mult) {
             }
         }
     }
-    if (small_mode && blocks < cctools::env_int("CC_WINO_SMALL_BELOW", 400) && blocks_s <= (1l << 20)) {
-        const double sst = 0.01 * cctools::env_int("CC_WINO_S_STAGE", 31);      // shared CU: two workgroups advance one stage each per ~3 600 cycles
+    if (small_mode && blocks < cctools::env_int("CC_WINO_SMALL_BELOW", 3000) && blocks_s <= (1l << 20)) {
+        const double sst = 0.01 * cctools::env_int("CC_WINO_S_STAGE", 25);      // shared CU: two workgroups advance one stage each per ~3 600 cycles
         const double sal = 0.01 * cctools::env_int("CC_WINO_S_ALONE", 42);
         const double sfx = 0.01 * cctools::env_int("CC_WINO_S_FIXED", 100);
         const int only_tile = cctools::env_int("CC_WINO_S_TILE", 0);           // tools / tests: 1 = four-wave form only, 2 = eight-wave form wherever it can run

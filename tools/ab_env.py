@@ -28,3 +28,10 @@ def apply(env=None):
     if env.get("CC_LIB_PATH"):
         config.debug.library_path = got["library_path"] = env["CC_LIB_PATH"]
     return got
+
+
+def assert_applied():
+    """The library the engine actually loaded is the one CC_LIB_PATH asked for (apply() must run before the first engine() call)."""
+    from cc_amd import _lib, config
+    if config.debug.library_path:
+        assert os.path.samefile(_lib.engine().path, config.debug.library_path), (_lib.engine().path, config.debug.library_path)
