@@ -60,7 +60,7 @@ def build_nets(kind="oracle", impl=None, align_corners=False, flow=True, mask=Tr
     return [n for n in (disp, pose, msk, flo)]
 
 
-def cc_forward(nets, batch, cfg, impl=None, keep=False):
+def cc_forward(nets, batch, cfg, impl=None, keep=False, tap=None):
     """train.py:454-509 for the full CC configuration (all four nets).
 
     batch = (tgt[B,3,H,W], [4 refs], K[B,3,3], Kinv[B,3,3]).  Returns a dict with
@@ -70,9 +70,12 @@ def cc_forward(nets, batch, cfg, impl=None, keep=False):
     iw, lf = impl.inverse_warp, impl.loss_functions
     disp_net, pose_net, mask_net, flow_net = nets
     tgt, refs, K, Kinv = batch
-    disparities = disp_net(tgt)                                                    # :454
+    # tap (cc_step_keep): every network output passes through tap() on its way INTO the losses -- an identity whose hook sees the
+    # gradient of the loss path alone (a DispResNet6 / Back2Future level also feeds the next decoder level inside the network)
+    tp = (lambda ts: [tap(t) for t in ts]) if tap is not None else (lambda ts: ts)
+    disparities = tp(disp_net(tgt))                                                # :454
     depth = [1 / d for d in disparities]                                           # :458
-    pose = pose_net(tgt, refs)                                                     # :459
+    pose = tp([pose_net(tgt, refs)])[0]                                            # :459
     out = {}
     if mask_net is None or flow_net is None:
         # BASELINE config 2: DispResNet6 + PoseNetB6, no mask, photometric + edge-aware smoothness
@@ -83,8 +86,9 @@ def cc_forward(nets, batch, cfg, impl=None, keep=False):
         if keep:
             out.update(disparities=disparities, pose=pose)
         return out
-    exp_mask = mask_net(tgt, refs)                                                 # :460
+    exp_mask = tp(mask_net(tgt, refs))                                             # :460
     flow_fwd, flow_bwd, _ = flow_net(tgt, refs[1:3])                               # :463
+    flow_fwd, flow_bwd = tp(flow_fwd), tp(flow_bwd)
     cam_fwd = [iw.pose2flow(d.squeeze(1), pose[:, 2], K, Kinv) for d in depth]     # :470
     cam_bwd = [iw.pose2flow(d.squeeze(1), pose[:, 1], K, Kinv) for d in depth]     # :471
     target = lf.consensus_exp_masks(cam_fwd, cam_bwd, flow_fwd, flow_bwd, tgt, refs[2], refs[1],
@@ -128,3 +132,29 @@ def cc_step(nets, optimizer, batch, cfg, impl=None):
     out["loss"].backward()
     optimizer.step()
     return {k: float(v) for k, v in out.items() if k.startswith("loss")}
+
+
+KEEP_ORDER = ("disparities", "pose", "exp_mask", "flow_fwd", "flow_bwd")
+
+
+def cc_step_keep(nets, optimizer, batch, cfg, impl=None):
+    """cc_step() that also returns d loss / d (network outputs): the gradients the loss path sends into the four networks, in the
+    order KEEP_ORDER (lists flattened, scale 0 first) -- what bench.py feeds into the engine's network backward passes to tell a
+    difference that arises INSIDE a network's backward from one that arrives with its output gradients.  -> (losses, [grad or None])"""
+    for n in nets:
+        if n is not None:
+            n.train()
+    taps = []
+
+    def tap(t):
+        c = t.clone()                   # identity node between the network and the losses
+        taps.append(c)
+        if c.requires_grad:
+            c.retain_grad()
+        return c
+    out = cc_forward(nets, batch, cfg, impl, keep=True, tap=tap)
+    optimizer.zero_grad()
+    out["loss"].backward()
+    grads = [(t.grad.detach().clone() if t.grad is not None else None) for t in taps]      # tap order = KEEP_ORDER
+    optimizer.step()
+    return {k: float(v.detach() if torch.is_tensor(v) else v) for k, v in out.items() if k.startswith("loss")}, grads

@@ -606,6 +606,76 @@ def check_convs(dev, cases=CONV_CASES, tcases=CONVT_CASES, tol=2e-5, seed=0, pre
     ops.packs.reset()
 
 
+# Winograd launches that hold the WHOLE reduction (fused epilogue, no split-K) with the non-smooth epilogues the step uses: ReLU /
+# LeakyReLU (+ residual) in the forward kernel (EPI_LIN) and `(sum) * act'(y1)` in the data-gradient of the consumer (EPI_GRAD: the
+# producer's activation backward deferred into it).  (B, Cin, H, W, C1, C2, act, residual)
+CONV_CASES_WINO_ACT = [
+    (4, 64, 64, 208, 64, 64, "relu", True),        # 64 x 64 blocks (208 of them) + the 32 x 32 instances of the second layer's gradient
+    (4, 128, 32, 104, 128, 96, "lrelu", False),    # 32 x 32 blocks, four waves
+    (4, 256, 16, 52, 256, 128, "relu", True),      # 32 x 32 blocks, eight waves (the reduction halved inside the workgroup)
+    (2, 32, 64, 208, 32, 48, "lrelu", True),       # 32 output channels: one 32-row block
+]
+CONV_CASES_WINO_ACT_SMALL = [                      # emulator sizes
+    (2, 48, 8, 32, 40, 48, "relu", True),
+    (1, 64, 6, 32, 64, 32, "lrelu", False),
+]
+
+
+def check_convs_act_pinned(dev, cases=CONV_CASES_WINO_ACT, tol=2e-5):
+    """x -> y1 = act(conv1(x) + b1 [+ res]) -> y2 = conv2(y1) + b2, every gradient, with the activation derivative PINNED: among
+    millions of pre-activations a few lie within the summation-order noise of zero, and a ReLU / LeakyReLU derivative that falls the
+    other way there moves single gradient elements by O(1) in ANY two implementations.  The reference therefore takes its derivative
+    mask from the device's own y1 (> 0); the test asserts that the masks differ only where the reference's pre-activation is within
+    1e-5 of zero (relative to the largest), counts those elements, and holds every gradient to the tight bar.  Both forms of the
+    activation backward are run: as a pass of its own (the layer's output has a non-conv consumer) and deferred into the consumer's
+    data-gradient epilogue (defer / pre_act: the form the tape uses inside the networks)."""
+    import torch.nn.functional as F
+    from cc_amd import ops
+    g = torch.Generator().manual_seed(33)
+
+    def rn(*s):
+        return torch.randn(*s, generator=g)
+    report = []
+    for (B, Cin, H, W, C1, C2, act, hr) in cases:
+        slope = 0.0 if act == "relu" else 0.2
+        x0, w1, b1 = rn(B, Cin, H, W), rn(C1, Cin, 3, 3) * (1.5 / (3 * Cin ** 0.5)), rn(C1) * 0.3
+        w2, b2 = rn(C2, C1, 3, 3) * (1.5 / (3 * C1 ** 0.5)), rn(C2) * 0.3
+        r0 = rn(B, C1, H, W) if hr else None
+        go = rn(B, C2, H, W)
+        with torch.no_grad():
+            pre = F.conv2d(x0, w1, b1, 1, 1)
+            if hr:
+                pre = pre + r0
+        for deferred in ((False, True) if not hr else (False,)):      # (the deferred form has no residual operand: _Conv2dFn)
+            ops.packs.reset()
+            td = [leaf(t, dev) if t is not None else None for t in (x0, w1, b1, r0, w2, b2)]
+            if deferred:
+                y1 = ops.conv2d(td[0], td[1], td[2], 1, 1, act, None, 1.0, slope, defer=True)
+                y2 = ops.conv2d(y1, td[4], td[5], 1, 1, None, pre_act=act, pre_slope=slope)
+            else:
+                y1 = ops.conv2d(td[0], td[1], td[2], 1, 1, act, td[3], 1.0, slope)
+                y2 = ops.conv2d(y1, td[4], td[5], 1, 1, None)
+            g1 = torch.autograd.grad(y2, [t for t in td if t is not None], go.to(dev))
+            mask = (y1.detach().cpu() > 0)
+            flips = mask != (pre > 0)
+            nflip = int(flips.sum())
+            if nflip:
+                assert float(pre[flips].abs().max()) <= 1e-5 * float(pre.abs().max()), ("flip away from zero", float(pre[flips].abs().max()))
+            assert nflip <= 1e-4 * pre.numel(), (nflip, pre.numel())
+            tc = [leaf(t, "cpu") if t is not None else None for t in (x0, w1, b1, r0, w2, b2)]
+            p1 = F.conv2d(tc[0], tc[1], tc[2], 1, 1)
+            if hr:
+                p1 = p1 + tc[3]
+            y1c = torch.where(mask, p1, slope * p1)                  # the activation with the device's derivative mask
+            y2c = F.conv2d(y1c, tc[4], tc[5], 1, 1)
+            g0 = torch.autograd.grad(y2c, [t for t in tc if t is not None], go)
+            errs = [rel(y1, y1c), rel(y2, y2c)] + [rel(a, b) for a, b in zip(g1, g0)]
+            assert max(errs) < tol, ((B, Cin, H, W, C1, C2, act, hr), deferred, errs)
+            report.append(((B, Cin, H, W, C1, C2, act, hr, deferred), nflip, max(errs)))
+    ops.packs.reset()
+    return report
+
+
 def check_conv_groups(dev, tol=2e-5, prepack=True, cases=((2, 6, 9, 14, 20, 12, 1), (1, 3, 12, 20, 16, 24, 2), (2, 40, 5, 8, 136, 16, 1), (1, 32, 4, 16, 72, 8, 1))):
     """Grouped convolution chains (cc_conv2d_*_group: the parallel decoder / feature branches of Back2Future as one launch
     per pass) vs per-branch torch convs: conv(stride s, LeakyReLU, deferred activation backward) -> conv(LeakyReLU) -> conv,

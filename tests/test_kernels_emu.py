@@ -77,6 +77,24 @@ def test_convs_winograd_small_tile(monkeypatch, tile):
     parity.check_conv_groups("cpu", cases=((2, 48, 16, 32, 64, 48, 1),))
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2])
+def test_convs_winograd_nonsmooth_epilogues_unsplit(monkeypatch, tile):
+    # ReLU / LeakyReLU (+ residual) in the fused forward epilogue and the deferred activation backward in the data-gradient epilogue
+    # of launches that hold the whole reduction, with the activation derivative pinned (parity.check_convs_act_pinned): 64 x 64 blocks
+    # and both 32 x 32 instances
+    monkeypatch.setenv("CC_WINO_MINQ", "1")
+    if tile == 0:
+        monkeypatch.setenv("CC_WINO_SMALL", "0")
+        monkeypatch.setenv("CC_WINO_SPLIT_BELOW", "0")
+    else:
+        monkeypatch.setenv("CC_WINO_SMALL", "2")
+        monkeypatch.setenv("CC_WINO_S_TILE", str(tile))
+        monkeypatch.setenv("CC_WINO_S_STAGE", "1")       # (cost model: never slice the reduction across workgroups)
+        monkeypatch.setenv("CC_WINO_S_ALONE", "1")
+    rep = parity.check_convs_act_pinned("cpu", cases=parity.CONV_CASES_WINO_ACT_SMALL)
+    assert len(rep) == 3
+
+
 def test_convs_winograd_weight_gradient(monkeypatch):
     # the small test maps on the Winograd F(3x3, 2x2) weight-gradient kernel (wino_wgrad.hip): odd heights, channel counts that are
     # not multiples of 64, tile rows that are not multiples of the 8-tile chunks, several splits

@@ -82,6 +82,17 @@ def test_convs_winograd():
     parity.check_conv_groups("cuda", cases=((4, 96, 8, 26, 128, 96, 1),))
 
 
+def test_convs_winograd_nonsmooth_epilogues_at_product_sizes():
+    # the PRODUCT library at sizes the planner does not slice: ReLU / LeakyReLU + residual in the Winograd forward epilogue, the
+    # deferred activation backward in the data-gradient epilogue (EPI_GRAD), on the 64 x 64 and both 32 x 32 instances; activation
+    # derivative pinned to the device's mask, flips counted and shown to sit at |pre-activation| < 1e-5 (parity.check_convs_act_pinned)
+    from cc_amd import _lib
+    assert _lib.engine().fn["cc_is_tools_build"]() == 0
+    rep = parity.check_convs_act_pinned("cuda")
+    for case, nflip, err in rep:
+        print("pinned-activation case %s: %d derivative flips, worst error %.2e" % (case, nflip, err))
+
+
 def test_convs_winograd_padded_input(monkeypatch):
     # 8x26-style maps: forward / data-gradient on the Winograd kernel over a zero-padded copy of the input (product thresholds),
     # then small shapes steered there through the tools build

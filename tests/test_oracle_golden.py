@@ -236,3 +236,22 @@ def test_headline_size_step(golden_dir):
         sq = sum(float(p.grad.double().pow(2).sum()) for p in n.parameters() if p.grad is not None)
         want = float(g["%s.gradnorm.%s" % (tag, name)])
         assert abs(sq ** 0.5 - want) <= 1e-5 * want, (name, sq ** 0.5, want)
+
+
+def test_dispresnet6_gradient_is_ill_conditioned_in_the_reference_arithmetic():
+    """Why bench.py's whole-vector gradient figure sits at 5e-4 while losses and gradient norms agree to 1e-5:
+    the oracle (bit-identical to the reference, above) moved by 1e-7 relative input noise -- one unit in the last place -- changes
+    its own DispResNet6 parameter gradient by orders of magnitude more than PoseNetB6's or Back2Future's (BatchNorm batch statistics
+    over a handful of values per channel at the deep levels).  Two correct fp32 evaluations cannot agree better than that."""
+    import torch
+    from oracle import step as S
+    from cc_amd import synthetic as syn
+    from tools import grad_pin
+    torch.manual_seed(0)
+    nets = S.build_nets("oracle")
+    init_sd = [{k: v.clone() for k, v in n.state_dict().items()} for n in nets]
+    batch = syn.sample(2, 64, 128, seed=1)
+    _, og = S.cc_step_keep(nets, S.make_optimizer(nets, S.StepConfig()), batch, S.StepConfig())
+    disp, pose, mask, flow = grad_pin.conditioning(init_sd, batch, og)
+    assert disp > 1e-5 and disp > 100 * pose and disp > 50 * flow, (disp, pose, mask, flow)
+    assert pose < 1e-6 and flow < 1e-5, (pose, flow)
