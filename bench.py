@@ -533,10 +533,17 @@ def main():
     comm = tr.comm_stats() if use_dist else None
     rank_losses = None
     if use_dist:
-        lt = torch.tensor([float(losses["loss"])], device=dev, dtype=torch.float64)
+        lt = torch.tensor([float(losses["loss"]), step_ms["median"]], device=dev, dtype=torch.float64)
         allv = [torch.zeros_like(lt) for _ in range(world)]
         dist.all_gather(allv, lt)
-        rank_losses = [round(float(v.item()), 6) for v in allv]
+        rank_losses = [round(float(v[0].item()), 6) for v in allv]
+        if comm is not None:
+            # what the first real multi-GPU run needs to explain itself: every rank's own median step time (a straggler shows here,
+            # the MAX is the metric), and backward stage B with the 227 MB all-reduce in flight against the same stage with the
+            # collectives skipped (RCCL's workgroups take CUs from the MFMA kernels; measured AFTER the timed region and the parity
+            # gate -- the ranks' weights diverge in those few steps, nothing is reported from them but the stage time)
+            comm["rank_step_ms_median"] = [round(float(v[1].item()), 3) for v in allv]
+            comm["stage_b_ms"] = {"with_allreduce_in_flight": tr.stage_b_ms()}
     if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -545,6 +552,14 @@ def main():
     if rank == 0:
         log("timed %d steps: %.2f ms/step, loss %.6f" % (args.steps, 1e3 * dt / args.steps, loss_val))
     tr.check_finite()
+    if use_dist and comm is not None and tr.graph_b is not None and not tr.opt.comm_probe:
+        # backward stage B with the collectives skipped (see comm.stage_b_ms above): a few untimed steps
+        tr.opt.comm_probe, tr.stage_b_events = "skip", []
+        for _ in range(6):
+            tr.step(batch)
+        sync()
+        comm["stage_b_ms"]["collectives_skipped"] = tr.stage_b_ms()
+        tr.opt.comm_probe = ""
 
     kernels, roof = None, None
     if not args.no_kernel_timing:

@@ -194,6 +194,8 @@ class _WgradReduces:
             arr = (ctypes.c_long * len(self.bias_jobs))(*self.bias_jobs)
             engine().call("cc_bias_grad_table", ctypes.addressof(arr), len(self.bias_jobs) // 12, STREAM)
         if self.desc:
+            if _dbg.reduce_trace is not None:       # tools/reduce_bytes.py: who writes how many partial-slab bytes
+                _dbg.reduce_trace.extend(self.desc)
             arr = (ctypes.c_long * len(self.desc))(*self.desc)
             engine().call("cc_wgrad_reduce_table", ctypes.addressof(arr), len(self.desc) // 16, STREAM)
         self.desc, self.keep, self.targets, self.bias_jobs = [], [], set(), []

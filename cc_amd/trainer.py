@@ -283,6 +283,7 @@ class CCTrainer:
         self.split_graphs = (self.opt.comm_active() and two_segments) if split_graphs is None else bool(split_graphs)
         self.comm_events = []            # per step: (before wait 0, after wait 0, before wait 1, after wait 1) on the compute stream
         self.comm_standalone_ms = None   # calibrate_comm(): each segment's all-reduce alone, nothing to hide under
+        self.stage_b_events = []         # per step: events around the replay of backward stage B (two-graph form, comm_debug events)
         self.static_batch = None
         self.losses = None
         self.nan_flags = []
@@ -453,6 +454,13 @@ class CCTrainer:
         self.comm_standalone_ms = out
         return out
 
+    def stage_b_ms(self):
+        """median stream time of backward stage B over the recent steps (after a device synchronise), or None"""
+        if not self.stage_b_events:
+            return None
+        v = sorted(a.elapsed_time(b) for a, b in self.stage_b_events)
+        return round(v[len(v) // 2], 3)
+
     def comm_stats(self):
         """Exposed communication of the recent steps (call after a device synchronise): median stream time the compute stream
         spent waiting for each segment's all-reduce; `overlapped` = the standalone duration (calibrate_comm) minus that."""
@@ -488,7 +496,17 @@ class CCTrainer:
             self.graph.replay()
             if self.graph_b is not None:
                 reduce_dp()
-                self.graph_b.replay()
+                if self.comm_debug.get("events"):
+                    # stage B (backward of MaskNet6 + Back2Future) runs with the big segment's all-reduce in flight: RCCL's copy / reduce
+                    # workgroups compete with the MFMA kernels for CUs -- its stream time per step, to be read against the same stage
+                    # with the collectives skipped (bench.py: comm.stage_b_ms)
+                    eb = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    eb[0].record()
+                    self.graph_b.replay()
+                    eb[1].record()
+                    self.stage_b_events = (self.stage_b_events + [eb])[-64:]
+                else:
+                    self.graph_b.replay()
             losses = self.losses
         else:
             losses = self._fwd_bwd(batch, between=reduce_dp if opt.comm_active() else None)

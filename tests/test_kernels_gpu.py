@@ -159,7 +159,13 @@ def test_convs_full_size_thin_layers():
     # the real thin layers of the 256x832 step (default thresholds): DispResNet6 iconv1 / head, MaskNet6 conv1, B2F feat1
     cases = [(2, 17, 256, 832, 16, 3, 1, 1, "relu", True, False), (2, 16, 256, 832, 1, 3, 1, 1, "sigmoid", True, False),
              (2, 15, 256, 832, 16, 7, 2, 3, "relu", True, False), (2, 3, 256, 832, 16, 3, 2, 1, "lrelu", True, False),
-             (2, 32, 128, 416, 32, 7, 1, 3, "relu", True, False)]
+             (2, 32, 128, 416, 32, 7, 1, 3, "relu", True, False),
+             # the 2-channel flow heads of Back2Future (k_conv_thinm<2> forward, k_wgrad_thinm<2> weight gradient, k_conv_thinc<2>
+             # data-gradient of the layer behind them) and MaskNet6's 4-channel heads at their product sizes and thresholds
+             (4, 32, 64, 208, 2, 3, 1, 1, None, True, False), (4, 2, 64, 208, 32, 3, 1, 1, "lrelu", True, False),
+             (4, 32, 128, 416, 4, 3, 1, 1, "sigmoid", True, False)]
+    from cc_amd import _lib
+    assert _lib.engine().fn["cc_is_tools_build"]() == 0          # the product library, its own thresholds
     parity.check_convs("cuda", cases=cases, tcases=[(2, 48, 64, 208, 16, 4, 2, 1, 0, "relu")], tol=5e-5)
 
 
