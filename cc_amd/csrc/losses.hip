@@ -76,6 +76,52 @@ __global__ __launch_bounds__(256) void k_pyramid_tile(const float* __restrict__ 
     }
 }
 
+// ... of up to PYR_MAXIMG images of one size in ONE launch (the target frame and the reference frames of a step): blockIdx.z = image
+constexpr int PYR_MAXIMG = 8;
+struct PyrMulti { const float* in[PYR_MAXIMG]; float* out[PYR_MAXIMG]; };
+__global__ __launch_bounds__(256) void k_pyramid_tile_multi(PyrMulti t, int nlevels, int planes, int H, int W) {
+    constexpr int TS = 36;
+    __shared__ __attribute__((aligned(16))) float tile[32 * TS];
+    const float* in = t.in[blockIdx.z];
+    float* out = t.out[blockIdx.z];
+    const int tw = W / 32;
+    const int ty = blockIdx.x / tw, tx = blockIdx.x - ty * tw;
+    const int pl = blockIdx.y;
+    const float* src = in + (size_t)pl * H * W + (size_t)(ty * 32) * W + tx * 32;
+    {
+        const int r = threadIdx.x >> 3, q = threadIdx.x & 7;
+        *(float4*)(tile + r * TS + 4 * q) = *(const float4*)(src + (size_t)r * W + 4 * q);
+    }
+    __syncthreads();
+    size_t off = 0;
+    for (int l = 1; l < nlevels; l++) {           // (the summation order of k_pyramid_tile: bit-identical results)
+        const int k = 1 << l, n = 32 >> l;
+        const int h = H >> l, w = W >> l;
+        if ((int)threadIdx.x < n * n) {
+            const int oy = threadIdx.x / n, ox = threadIdx.x - oy * n;
+            float s = 0.f;
+            if (k >= 4) {
+                for (int y = 0; y < k; y++) {
+                    const float4* row = (const float4*)(tile + (oy * k + y) * TS + ox * k);
+                    for (int x4 = 0; x4 < k / 4; x4 += 2) {
+                        const float4 a = row[x4];
+                        const float4 b = (x4 + 1 < k / 4) ? row[x4 + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        s += a.x; s += a.y; s += a.z; s += a.w;
+                        if (x4 + 1 < k / 4) { s += b.x; s += b.y; s += b.z; s += b.w; }
+                    }
+                }
+            } else {
+                for (int y = 0; y < k; y++) {
+                    const float2 a = *(const float2*)(tile + (oy * k + y) * TS + ox * k);
+                    s += a.x; s += a.y;
+                }
+            }
+            out[off + (size_t)pl * h * w + (size_t)(ty * n + oy) * w + tx * n + ox] = s / (float)(k * k);
+        }
+        off += (size_t)planes * h * w;
+    }
+}
+
 // ------------------------------------------------------------------ occlusion masks
 // loss_functions.py:343-352 occlusion_masks: occ = sum_c(f_fw + f_bw) > 0.08*(|f_fw|^2 + |f_bw|^2) + 1
 // (signed sum; occ_fw == occ_bw).  Output is (1 - occ), the factor the losses multiply by.
@@ -402,11 +448,15 @@ __global__ __launch_bounds__(256) void k_sum_refs_scale_jobs(JobTab t, int R, in
 
 // edge-aware smoothness, all levels: slots 0 img level [B,3,H,W], 1 pred [B,C,H,W], 2 gpred (or 0), 3 partials of this job
 // table B = batch * C (one (image, channel) plane per "batch item")
+// C == 0: the jobs of SEVERAL terms in one launch (train.py:497-501: depth, flow_fwd, flow_bwd, exp_mask -- 1 / 2 / 2 / 4 channels);
+// slot 4 then holds the job's channel count and t.B the batch size
 __global__ __launch_bounds__(256) void k_edge_smooth_jobs(JobTab t, int C, float gscale) {
     __shared__ float red[4];
     CC_JOB_PIXEL(t, j, bc, p, HW)
-    const int H = t.H[j], W = t.W[j], b = bc / C;
-    const float inv_nx = 1.f / ((float)t.B * (H - 1) * W), inv_ny = 1.f / ((float)t.B * H * (W - 1));
+    const int Cj = C ? C : (int)t.slot[j][4];
+    const int planes = C ? t.B : t.B * Cj;
+    const int H = t.H[j], W = t.W[j], b = bc / Cj;
+    const float inv_nx = 1.f / ((float)planes * (H - 1) * W), inv_ny = 1.f / ((float)planes * H * (W - 1));
     float part[1] = {0.f};
     if (p < HW) {
         const int y = p / W, x = p - y * W;
@@ -556,6 +606,23 @@ int cc_pyramid_build(const float* level0, float* out_packed, int nlevels, int pl
                            out_packed + off, H, W, h, w, planes);
         off += (size_t)planes * h * w;
     }
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_pyramid_build_multi(const long* level0_host, const long* out_packed_host, int nimg, int nlevels, int planes, int H, int W,
+                           void* stream) {
+    if (!level0_host || !out_packed_host || nimg < 1 || nimg > PYR_MAXIMG || nlevels < 2 || nlevels > 6 || planes <= 0 || H % 32 != 0 ||
+        W % 32 != 0 || H <= 0 || W <= 0)
+        return CC_ERR_ARG;
+    PyrMulti t = {};
+    for (int i = 0; i < nimg; i++) {
+        if (level0_host[i] % 16 != 0 || !out_packed_host[i]) return CC_ERR_ARG;
+        t.in[i] = reinterpret_cast<const float*>(level0_host[i]);
+        t.out[i] = reinterpret_cast<float*>(out_packed_host[i]);
+    }
+    hipLaunchKernelGGL(k_pyramid_tile_multi, dim3((unsigned)((H / 32) * (W / 32)), (unsigned)planes, (unsigned)nimg), dim3(256), 0,
+                       (hipStream_t)stream, t, nlevels, planes, H, W);
     CC_CHECK_LAUNCH();
     return CC_OK;
 }
@@ -742,8 +809,23 @@ size_t cc_loss_jobs_num_blocks(const long* jobs, int njobs, int planes) {
 int cc_edge_smooth_fwd_bwd_jobs(const long* jobs, int njobs, int B, int C, float* partials, float* loss_accum, float gscale,
                                 void* stream) {
     ccjobs::JobTab t;
-    const int nblk = loss_jobs_tab(t, jobs, njobs, B * C);
-    if (nblk <= 0 || C <= 0) return CC_ERR_ARG;
+    int nblk;
+    if (C > 0) {
+        nblk = loss_jobs_tab(t, jobs, njobs, B * C);
+    } else {
+        // per-job channel counts (slot 4): job j owns B * C_j * ceil(H W / 256) blocks
+        if (C < 0 || !jobs || njobs <= 0 || njobs > ccjobs::MAXJOBS || B <= 0) return CC_ERR_ARG;
+        nblk = ccjobs::fill(t, jobs, njobs, B, ccjobs::pix_blocks);
+        int tot = 0;
+        for (int j = 0; j < njobs; j++) {
+            const int cj = (int)t.slot[j][4];
+            if (cj <= 0) return CC_ERR_ARG;
+            tot += B * cj * ccjobs::pix_blocks(t.H[j], t.W[j]);
+            t.blk_end[j] = tot;
+        }
+        nblk = tot;
+    }
+    if (nblk <= 0) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_edge_smooth_jobs, dim3((unsigned)nblk), dim3(256), 0, s, t, C, gscale);
     hipLaunchKernelGGL(k_reduce_add, dim3(1), dim3(256), 0, s, (const float*)partials, nblk, 1.0f, loss_accum);

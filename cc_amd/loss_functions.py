@@ -152,6 +152,43 @@ class _PyramidCache:
     def clear(self):
         self.items.clear()
 
+    def _entry(self, img):
+        key = id(img)
+        ent = self.items.get(key)
+        if ent is None or ent[0] is not img or ent[1] != img._version:
+            ent = (img, img._version, {})
+            self.items[key] = ent
+            while len(self.items) > self.cap:
+                self.items.pop(next(iter(self.items)))
+        return ent
+
+    def prefetch(self, imgs):
+        """The 2^l pyramids of several same-sized frames (the target and the reference frames of a step) in ONE launch
+        (cc_pyramid_build_multi) instead of one per frame at its first use.  Frames that do not qualify are left to get()."""
+        import ctypes
+        todo = []
+        for img in imgs:
+            H, W = img.shape[2], img.shape[3]
+            if H % 32 or W % 32 or img.dtype != torch.float32 or not img.is_contiguous() or img.data_ptr() % 16:
+                continue
+            ent = self._entry(img)
+            if (H >> 1, W >> 1) not in ent[2]:
+                todo.append((img, ent))
+        if len(todo) < 2 or len(todo) > 8 or len({tuple(i.shape) for i, _ in todo}) != 1:
+            return
+        B, C, H, W = todo[0][0].shape
+        sizes = [(H >> k, W >> k) for k in range(1, 6)]
+        n = sum(B * C * a * b for a, b in sizes)
+        packed = [torch.empty(n, device=todo[0][0].device, dtype=torch.float32) for _ in todo]
+        src = (ctypes.c_long * len(todo))(*[i.detach().data_ptr() for i, _ in todo])
+        dst = (ctypes.c_long * len(todo))(*[p.data_ptr() for p in packed])
+        engine().call("cc_pyramid_build_multi", ctypes.addressof(src), ctypes.addressof(dst), len(todo), 6, B * C, H, W, STREAM)
+        for (img, ent), pk in zip(todo, packed):
+            off = 0
+            for a, b in sizes:
+                ent[2][(a, b)] = pk[off:off + B * C * a * b].view(B, C, a, b)
+                off += B * C * a * b
+
     def get(self, img, h, w):
         H, W = img.shape[2], img.shape[3]
         if (h, w) == (H, W):
@@ -991,6 +1028,31 @@ def edge_aware_smoothness_loss(img, pred_disp):
         nb = E.call("cc_elem_num_blocks", h * w) * B * C
         E.call("cc_edge_smooth_fwd_bwd", im, p, g, _empty(nb, p), acc, 1.0, B, C, h, w, STREAM)
     return _PerScaleFn.apply(launch, *pred_disp)
+
+
+def edge_aware_smoothness_sum(img, pred_lists):
+    """sum(edge_aware_smoothness_loss(img, preds) for preds in pred_lists) -- train.py:497-501's four terms (depth, flow_fwd,
+    flow_bwd, exp_mask) as ONE job table: one launch + one reduction instead of four of each, one gradient-scaling launch in the
+    backward pass.  Engine extension (cc_amd.trainer.cc_forward); same per-term arithmetic, the partial sums of all terms are added
+    in one fixed order."""
+    flat = [p for preds in pred_lists for p in preds]
+    if len(flat) > MAX_JOBS or len({p.shape[0] for p in flat}) != 1:
+        t = None
+        for preds in pred_lists:
+            v = edge_aware_smoothness_loss(img, preds)
+            t = v if t is None else t + v
+        return t
+    E = engine()
+
+    def issue(ps, gs, acc):
+        B = ps[0].shape[0]
+        offs, tot = _partials_for([p.shape for p in ps], lambda shp: shp[0] * shp[1])
+        part = _empty(tot, ps[0])
+        jb = _Jobs()
+        for p, g, o in zip(ps, gs, offs):
+            jb.add([pyramid_cache.get(img, p.shape[2], p.shape[3]), p, g, _off(part, o), p.shape[1]], p.shape[2], p.shape[3])
+        E.call("cc_edge_smooth_fwd_bwd_jobs", jb.pack(), len(jb), B, 0, part, acc, 1.0, STREAM)
+    return _ScaleJobsFn.apply(issue, *flat)
 
 
 def smooth_loss(pred_disp):

@@ -69,6 +69,7 @@ def cc_forward(nets, batch, cfg, keep=False, cut=None):
                 outs.append(t)
         return outs
 
+    LF.pyramid_cache.prefetch([tgt] + list(refs))        # the frames' scale pyramids (every loss pools them): one launch for all five
     disparities = _cut("dp", list(disp_net(tgt)))                                      # :454
     depth = LF.reciprocal_levels(disparities)                                          # :458  [1 / d for d in disparities]
     pose = _cut("dp", [pose_net(tgt, refs)])[0]                                        # :459
@@ -96,8 +97,7 @@ def cc_forward(nets, batch, cfg, keep=False, cut=None):
     if cfg.smoothness_type == "regular":                                               # :497-501
         l3s = [LF.smooth_loss(depth), LF.smooth_loss(flow_fwd), LF.smooth_loss(flow_bwd), LF.smooth_loss(exp_mask)]
     else:
-        l3s = [LF.edge_aware_smoothness_loss(tgt, depth), LF.edge_aware_smoothness_loss(tgt, flow_fwd),
-               LF.edge_aware_smoothness_loss(tgt, flow_bwd), LF.edge_aware_smoothness_loss(tgt, exp_mask)]
+        l3s = [LF.edge_aware_smoothness_sum(tgt, [depth, flow_fwd, flow_bwd, exp_mask])]      # the four terms, one job table
     with torch.no_grad():
         l3 = torch.stack(l3s).sum()                                                    # reported; the total below takes the terms
     l4 = LF.photometric_flow_loss(tgt, refs[1:3], [flow_bwd, flow_fwd], flow_exp_mask,

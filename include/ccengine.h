@@ -150,6 +150,11 @@ size_t cc_elem_num_blocks(int n);
 int cc_adaptive_avg_pool(const float* in, float* out, int planes, int H, int W, int h, int w, void* stream);
 /* the same for levels 1..nlevels-1 (sizes H>>l x W>>l), packed back to back in out_packed */
 int cc_pyramid_build(const float* level0, float* out_packed, int nlevels, int planes, int H, int W, void* stream);
+/* ... of nimg (<= 8) same-sized images in one launch: the target frame and the reference frames of a training step (each loss pools
+ * them per scale, loss_functions.py:36-37,89-90).  level0_host / out_packed_host: HOST arrays of nimg device addresses; H, W
+ * multiples of 32, 2 <= nlevels <= 6.  Bit-identical to cc_pyramid_build per image. */
+int cc_pyramid_build_multi(const long* level0_host, const long* out_packed_host, int nimg, int nlevels, int planes, int H, int W,
+                           void* stream);
 
 /* loss_functions.py:343-352 occlusion_masks -> (1 - occ) [B,1,H,W] (occ_fw == occ_bw) */
 int cc_flow_noocc(const float* flow_bw, const float* flow_fw, float* out, int B, int H, int W, void* stream);
@@ -416,7 +421,8 @@ int cc_ssim_err_fwd_jobs(const long* jobs, int njobs, int B, float wssim, const 
  *   cc_consensus_target_jobs  slots: err_cam_fwd, err_cam_bwd, err_flow_fwd, valid_cam_fwd, valid_cam_bwd, target (:189-193)
  *   cc_sum_refs_scale_jobs    slots: gd_all [R][B][HW] (or 0), gdepth [B][HW], gmask [B][MC][HW] (or 0), scales (MC floats):
  *                             gdepth = sum_r gd_all[r]; gmask[:, c] *= scales[c]
- *   cc_edge_smooth_fwd_bwd_jobs  slots: img level, pred [B,C,H,W], gpred (or 0), this job's partials  (:287-319, all scales)
+ *   cc_edge_smooth_fwd_bwd_jobs  slots: img level, pred [B,C,H,W], gpred (or 0), this job's partials  (:287-319, all scales);
+ *                             C = 0: the jobs of several terms share the launch (train.py:497-501), slot 4 = the job's channel count
  *   cc_bce_ones_fwd_bwd_jobs     slots: mask, gmask (or 0), partials; planes = B * C                  (:148-155)
  *   cc_consensus_bce_fwd_bwd_jobs slots: exp_mask, census_bwd, census_fwd, tgt_bwd, tgt_fwd, gmask (or 0), partials (:221-261)
  *   The three losses expect the per-job partial areas back to back starting at `partials` (cc_loss_jobs_num_blocks floats in

@@ -172,6 +172,11 @@ def check_losses(dev, B=2, H=64, W=96, smooth=0):
         assert torch.isnan(LF.smooth_loss(a[nm])) and torch.isnan(L.smooth_loss(o[nm]))
         _cmp("edge_aware_smoothness_loss " + nm, LF.edge_aware_smoothness_loss(a["tgt"], a[nm]),
              L.edge_aware_smoothness_loss(o["tgt"], o[nm]), a[nm], o[nm])
+    # the four smoothness terms of the training step as ONE job table (engine extension, cc_amd.trainer.cc_forward)
+    a, o = _pyr(dev, B, H, W, smooth)
+    _cmp("edge_aware_smoothness_sum", LF.edge_aware_smoothness_sum(a["tgt"], [a["depth"], a["ff"], a["fb"], a["mask"]]),
+         sum(L.edge_aware_smoothness_loss(o["tgt"], o[nm]) for nm in ("depth", "ff", "fb", "mask")),
+         a["depth"] + a["ff"] + a["fb"] + a["mask"], o["depth"] + o["ff"] + o["fb"] + o["mask"])
     a, o = _pyr(dev, B, H, W, smooth)
     with torch.no_grad():
         cf1 = [IW.pose2flow(d[:, 0], a["pose"][:, 2], a["K"], a["Kinv"]) for d in a["depth"]]
@@ -229,6 +234,22 @@ def check_pyramid(dev):
         lv = packed[off:off + 6 * h * w].view(2, 3, h, w).cpu()
         assert float((lv - torch.nn.functional.adaptive_avg_pool2d(x, (h, w))).abs().max()) < 1e-6
         off += 6 * h * w
+    # the frames of a step in ONE launch (loss_functions.pyramid_cache.prefetch -> cc_pyramid_build_multi): bit-identical to the
+    # per-image launch, and what get() then returns
+    from cc_amd import loss_functions as LF
+    frames = [f.to(dev) for f in syn.frames(2, 64, 96, seed=12, n_frames=3)]
+    LF.pyramid_cache.clear()
+    LF.pyramid_cache.prefetch(frames)
+    for f in frames:
+        single = torch.empty_like(packed)
+        engine().call("cc_pyramid_build", f, single, 6, 6, 64, 96, STREAM)
+        off = 0
+        for l in (1, 2, 3, 4, 5):
+            h, w = 64 >> l, 96 >> l
+            assert (h, w) in LF.pyramid_cache.items[id(f)][2], "prefetch did not fill the cache"
+            assert torch.equal(LF.pyramid_cache.get(f, h, w), single[off:off + 6 * h * w].view(2, 3, h, w))
+            off += 6 * h * w
+    LF.pyramid_cache.clear()
 
 
 def check_warps_bit_exact_vs_golden(dev, golden_dir):
