@@ -448,6 +448,20 @@ __global__ __launch_bounds__(256) void k_sum_refs_scale_jobs(JobTab t, int R, in
 
 // edge-aware smoothness, all levels: slots 0 img level [B,3,H,W], 1 pred [B,C,H,W], 2 gpred (or 0), 3 partials of this job
 // table B = batch * C (one (image, channel) plane per "batch item")
+// the edge weights of one pyramid level, once per (image, scale): slots 0 img level [B,3,H,W], 1 out [B,2,H,W] = (w(p, p + 1),
+// w(p, p + W)), 0 beyond the last column / row.  The smoothness terms of a step (depth, two flows, the 4-channel masks: 9 planes per
+// image and scale) share them instead of evaluating exp(-|dI| / 3) four times per pixel and plane (same expression, same bits).
+__global__ __launch_bounds__(256) void k_edge_weights_jobs(JobTab t) {
+    CC_JOB_PIXEL(t, j, b, p, HW)
+    if (p >= HW) return;
+    const int W = t.W[j], H = t.H[j];
+    const int y = p / W, x = p - y * W;
+    const float* im = ccjobs::ptr<const float>(t, j, 0) + (size_t)b * 3 * HW;
+    float* o = ccjobs::ptr<float>(t, j, 1) + (size_t)b * 2 * HW;
+    o[p] = (x + 1 < W) ? edge_w(im, HW, p, p + 1) : 0.f;
+    o[HW + p] = (y + 1 < H) ? edge_w(im, HW, p, p + W) : 0.f;
+}
+
 // C == 0: the jobs of SEVERAL terms in one launch (train.py:497-501: depth, flow_fwd, flow_bwd, exp_mask -- 1 / 2 / 2 / 4 channels);
 // slot 4 then holds the job's channel count and t.B the batch size
 __global__ __launch_bounds__(256) void k_edge_smooth_jobs(JobTab t, int C, float gscale) {
@@ -463,27 +477,29 @@ __global__ __launch_bounds__(256) void k_edge_smooth_jobs(JobTab t, int C, float
         const float* im = ccjobs::ptr<const float>(t, j, 0) + (size_t)b * 3 * HW;
         const float* pr = ccjobs::ptr<const float>(t, j, 1) + (size_t)bc * HW;
         float* gpred = ccjobs::ptr<float>(t, j, 2);
+        // slot 5 (optional): the level's edge weights [B,2,H,W] from k_edge_weights_jobs -- four loads instead of 24 + four exp()
+        const float* wg = t.slot[j][5] ? ccjobs::ptr<const float>(t, j, 5) + (size_t)b * 2 * HW : nullptr;
         const float v = pr[p];
         float g = 0.f;
         if (y + 1 < H) {
             const float d = v - pr[p + W];
-            const float w = edge_w(im, HW, p, p + W);
+            const float w = wg ? wg[HW + p] : edge_w(im, HW, p, p + W);
             part[0] += fabsf(d) * w * inv_nx;
             g += sgn(d) * w * inv_nx;
         }
         if (y > 0) {
             const float d = pr[p - W] - v;
-            g -= sgn(d) * edge_w(im, HW, p - W, p) * inv_nx;
+            g -= sgn(d) * (wg ? wg[HW + p - W] : edge_w(im, HW, p - W, p)) * inv_nx;
         }
         if (x + 1 < W) {
             const float d = v - pr[p + 1];
-            const float w = edge_w(im, HW, p, p + 1);
+            const float w = wg ? wg[p] : edge_w(im, HW, p, p + 1);
             part[0] += fabsf(d) * w * inv_ny;
             g += sgn(d) * w * inv_ny;
         }
         if (x > 0) {
             const float d = pr[p - 1] - v;
-            g -= sgn(d) * edge_w(im, HW, p - 1, p) * inv_ny;
+            g -= sgn(d) * (wg ? wg[p - 1] : edge_w(im, HW, p - 1, p)) * inv_ny;
         }
         if (gpred) gpred[(size_t)bc * HW + p] = g * gscale;
     }
@@ -829,6 +845,15 @@ int cc_edge_smooth_fwd_bwd_jobs(const long* jobs, int njobs, int B, int C, float
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_edge_smooth_jobs, dim3((unsigned)nblk), dim3(256), 0, s, t, C, gscale);
     hipLaunchKernelGGL(k_reduce_add, dim3(1), dim3(256), 0, s, (const float*)partials, nblk, 1.0f, loss_accum);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
+int cc_edge_weights_jobs(const long* jobs, int njobs, int B, void* stream) {
+    ccjobs::JobTab t;
+    const int nblk = loss_jobs_tab(t, jobs, njobs, B);
+    if (nblk <= 0) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_edge_weights_jobs, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, t);
     CC_CHECK_LAUNCH();
     return CC_OK;
 }

@@ -189,6 +189,22 @@ class _PyramidCache:
                 ent[2][(a, b)] = pk[off:off + B * C * a * b].view(B, C, a, b)
                 off += B * C * a * b
 
+    def edge_weights(self, img, sizes):
+        """{(h, w): [B,2,h,w] edge weights of the pooled image} for the given level sizes -- computed once per (image, scale) by ONE
+        cc_edge_weights_jobs launch for all missing levels and shared by every smoothness term of the step."""
+        ent = self._entry(img)
+        miss = [hw for hw in dict.fromkeys(sizes) if ("ew",) + hw not in ent[2]]
+        if miss:
+            B = img.shape[0]
+            jb = _Jobs()
+            for (h, w) in miss:
+                lv = self.get(img, h, w)
+                out = torch.empty(B, 2, h, w, device=lv.device, dtype=torch.float32)
+                ent[2][("ew", h, w)] = out
+                jb.add([lv, out], h, w)
+            engine().call("cc_edge_weights_jobs", jb.pack(), len(jb), B, STREAM)
+        return {hw: ent[2][("ew",) + hw] for hw in sizes}
+
     def get(self, img, h, w):
         H, W = img.shape[2], img.shape[3]
         if (h, w) == (H, W):
@@ -1049,8 +1065,10 @@ def edge_aware_smoothness_sum(img, pred_lists):
         offs, tot = _partials_for([p.shape for p in ps], lambda shp: shp[0] * shp[1])
         part = _empty(tot, ps[0])
         jb = _Jobs()
+        ew = pyramid_cache.edge_weights(img, [(p.shape[2], p.shape[3]) for p in ps]) if img.shape[1] == 3 else {}
         for p, g, o in zip(ps, gs, offs):
-            jb.add([pyramid_cache.get(img, p.shape[2], p.shape[3]), p, g, _off(part, o), p.shape[1]], p.shape[2], p.shape[3])
+            hw = (p.shape[2], p.shape[3])
+            jb.add([pyramid_cache.get(img, hw[0], hw[1]), p, g, _off(part, o), p.shape[1], ew.get(hw)], hw[0], hw[1])
         E.call("cc_edge_smooth_fwd_bwd_jobs", jb.pack(), len(jb), B, 0, part, acc, 1.0, STREAM)
     return _ScaleJobsFn.apply(issue, *flat)
 

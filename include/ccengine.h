@@ -439,6 +439,10 @@ int cc_sum_refs_scale_jobs(const long* jobs, int njobs, int B, int R, int MC, vo
 size_t cc_loss_jobs_num_blocks(const long* jobs, int njobs, int planes);
 int cc_edge_smooth_fwd_bwd_jobs(const long* jobs, int njobs, int B, int C, float* partials, float* loss_accum, float gscale,
                                 void* stream);
+/* the edge weights exp(-mean_c |dI| ) of loss_functions.py:296-306 once per (image, scale): slots img level [B,3,H,W], out [B,2,H,W]
+ * = (weight of the pair (p, p + 1), of (p, p + W)).  A job of cc_edge_smooth_fwd_bwd_jobs with this tensor in slot 5 reads the four
+ * weights of a pixel instead of recomputing them per pixel and plane: same expression, bit-identical losses and gradients. */
+int cc_edge_weights_jobs(const long* jobs, int njobs, int B, void* stream);
 int cc_bce_ones_fwd_bwd_jobs(const long* jobs, int njobs, int planes, float* partials, float* loss_accum, float gscale, void* stream);
 int cc_consensus_bce_fwd_bwd_jobs(const long* jobs, int njobs, int B, float* partials, float* loss_accum, float thresh, float wbce,
                                   float gscale, void* stream);
