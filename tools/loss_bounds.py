@@ -45,12 +45,11 @@ def main():
     for k in KERNELS:
         dk = next((n for n in dur if n == k or n.startswith(k + "<")), None)
         tk = next((n for n in tr if n == k or n.startswith(k + "<")), None)
-        sk = next((n for n in sqr if n == k or n.startswith(k + "<") or k.startswith(n)), None)
+        sk = next((n for n in sqr if n == k or n.startswith(k + "<")), None)
         if not dk:
             continue
         us = dur[dk][0]
         mb = tr[tk]["hbm_bytes_per_launch"] / 1e6 if tk else float("nan")
-        tbs = mb / us / 1e3 * 1e3 / 1e3 if tk else float("nan")       # MB / us = TB/s
         tbs = mb / us
         c = sqr.get(sk, {})
         wc = c.get("WAVE_CYCLES", 0) or float("nan")
