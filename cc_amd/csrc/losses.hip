@@ -464,15 +464,25 @@ __global__ __launch_bounds__(256) void k_edge_weights_jobs(JobTab t) {
 
 // C == 0: the jobs of SEVERAL terms in one launch (train.py:497-501: depth, flow_fwd, flow_bwd, exp_mask -- 1 / 2 / 2 / 4 channels);
 // slot 4 then holds the job's channel count and t.B the batch size
+// PPT pixels per work-item (PPT = 4 in the merged form: 24 jobs x 9 planes are 40 k workgroups of 256 pixels, and the launch was
+// bound by per-workgroup fixed cost -- job search, index arithmetic, block reduction -- not by its 88 MB: 99 us)
+template <int PPT>
 __global__ __launch_bounds__(256) void k_edge_smooth_jobs(JobTab t, int C, float gscale) {
     __shared__ float red[4];
-    CC_JOB_PIXEL(t, j, bc, p, HW)
+    int first__;
+    const int j = ccjobs::find(t, (int)blockIdx.x, first__);
+    const int HW = t.H[j] * t.W[j], nb1 = (HW + 255) >> 8, nb__ = (nb1 + PPT - 1) / PPT;
+    const int local__ = (int)blockIdx.x - first__;
+    const int bc = local__ / nb__, blk = local__ - bc * nb__;
     const int Cj = C ? C : (int)t.slot[j][4];
     const int planes = C ? t.B : t.B * Cj;
     const int H = t.H[j], W = t.W[j], b = bc / Cj;
     const float inv_nx = 1.f / ((float)planes * (H - 1) * W), inv_ny = 1.f / ((float)planes * H * (W - 1));
     float part[1] = {0.f};
-    if (p < HW) {
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+      const int p = (blk * PPT + k) * 256 + (int)threadIdx.x;
+      if (p < HW) {
         const int y = p / W, x = p - y * W;
         const float* im = ccjobs::ptr<const float>(t, j, 0) + (size_t)b * 3 * HW;
         const float* pr = ccjobs::ptr<const float>(t, j, 1) + (size_t)bc * HW;
@@ -502,9 +512,15 @@ __global__ __launch_bounds__(256) void k_edge_smooth_jobs(JobTab t, int C, float
             g -= sgn(d) * (wg ? wg[p - 1] : edge_w(im, HW, p - 1, p)) * inv_ny;
         }
         if (gpred) gpred[(size_t)bc * HW + p] = g * gscale;
+      }
     }
     cc::block_sum_256<1>(part, red);
-    if (threadIdx.x == 0) ccjobs::ptr<float>(t, j, 3)[local__] = part[0];
+    // the partial areas keep their 256-pixel granularity (the host lays them out back to back per job and sums them all): this
+    // workgroup's sum goes to the first of its PPT places, zeros to the others
+    if ((int)threadIdx.x < PPT) {
+        const int idx = blk * PPT + (int)threadIdx.x;
+        if (idx < nb1) ccjobs::ptr<float>(t, j, 3)[(size_t)bc * nb1 + idx] = threadIdx.x == 0 ? part[0] : 0.f;
+    }
 }
 
 // explainability BCE, all levels: slots 0 mask (n = B*C*H*W elements: table B = batch * C), 1 gmask (or 0), 2 partials
@@ -825,26 +841,31 @@ size_t cc_loss_jobs_num_blocks(const long* jobs, int njobs, int planes) {
 int cc_edge_smooth_fwd_bwd_jobs(const long* jobs, int njobs, int B, int C, float* partials, float* loss_accum, float gscale,
                                 void* stream) {
     ccjobs::JobTab t;
-    int nblk;
+    int nblk, npart = -1;
     if (C > 0) {
         nblk = loss_jobs_tab(t, jobs, njobs, B * C);
+        npart = nblk;
     } else {
         // per-job channel counts (slot 4): job j owns B * C_j * ceil(H W / 256) blocks
         if (C < 0 || !jobs || njobs <= 0 || njobs > ccjobs::MAXJOBS || B <= 0) return CC_ERR_ARG;
         nblk = ccjobs::fill(t, jobs, njobs, B, ccjobs::pix_blocks);
         int tot = 0;
+        npart = 0;
         for (int j = 0; j < njobs; j++) {
             const int cj = (int)t.slot[j][4];
             if (cj <= 0) return CC_ERR_ARG;
-            tot += B * cj * ccjobs::pix_blocks(t.H[j], t.W[j]);
+            const int nb1 = ccjobs::pix_blocks(t.H[j], t.W[j]);
+            tot += B * cj * ((nb1 + 3) / 4);          // four 256-pixel pieces per workgroup
+            npart += B * cj * nb1;                    // partial sums keep the 256-pixel layout
             t.blk_end[j] = tot;
         }
         nblk = tot;
     }
     if (nblk <= 0) return CC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_edge_smooth_jobs, dim3((unsigned)nblk), dim3(256), 0, s, t, C, gscale);
-    hipLaunchKernelGGL(k_reduce_add, dim3(1), dim3(256), 0, s, (const float*)partials, nblk, 1.0f, loss_accum);
+    if (C > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_smooth_jobs<1>), dim3((unsigned)nblk), dim3(256), 0, s, t, C, gscale);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_smooth_jobs<4>), dim3((unsigned)nblk), dim3(256), 0, s, t, C, gscale);
+    hipLaunchKernelGGL(k_reduce_add, dim3(1), dim3(256), 0, s, (const float*)partials, npart, 1.0f, loss_accum);
     CC_CHECK_LAUNCH();
     return CC_OK;
 }

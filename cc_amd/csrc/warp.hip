@@ -448,39 +448,47 @@ __global__ __launch_bounds__(256) void k_rigid_noocc_fused(const float* __restri
 
 // ------------------------------------------------------------------ job-table forms (all pyramid levels x reference frames
 // of one loss in ONE launch; jobs.h).  Same per-pixel arithmetic as the single-call kernels above (shared device functions).
+// Round 5: WPPT pixels per work-item, 256 apart (a workgroup = WPPT consecutive 256-pixel pieces of one image).  The 24 jobs of a
+// loss pass are 9-18 k workgroups of 256 pixels; job search, slot pointers, the P / Kinv rows and (backward) the block reduction are
+// per-workgroup costs, and the pixels of a work-item are independent load chains (measured on the smoothness kernel: 99 -> 57 us).
+constexpr int WPPT = 4;
+#define CC_WARP_JOB_BLOCK(t, j, b, blk, H, W, HW, nb1)                                      \
+    int first__;                                                                            \
+    const int j = ccjobs::find(t, (int)blockIdx.x, first__);                                \
+    const int H = t.H[j], W = t.W[j], HW = H * W, nb1 = (HW + 255) >> 8;                    \
+    const int nb4__ = (nb1 + WPPT - 1) / WPPT;                                              \
+    const int local__ = (int)blockIdx.x - first__;                                          \
+    const int b = local__ / nb4__, blk = local__ - b * nb4__;
+
 // rigid fwd slots: 0 img [B,C,H,W], 1 depth [B,H,W], 2 P [B,12], 3 Kinv [B,9], 4 out
 template <bool AC, bool BORDER>
 __global__ __launch_bounds__(256) void k_inverse_warp_fwd_jobs(JobTab t, int C) {
-    int first;
-    const int j = ccjobs::find(t, (int)blockIdx.x, first);
-    const int H = t.H[j], W = t.W[j], HW = H * W, nb = (HW + 255) >> 8;
-    const int local = (int)blockIdx.x - first;
-    const int b = local / nb, p = (local - b * nb) * 256 + (int)threadIdx.x;
-    if (p >= HW) return;
+    CC_WARP_JOB_BLOCK(t, j, b, blk, H, W, HW, nb1)
     const float* __restrict__ img = ccjobs::ptr<const float>(t, j, 0);
     const float* __restrict__ depth = ccjobs::ptr<const float>(t, j, 1);
     const float* __restrict__ P = ccjobs::ptr<const float>(t, j, 2);
     const float* __restrict__ Kinv = ccjobs::ptr<const float>(t, j, 3);
     float* __restrict__ out = ccjobs::ptr<float>(t, j, 4);
-    const int y = p / W, x = p - y * W;
-    Rigid r;
-    rigid_project(P + 12 * b, Kinv + 9 * b, (float)x, (float)y, depth[(size_t)b * HW + p], W, H, !BORDER, r);
-    Bilinear bl;
-    bilinear_setup<AC, BORDER>(r.xn, r.yn, W, H, bl);
     const float* src = img + (size_t)b * C * HW;
-    float* dst = out + (size_t)b * C * HW + p;
-    sample_channels(src, dst, C, HW, W, bl);
+#pragma unroll
+    for (int k = 0; k < WPPT; k++) {
+        const int p = (blk * WPPT + k) * 256 + (int)threadIdx.x;
+        if (p >= HW) break;
+        const int y = p / W, x = p - y * W;
+        Rigid r;
+        rigid_project(P + 12 * b, Kinv + 9 * b, (float)x, (float)y, depth[(size_t)b * HW + p], W, H, !BORDER, r);
+        Bilinear bl;
+        bilinear_setup<AC, BORDER>(r.xn, r.yn, W, H, bl);
+        float* dst = out + (size_t)b * C * HW + p;
+        sample_channels(src, dst, C, HW, W, bl);
+    }
 }
 
 // rigid bwd slots: 0 gout, 1 img, 2 depth, 3 P, 4 Kinv, 5 gdepth [B,H,W], 6 gP partials [B][nb][12]
 template <bool AC, bool BORDER>
 __global__ __launch_bounds__(256) void k_inverse_warp_bwd_jobs(JobTab t, int C) {
     __shared__ float red[4 * 12];
-    int first;
-    const int j = ccjobs::find(t, (int)blockIdx.x, first);
-    const int H = t.H[j], W = t.W[j], HW = H * W, nb = (HW + 255) >> 8;
-    const int local = (int)blockIdx.x - first;
-    const int b = local / nb, blk = local - b * nb, p = blk * 256 + (int)threadIdx.x;
+    CC_WARP_JOB_BLOCK(t, j, b, blk, H, W, HW, nb)
     const float* __restrict__ gout = ccjobs::ptr<const float>(t, j, 0);
     const float* __restrict__ img = ccjobs::ptr<const float>(t, j, 1);
     const float* __restrict__ depth = ccjobs::ptr<const float>(t, j, 2);
@@ -491,49 +499,62 @@ __global__ __launch_bounds__(256) void k_inverse_warp_bwd_jobs(JobTab t, int C) 
     float gP[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) gP[i] = 0.f;
-    if (p < HW) {
-        const int y = p / W, x = p - y * W;
-        Rigid r;
-        rigid_project(P + 12 * b, Kinv + 9 * b, (float)x, (float)y, depth[(size_t)b * HW + p], W, H, !BORDER, r);
-        Bilinear bl;
-        bilinear_setup<AC, BORDER>(r.xn, r.yn, W, H, bl);
-        float gix, giy, gd;
-        sample_grad(img + (size_t)b * C * HW, gout + (size_t)b * C * HW + p, C, HW, W, bl, nullptr, gix, giy);
-        rigid_backward(P + 12 * b, r, gix * bl.gmx, giy * bl.gmy, W, H, gd, gP);
-        gdepth[(size_t)b * HW + p] = gd;
+#pragma unroll
+    for (int k = 0; k < WPPT; k++) {
+        const int p = (blk * WPPT + k) * 256 + (int)threadIdx.x;
+        if (p < HW) {
+            const int y = p / W, x = p - y * W;
+            Rigid r;
+            rigid_project(P + 12 * b, Kinv + 9 * b, (float)x, (float)y, depth[(size_t)b * HW + p], W, H, !BORDER, r);
+            Bilinear bl;
+            bilinear_setup<AC, BORDER>(r.xn, r.yn, W, H, bl);
+            float gix, giy, gd;
+            sample_grad(img + (size_t)b * C * HW, gout + (size_t)b * C * HW + p, C, HW, W, bl, nullptr, gix, giy);
+            float g1[12];                                 // (rigid_backward assigns: this pixel's contribution)
+            rigid_backward(P + 12 * b, r, gix * bl.gmx, giy * bl.gmy, W, H, gd, g1);
+#pragma unroll
+            for (int i = 0; i < 12; i++) gP[i] += g1[i];
+            gdepth[(size_t)b * HW + p] = gd;
+        }
     }
     cc::block_sum_256<12>(gP, red);
-    if (threadIdx.x == 0) {
-        float* o = gP_part + ((size_t)b * nb + blk) * 12;
+    // the pose-gradient partials keep their [B][ceil(HW / 256)][12] layout (the host sizes it, k_pose_grad_jobs sums it): this
+    // workgroup's sums go to the first of its WPPT rows, zeros to the others
+    if ((int)threadIdx.x < WPPT) {
+        const int row = blk * WPPT + (int)threadIdx.x;
+        if (row < nb) {
+            float* o = gP_part + ((size_t)b * nb + row) * 12;
 #pragma unroll
-        for (int i = 0; i < 12; i++) o[i] = gP[i];
+            for (int i = 0; i < 12; i++) o[i] = threadIdx.x == 0 ? gP[i] : 0.f;
+        }
     }
 }
 
 // flow fwd slots: 0 img, 1 flow [B,2,H,W], 2 out;   flow bwd slots: 0 gout, 1 img, 2 flow, 3 gflow
 template <bool AC, bool BORDER>
 __global__ __launch_bounds__(256) void k_flow_warp_fwd_jobs(JobTab t, int C) {
-    int first;
-    const int j = ccjobs::find(t, (int)blockIdx.x, first);
-    const int H = t.H[j], W = t.W[j], HW = H * W, nb = (HW + 255) >> 8;
-    const int local = (int)blockIdx.x - first;
-    const int b = local / nb, p = (local - b * nb) * 256 + (int)threadIdx.x;
-    if (p >= HW) return;
+    CC_WARP_JOB_BLOCK(t, j, b, blk, H, W, HW, nb1)
     const float* __restrict__ img = ccjobs::ptr<const float>(t, j, 0);
     const float* __restrict__ flow = ccjobs::ptr<const float>(t, j, 1);
     float* __restrict__ out = ccjobs::ptr<float>(t, j, 2);
-    const int y = p / W, x = p - y * W;
-    float xn, yn, dxn, dyn;
-    flow_coords<false>((float)x, (float)y, flow[((size_t)b * 2) * HW + p], flow[((size_t)b * 2 + 1) * HW + p], W, H, xn, yn, dxn, dyn);
-    Bilinear bl;
-    bilinear_setup<AC, BORDER>(xn, yn, W, H, bl);
     const float* src = img + (size_t)b * C * HW;
-    float* dst = out + (size_t)b * C * HW + p;
-    sample_channels(src, dst, C, HW, W, bl);
+#pragma unroll
+    for (int k = 0; k < WPPT; k++) {
+        const int p = (blk * WPPT + k) * 256 + (int)threadIdx.x;
+        if (p >= HW) break;
+        const int y = p / W, x = p - y * W;
+        float xn, yn, dxn, dyn;
+        flow_coords<false>((float)x, (float)y, flow[((size_t)b * 2) * HW + p], flow[((size_t)b * 2 + 1) * HW + p], W, H, xn, yn, dxn, dyn);
+        Bilinear bl;
+        bilinear_setup<AC, BORDER>(xn, yn, W, H, bl);
+        float* dst = out + (size_t)b * C * HW + p;
+        sample_channels(src, dst, C, HW, W, bl);
+    }
 }
 
 template <bool AC, bool BORDER>
 __global__ __launch_bounds__(256) void k_flow_warp_bwd_jobs(JobTab t, int C) {
+    // (one pixel per work-item: with WPPT = 4 this kernel was slower, 26.0 vs 23.4 us -- no block reduction to amortise)
     int first;
     const int j = ccjobs::find(t, (int)blockIdx.x, first);
     const int H = t.H[j], W = t.W[j], HW = H * W, nb = (HW + 255) >> 8;
@@ -588,21 +609,21 @@ __global__ __launch_bounds__(256) void k_rigid_noocc_jobs(JobTab t) {
 
 // pose2flow of every level (train.py:470-471 flows_cam_fwd / _bwd): slots 0 depth, 1 P [B,12], 2 Kinv, 3 flow [B,2,H,W]
 __global__ __launch_bounds__(256) void k_pose2flow_fwd_jobs(JobTab t, int rewrite) {
-    int first;
-    const int j = ccjobs::find(t, (int)blockIdx.x, first);
-    const int H = t.H[j], W = t.W[j], HW = H * W, nb = (HW + 255) >> 8;
-    const int local = (int)blockIdx.x - first;
-    const int b = local / nb, p = (local - b * nb) * 256 + (int)threadIdx.x;
-    if (p >= HW) return;
+    CC_WARP_JOB_BLOCK(t, j, b, blk, H, W, HW, nb1)
     const float* __restrict__ depth = ccjobs::ptr<const float>(t, j, 0);
     const float* __restrict__ P = ccjobs::ptr<const float>(t, j, 1);
     const float* __restrict__ Kinv = ccjobs::ptr<const float>(t, j, 2);
     float* __restrict__ flow = ccjobs::ptr<float>(t, j, 3);
-    const int y = p / W, x = p - y * W;
-    Rigid r;
-    rigid_project(P + 12 * b, Kinv + 9 * b, (float)x, (float)y, depth[(size_t)b * HW + p], W, H, rewrite != 0, r);
-    flow[((size_t)b * 2 + 0) * HW + p] = (float)(W - 1) * (r.xn / 2.0f + 0.5f) - (float)x;
-    flow[((size_t)b * 2 + 1) * HW + p] = (float)(H - 1) * (r.yn / 2.0f + 0.5f) - (float)y;
+#pragma unroll
+    for (int k = 0; k < WPPT; k++) {
+        const int p = (blk * WPPT + k) * 256 + (int)threadIdx.x;
+        if (p >= HW) break;
+        const int y = p / W, x = p - y * W;
+        Rigid r;
+        rigid_project(P + 12 * b, Kinv + 9 * b, (float)x, (float)y, depth[(size_t)b * HW + p], W, H, rewrite != 0, r);
+        flow[((size_t)b * 2 + 0) * HW + p] = (float)(W - 1) * (r.xn / 2.0f + 0.5f) - (float)x;
+        flow[((size_t)b * 2 + 1) * HW + p] = (float)(H - 1) * (r.yn / 2.0f + 0.5f) - (float)y;
+    }
 }
 
 // inverse_warp.py:31-45 pixel2cam and :48-79 cam2pixel as stand-alone maps (the training path uses the fused kernels above;
@@ -981,10 +1002,15 @@ static int warp_jobs_tab(ccjobs::JobTab& t, const long* jobs, int njobs, int B) 
     if (!jobs || njobs <= 0 || njobs > ccjobs::MAXJOBS || B <= 0) return -1;
     return ccjobs::fill(t, jobs, njobs, B, ccjobs::pix_blocks);
 }
+// ... for the kernels that give every work-item WPPT pixels (256 apart): ceil(ceil(H W / 256) / WPPT) workgroups per image
+static int warp_jobs_tab4(ccjobs::JobTab& t, const long* jobs, int njobs, int B) {
+    if (!jobs || njobs <= 0 || njobs > ccjobs::MAXJOBS || B <= 0) return -1;
+    return ccjobs::fill(t, jobs, njobs, B, [](int H, int W) { return (ccjobs::pix_blocks(H, W) + WPPT - 1) / WPPT; });
+}
 
 int cc_inverse_warp_fwd_jobs(const long* jobs, int njobs, int B, int C, int padding_border, int align_corners, void* stream) {
     ccjobs::JobTab t;
-    const int nblk = warp_jobs_tab(t, jobs, njobs, B);
+    const int nblk = warp_jobs_tab4(t, jobs, njobs, B);
     if (nblk <= 0) return CC_ERR_ARG;
     CC_DISPATCH_AC_PAD(k_inverse_warp_fwd_jobs, align_corners, padding_border, dim3((unsigned)nblk), dim3(256), 0,
                        (hipStream_t)stream, t, C);
@@ -994,7 +1020,7 @@ int cc_inverse_warp_fwd_jobs(const long* jobs, int njobs, int B, int C, int padd
 
 int cc_inverse_warp_bwd_jobs(const long* jobs, int njobs, int B, int C, int padding_border, int align_corners, void* stream) {
     ccjobs::JobTab t;
-    const int nblk = warp_jobs_tab(t, jobs, njobs, B);
+    const int nblk = warp_jobs_tab4(t, jobs, njobs, B);
     if (nblk <= 0) return CC_ERR_ARG;
     CC_DISPATCH_AC_PAD(k_inverse_warp_bwd_jobs, align_corners, padding_border, dim3((unsigned)nblk), dim3(256), 0,
                        (hipStream_t)stream, t, C);
@@ -1004,7 +1030,7 @@ int cc_inverse_warp_bwd_jobs(const long* jobs, int njobs, int B, int C, int padd
 
 int cc_flow_warp_fwd_jobs(const long* jobs, int njobs, int B, int C, int padding_border, int align_corners, void* stream) {
     ccjobs::JobTab t;
-    const int nblk = warp_jobs_tab(t, jobs, njobs, B);
+    const int nblk = warp_jobs_tab4(t, jobs, njobs, B);
     if (nblk <= 0) return CC_ERR_ARG;
     CC_DISPATCH_AC_PAD(k_flow_warp_fwd_jobs, align_corners, padding_border, dim3((unsigned)nblk), dim3(256), 0,
                        (hipStream_t)stream, t, C);
@@ -1033,7 +1059,7 @@ int cc_rigid_noocc_jobs(const long* jobs, int njobs, int B, void* stream) {
 
 int cc_pose2flow_fwd_jobs(const long* jobs, int njobs, int B, int rewrite_oob, void* stream) {
     ccjobs::JobTab t;
-    const int nblk = warp_jobs_tab(t, jobs, njobs, B);
+    const int nblk = warp_jobs_tab4(t, jobs, njobs, B);
     if (nblk <= 0) return CC_ERR_ARG;
     hipLaunchKernelGGL(k_pose2flow_fwd_jobs, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, t, rewrite_oob);
     CC_CHECK_LAUNCH();

@@ -31,7 +31,6 @@ __device__ __forceinline__ void put(float* o, float s, int accum) { *o = accum ?
 
 __global__ __launch_bounds__(256) void k_wgrad_reduce_table(RT t) {
     __shared__ float4 part[16][16];
-    __shared__ float comb[4][9][64];
     int k = 0, first = 0;
 #pragma unroll 1
     for (int q = 0; q + 1 < t.n; q++)
@@ -78,59 +77,42 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_table(RT t) {
         const int i = rem / St, j = rem - i * St;
         put(d.gw + (long)m * d.o_sm + (long)c * d.o_sc + i * d.p[4] + j * d.p[5], s, d.accum);
     } else if (d.kind == 1) {
-        // 64 (m, c) positions per workgroup x 4 sub-ranges of the slabs (one wave each): a position's T taps are T coalesced slab
-        // reads and ONE run of T consecutive floats in gw.  The launch is as long as its longest dependent chain: with one work-item
-        // walking all slabs of its position (until round 5) a layer split 64-84 ways was 32-42 dependent rounds of loads; four waves
-        // walk a quarter each (contiguous ranges) and wave 0 adds the four partial sums in range order (fixed order: deterministic).
+        // one work-item per (m, c): its T taps are T coalesced slab reads and ONE run of T consecutive floats in gw (a work-item
+        // per slab element writes every 36-byte run from 9 different workgroups)
         const int T = d.p[0], M = d.p[1], Cin = d.p[2], Cp32 = d.p[3];
-        const int sub = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-        const long mc = (long)bid * 64 + lane;             // over [m][c]
+        const long mc = (long)bid * 256 + threadIdx.x;     // over [m][c]
         const long per = (long)M * Cp32;
+        if (mc >= per) return;
         const int c = (int)(mc % Cp32), m = (int)(mc / Cp32);
-        const bool live = mc < per && c < Cin;
+        if (c >= Cin) return;
         const long tot = (long)T * per;
-        const int chunk = (d.nsplit + 3) >> 2;
-        const int z0 = sub * chunk, z1 = (z0 + chunk < d.nsplit) ? z0 + chunk : d.nsplit;
         float* o = d.gw + (long)m * d.o_sm + (long)c * d.o_sc;
         if (T == 9) {
             // the nine taps side by side: nine independent loads per slab instead of nine dependent passes over the slabs
             float s9[9];
 #pragma unroll
             for (int tt = 0; tt < 9; tt++) s9[tt] = 0.f;
-            if (live) {
-                int z = z0;
-                for (; z + 2 <= z1; z += 2) {
-                    const float* wz = ws + (long)z * tot + mc;
-                    float v0[9], v1[9];
+            int z = 0;
+            for (; z + 2 <= d.nsplit; z += 2) {
+                const float* wz = ws + (long)z * tot + mc;
+                float v0[9], v1[9];
 #pragma unroll
-                    for (int tt = 0; tt < 9; tt++) { v0[tt] = wz[(long)tt * per]; v1[tt] = wz[tot + (long)tt * per]; }
+                for (int tt = 0; tt < 9; tt++) { v0[tt] = wz[(long)tt * per]; v1[tt] = wz[tot + (long)tt * per]; }
 #pragma unroll
-                    for (int tt = 0; tt < 9; tt++) { s9[tt] += v0[tt]; s9[tt] += v1[tt]; }
-                }
-                for (; z < z1; z++) {
-                    const float* wz = ws + (long)z * tot + mc;
+                for (int tt = 0; tt < 9; tt++) { s9[tt] += v0[tt]; s9[tt] += v1[tt]; }
+            }
+            for (; z < d.nsplit; z++) {
+                const float* wz = ws + (long)z * tot + mc;
 #pragma unroll
-                    for (int tt = 0; tt < 9; tt++) s9[tt] += wz[(long)tt * per];
-                }
+                for (int tt = 0; tt < 9; tt++) s9[tt] += wz[(long)tt * per];
             }
 #pragma unroll
-            for (int tt = 0; tt < 9; tt++) comb[sub][tt][lane] = s9[tt];
-            __syncthreads();
-            if (sub == 0 && live) {
-#pragma unroll
-                for (int tt = 0; tt < 9; tt++) {
-                    float sum = comb[0][tt][lane];
-                    sum += comb[1][tt][lane];
-                    sum += comb[2][tt][lane];
-                    sum += comb[3][tt][lane];
-                    put(o + tt, sum, d.accum);
-                }
-            }
-        } else if (sub == 0 && live) {
+            for (int tt = 0; tt < 9; tt++) put(o + tt, s9[tt], d.accum);
+        } else {
             for (int tt = 0; tt < T; tt++) {
-                float sum = 0.f;
-                for (int z = 0; z < d.nsplit; z++) sum += ws[(long)z * tot + (long)tt * per + mc];
-                put(o + tt, sum, d.accum);
+                float s = 0.f;
+                for (int z = 0; z < d.nsplit; z++) s += ws[(long)z * tot + (long)tt * per + mc];
+                put(o + tt, s, d.accum);
             }
         }
     } else if (d.kind == 4) {
@@ -190,7 +172,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_table(RT t) {
 long blocks_of(const long* h) {
     switch ((int)h[0]) {
         case 0: return h[13] ? (h[7] * h[8] / 4 + 255) / 256 : (h[7] * h[8] + 255) / 256;
-        case 1: return (h[8] * h[10] + 63) / 64;
+        case 1: return (h[8] * h[10] + 255) / 256;
         case 2: return h[15] * h[7] * 4;
         case 4: return (h[7] + 3) / 4;
         default: return -1;
