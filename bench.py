@@ -31,7 +31,11 @@ sys.path.insert(0, ROOT)
 # asynchronous collective is -- blocks the calling thread until that event has completed; the host then enqueues the optimizer
 # launch and the next hipGraph replay with an idle GPU: measured +0.6 ms per step on one GPU with a one-rank RCCL group, gone with
 # the per-queue submission thread (profiles/r03_ab_round3.txt, r3z).  A single rank keeps the default (0.18 ms faster there).
-if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("CC_FORCE_COMM", "0") == "1":
+# Round 5: with the networks on streams of their own (cc_amd.config.net_streams, the default) the data-parallel step is ONE graph with
+# parallel branches and the two all-reduces behind it; AMD_DIRECT_DISPATCH=0 costs such a graph +1.35 ms per replay (18.13 vs 16.79 ms,
+# profiles/r05_ab_round5.txt) and the one-rank rehearsal runs at 16.89 ms with direct dispatch on: the setting is only applied to the
+# staged two-graph form (CC_NET_STREAMS=0).
+if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("CC_FORCE_COMM", "0") == "1") and os.environ.get("CC_NET_STREAMS") == "0":
     os.environ.setdefault("AMD_DIRECT_DISPATCH", "0")
 
 import torch                      # noqa: E402
@@ -543,7 +547,7 @@ def main():
             # collectives skipped (RCCL's workgroups take CUs from the MFMA kernels; measured AFTER the timed region and the parity
             # gate -- the ranks' weights diverge in those few steps, nothing is reported from them but the stage time)
             comm["rank_step_ms_median"] = [round(float(v[1].item()), 3) for v in allv]
-            comm["stage_b_ms"] = {"with_allreduce_in_flight": tr.stage_b_ms()}
+            comm["stage_b_ms"] = {"with_allreduce_in_flight": tr.stage_b_ms()} if tr.graph_b is not None else None
     if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -660,7 +664,8 @@ def main():
                        "loss": round(loss_val, 6), "rccl_ranks": dist.get_world_size() if use_dist else 1,
                        "rank_losses": rank_losses,
                        "hip_runtime": {"AMD_DIRECT_DISPATCH": os.environ.get("AMD_DIRECT_DISPATCH", "default (1)")},
-                       "dead_occlusion_decoders_elided": bool(args.elide_occ), "ab_switches": ab_switches or None},
+                       "dead_occlusion_decoders_elided": bool(args.elide_occ), "ab_switches": ab_switches or None,
+                       "net_streams": (len(tr.net_streams) if tr.net_streams else 0)},
             "step_ms": step_ms, "comm": comm,
             "roofline": roof, "kernels": kernels,
         }

@@ -15,6 +15,15 @@ strict_nan_checks = False
 # fixed-point integers instead (cc_feature_warp_bwd_det: four launches per warp instead of two, ~+0.3 ms per step).
 deterministic = False
 
+# True: the four networks of a CCTrainer step run on HIP streams of their own (DispResNet6 and Back2Future on one side stream
+# each, PoseNetB6 and MaskNet6 on the step's stream; forward and backward), joined before the losses / the optimizer.  Their layer
+# chains are independent between the input frames and the losses (train.py:454-463 calls them one after the other), and most of
+# their launches on the <= 32x104 levels leave CUs idle: as branches of the captured hipGraph they overlap (tools/overlap_probe.py:
+# two chains of 208-416-workgroup convolutions, 1.69 -> 1.14 ms; the full step 20.6 -> 16.7 ms).  Same kernels, same arithmetic,
+# same results.  True / 2: two side streams; 3: a third one for MaskNet6 (measured: no better); False / 0: one stream (rounds 1-4).
+# Has no effect on CPU tensors (tests/hipemu).
+net_streams = True
+
 
 class _Debug:
     """A/B and diagnosis switches of the host glue.  The product reads nothing from the process environment: these are plain attributes that

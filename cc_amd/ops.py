@@ -174,7 +174,7 @@ class _WgradQueue:
                               (B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc)))
         if items:
             _wgrad_list(items)
-        wgrad_reduces.flush()
+        wgrad_reduces._cur().flush()          # (this stream's reductions: the proxy runs every stream's queue on its own stream)
 
 
 class _WgradReduces:
@@ -217,8 +217,58 @@ class _WgradReduces:
         self.keep.append((ws, gbias, gy))
 
 
-wgrad_queue = _WgradQueue()
-wgrad_reduces = _WgradReduces()
+def _stream_key():
+    """(key, torch stream or None) of the stream the caller launches on.  The parked work of a backward stage is kept PER STREAM:
+    with config.net_streams the networks run on streams of their own, and a shape-mate group / reduce table launched on one stream
+    must not read operands another stream is still producing."""
+    if torch.cuda.is_available():
+        st = torch.cuda.current_stream()
+        return st.cuda_stream, st
+    return 0, None
+
+
+class _PerStream:
+    """Proxy of one parked-work object per stream.  Attribute access goes to the current stream's instance; flush() runs every
+    instance's flush ON ITS OWN STREAM (ordered behind the kernels that produced its operands); the caller joins the streams."""
+
+    def __init__(self, factory):
+        object.__setattr__(self, "_factory", factory)
+        object.__setattr__(self, "_inst", {})
+        object.__setattr__(self, "enabled", False)
+
+    def _cur(self):
+        key, st = _stream_key()
+        ent = self._inst.get(key)
+        if ent is None:
+            ent = self._inst[key] = (self._factory(), st)
+        return ent[0]
+
+    def __getattr__(self, name):
+        return getattr(self._cur(), name)
+
+    def __setattr__(self, name, value):
+        if name == "enabled":
+            object.__setattr__(self, name, value)
+        else:
+            setattr(self._cur(), name, value)
+
+    def flush(self):
+        for key in list(self._inst):
+            inst, st = self._inst[key]
+            if st is None or st.cuda_stream == torch.cuda.current_stream().cuda_stream:
+                inst.flush()
+            else:
+                with torch.cuda.stream(st):
+                    inst.flush()
+        self._inst.clear()          # (all empty now; streams() lists what has parked work since the last flush)
+
+    def streams(self):
+        """the streams that have (had) parked work: the caller makes its stream wait for them after flush()"""
+        return [st for _, st in self._inst.values() if st is not None]
+
+
+wgrad_queue = _PerStream(_WgradQueue)
+wgrad_reduces = _PerStream(_WgradReduces)
 
 
 def _act_bwd_bias(gys, ys, geffs, gbs, ref, B, C, H, W, gy_bs, act, act_a, act_b, accumulate):

@@ -48,7 +48,29 @@ def build_nets(device, flow=True, mask=True, init=True):
     return nets
 
 
-def cc_forward(nets, batch, cfg, keep=False, cut=None):
+def _fork(streams):
+    """the given side streams wait for the current stream (inside a hipGraph capture this is also what brings them into it)"""
+    streams = [st for st in streams if st is not None]
+    if not streams:
+        return
+    cur = torch.cuda.current_stream()
+    for st in streams:
+        if st is not None and st.cuda_stream != cur.cuda_stream:
+            st.wait_stream(cur)
+
+
+def _join(streams):
+    """the current stream waits for the given side streams (each must have been forked from it in this capture region)"""
+    streams = [st for st in streams if st is not None]
+    if not streams:
+        return
+    cur = torch.cuda.current_stream()
+    for st in streams:
+        if st is not None and st.cuda_stream != cur.cuda_stream:
+            cur.wait_stream(st)
+
+
+def cc_forward(nets, batch, cfg, keep=False, cut=None, streams=None):
     """train.py:454-509.  batch = (tgt, [4 refs], K, Kinv).
     cut: optional dict; when given, the losses are computed on detached copies of the network outputs and
     cut['dp'] / cut['mf'] receive the (output, detached copy) pairs of DispResNet6 + PoseNetB6 / MaskNet6 + Back2Future, so
@@ -70,9 +92,29 @@ def cc_forward(nets, batch, cfg, keep=False, cut=None):
         return outs
 
     LF.pyramid_cache.prefetch([tgt] + list(refs))        # the frames' scale pyramids (every loss pools them): one launch for all five
-    disparities = _cut("dp", list(disp_net(tgt)))                                      # :454
+
+    forked = []
+
+    def _on(st, fn):
+        """fn() on side stream st (config.net_streams: streams = (for DispResNet6, for Back2Future)), forked from the current one"""
+        if st is None:
+            return fn()
+        _fork([st])
+        forked.append(st)
+        with torch.cuda.stream(st):
+            return fn()
+    s_disp, s_flow, s_mask = (tuple(streams) + (None, None, None))[:3] if streams else (None, None, None)
+    full = not (mask_net is None or flow_net is None)
+    # (independent of each other between the frames and the losses: launched first so that the side streams have work while the
+    # step's stream runs the other two networks; train.py:454-463 order of the results is kept below)
+    disp_out = _on(s_disp, lambda: list(disp_net(tgt)))                                # :454
+    flow_out = _on(s_flow, lambda: flow_net(tgt, refs[1:3])) if full else None         # :463
+    mask_out = _on(s_mask, lambda: list(mask_net(tgt, refs))) if full else None        # :460
+    pose_out = pose_net(tgt, refs)                                                     # :459
+    _join(forked)
+    disparities = _cut("dp", disp_out)
     depth = LF.reciprocal_levels(disparities)                                          # :458  [1 / d for d in disparities]
-    pose = _cut("dp", [pose_net(tgt, refs)])[0]                                        # :459
+    pose = _cut("dp", [pose_out])[0]
     out = {}
     if mask_net is None or flow_net is None:                                           # BASELINE config 2
         l1 = LF.photometric_reconstruction_loss(tgt, refs, K, Kinv, depth, [None] * len(depth), pose,
@@ -82,8 +124,8 @@ def cc_forward(nets, batch, cfg, keep=False, cut=None):
         if keep:
             out.update(disparities=disparities, pose=pose)
         return out
-    exp_mask = _cut("mf", list(mask_net(tgt, refs)))                                   # :460
-    flow_fwd, flow_bwd, _ = flow_net(tgt, refs[1:3])                                   # :463
+    exp_mask = _cut("mf", mask_out)
+    flow_fwd, flow_bwd, _ = flow_out
     flow_fwd, flow_bwd = _cut("mf", list(flow_fwd)), _cut("mf", list(flow_bwd))
     cam_fwd, cam_bwd = LF.rigid_flows_levels(depth, pose, (2, 1), K, Kinv)             # :470-471  pose2flow per scale
     target = LF.consensus_exp_masks(cam_fwd, cam_bwd, flow_fwd, flow_bwd, tgt, refs[2], refs[1],
@@ -280,7 +322,19 @@ class CCTrainer:
         # two stages / two graphs only when both gradient segments exist (with MaskNet6 + Back2Future frozen -- README's
         # --fix-masknet --fix-flownet -- stage B is empty: one graph, one all-reduce)
         two_segments = 0 < self.n_dp < self.opt.n
-        self.split_graphs = (self.opt.comm_active() and two_segments) if split_graphs is None else bool(split_graphs)
+        # With the networks on streams of their own the backward passes of DispResNet6 and Back2Future overlap only inside ONE
+        # backward call (= one graph): the staged form then costs more (the two longest backward chains one after the other: +25 % of
+        # the step on one GPU) than hiding the first segment's all-reduce under stage B saves, so the data-parallel step keeps the
+        # single graph and issues both all-reduces behind it (the second one runs under the first segment's optimizer update).
+        # split_graphs=True asks for the staged form explicitly.
+        dev0 = next(p for n in nets if n is not None for p in n.parameters()).device
+        # config.net_streams: one side stream each for DispResNet6 and Back2Future (forward AND backward: autograd runs a node's
+        # backward on the stream of its forward); HIP devices only
+        nst = int(config.net_streams) if config.net_streams else 0          # True / 2: two side streams; 3: a third one for MaskNet6
+        nst = 2 if nst == 1 else nst
+        self.net_streams = tuple(torch.cuda.Stream(dev0) for _ in range(nst)) if (nst and dev0.type == "cuda") else None
+        self.split_graphs = (self.opt.comm_active() and two_segments and not self.net_streams) if split_graphs is None \
+            else bool(split_graphs)
         self.comm_events = []            # per step: (before wait 0, after wait 0, before wait 1, after wait 1) on the compute stream
         self.comm_standalone_ms = None   # calibrate_comm(): each segment's all-reduce alone, nothing to hide under
         self.stage_b_events = []         # per step: events around the replay of backward stage B (two-graph form, comm_debug events)
@@ -294,7 +348,7 @@ class CCTrainer:
     #      backward of DispResNet6 + PoseNetB6                                   -> all-reduce(flat_g[:n_dp]) starts
     #   B: backward of MaskNet6 + Back2Future                                    -> all-reduce(flat_g[n_dp:]) (exposed)
     # The nets only meet in the losses, so the two backward stages are independent given the output gradients.
-    def _stage_a(self, batch):
+    def _stage_a(self, batch, fuse_b=False):
         tape.BN_COUNTERS = self.bn_counters
         self.bn_counters.begin()
         LF.pyramid_cache.clear()
@@ -305,7 +359,7 @@ class CCTrainer:
         cut = {}
         LF.head_grads.begin()              # the loss terms' gradients of a shared network output meet in one accumulator
         try:
-            out = cc_forward(self.nets, batch, self.cfg, cut=cut)
+            out = cc_forward(self.nets, batch, self.cfg, cut=cut, streams=self.net_streams)
             self.bn_counters.commit()
             pairs = cut.get("dp", []) + cut.get("mf", [])
             g = torch.autograd.grad(out["loss"], [d for _, d in pairs], allow_unused=True) if pairs else ()   # :567, losses only
@@ -315,16 +369,42 @@ class CCTrainer:
         dp = [(t, gt) for (t, _), gt in zip(pairs[:ndp], g[:ndp]) if gt is not None]
         mf = [(t, gt) for (t, _), gt in zip(pairs[ndp:], g[ndp:]) if gt is not None]
         ops.wgrad_queue.enabled = not config.debug.no_wgrad_queue
-        if dp:
-            torch.autograd.backward([t for t, _ in dp], [gt for _, gt in dp])
-        ops.wgrad_queue.flush()              # the segment's gradients are complete before its all-reduce is issued
+        if fuse_b and self.net_streams:
+            # one backward call for all four networks: every network's backward waits for the loss gradients only, so DispResNet6
+            # (side stream 0), Back2Future (side stream 1) and PoseNetB6 + MaskNet6 (this stream) run side by side.  (Two calls
+            # would order the second behind the join of the first.)  The gradient tensors stay referenced until the streams have
+            # been joined: they were allocated on this stream and are read on the others.
+            both = dp + mf
+            if both:
+                _fork(self.net_streams)
+                torch.autograd.backward([t for t, _ in both], [gt for _, gt in both])
+            self._sync_streams(bool(both))
+            mf = []
+        else:
+            if dp:
+                _fork(self.net_streams or ())
+                torch.autograd.backward([t for t, _ in dp], [gt for _, gt in dp])
+            self._sync_streams(bool(dp))     # the segment's gradients are complete before its all-reduce is issued
         losses = {k: v.detach() for k, v in out.items() if torch.is_tensor(v) and k.startswith("loss")}
         return losses, mf
 
+    def _sync_streams(self, forked=True):
+        """join the networks' side streams (forked before the backward call), run what the backward stage has parked (each stream's
+        own launches on that stream, re-forked from this one), join again: everything the stage produced is then ordered before
+        what follows on this stream"""
+        if self.net_streams and forked:
+            _join(self.net_streams)
+        sts = {st.cuda_stream: st for st in ops.wgrad_queue.streams() + ops.wgrad_reduces.streams()}
+        _fork(sts.values())
+        ops.wgrad_queue.flush()
+        ops.wgrad_reduces.flush()
+        _join(sts.values())
+
     def _stage_b(self, mf):
         if mf:
+            _fork(self.net_streams or ())
             torch.autograd.backward([t for t, _ in mf], [gt for _, gt in mf])
-        ops.wgrad_queue.flush()
+        self._sync_streams(bool(mf))
 
     def _stage_end(self):
         tape.BN_COUNTERS = None
@@ -337,7 +417,7 @@ class CCTrainer:
     def _fwd_bwd(self, batch, between=None):
         """forward + backward of one mini-batch; `between()` runs between the two backward stages."""
         try:
-            losses, mf = self._stage_a(batch)
+            losses, mf = self._stage_a(batch, fuse_b=between is None)      # (no collective between the stages: one backward call)
             if between is not None:
                 between()
             self._stage_b(mf)
@@ -473,9 +553,11 @@ class CCTrainer:
         med = [sorted(col)[len(col) // 2] for col in zip(*per)]
         r = {"segments_mb": [round(4e-6 * (hi - lo), 1) for lo, hi in segs], "exposed_ms": [round(v, 3) for v in med],
              "exposed_ms_total": round(sum(med), 3), "steps_sampled": len(per),
-             "design": "two all-reduces per step (the [DispResNet6|PoseNetB6] segment is issued after backward stage A and runs "
-                       "under stage B; the [MaskNet6|Back2Future] segment after stage B) in place of north_star's single "
-                       "all-reduce; one all-reduce when only one segment is trainable"}
+             "design": ("two all-reduces per step (the [DispResNet6|PoseNetB6] segment is issued after backward stage A and runs "
+                        "under stage B; the [MaskNet6|Back2Future] segment after stage B) in place of north_star's single "
+                        "all-reduce; one all-reduce when only one segment is trainable") if self.graph_b is not None or not self.use_graph
+             else ("per-network streams: ONE graph (the four networks' backward passes side by side), both segment all-reduces "
+                   "issued behind it; the second one runs under the first segment's optimizer update")}
         if self.comm_standalone_ms and len(self.comm_standalone_ms) == len(med):
             r["standalone_ms"] = [round(v, 3) for v in self.comm_standalone_ms]
             r["overlapped_ms"] = round(sum(max(0.0, a - b) for a, b in zip(self.comm_standalone_ms, med)), 3)

@@ -223,7 +223,8 @@ def test_step_with_rccl_process_group_of_one(monkeypatch):
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         tr, b1, b2, b3 = run()
-        assert tr.split_graphs and tr.graph_b is not None
+        # (per-network streams, the default: one graph, both all-reduces behind it; config.net_streams = False: the staged form)
+        assert tr.split_graphs == (not tr.net_streams) and (tr.graph_b is not None) == tr.split_graphs
         # the record the N > 1 bench line carries: exposed time of each segment's all-reduce (events around work.wait()),
         # each segment alone on an idle device, their difference
         alone = tr.calibrate_comm(reps=2)

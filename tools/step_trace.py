@@ -23,7 +23,18 @@ if periods:
     print("step period (optimizer end to optimizer end), last %d steps: %s ms" % (len(periods), " ".join("%.3f" % p for p in periods)))
 t0, t1 = step[0][0], step[-1][1]
 busy = sum(e - s for s, e, _ in step)
-gaps = sum(max(0, step[i + 1][0] - step[i][1]) for i in range(len(step) - 1))
+# with the networks on streams of their own (round 5) kernels overlap: time covered by at least one kernel, and by two or more
+covered, two, cur_end, sec_end = 0, 0, None, None
+ev = sorted([(s_, 1) for s_, e_, _ in step] + [(e_, -1) for s_, e_, _ in step])
+depth, last = 0, ev[0][0]
+for t_, d_ in ev:
+    if depth >= 1:
+        covered += t_ - last
+    if depth >= 2:
+        two += t_ - last
+    depth += d_
+    last = t_
+gaps = (step[-1][1] - step[0][0]) - covered
 agg = collections.defaultdict(lambda: [0, 0])
 for s, e, n in step:
     n = re.sub(r"\(anonymous namespace\)::", "", n)
@@ -31,7 +42,8 @@ for s, e, n in step:
     n = n.split("(")[0][:70]
     agg[n][0] += 1
     agg[n][1] += e - s
-print("one replayed step: %d kernels, wall %.3f ms, kernel-busy %.3f ms, gaps %.3f ms" % (len(step), (t1 - t0) / 1e6, busy / 1e6, gaps / 1e6))
+print("one replayed step: %d kernels, wall %.3f ms, sum of kernel durations %.3f ms, covered by >= 1 kernel %.3f ms (by >= 2: %.3f ms), gaps %.3f ms"
+      % (len(step), (t1 - t0) / 1e6, busy / 1e6, covered / 1e6, two / 1e6, gaps / 1e6))
 print("%-72s %6s %10s %9s %6s" % ("kernel", "calls", "total_us", "avg_us", "%"))
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-72s %6d %10.1f %9.2f %6.2f" % (n, c, t / 1e3, t / 1e3 / c, 100.0 * t / (t1 - t0)))
