@@ -296,3 +296,33 @@ def test_checkpoint_resume_on_device(tmp_path):
         assert torch.equal(bn3, bn3b)
     finally:
         config.deterministic = old
+
+
+@pytest.mark.parametrize("use_graph,size", [(False, (2, 128, 192)), (True, (2, 128, 192)), (True, (4, 256, 832))])
+def test_network_streams_change_nothing_but_the_schedule(use_graph, size, monkeypatch):
+    """config.net_streams (round 5): DispResNet6 and Back2Future on HIP streams of their own, forward and backward, one backward call
+    for all four networks.  Same kernels on the same operands in the same per-tensor order: in config.deterministic mode three steps
+    with and without the side streams must give IDENTICAL losses, gradient bucket and parameters (a missing cross-stream dependency
+    or a buffer re-used while another stream still reads it shows up as a difference), eagerly and under hipGraph replay; the run with
+    streams is repeated to see that it reproduces itself."""
+    from cc_amd import config
+    monkeypatch.setattr(config, "deterministic", True)
+    dev = torch.device("cuda")
+    bc = syn.sample(*size, seed=3, smooth=3 if size[1] > 128 else 0)      # (the last case: the benchmarked configuration)
+    batch = (bc[0].to(dev), [r.to(dev) for r in bc[1]], bc[2].to(dev), bc[3].to(dev))
+
+    def run(streams):
+        monkeypatch.setattr(config, "net_streams", streams)
+        nets = T.build_nets(dev, init=False)
+        for n in nets:
+            n.load_state_dict(syn.seeded_state_dict(n, 0))
+        tr = T.CCTrainer(nets, T.StepConfig(), use_graph=use_graph)
+        assert (tr.net_streams is not None) == bool(streams)
+        ls = [{k: float(v) for k, v in tr.step(batch).items()} for _ in range(3)]
+        torch.cuda.synchronize()
+        return ls, tr.opt.flat_g.clone(), tr.opt.flat_p.clone()
+    a = run(False)
+    others = [run(True), run(True)] + ([run(3)] if size[1] == 128 else [])
+    for other in others:
+        assert a[0] == other[0], (a[0], other[0])
+        assert torch.equal(a[1], other[1]) and torch.equal(a[2], other[2])
