@@ -8,7 +8,7 @@
 #   quick             bench without the CPU leg and without per-kernel timing, 30 steps
 #   comm              the forced-communication line (1-rank RCCL group)
 #   cfg               other configurations: --freeze, c2, 1664x512 b=2, batch 8
-#   prof              rocprofv3 --kernel-trace --stats of the bench + step_trace table of ONE replayed step
+#   prof / prof0      rocprofv3 --kernel-trace --stats of the bench + step_trace table of ONE replayed step (prof0: CC_NET_STREAMS=0)
 #   pmc               FETCH_SIZE / WRITE_SIZE passes -> gpurun_out/pmc_traffic.json (+ copy to profiles/)
 #   sq                SQ counter pass (tools/pmc_sq.py)
 #   layers            per-layer-shape table (tools/layer_rates.py)
@@ -65,14 +65,17 @@ for STEP in "$@"; do
       ( timeout 400 python bench.py $NOCPU --steps 20 --warmup 5 $C ) > $O/bench_${TAG}_cfg$F.log 2> $O/bench_${TAG}_cfg$F.err
       echo "$C: $(grep timed $O/bench_${TAG}_cfg$F.err)"
     done ;;
-  prof)
-    ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o $TAG -- python $R/bench.py --steps 5 --warmup 2 $NOCPU ) > $O/rocprof_$TAG.log 2>&1; echo "rocprof rc=$?"
+  prof|prof0)
+    # prof: the step as it runs (networks on their side streams: kernels overlap); prof0: CC_NET_STREAMS=0, kernels one after the other
+    # (per-kernel durations that mean the kernel, the reference for roofline.avg_launch_us)
+    PE=""; [ "$K" = prof0 ] && PE="CC_NET_STREAMS=0"
+    ( cd /tmp && env $PE timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o $TAG -- python $R/bench.py --steps 5 --warmup 2 $NOCPU ) > $O/rocprof_$TAG.log 2>&1; echo "rocprof rc=$?"
     S=$(find $O/prof_$TAG -name "*kernel_stats.csv" | head -1); T=$(find $O/prof_$TAG -name "*kernel_trace.csv" | head -1)
     [ -n "$S" ] && cp "$S" $O/rocprof_kernel_stats_$TAG.csv
     python tools/step_trace.py "$T" > $O/step_trace_$TAG.txt 2>&1; head -${TRACE_ROWS:-45} $O/step_trace_$TAG.txt
     find $O/prof_$TAG -name "*kernel_trace.csv" -size +20M -delete ;;
   pmc)
-    CMD="python $R/bench.py --no-graph --steps 1 --warmup 1 $NOCPU"
+    CMD="env CC_NET_STREAMS=0 python $R/bench.py --no-graph --steps 1 --warmup 1 $NOCPU"      # (per-kernel counters: kernels one after the other)
     for C in FETCH_SIZE WRITE_SIZE; do
       rm -rf /tmp/pmc_$C
       ( cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -o run -- $CMD ) > $O/pmc_$C.log 2>&1; echo "pmc $C rc=$?"
@@ -82,11 +85,11 @@ for STEP in "$@"; do
     cp $O/pmc_traffic.json profiles/pmc_traffic.json ;;
   sq)
     rm -rf /tmp/pmc_sq
-    ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d /tmp/pmc_sq -o run -- python $R/bench.py --no-graph --steps 1 --warmup 1 $NOCPU ) > $O/pmc_sq_$TAG.log 2>&1; echo "pmc sq rc=$?"
+    ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d /tmp/pmc_sq -o run -- env CC_NET_STREAMS=0 python $R/bench.py --no-graph --steps 1 --warmup 1 $NOCPU ) > $O/pmc_sq_$TAG.log 2>&1; echo "pmc sq rc=$?"
     F=$(find /tmp/pmc_sq -name "*counter_collection.csv" | head -1)
     PMC_ROWS=${PMC_ROWS:-400} python tools/pmc_sq.py "$F" > $O/pmc_sq_$TAG.txt 2>&1; grep -E "^kernel|ssim|warp_|pose2flow" $O/pmc_sq_$TAG.txt | cut -c1-200 ;;
   layers)
-    ( CC_TIMING_DETAIL=1 CC_TIMING_DUMP=$O/layers_$TAG.tsv timeout 400 python bench.py --steps 5 --warmup 3 --no-cpu-baseline ) > $O/bench_${TAG}_layers.log 2> $O/bench_${TAG}_layers.err
+    ( CC_TIMING_DETAIL=1 CC_TIMING_DUMP=$O/layers_$TAG.tsv timeout 400 python bench.py --steps 5 --warmup 3 --no-cpu-baseline )      # (the table comes from bench.py's isolated pass: side streams off) > $O/bench_${TAG}_layers.log 2> $O/bench_${TAG}_layers.err
     python tools/layer_rates.py $O/layers_$TAG.tsv > $O/layer_rates_$TAG.txt; head -${LAYER_ROWS:-40} $O/layer_rates_$TAG.txt | cut -c1-170 ;;
   ab)
     export CC_LIB_PATH=${CC_LIB_PATH:-$TOOLS_LIB}
