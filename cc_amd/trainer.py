@@ -332,7 +332,10 @@ class CCTrainer:
         # backward on the stream of its forward); HIP devices only
         nst = int(config.net_streams) if config.net_streams else 0          # True / 2: two side streams; 3: a third one for MaskNet6
         nst = 2 if nst == 1 else nst
-        self.net_streams = tuple(torch.cuda.Stream(dev0) for _ in range(nst)) if (nst and dev0.type == "cuda") else None
+        # (stream priorities, config.debug.net_stream_priority: (DispResNet6's, Back2Future's[, MaskNet6's]); -1 = high.  Measured in
+        # round 5, see profiles/r05_ab_round5.txt)
+        pri = tuple(config.debug.net_stream_priority) + (0, 0, 0)
+        self.net_streams = tuple(torch.cuda.Stream(dev0, priority=pri[i]) for i in range(nst)) if (nst and dev0.type == "cuda") else None
         self.split_graphs = (self.opt.comm_active() and two_segments and not self.net_streams) if split_graphs is None \
             else bool(split_graphs)
         self.comm_events = []            # per step: (before wait 0, after wait 0, before wait 1, after wait 1) on the compute stream

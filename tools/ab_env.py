@@ -25,6 +25,8 @@ def apply(env=None):
             got[attr] = True
     if env.get("CC_NET_STREAMS") is not None:          # product switch cc_amd.config.net_streams (A/B: 0 / 1)
         config.net_streams = got["net_streams"] = int(env["CC_NET_STREAMS"])           # 0 / 1 (= 2 side streams) / 3
+    if env.get("CC_NET_STREAM_PRIORITY"):              # e.g. "0,-1": Back2Future's stream high
+        config.debug.net_stream_priority = got["net_stream_priority"] = tuple(int(v) for v in env["CC_NET_STREAM_PRIORITY"].replace(":", ",").split(","))
     if env.get("CC_CAPTURE_MODE"):
         config.debug.capture_mode = got["capture_mode"] = env["CC_CAPTURE_MODE"]
     if env.get("CC_LIB_PATH"):
