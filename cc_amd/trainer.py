@@ -141,7 +141,7 @@ def cc_forward(nets, batch, cfg, keep=False, cut=None, streams=None):
     else:
         l3s = [LF.edge_aware_smoothness_sum(tgt, [depth, flow_fwd, flow_bwd, exp_mask])]      # the four terms, one job table
     with torch.no_grad():
-        l3 = torch.stack(l3s).sum()                                                    # reported; the total below takes the terms
+        l3 = l3s[0].detach() if len(l3s) == 1 else torch.stack(l3s).sum()              # reported; the total below takes the terms
     l4 = LF.photometric_flow_loss(tgt, refs[1:3], [flow_bwd, flow_fwd], flow_exp_mask,
                                   lambda_oob=cfg.lambda_oob, qch=cfg.qch, wssim=cfg.wssim)             # :503
     l5 = LF.consensus_depth_flow_mask(exp_mask, rig_bwd, rig_fwd, target, target,

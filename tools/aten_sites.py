@@ -2,6 +2,9 @@
 """Which lines of cc_amd still launch ATen kernels inside the training step?
 
     python tools/aten_sites.py [out.txt]        (on the GPU box)
+    python tools/aten_sites.py --cpu [out.txt]  (anywhere: the step on the x86 emulation build at 2 x 64 x 128; every ATen operator
+                                                 that computes something -- views excluded -- by the cc_amd source line that called it,
+                                                 from a TorchDispatchMode: this is the exact list, the GPU form adds durations)
 
 One eager step (B=4, 832x256, full CC).  (1) torch.profiler: the device kernels that do not come from libccengine, by ATen
 operator.  (2) the Python-level tensor operations of cc_amd (add / mul / copy_ / fill / cat / zeros ... called from the package's
@@ -18,6 +21,47 @@ from torch.profiler import ProfilerActivity, profile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from cc_amd import synthetic as syn, trainer as T      # noqa: E402
+
+
+
+def cpu_sites(out):
+    """--cpu: dispatch-level list on the emulation build."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from hipemu.emu import emulated_engine
+    free = ("view", "slice", "select", "as_strided", "detach", "alias", "expand", "unbind", "unsqueeze", "squeeze", "permute", "transpose",
+            "t.default", "_unsafe_view", "reshape", "split", "narrow", "empty", "_local_scalar", "unfold", "chunk", "set_", "resize_",
+            "lift_fresh", "_to_copy")
+    sites = collections.Counter()
+
+    class Mode(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = str(func)
+            if not any(f in name for f in free):
+                s = None
+                for fr in reversed(traceback.extract_stack()[:-1]):
+                    if "/cc_amd/" in fr.filename:
+                        s = "%s:%d %s" % (os.path.relpath(fr.filename, ROOT), fr.lineno, (fr.line or "").strip()[:100])
+                        break
+                sites[(name.replace("aten.", ""), s or "(no cc_amd frame)")] += 1
+            return func(*args, **(kwargs or {}))
+    batch = syn.sample(2, 64, 128, seed=1)
+    with emulated_engine():
+        nets = T.build_nets("cpu")
+        tr = T.CCTrainer(nets, T.StepConfig(), use_graph=False)
+        tr.step(batch)
+        with Mode():
+            tr.step(batch)
+    print("ATen operators that compute something in one training step (full CC; emulation build, 2 x 64 x 128), by calling line of cc_amd:", file=out)
+    for (nm, s), n in sorted(sites.items(), key=lambda kv: (-kv[1], kv[0])):
+        print("%4d  %-28s %s" % (n, nm, s), file=out)
+    print("%4d  in total (the engine's own launches are not ATen operators and are not listed)" % sum(sites.values()), file=out)
+
+
+if "--cpu" in sys.argv:
+    args = [a for a in sys.argv[1:] if a != "--cpu"]
+    cpu_sites(open(args[0], "w") if args else sys.stdout)
+    sys.exit(0)
 
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
