@@ -26,16 +26,14 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# Data-parallel ranks (and the one-rank rehearsal, CC_FORCE_COMM=1) run the HIP runtime with AMD_DIRECT_DISPATCH=0 -- set before
-# the runtime is loaded.  With direct dispatch (the default) a stream-wait on ANOTHER stream's event -- what work.wait() of an
-# asynchronous collective is -- blocks the calling thread until that event has completed; the host then enqueues the optimizer
-# launch and the next hipGraph replay with an idle GPU: measured +0.6 ms per step on one GPU with a one-rank RCCL group, gone with
-# the per-queue submission thread (profiles/r03_ab_round3.txt, r3z).  A single rank keeps the default (0.18 ms faster there).
-# Round 5: with the networks on streams of their own (cc_amd.config.net_streams, the default) the data-parallel step is ONE graph with
-# parallel branches and the two all-reduces behind it; AMD_DIRECT_DISPATCH=0 costs such a graph +1.35 ms per replay (18.13 vs 16.79 ms,
-# profiles/r05_ab_round5.txt) and the one-rank rehearsal runs at 16.89 ms with direct dispatch on: the setting is only applied to the
-# staged two-graph form (CC_NET_STREAMS=0).
-if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("CC_FORCE_COMM", "0") == "1") and os.environ.get("CC_NET_STREAMS") == "0":
+# The legacy STAGED data-parallel form (--pipeline staged with CC_NET_STREAMS=0) runs the HIP runtime with AMD_DIRECT_DISPATCH=0 -- set
+# before the runtime is loaded.  With direct dispatch (the default) a stream-wait on ANOTHER stream's event -- what work.wait() of an
+# asynchronous process-group collective is -- blocks the calling thread until that event has completed; the host then enqueues the
+# optimizer launch and the next hipGraph replay with an idle GPU: measured +0.6 ms per step (profiles/r03_ab_round3.txt, r3z).  A
+# graph with parallel branches pays +1.35 ms per replay for the setting (profiles/r05_ab_round5.txt), so it is applied to that form
+# only.  The default form (round 6, per-network pipelines) has no host-side wait at all: its collectives are nodes of the graph.
+if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("CC_FORCE_COMM", "0") == "1") and os.environ.get("CC_NET_STREAMS") == "0" \
+        and "staged" in " ".join(sys.argv):
     os.environ.setdefault("AMD_DIRECT_DISPATCH", "0")
 
 import torch                      # noqa: E402
@@ -64,9 +62,10 @@ def parse():
                          "forward, only DispResNet6 + PoseNetB6 are trained (227 MB gradient bucket); reported beside the metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--split-graphs", choices=("auto", "0", "1"), default="auto",
-                    help="data-parallel step form: two hipGraphs with the first all-reduce between them (auto: when both gradient "
-                         "segments exist and a process group is active), or one graph and both all-reduces after it")
+    ap.add_argument("--pipeline", choices=("per_network", "post", "staged"), default="per_network",
+                    help="per_network (default): every network's gradient all-reduce -> Adam segment -> weight images at the end of ITS "
+                         "backward pass, on its own stream inside the one hipGraph; post: round 5 (one graph, two process-group "
+                         "all-reduces behind it); staged: rounds 3-4 (two graphs, the first all-reduce between them)")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU steps after one warm-up (median is reported)")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="0 = min(usable threads (affinity / cgroup quota), 64): with all 256 hardware threads of the GPU box the "
@@ -494,8 +493,7 @@ def main():
     if os.environ.get("CC_COMM_PROBE"):
         comm_debug["probe"] = os.environ["CC_COMM_PROBE"]
     ab_env.assert_applied()
-    tr = T.CCTrainer(nets, cfg, use_graph=not args.no_graph,
-                     split_graphs=None if args.split_graphs == "auto" else args.split_graphs == "1", comm_debug=comm_debug)
+    tr = T.CCTrainer(nets, cfg, use_graph=not args.no_graph, pipeline=ab_switches.get("pipeline", args.pipeline), comm_debug=comm_debug)
 
     def sync():
         torch.cuda.synchronize()
@@ -514,8 +512,8 @@ def main():
             if i == 0 and want_cpu:      # (parity gate) gradient norms of the first step, parameters after its update
                 first_gn = [float(torch.sqrt(sum((p_.grad.double() ** 2).sum() for p_ in n_.parameters() if p_.requires_grad)))
                             for n_ in nets if n_ is not None and any(p_.requires_grad for p_ in n_.parameters())]
-                first_params = tr.opt.flat_p[:tr.opt.n].detach().cpu().clone()
-                first_grads = tr.opt.flat_g[:tr.opt.n].detach().cpu().clone()
+                first_params = tr.opt.gather(tr.opt.flat_p).detach().cpu().clone()       # (chain order, without the bucket's padding)
+                first_grads = tr.opt.gather(tr.opt.flat_g).detach().cpu().clone()
             log("warm-up step %d done at %.1f s" % (i, time.perf_counter() - t_w))
     comm_cal = tr.calibrate_comm() if use_dist else None            # each segment's all-reduce alone (outside the timed region)
     sync()
@@ -564,6 +562,33 @@ def main():
         sync()
         comm["stage_b_ms"]["collectives_skipped"] = tr.stage_b_ms()
         tr.opt.comm_probe = ""
+
+    if use_dist and comm is not None and tr.pipeline == "per_network" and not tr.opt.comm_probe and not args.no_graph:
+        # EXPOSED communication of the per-network form: its collectives are nodes of the replayed graph (no event can bracket them),
+        # so the same step is captured once more with the collectives skipped and timed over a few steps AFTER the timed region and the
+        # parity gate (the ranks' weights diverge in those steps; nothing else is reported from them).  exposed = with - without.
+        n_ab = max(5, min(args.steps, 20))
+        tr.opt.comm_probe, tr.graph = "skip", None
+
+        def _time_steps():
+            for _ in range(3):
+                tr.step(batch)
+            sync()
+            ta = time.perf_counter()
+            for _ in range(n_ab):
+                tr.step(batch)
+            sync()
+            t_ = torch.tensor([(time.perf_counter() - ta) / n_ab * 1e3], device=dev, dtype=torch.float64)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            return float(t_.item())
+        ms_skip = _time_steps()
+        tr.opt.comm_probe, tr.graph = "", None
+        ms_with = _time_steps()
+        comm["step_ms_with_collectives"] = round(ms_with, 3)
+        comm["step_ms_collectives_skipped"] = round(ms_skip, 3)
+        comm["exposed_ms_total"] = round(ms_with - ms_skip, 3)
+        comm["exposed_how"] = ("max-over-ranks wall-clock mean of %d replayed steps with the collectives in the graph minus the same with "
+                               "them skipped (re-captured; measured back to back after the timed region)" % n_ab)
 
     kernels, roof = None, None
     if not args.no_kernel_timing:
@@ -693,7 +718,7 @@ def main():
                        "rank_losses": rank_losses,
                        "hip_runtime": {"AMD_DIRECT_DISPATCH": os.environ.get("AMD_DIRECT_DISPATCH", "default (1)")},
                        "dead_occlusion_decoders_elided": bool(args.elide_occ), "ab_switches": ab_switches or None,
-                       "net_streams": (len(tr.net_streams) if tr.net_streams else 0)},
+                       "net_streams": (len(tr.net_streams) if tr.net_streams else 0), "pipeline": tr.pipeline},
             "step_ms": step_ms, "comm": comm,
             "roofline": roof, "kernels": kernels,
         }

@@ -38,6 +38,7 @@ class _Debug:
     force_comm = False           # issue the gradient collectives on a one-rank process group too (tests, tools)
     capture_mode = "thread_local"    # hipGraph capture error mode of CCTrainer
     net_stream_priority = (0, 0, 0)  # HIP stream priorities of the networks' side streams (0 normal, -1 high)
+    pipe_skip_tail = ()          # per-network pipeline, measurement only: names of the networks whose Adam segment + weight-image refresh are skipped
     reduce_trace = None          # a list: every weight-gradient reduce descriptor of the step is appended to it (tools/reduce_bytes.py)
     library_path = None          # another build of libccengine.so (the tools build): picked up by _lib.engine() on first use
 

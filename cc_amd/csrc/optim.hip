@@ -76,6 +76,13 @@ int cc_adam_step_segment(float* params, const float* grads, float* exp_avg, floa
     return CC_OK;
 }
 
+int cc_adam_tick(float* step_dev, void* stream) {
+    if (!step_dev) return CC_ERR_ARG;
+    hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+    CC_CHECK_LAUNCH();
+    return CC_OK;
+}
+
 int cc_fill(float* p, long n, float value, void* stream) {
     if (n <= 0) return CC_ERR_ARG;
     hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, p, n, value);

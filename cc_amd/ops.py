@@ -33,29 +33,32 @@ def _ws(nbytes, ref):
 
 # ----------------------------------------------------------------------------- per-step weight prepack
 class PackRegistry:
-    """The [tap][c][m] weight images of every conv layer (forward + data-gradient layouts), refreshed by ONE
-    cc_repack_table launch per training step (trainer calls prepack_all() at the start of forward) instead of one
-    tiny repack launch inside each of the ~540 conv calls.  Outside a trainer step `valid` is False and every conv
-    call repacks for itself."""
+    """The [tap][c][m] weight images of every conv layer (forward + data-gradient layouts), refreshed by cc_repack_table launches
+    instead of one tiny repack launch inside each of the ~540 conv calls.  Two refresh protocols (cc_amd/trainer.py):
+      * legacy step forms: ONE launch for all layers at the start of a trainer step (prepack_all), the images go stale when the
+        optimizer runs behind the step (invalidate);
+      * per-network pipeline (round 6): every network's images are rebuilt right behind ITS Adam segment, on that network's stream
+        (repack_range), so the next step starts with fresh images and no launch (begin_step).
+    Outside a trainer step `valid` is False and every conv call repacks for itself."""
 
     def __init__(self):
         self.entries = {}
         self.valid = False
         self.recording = False      # new layers are registered only inside a trainer step (not by eval passes at other sizes)
-        self.epoch = 0
-        self.dirty = False
+        self.dirty = False          # layers registered since the table was built
         self.table = None
         self.total_blocks = 0
+        self.range_tables = {}      # (lo_ptr, hi_ptr) -> (n entries it was built from, table, blocks, entries)
 
     def get(self, kind, w, geom):
-        """-> prepacked buffer (tensor) or None.  Unknown layers are registered for the next prepack_all()."""
+        """-> prepacked buffer (tensor) or None.  Unknown layers are registered for the next refresh."""
         key = (kind, w.data_ptr(), geom)
         ent = self.entries.get(key)
         if ent is None:
             if self.recording:
                 self._register(key, kind, w, geom)
             return None
-        if ent is False or not self.valid or ent["epoch"] != self.epoch:
+        if ent is False or not self.valid or not ent["ok"]:
             return None
         return ent["buf"]
 
@@ -72,12 +75,12 @@ class PackRegistry:
         host = (ctypes.c_long * (16 * max(4, stride * stride)))()       # one 16-long descriptor per output parity class
         nd = E.fn[fn + "_desc"](*geom, w.data_ptr(), buf.data_ptr(), ctypes.addressof(host))
         descs = [[int(host[16 * i + k]) for k in range(16)] for i in range(nd)]
-        self.entries[key] = {"buf": buf, "descs": descs, "epoch": -1, "w": w}
+        self.entries[key] = {"buf": buf, "descs": descs, "ok": False, "w": w}
         self.dirty = True
 
     def ensure(self, kind, w, geom):
         """-> the image buffer of (kind, w, geom), registered on the spot when unknown (launch plans hold its address);
-        its CONTENT is valid after the next prepack_all().  None: this geometry does not run on the patch kernel."""
+        its CONTENT is valid after the next refresh.  None: this geometry does not run on the patch kernel."""
         key = (kind, w.data_ptr(), geom)
         ent = self.entries.get(key)
         if ent is None:
@@ -85,36 +88,78 @@ class PackRegistry:
             ent = self.entries[key]
         return ent["buf"] if ent else None
 
+    @staticmethod
+    def _table(live):
+        rows, blk = [], 0
+        for e in live:
+            for d in e["descs"]:
+                d = list(d)
+                d[14] = blk
+                blk += d[15]
+                rows.append(d)
+        return torch.tensor(rows, dtype=torch.int64, device=live[0]["buf"].device).contiguous(), blk
+
     def prepack_all(self):
-        """Start of a trainer step: refresh every registered image (the weights changed in Adam) and open registration."""
+        """Refresh every registered image with one launch (the weights changed) and open registration."""
         live = [e for e in self.entries.values() if e]
         self.recording = True
         if not live:
             return
         if self.dirty or self.table is None:
-            rows, blk = [], 0
-            for e in live:
-                for d in e["descs"]:
-                    d = list(d)
-                    d[14] = blk
-                    blk += d[15]
-                    rows.append(d)
-            self.table = torch.tensor(rows, dtype=torch.int64, device=live[0]["buf"].device).contiguous()
-            self.total_blocks = blk
+            self.table, self.total_blocks = self._table(live)
             self.dirty = False
         engine().call("cc_repack_table", self.table, self.table.shape[0], self.total_blocks, STREAM)
-        self.epoch += 1
         for e in live:
-            e["epoch"] = self.epoch
+            e["ok"] = True
         self.valid = True
 
-    def invalidate(self):
+    def begin_step(self):
+        """Start of a trainer step of the per-network pipeline: the images were rebuilt behind the previous step's Adam segments --
+        nothing to launch unless a layer is new or somebody marked the images stale (mark_stale)."""
+        live = [e for e in self.entries.values() if e]
+        if live and all(e["ok"] for e in live):
+            self.recording = True
+            self.valid = True
+            return
+        self.prepack_all()
+
+    def repack_range(self, lo_ptr, hi_ptr):
+        """Rebuild the images of the layers whose weights live in [lo_ptr, hi_ptr) (one network's segment of the parameter bucket,
+        just updated by its Adam segment) with one launch on the current stream."""
+        n_ent = len(self.entries)
+        ent = self.range_tables.get((lo_ptr, hi_ptr))
+        if ent is None or ent[0] != n_ent:
+            live = [e for e in self.entries.values() if e and lo_ptr <= e["w"].data_ptr() < hi_ptr]
+            tab, blk = self._table(live) if live else (None, 0)
+            ent = self.range_tables[(lo_ptr, hi_ptr)] = (n_ent, tab, blk, live)
+        _, tab, blk, live = ent
+        if tab is None:
+            return
+        engine().call("cc_repack_table", tab, tab.shape[0], blk, STREAM)
+        for e in live:
+            e["ok"] = True
+
+    def mark_stale(self):
+        """the weights changed outside the trainer's own optimizer (load_state_dict, a user's in-place edit)"""
+        for e in self.entries.values():
+            if e:
+                e["ok"] = False
+
+    def end_step(self):
+        """per-network pipeline: the images stay (they match the updated weights); conv calls outside a step repack for themselves"""
         self.valid = False
         self.recording = False
+
+    def invalidate(self):
+        """legacy step forms: the optimizer runs behind the step -- every image is stale afterwards"""
+        self.valid = False
+        self.recording = False
+        self.mark_stale()
 
     def reset(self):
         """Forget every registered layer (tests; a new set of networks)."""
         self.entries.clear()
+        self.range_tables.clear()
         self.valid, self.dirty, self.table, self.total_blocks = False, False, None, 0
 
 
@@ -176,6 +221,10 @@ class _WgradQueue:
             _wgrad_list(items)
         wgrad_reduces._cur().flush()          # (this stream's reductions: the proxy runs every stream's queue on its own stream)
 
+    def drop(self):
+        """error path: forget the parked launches (their operands die with the failed step)"""
+        self.pending = {}
+
 
 class _WgradReduces:
     """Second stages (sums of the split-K partial slabs) of the weight-gradient launches of a backward stage, parked while the
@@ -198,6 +247,9 @@ class _WgradReduces:
                 _dbg.reduce_trace.extend(self.desc)
             arr = (ctypes.c_long * len(self.desc))(*self.desc)
             engine().call("cc_wgrad_reduce_table", ctypes.addressof(arr), len(self.desc) // 16, STREAM)
+        self.desc, self.keep, self.targets, self.bias_jobs = [], [], set(), []
+
+    def drop(self):
         self.desc, self.keep, self.targets, self.bias_jobs = [], [], set(), []
 
     def park_bias(self, gy, gbias, B, C, H, W, gy_bs):
@@ -253,14 +305,25 @@ class _PerStream:
             setattr(self._cur(), name, value)
 
     def flush(self):
+        """every stream's parked work, launched on ITS stream -> the streams touched (the caller joins them)"""
+        touched = []
         for key in list(self._inst):
             inst, st = self._inst[key]
             if st is None or st.cuda_stream == torch.cuda.current_stream().cuda_stream:
                 inst.flush()
             else:
+                touched.append(st)
                 with torch.cuda.stream(st):
                     inst.flush()
         self._inst.clear()          # (all empty now; streams() lists what has parked work since the last flush)
+        return touched
+
+    def drop(self):
+        """error path of a trainer step: forget every stream's parked work WITHOUT launching it (no fork / join is in place, and the
+        operands belong to a step that failed)"""
+        for inst, _ in self._inst.values():
+            inst.drop()
+        self._inst.clear()
 
     def streams(self):
         """the streams that have (had) parked work: the caller makes its stream wait for them after flush()"""
@@ -286,7 +349,7 @@ def _act_bwd_bias(gys, ys, geffs, gbs, ref, B, C, H, W, gy_bs, act, act_a, act_b
     if has_gb and accumulate and wgrad_queue.enabled and not _dbg.no_wgrad_defer:
         ptrs = [t.data_ptr() for t in gbs]
         if wgrad_reduces.targets.intersection(ptrs):
-            wgrad_reduces.flush()
+            wgrad_reduces._cur().flush()       # (this stream's table only: the proxy's flush() would launch every stream's)
         wgrad_reduces.targets.update(ptrs)
         red = (ctypes.c_long * (16 * G))()
         nred = ctypes.c_int(0)
@@ -324,7 +387,7 @@ def _wgrad_group(a_list, x_list, gw_list, ref, B, M, AH, AW, a_bs, Cin, IH, IW, 
                 _wgrad_group([a], [x], [gw], ref, B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, accumulate)
             return
         if wgrad_reduces.targets.intersection(ptrs):      # a weight used twice in one stage: two parked `gw +=` would race
-            wgrad_reduces.flush()
+            wgrad_reduces._cur().flush()
         wgrad_reduces.targets.update(ptrs)
         red = (ctypes.c_long * (16 * G))()
         nred = ctypes.c_int(0)

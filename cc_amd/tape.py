@@ -84,6 +84,11 @@ class BnCounters:
 
 BN_COUNTERS = None
 
+# Set by CCTrainer for the duration of a pipelined step: called with the network module at the END of that network's backward
+# pass (inside its autograd node, i.e. on the network's stream, behind its last gradient launch) -- the trainer then runs the
+# network's gradient exchange, Adam segment and weight-image refresh right there instead of behind the whole backward pass.
+NET_DONE = None
+
 class TT:
     """A tensor on the tape + the state of its gradient during the backward pass."""
     __slots__ = ("t", "act", "act_a", "act_b", "uses", "remaining", "grad", "pend", "pre", "needs")
@@ -311,7 +316,7 @@ class Tape:
             if want_b and acc and ops.wgrad_queue.enabled and not ops._dbg.no_wgrad_defer:
                 ptrs = [t.data_ptr() for t in ops_gb]
                 if ops.wgrad_reduces.targets.intersection(ptrs) or len(set(ptrs)) != len(ptrs):
-                    ops.wgrad_reduces.flush()
+                    ops.wgrad_reduces._cur().flush()
                 ops.wgrad_reduces.targets.update(ptrs)
                 red = (ctypes.c_long * (16 * n))()
                 nred = ctypes.c_int(0)
@@ -737,7 +742,7 @@ class _NetFn(torch.autograd.Function):
         tape = Tape(record=any(need))
         ins = [tape.leaf(t, needs=need[i]) for i, t in enumerate(tensors[:n_in])]
         outs = body(tape, *ins)
-        ctx.tape, ctx.ins, ctx.outs, ctx.n_in = tape, ins, outs, n_in
+        ctx.tape, ctx.ins, ctx.outs, ctx.n_in, ctx.body = tape, ins, outs, n_in, body
         ctx.params = tensors[n_in:]
         ctx.set_materialize_grads(False)
         return tuple(o.t for o in outs)
@@ -752,6 +757,8 @@ class _NetFn(torch.autograd.Function):
             ent = tape.param_grads.get(id(p))
             gpar.append(ent[1] if ent is not None else None)
         ctx.tape = None
+        if NET_DONE is not None:
+            NET_DONE(getattr(ctx.body, "__self__", None))
         return (None, None) + tuple(gin) + tuple(gpar)
 
 

@@ -8,7 +8,12 @@ MI355X-first structure around that body:
   * all parameters live in ONE flat fp32 bucket (views re-pointed into it), gradients in a second one:
     a single RCCL all-reduce per step over xGMI (297 MB for the four nets) and a single fused Adam launch;
   * forward + backward of a step are captured once into a hipGraph (static shapes, no host syncs on the path)
-    and replayed, which removes the ~1.5 k kernel-launch and Python/autograd dispatch costs from the step.
+    and replayed, which removes the ~1.5 k kernel-launch and Python/autograd dispatch costs from the step;
+  * round 6, pipeline "per_network" (the default): the four networks run on HIP streams of their own, and at the end of a
+    network's backward pass ITS stream exchanges ITS segment of the gradient bucket (RCCL all-reduce enqueued on that stream:
+    a node of the graph branch), runs ITS Adam segment and rebuilds ITS weight images -- under the other networks' backward
+    passes.  Only the last finisher's exchange is exposed; on one GPU the optimizer and the weight-image refresh leave the
+    critical path the same way.
 """
 import torch
 import torch.distributed as dist
@@ -70,6 +75,14 @@ def _join(streams):
             cur.wait_stream(st)
 
 
+def _tensors(x):
+    if torch.is_tensor(x):
+        yield x
+    elif isinstance(x, (list, tuple)):
+        for y in x:
+            yield from _tensors(y)
+
+
 def cc_forward(nets, batch, cfg, keep=False, cut=None, streams=None):
     """train.py:454-509.  batch = (tgt, [4 refs], K, Kinv).
     cut: optional dict; when given, the losses are computed on detached copies of the network outputs and
@@ -105,13 +118,25 @@ def cc_forward(nets, batch, cfg, keep=False, cut=None, streams=None):
             return fn()
     s_disp, s_flow, s_mask = (tuple(streams) + (None, None, None))[:3] if streams else (None, None, None)
     full = not (mask_net is None or flow_net is None)
-    # (independent of each other between the frames and the losses: launched first so that the side streams have work while the
-    # step's stream runs the other two networks; train.py:454-463 order of the results is kept below)
-    disp_out = _on(s_disp, lambda: list(disp_net(tgt)))                                # :454
+    # (independent of each other between the frames and the losses: the side streams' networks are launched first so that they have
+    # work while the step's stream runs the other two; train.py:454-463 order of the results is kept below.  The autograd engine
+    # runs ready nodes latest-created first, so the backward passes are ENQUEUED pose, mask, disp, flow: shortest first, which is the
+    # order the per-network pipeline issues the networks' gradient exchanges in -- one RCCL communicator executes its collectives in
+    # issue order, and Back2Future, the longest backward, must not hold up DispResNet6's segment)
     flow_out = _on(s_flow, lambda: flow_net(tgt, refs[1:3])) if full else None         # :463
+    disp_out = _on(s_disp, lambda: list(disp_net(tgt)))                                # :454
     mask_out = _on(s_mask, lambda: list(mask_net(tgt, refs))) if full else None        # :460
     pose_out = pose_net(tgt, refs)                                                     # :459
     _join(forked)
+    if forked and not torch.cuda.is_current_stream_capturing():
+        # eager mode: these tensors were allocated on a side stream and are read by the loss kernels on this one -- tell the caching
+        # allocator, so that a block freed here is not handed back to its home stream while this stream still reads it (under
+        # capture the graph's private pool is not recycled across streams: nothing to record)
+        cur = torch.cuda.current_stream()
+        for st, outs in ((s_disp, disp_out), (s_flow, flow_out), (s_mask, mask_out)):
+            if st is not None and outs is not None:
+                for t in _tensors(outs):
+                    t.record_stream(cur)
     disparities = _cut("dp", disp_out)
     depth = LF.reciprocal_levels(disparities)                                          # :458  [1 / d for d in disparities]
     pose = _cut("dp", [pose_out])[0]
@@ -178,42 +203,71 @@ class _SideStreamWork:
 
 
 class FlatAdam:
-    """train.py:307-310 ``torch.optim.Adam(chain(all params), lr, betas)`` as ONE flat bucket + ONE kernel."""
+    """train.py:307-310 ``torch.optim.Adam(chain(all params), lr, betas)`` as ONE flat bucket + fused kernels.
+
+    Bucket layout: the parameters in train.py:305's chain order (DispResNet6 | PoseNetB6 | MaskNet6 | Back2Future), every NETWORK's
+    range starting on a 256-byte boundary (<= 63 zero floats of padding between two networks: zero gradient, zero update), so that
+    each network is a segment that can be exchanged (RCCL), updated (cc_adam_step_segment, float4) and re-imaged on its own."""
+    ALIGN = 64          # floats
 
     def __init__(self, nets, cfg):
-        params = [p for n in nets if n is not None for p in n.parameters() if p.requires_grad]
+        per_net = [([p for p in n.parameters() if p.requires_grad] if n is not None else []) for n in nets]
+        params = [p for ps in per_net for p in ps]
         self.params = params
         # module buffers (BatchNorm running statistics / counters) and frozen parameters: not in the bucket, but part of what rank 0
         # hands to the other ranks at start-up (train.py:300-303: DataParallel replicates the whole module from device 0)
         self.extra_state = [b for n in nets if n is not None for b in n.buffers()] + \
                            [p for n in nets if n is not None for p in n.parameters() if not p.requires_grad]
         dev = params[0].device
-        n = sum(p.numel() for p in params)
-        pad = (-n) % 4
-        self.n = n
-        self.flat_p = torch.zeros(n + pad, device=dev, dtype=torch.float32)
-        self.flat_g = torch.zeros(n + pad, device=dev, dtype=torch.float32)
+        self.n = sum(p.numel() for p in params)          # parameters (without the alignment padding)
+        self.net_ranges, self.offsets, off = [], [], 0   # per network: (lo, hi) of its parameters or None; per parameter: its offset
+        for ps in per_net:
+            if not ps:
+                self.net_ranges.append(None)
+                continue
+            off = -(-off // self.ALIGN) * self.ALIGN
+            lo = off
+            for p in ps:
+                self.offsets.append(off)
+                off += p.numel()
+            self.net_ranges.append((lo, off))
+        size = -(-off // self.ALIGN) * self.ALIGN
+        self.flat_p = torch.zeros(size, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(size, device=dev, dtype=torch.float32)
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.float32)
-        off = 0
-        for p in params:
+        for p, off in zip(params, self.offsets):
             k = p.numel()
             self.flat_p[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat_p[off:off + k].view_as(p.data)
             p.grad = self.flat_g[off:off + k].view_as(p.data)
-            off += k
         self.lr, self.betas = cfg.lr, cfg.betas
         # conv weights / biases: the wgrad and bias-gradient kernels accumulate straight into the flat bucket
         # (the trainer switches ops.grad_sinks to this table for the duration of its own forward+backward only)
         self.sinks = {p.data_ptr(): p.grad for p in params}
         ops.packs.reset()          # weight images registered against the pre-bucket storages are stale now
-        # measurement aid (tools/gpu_r3z.sh: what does the data-parallel step form cost without RCCL?): "skip" / "sidestream" REPLACE
+        # measurement aid (bench.py: what does the step cost without the exchange?): "skip" / "sidestream" REPLACE
         # the gradient exchange -- the ranks diverge.  Off unless a tools script sets it on the instance AND says so loudly.
         self.comm_probe = ""
+        self._rccl = None
 
     def zero_grad(self):
         engine().call("cc_fill", self.flat_g, self.flat_g.numel(), 0.0, STREAM)
+
+    def gather(self, flat):
+        """the parameters' elements of a bucket-shaped tensor in chain order, without the alignment padding
+        (== torch.cat([p.reshape(-1) for p in params]) for flat_p)"""
+        return torch.cat([flat[lo:hi] for lo, hi in (r for r in self.net_ranges if r is not None)])
+
+    def segment(self, i):
+        """[lo, hi) of network i's bucket segment as exchanged / updated: from its first parameter to the next network's first
+        (its padding included; the last one runs to the end of the bucket), or None"""
+        r = self.net_ranges[i]
+        if r is None:
+            return None
+        nxt = [q[0] for q in self.net_ranges[i + 1:] if q is not None]
+        return r[0], (nxt[0] if nxt else self.flat_p.numel())
 
     @staticmethod
     def world():
@@ -222,13 +276,14 @@ class FlatAdam:
     @staticmethod
     def comm_active():
         """collectives are issued when there is more than one rank -- or when config.debug.force_comm asks for them on a one-rank
-        process group (exercises the RCCL / two-graph path on a single GPU: tests, tools)"""
+        process group (exercises the RCCL path on a single GPU: tests, tools)"""
         if not (dist.is_available() and dist.is_initialized()):
             return False
         return dist.get_world_size() > 1 or config.debug.force_comm
 
     def all_reduce(self, lo=0, hi=None, async_op=False):
-        """SUM-all-reduce flat_g[lo:hi] over the ranks (RCCL over xGMI; gloo in the CPU tests).  -> work handle or None."""
+        """SUM-all-reduce flat_g[lo:hi] over the ranks through torch.distributed (RCCL's process group on HIP devices, gloo in the
+        CPU tests).  -> work handle or None."""
         if self.comm_active():
             hi = self.flat_g.numel() if hi is None else hi
             if hi > lo:
@@ -239,17 +294,40 @@ class FlatAdam:
                 return dist.all_reduce(self.flat_g[lo:hi], async_op=async_op)
         return None
 
+    def rccl(self):
+        """the trainer's own RCCL communicator (cc_amd/rccl.py), created on first use OUTSIDE any stream capture: collectives that
+        are enqueued on the caller's stream; HIP devices with an RCCL process group only, None otherwise (gloo: all_reduce())"""
+        if self._rccl is None and self.flat_g.is_cuda and self.comm_active() and dist.get_backend() == "nccl":
+            from . import rccl
+            self._rccl = rccl.Communicator(self.flat_g.device)
+        return self._rccl
+
+    def all_reduce_here(self, lo, hi):
+        """SUM-all-reduce flat_g[lo:hi] ORDERED ON THE CURRENT STREAM (what follows on this stream sees the sum; inside a capture it is
+        a node of the graph): ncclAllReduce on this stream on HIP devices, a blocking process-group call otherwise."""
+        if not self.comm_active() or hi <= lo or self.comm_probe == "skip":
+            return
+        comm = self.rccl()
+        if comm is not None:
+            comm.all_reduce_sum_(self.flat_g[lo:hi])
+        else:
+            dist.all_reduce(self.flat_g[lo:hi])
+
     def grad_scale(self):
         return 1.0 / self.world()
 
     def step(self, grad_scale=1.0):
-        engine().call("cc_adam_step", self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.step_dev, self.n,
+        engine().call("cc_adam_step", self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.step_dev, self.flat_p.numel(),
                       float(self.lr), float(self.betas[0]), float(self.betas[1]), 1e-8, float(grad_scale), STREAM)
+
+    def tick(self):
+        """advance the step counter alone (the segments of this step then update with tick = 0, from any stream)"""
+        engine().call("cc_adam_tick", self.step_dev, STREAM)
 
     def step_segment(self, lo, hi, tick, grad_scale=1.0):
         """The update of elements [lo, hi) of the bucket (lo % 4 == 0); tick: advance the step counter (first segment only)."""
-        hi = self.n if hi is None else hi
-        assert lo % 4 == 0 and 0 <= lo < hi <= self.n
+        hi = self.flat_p.numel() if hi is None else hi
+        assert lo % 4 == 0 and 0 <= lo < hi <= self.flat_p.numel()
         engine().call("cc_adam_step_segment", self.flat_p[lo:hi], self.flat_g[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
                       self.step_dev, hi - lo, float(self.lr), float(self.betas[0]), float(self.betas[1]), 1e-8, float(grad_scale),
                       int(tick), STREAM)
@@ -257,28 +335,25 @@ class FlatAdam:
     def state_dict(self):
         """The layout of ``torch.optim.Adam.state_dict()`` (what train.py:408-410 stores in optimizer_checkpoint.pth.tar):
         per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` cut out of the flat buckets, one param group."""
-        state, off = {}, 0
-        for i, p in enumerate(self.params):
+        state = {}
+        for i, (p, off) in enumerate(zip(self.params, self.offsets)):
             k = p.numel()
             state[i] = {"step": self.step_dev.detach().clone().reshape(()),
                         "exp_avg": self.exp_avg[off:off + k].view_as(p).clone(),
                         "exp_avg_sq": self.exp_avg_sq[off:off + k].view_as(p).clone()}
-            off += k
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
                  "params": list(range(len(self.params)))}
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
         """Accepts a ``torch.optim.Adam`` state dict over the same parameter order (chain of the four nets)."""
-        off = 0
-        for i, p in enumerate(self.params):
+        for i, (p, off) in enumerate(zip(self.params, self.offsets)):
             k = p.numel()
             st = sd["state"].get(i)
             if st is not None:
                 self.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
                 self.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
                 self.step_dev.fill_(float(st["step"]))
-            off += k
         g = sd["param_groups"][0]
         self.lr, self.betas = g["lr"], tuple(g["betas"])
 
@@ -291,13 +366,24 @@ class FlatAdam:
                 dist.broadcast(t.data, 0)
 
 
+NET_NAMES = ("disp", "pose", "mask", "flow")
+
+
 class CCTrainer:
     """One rank of the data-parallel CC training job."""
 
-    def __init__(self, nets, cfg, use_graph=True, split_graphs=None, comm_debug=None):
-        """comm_debug (measurement scripts only; default: plain product step): dict with any of
-             'events': True  -- record HIP events around the waits for the gradient all-reduces (comm_stats(); bench.py asks for it)
-             'join': 'single' -- one join + one optimizer launch instead of the segmented update (A/B)
+    def __init__(self, nets, cfg, use_graph=True, split_graphs=None, comm_debug=None, pipeline=None):
+        """pipeline: how backward, gradient exchange, optimizer and weight-image refresh are arranged
+             "per_network" (default)  each network's stream runs  flush -> all-reduce(its segment) -> Adam(its segment) -> weight images
+                                      at the end of ITS backward pass, inside the one graph (eagerly on CPU tensors: same calls, same
+                                      order -- the form the gloo tests run);
+             "post"                   round 5: one graph, the [DispResNet6|PoseNetB6] and [MaskNet6|Back2Future] all-reduces issued
+                                      behind it through the process group, segmented Adam, weight images at the next step's start;
+             "staged"                 rounds 3-4: two graphs, the first segment's all-reduce between them (under backward stage B).
+           split_graphs (legacy switch of bench.py / the tests): True = "staged", False = "post".
+           comm_debug (measurement scripts only; default: plain product step): dict with any of
+             'events': True  -- (post / staged) record HIP events around the waits for the gradient all-reduces (comm_stats())
+             'join': 'single' -- (post / staged) one join + one optimizer launch instead of the segmented update (A/B)
              'probe': 'skip' | 'sidestream' -- REPLACE the all-reduces by nothing / a 16-byte side-stream kernel: the ranks diverge;
                       announced on stderr."""
         self.nets, self.cfg = nets, cfg
@@ -316,17 +402,19 @@ class CCTrainer:
         self.use_graph = use_graph
         self.graph = None
         self.graph_b = None
-        # gradient segments of the flat bucket: [DispResNet6 | PoseNetB6] [MaskNet6 | Back2Future] (parameter order of
-        # FlatAdam = train.py:305's chain)
-        self.n_dp = sum(p.numel() for n in nets[:2] if n is not None for p in n.parameters() if p.requires_grad)
-        # two stages / two graphs only when both gradient segments exist (with MaskNet6 + Back2Future frozen -- README's
-        # --fix-masknet --fix-flownet -- stage B is empty: one graph, one all-reduce)
-        two_segments = 0 < self.n_dp < self.opt.n
-        # With the networks on streams of their own the backward passes of DispResNet6 and Back2Future overlap only inside ONE
-        # backward call (= one graph): the staged form then costs more (the two longest backward chains one after the other: +25 % of
-        # the step on one GPU) than hiding the first segment's all-reduce under stage B saves, so the data-parallel step keeps the
-        # single graph and issues both all-reduces behind it (the second one runs under the first segment's optimizer update).
-        # split_graphs=True asks for the staged form explicitly.
+        # gradient segments of the legacy forms: [DispResNet6 | PoseNetB6] [MaskNet6 | Back2Future] (parameter order of
+        # FlatAdam = train.py:305's chain); n_dp = first element of the second one
+        tail = [r[0] for r in self.opt.net_ranges[2:] if r is not None]
+        head = [r for r in self.opt.net_ranges[:2] if r is not None]
+        self.n_dp = tail[0] if (tail and head) else (self.opt.flat_p.numel() if head else 0)
+        two_segments = bool(tail and head)
+        if pipeline is None:
+            pipeline = "per_network" if split_graphs is None else ("staged" if split_graphs else "post")
+        assert pipeline in ("per_network", "post", "staged"), pipeline
+        if pipeline == "staged" and not two_segments:     # (MaskNet6 + Back2Future frozen -- README's --fix-masknet --fix-flownet)
+            pipeline = "post"
+        self.pipeline = pipeline
+        self.split_graphs = pipeline == "staged"
         dev0 = next(p for n in nets if n is not None for p in n.parameters()).device
         # config.net_streams: one side stream each for DispResNet6 and Back2Future (forward AND backward: autograd runs a node's
         # backward on the stream of its forward); HIP devices only
@@ -336,29 +424,35 @@ class CCTrainer:
         # round 5, see profiles/r05_ab_round5.txt)
         pri = tuple(config.debug.net_stream_priority) + (0, 0, 0)
         self.net_streams = tuple(torch.cuda.Stream(dev0, priority=pri[i]) for i in range(nst)) if (nst and dev0.type == "cuda") else None
-        self.split_graphs = (self.opt.comm_active() and two_segments and not self.net_streams) if split_graphs is None \
-            else bool(split_graphs)
+        self._net_index = {id(n): i for i, n in enumerate(nets) if n is not None}
+        self._done = set()
+        self.segment_calls = []          # per_network, most recent step: [(network index, lo, hi)] in issue order (tests, bench)
+        self._packed_version = None      # flat_p._version the weight images were built for (per_network)
         self.comm_events = []            # per step: (before wait 0, after wait 0, before wait 1, after wait 1) on the compute stream
         self.comm_standalone_ms = None   # calibrate_comm(): each segment's all-reduce alone, nothing to hide under
         self.stage_b_events = []         # per step: events around the replay of backward stage B (two-graph form, comm_debug events)
         self.static_batch = None
         self.losses = None
         self.nan_flags = []
+        if self.pipeline == "per_network" and self.opt.comm_active():
+            self.opt.rccl()              # the communicator must exist before any capture
 
-    # The step is cut into stages so that the gradient exchange of the big DispResNet6 + PoseNetB6 segment (227 MB of the
-    # 297 MB bucket) runs UNDER the backward pass of Back2Future + MaskNet6 (the longest stage):
-    #   A: weight images, zero grads, forward of the four nets + losses (train.py:454-509), d loss / d (net outputs),
-    #      backward of DispResNet6 + PoseNetB6                                   -> all-reduce(flat_g[:n_dp]) starts
-    #   B: backward of MaskNet6 + Back2Future                                    -> all-reduce(flat_g[n_dp:]) (exposed)
-    # The nets only meet in the losses, so the two backward stages are independent given the output gradients.
-    def _stage_a(self, batch, fuse_b=False):
+    # ------------------------------------------------------------------------------------------------ the step's pieces
+    def _begin(self, batch):
         tape.BN_COUNTERS = self.bn_counters
         self.bn_counters.begin()
         LF.pyramid_cache.clear()
-        ops.packs.prepack_all()            # every conv layer's [tap][c][m] weight images, one launch (weights changed in Adam)
+        if self.pipeline == "per_network":
+            ops.packs.begin_step()         # fresh from the previous step's per-network refresh: no launch
+            self.opt.tick()                # the networks' Adam segments of this step all read the advanced counter
+        else:
+            ops.packs.prepack_all()        # every conv layer's [tap][c][m] weight images, one launch (weights changed in Adam)
         self.opt.zero_grad()                                                # :566
         ops.grad_sinks = self.opt.sinks
         LF.scalar_pool.begin(batch[0].device)
+
+    def _loss_grads(self, batch):
+        """forward of the four nets + losses (train.py:454-509) and d loss / d (network outputs) -> (losses, dp pairs, mf pairs)"""
         cut = {}
         LF.head_grads.begin()              # the loss terms' gradients of a shared network output meet in one accumulator
         try:
@@ -372,23 +466,39 @@ class CCTrainer:
         dp = [(t, gt) for (t, _), gt in zip(pairs[:ndp], g[:ndp]) if gt is not None]
         mf = [(t, gt) for (t, _), gt in zip(pairs[ndp:], g[ndp:]) if gt is not None]
         ops.wgrad_queue.enabled = not config.debug.no_wgrad_queue
+        losses = {k: v.detach() for k, v in out.items() if torch.is_tensor(v) and k.startswith("loss")}
+        return losses, dp, mf
+
+    def _backward(self, pairs):
+        """ONE backward call for the given (network output, gradient) pairs: every network's backward waits for the loss gradients
+        only, so DispResNet6 (side stream 0), Back2Future (side stream 1) and PoseNetB6 + MaskNet6 (this stream) run side by side.
+        (Two calls would order the second behind the join of the first.)  The gradient tensors stay referenced by the caller until
+        the streams have been joined: they were allocated on this stream and are read on the others."""
+        if not pairs:
+            return
+        _fork(self.net_streams or ())
+        if self.net_streams and not torch.cuda.is_current_stream_capturing():
+            for _, gt in pairs:                                  # (eager mode: see cc_forward)
+                for st in self.net_streams:
+                    gt.record_stream(st)
+        torch.autograd.backward([t for t, _ in pairs], [gt for _, gt in pairs])
+
+    # The legacy forms cut the step into stages so that the gradient exchange of the big DispResNet6 + PoseNetB6 segment (227 MB of the
+    # 297 MB bucket) runs UNDER the backward pass of Back2Future + MaskNet6 (the longest stage):
+    #   A: weight images, zero grads, forward of the four nets + losses (train.py:454-509), d loss / d (net outputs),
+    #      backward of DispResNet6 + PoseNetB6                                   -> all-reduce(flat_g[:n_dp]) starts
+    #   B: backward of MaskNet6 + Back2Future                                    -> all-reduce(flat_g[n_dp:]) (exposed)
+    # The nets only meet in the losses, so the two backward stages are independent given the output gradients.
+    def _stage_a(self, batch, fuse_b=False):
+        self._begin(batch)
+        losses, dp, mf = self._loss_grads(batch)
         if fuse_b and self.net_streams:
-            # one backward call for all four networks: every network's backward waits for the loss gradients only, so DispResNet6
-            # (side stream 0), Back2Future (side stream 1) and PoseNetB6 + MaskNet6 (this stream) run side by side.  (Two calls
-            # would order the second behind the join of the first.)  The gradient tensors stay referenced until the streams have
-            # been joined: they were allocated on this stream and are read on the others.
-            both = dp + mf
-            if both:
-                _fork(self.net_streams)
-                torch.autograd.backward([t for t, _ in both], [gt for _, gt in both])
-            self._sync_streams(bool(both))
+            self._backward(dp + mf)
+            self._sync_streams(bool(dp + mf))
             mf = []
         else:
-            if dp:
-                _fork(self.net_streams or ())
-                torch.autograd.backward([t for t, _ in dp], [gt for _, gt in dp])
+            self._backward(dp)
             self._sync_streams(bool(dp))     # the segment's gradients are complete before its all-reduce is issued
-        losses = {k: v.detach() for k, v in out.items() if torch.is_tensor(v) and k.startswith("loss")}
         return losses, mf
 
     def _sync_streams(self, forked=True):
@@ -404,29 +514,98 @@ class CCTrainer:
         _join(sts.values())
 
     def _stage_b(self, mf):
-        if mf:
-            _fork(self.net_streams or ())
-            torch.autograd.backward([t for t, _ in mf], [gt for _, gt in mf])
+        self._backward(mf)
         self._sync_streams(bool(mf))
 
-    def _stage_end(self):
+    def _stage_end(self, failed=False):
         tape.BN_COUNTERS = None
-        ops.wgrad_queue.flush()
+        tape.NET_DONE = None
+        if failed:
+            # a stage raised part-way: the parked launches' operands belong to the failed step and no fork / join is in place for
+            # the side streams -- drop them instead of launching
+            ops.wgrad_queue.drop()
+            ops.wgrad_reduces.drop()
+        else:
+            ops.wgrad_queue.flush()
         ops.wgrad_queue.enabled = False
         LF.scalar_pool.end()
         ops.grad_sinks = {}
-        ops.packs.invalidate()
+        if self.pipeline == "per_network" and not failed:
+            ops.packs.end_step()
+        else:
+            ops.packs.invalidate()
 
     def _fwd_bwd(self, batch, between=None):
-        """forward + backward of one mini-batch; `between()` runs between the two backward stages."""
+        """(legacy forms) forward + backward of one mini-batch; `between()` runs between the two backward stages."""
+        ok = False
         try:
             losses, mf = self._stage_a(batch, fuse_b=between is None)      # (no collective between the stages: one backward call)
             if between is not None:
                 between()
             self._stage_b(mf)
+            ok = True
         finally:
-            self._stage_end()
+            self._stage_end(failed=not ok)
         return losses
+
+    # ------------------------------------------------------------------------------------------------ per-network pipeline
+    def _net_done(self, module):
+        """tape.NET_DONE: called at the end of `module`'s backward pass, inside its autograd node -- on the network's stream, behind
+        its last gradient launch."""
+        i = self._net_index.get(id(module))
+        if i is not None and i not in self._done:
+            self._finish_network(i)
+
+    def _finish_network(self, i):
+        """The tail of network i's gradient pipeline on the CURRENT stream: what its backward left parked (weight-gradient groups,
+        reduce and bias tables), the all-reduce of its bucket segment, its Adam segment, its weight images.  The other networks'
+        streams keep running their backward passes meanwhile."""
+        self._done.add(i)
+        seg = self.opt.segment(i)
+        if seg is None:
+            return
+        ops.wgrad_queue._cur().flush()          # (this stream's queue; it flushes this stream's reduce / bias tables behind it)
+        lo, hi = seg
+        self.segment_calls.append((i, lo, hi))
+        if NET_NAMES[i] in config.debug.pipe_skip_tail:      # (measurement: what does this network's tail cost the step?)
+            return
+        self.opt.all_reduce_here(lo, hi)
+        self.opt.step_segment(lo, hi, False, self.opt.grad_scale())
+        base = self.opt.flat_p.data_ptr()
+        ops.packs.repack_range(base + 4 * lo, base + 4 * hi)
+
+    def _step_pipelined(self, batch):
+        """train.py:445-568 with every network's exchange + update behind ITS backward pass (see the class docstring)"""
+        ok = False
+        self._done = set()
+        self.segment_calls = []
+        try:
+            self._begin(batch)
+            losses, dp, mf = self._loss_grads(batch)
+            tape.NET_DONE = self._net_done
+            both = dp + mf
+            self._backward(both)
+            tape.NET_DONE = None
+            self._sync_streams(bool(both))
+            for i in range(len(self.nets)):     # networks that are not on the tape (alternative architectures) or received no gradient
+                if i not in self._done:
+                    self._finish_network(i)
+            ok = True
+        finally:
+            self._stage_end(failed=not ok)
+        return losses
+
+    def _weights_touched(self):
+        """did anybody but this trainer write the parameters since the weight images were built?  (torch in-place ops bump the
+        bucket's version counter -- load_state_dict, p.data.mul_(..); the Adam kernel does not)"""
+        # (a Parameter re-pointed into the bucket keeps a version counter of its own: p.copy_() bumps p's, flat_p[..].copy_() the bucket's)
+        v = self.opt.flat_p._version + sum(p._version for p in self.opt.params)
+        if self._packed_version is None:
+            self._packed_version = v
+        if v != self._packed_version:
+            self._packed_version = v
+            return True
+        return False
 
     def _copy_in(self, batch):
         tgt, refs, K, Kinv = batch
@@ -448,17 +627,27 @@ class CCTrainer:
         tgt, refs, K, Kinv = batch
         self.static_batch = (tgt.clone(), [r.clone() for r in refs], K.clone(), Kinv.clone())
         # the eager warm-up passes must leave no trace: BatchNorm running statistics / num_batches_tracked would otherwise
-        # absorb the first batch three times where the reference absorbs it once (train.py:454 runs each batch once)
+        # absorb the first batch three times where the reference absorbs it once (train.py:454 runs each batch once) -- and the
+        # pipelined step contains the optimizer, so parameters, moments and step counter are put back as well
         bn_state = [(b, b.detach().clone()) for n in self.nets if n is not None for b in n.buffers()]
+        pipelined = self.pipeline == "per_network"
+        opt_state = [(t, t.detach().clone()) for t in (self.opt.flat_p, self.opt.exp_avg, self.opt.exp_avg_sq, self.opt.step_dev)] \
+            if pipelined else []
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):
-                self._fwd_bwd(self.static_batch)
+                self._step_pipelined(self.static_batch) if pipelined else self._fwd_bwd(self.static_batch)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        for b, saved in bn_state:
+        for b, saved in bn_state + opt_state:
             b.copy_(saved)
+        if pipelined:
+            ops.packs.mark_stale()
+            ops.packs.prepack_all()         # the images of the restored weights: the captured step starts from them
+            ops.packs.end_step()
+            self._packed_version = None
+            self._weights_touched()
         LF.check_finite()                   # the warm-up's own flags (and drop them: the captured step registers its own)
         # thread_local: only the capturing thread's calls are policed -- a process-group watchdog thread (multi-GPU runs)
         # polling its events must not invalidate the capture
@@ -467,16 +656,18 @@ class CCTrainer:
         if self.split_graphs:
             # two graphs sharing one memory pool: the collective of the first gradient segment is issued between them
             self.graph_b = torch.cuda.CUDAGraph()
+            ok = False
             try:
                 with torch.cuda.graph(self.graph, capture_error_mode=mode):
                     self.losses, mf = self._stage_a(self.static_batch)
                 with torch.cuda.graph(self.graph_b, pool=self.graph.pool(), capture_error_mode=mode):
                     self._stage_b(mf)
+                ok = True
             finally:
-                self._stage_end()
+                self._stage_end(failed=not ok)
         else:
             with torch.cuda.graph(self.graph, capture_error_mode=mode):
-                self.losses = self._fwd_bwd(self.static_batch)
+                self.losses = self._step_pipelined(self.static_batch) if pipelined else self._fwd_bwd(self.static_batch)
         # the NaN flags of the captured step live in the graph's private pool and are rewritten by every replay: keep them
         # as persistent handles (the reference asserts on NaN at every step, loss_functions.py:60,105,115)
         self.nan_flags = LF.take_nan_flags()
@@ -489,14 +680,10 @@ class CCTrainer:
     def grad_norms(self):
         """L2 norm of the most recent step's (all-reduced, unscaled) gradient per network, from the flat bucket
         -> {'disp'|'pose'|'mask'|'flow': 0-dim float64 device tensor}.  Diagnostic / parity-test hook."""
-        out, off = {}, 0
-        for name, n in zip(("disp", "pose", "mask", "flow"), self.nets):
-            if n is None:
-                continue
-            k = sum(p.numel() for p in n.parameters() if p.requires_grad)
-            if k:
-                out[name] = self.opt.flat_g[off:off + k].double().pow(2).sum().sqrt()
-            off += k
+        out = {}
+        for name, r in zip(NET_NAMES, self.opt.net_ranges):
+            if r is not None:
+                out[name] = self.opt.flat_g[r[0]:r[1]].double().pow(2).sum().sqrt()
         return out
 
     def save_checkpoint(self, save_path, epoch, is_best=False):
@@ -512,13 +699,16 @@ class CCTrainer:
                               is_best)
 
     def segments(self):
-        """[(lo, hi)] of the flat gradient bucket as exchanged: [DispResNet6 | PoseNetB6] [MaskNet6 | Back2Future]"""
+        """[(lo, hi)] of the flat gradient bucket as exchanged: one per trainable network (per_network), or
+        [DispResNet6 | PoseNetB6] [MaskNet6 | Back2Future] (post / staged)"""
         n = self.opt.flat_g.numel()
-        return [(0, self.n_dp), (self.n_dp, n)] if 0 < self.n_dp < self.opt.n else [(0, n)]
+        if self.pipeline == "per_network":
+            return [s for s in (self.opt.segment(i) for i in range(len(self.nets))) if s is not None]
+        return [(0, self.n_dp), (self.n_dp, n)] if 0 < self.n_dp < n else [(0, n)]
 
     def calibrate_comm(self, reps=3):
         """Each gradient segment's all-reduce ALONE on an idle device (median of `reps`, host-synchronised): the yardstick
-        the exposed times of comm_stats() are read against.  Outside any timed region; needs an initialised process group."""
+        the exposed communication is read against.  Outside any timed region; needs an initialised process group."""
         if not self.opt.comm_active():
             return None
         out = []
@@ -528,8 +718,11 @@ class CCTrainer:
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                w = dist.all_reduce(self.opt.flat_g[lo:hi], async_op=True)
-                w.wait()
+                if self.pipeline == "per_network":
+                    self.opt.all_reduce_here(lo, hi)
+                else:
+                    w = dist.all_reduce(self.opt.flat_g[lo:hi], async_op=True)
+                    w.wait()
                 e1.record()
                 torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1))
@@ -545,8 +738,27 @@ class CCTrainer:
         return round(v[len(v) // 2], 3)
 
     def comm_stats(self):
-        """Exposed communication of the recent steps (call after a device synchronise): median stream time the compute stream
-        spent waiting for each segment's all-reduce; `overlapped` = the standalone duration (calibrate_comm) minus that."""
+        """What the data-parallel step exchanges and how (call after a device synchronise).  per_network: the segments in issue
+        order and each one's all-reduce alone (calibrate_comm); the EXPOSED time of the exchange inside a replayed graph cannot
+        be bracketed by events -- bench.py measures it as step time with the collectives minus step time with them skipped.
+        post / staged: median stream time the compute stream spent waiting for each segment's all-reduce; `overlapped` = the
+        standalone duration minus that."""
+        if self.pipeline == "per_network":
+            if not self.opt.comm_active():
+                return None
+            order = [NET_NAMES[i] for i, _, _ in self.segment_calls]
+            segs = {NET_NAMES[i]: (lo, hi) for i, lo, hi in self.segment_calls}
+            r = {"design": ("per-network gradient pipelines inside ONE graph: at the end of a network's backward pass its own stream "
+                            "issues ncclAllReduce on its segment of the flat bucket (a node of that graph branch), then its Adam segment, "
+                            "then its weight images; issue order = order the backward passes are enqueued (shortest first); only the "
+                            "last finisher's exchange is not covered by another network's backward"),
+                 "issue_order": order, "segments_mb": [round(4e-6 * (segs[k][1] - segs[k][0]), 1) for k in order],
+                 "collective": "ncclAllReduce on the network's stream (cc_amd/rccl.py)" if self.opt._rccl is not None
+                 else "torch.distributed.all_reduce (blocking)"}
+            if self.comm_standalone_ms:
+                by_seg = dict(zip(self.segments(), self.comm_standalone_ms))
+                r["standalone_ms"] = [round(by_seg.get(segs[k], float("nan")), 3) for k in order]
+            return r
         if not self.comm_events:
             return None
         segs = self.segments()
@@ -568,6 +780,22 @@ class CCTrainer:
 
     def step(self, batch):
         """train.py:445-568 for one mini-batch: returns the (device) loss tensors of this step."""
+        if self.pipeline == "per_network":
+            if self._weights_touched():
+                ops.packs.mark_stale()
+                if self.graph is not None:
+                    ops.packs.prepack_all()     # (the captured step contains no start-of-step refresh)
+                    ops.packs.end_step()
+            if self.use_graph:
+                if self.graph is None:
+                    self.capture(batch)
+                self._copy_in(batch)
+                self.graph.replay()
+                return self.losses
+            return self._step_pipelined(batch)
+        return self._step_legacy(batch)
+
+    def _step_legacy(self, batch):
         opt = self.opt
         works = []
 
@@ -594,12 +822,13 @@ class CCTrainer:
                     self.graph_b.replay()
             losses = self.losses
         else:
-            losses = self._fwd_bwd(batch, between=reduce_dp if opt.comm_active() else None)
+            losses = self._fwd_bwd(batch, between=reduce_dp if (opt.comm_active() and self.split_graphs) else None)
+        n = opt.flat_p.numel()
         if opt.comm_active():
             if not works:
                 works.append(opt.all_reduce(0, self.n_dp, async_op=True))
             works.append(opt.all_reduce(self.n_dp, None, async_op=True))      # mask + flow segment (70 MB): exposed
-            cut = self.n_dp // 4 * 4            # float4 update: cut at a 16-byte boundary (the <= 3 elements left go second)
+            cut = self.n_dp                     # (a network boundary: 256-byte aligned)
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] \
                 if (losses["loss"].is_cuda and self.comm_debug.get("events")) else None
             join = self.comm_debug.get("join", "segmented")          # A/B (tools/gpu_r3z.sh): "single" = one join, one Adam launch
@@ -612,7 +841,7 @@ class CCTrainer:
                     self.comm_events = (self.comm_events + [ev[:2]])[-64:]
                 opt.step(opt.grad_scale())
                 return losses
-            if 0 < cut < opt.n and len(works) == 2 and all(w is not None for w in works):
+            if 0 < cut < n and len(works) == 2 and all(w is not None for w in works):
                 # the big segment's update runs while the small segment is still being exchanged.  work.wait() makes the
                 # compute stream wait for the collective: the stream time between the events around it is the EXPOSED part
                 # of that collective (what backward stage B / the first Adam segment did not hide)

@@ -479,6 +479,9 @@ int cc_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
  * later segments of one optimizer step), so that a segment can be updated while the next one's all-reduce is in flight. */
 int cc_adam_step_segment(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* step_dev, long n, float lr,
                          float beta1, float beta2, float eps, float grad_scale, int tick, void* stream);
+/* step_dev += 1 alone: the per-network pipeline (cc_amd/trainer.py, round 6) advances the counter ONCE at the start of the step and
+ * then updates the networks' bucket segments with tick = 0 from different streams, as their gradients arrive. */
+int cc_adam_tick(float* step_dev, void* stream);
 int cc_fill(float* p, long n, float value, void* stream);
 
 #ifdef __cplusplus

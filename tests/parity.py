@@ -1105,6 +1105,7 @@ def check_adam(dev, n=10007, steps=3):
     mk = lambda: [t.to(dev) for t in (p0.clone(), torch.zeros(n), torch.zeros(n), torch.zeros(1))]
     pa, ma, va, sa = mk()       # one launch
     pb, mb, vb, sb = mk()       # two segments
+    pc, mc, vc, sc = mk()       # round 6: cc_adam_tick first, then three segments without a tick, last one first (per-network pipeline)
     cut = (n // 3) // 4 * 4
     scale = 0.5
     for _ in range(steps):
@@ -1115,8 +1116,13 @@ def check_adam(dev, n=10007, steps=3):
         E.call("cc_adam_step", pa, gd, ma, va, sa, n, 2e-4, 0.9, 0.999, 1e-8, scale, STREAM)
         E.call("cc_adam_step_segment", pb[:cut], gd[:cut], mb[:cut], vb[:cut], sb, cut, 2e-4, 0.9, 0.999, 1e-8, scale, 1, STREAM)
         E.call("cc_adam_step_segment", pb[cut:], gd[cut:], mb[cut:], vb[cut:], sb, n - cut, 2e-4, 0.9, 0.999, 1e-8, scale, 0, STREAM)
-    assert float(sa) == steps and float(sb) == steps
+        E.call("cc_adam_tick", sc, STREAM)
+        cut2 = cut + (n - cut) // 2 // 4 * 4
+        for lo, hi in ((cut2, n), (0, cut), (cut, cut2)):
+            E.call("cc_adam_step_segment", pc[lo:hi], gd[lo:hi], mc[lo:hi], vc[lo:hi], sc, hi - lo, 2e-4, 0.9, 0.999, 1e-8, scale, 0, STREAM)
+    assert float(sa) == steps and float(sb) == steps and float(sc) == steps
     assert torch.equal(pa.cpu(), pb.cpu()) and torch.equal(ma.cpu(), mb.cpu()) and torch.equal(va.cpu(), vb.cpu())
+    assert torch.equal(pa.cpu(), pc.cpu()) and torch.equal(ma.cpu(), mc.cpu()) and torch.equal(va.cpu(), vc.cpu())
     err = float((pa.cpu() - ref_p.detach()).abs().max())
     assert err <= 1e-6, err          # a few ulp (different but equivalent operation order: lr / bc1 folded into the step size)
 

@@ -80,10 +80,10 @@ def test_full_step_against_reference_golden(golden_dir, use_graph):
         want = float(g["gradnorm." + name])
         assert abs(float(v) - want) <= 1e-3 * want, (name, float(v), want)
     # the small-parameter gradients the fixture stores in full (biases of <= 64 channels)
-    off, worst = 0, (0.0, "")
+    worst, offs = (0.0, ""), iter(tr.opt.offsets)          # (every network's range of the bucket starts on a 256-byte boundary)
     for name, n in zip(("disp", "pose", "mask", "flow"), nets):
         for pn, p in n.named_parameters():
-            k = p.numel()
+            k, off = p.numel(), next(offs)
             key = "grad.%s.%s" % (name, pn)
             if key in g:
                 gw = torch.from_numpy(g[key]).double().reshape(-1)
@@ -91,7 +91,6 @@ def test_full_step_against_reference_golden(golden_dir, use_graph):
                 r = float((gg - gw).norm()) / (float(gw.norm()) + 1e-12)
                 worst = max(worst, (r, key))
                 assert r <= 1e-2, (key, r)
-            off += k
     print("worst small-parameter gradient mismatch vs the reference: %.2e (%s)" % worst)
     got2 = {k: float(v) for k, v in tr.step(batch).items()}
     assert abs(got2["loss"] - float(g["loss_after_adam"])) <= 1e-4 * abs(float(g["loss_after_adam"]))
@@ -137,36 +136,70 @@ def test_training_step_reaches_no_vendor_conv_or_batchnorm_kernel():
 
 
 @pytest.mark.parametrize("deterministic", [False, True])
-def test_two_graph_step_matches_single_graph(deterministic, monkeypatch):
-    """The data-parallel form of the step (two hipGraphs sharing a pool, the gradient all-reduce of the first segment issued
-    between the replays) on one GPU: same losses, gradients and parameters as the single-graph step -- bit for bit with
-    config.deterministic (the feature-warp scatter as integer atomics), to 1e-4 of the gradient norm with float atomics."""
+def test_step_forms_agree(deterministic, monkeypatch):
+    """The three arrangements of one training step -- "per_network" (round 6, the default: every network's exchange / Adam segment /
+    weight images at the end of ITS backward pass, inside the one hipGraph), "post" (one graph, optimizer behind it) and "staged"
+    (two hipGraphs sharing a pool, the first segment's all-reduce between the replays) -- on one GPU: same losses, gradients and
+    parameters over two steps -- bit for bit with config.deterministic (the feature-warp scatter as integer atomics), to 1e-4 of
+    the gradient norm with float atomics."""
     from cc_amd import config
     monkeypatch.setattr(config, "deterministic", deterministic)
     dev = torch.device("cuda")
     bc = syn.sample(2, 128, 192, seed=1)
     batch = (bc[0].to(dev), [r.to(dev) for r in bc[1]], bc[2].to(dev), bc[3].to(dev))
     res = []
-    for split in (False, True):
+    for form in ("post", "staged", "per_network"):
         nets = T.build_nets(dev, init=False)
         for n in nets:
             n.load_state_dict(syn.seeded_state_dict(n, 0))
-        tr = T.CCTrainer(nets, T.StepConfig(), use_graph=True, split_graphs=split)
+        tr = T.CCTrainer(nets, T.StepConfig(), use_graph=True, pipeline=form)
         l1 = {k: float(v) for k, v in tr.step(batch).items()}
         g1 = tr.opt.flat_g.clone()
         l2 = {k: float(v) for k, v in tr.step(batch).items()}
-        assert (tr.graph_b is not None) == split
-        res.append((l1, g1, l2, tr.opt.flat_p.clone()))
-    (a1, ga, a2, pa), (b1, gb, b2, pb) = res
-    for k in a1:
-        assert abs(a1[k] - b1[k]) <= 1e-6 * abs(a1[k]) + 1e-9, (k, a1[k], b1[k])
-        assert abs(a2[k] - b2[k]) <= 1e-5 * abs(a2[k]) + 1e-9, (k, a2[k], b2[k])
-    if deterministic:
-        assert a1 == b1 and a2 == b2 and torch.equal(ga, gb) and torch.equal(pa, pb)
-        return
-    # feature-warp backward scatters with float atomics (like the reference's grid_sample): not bit-reproducible
-    assert float((ga - gb).norm() / ga.norm()) < 1e-4
-    assert float((pa - pb).abs().max()) <= 2.001e-4
+        l3 = {k: float(v) for k, v in tr.step(batch).items()}
+        assert (tr.graph_b is not None) == (form == "staged") and tr.pipeline == form
+        assert float(tr.opt.step_dev) == 3.0
+        res.append((l1, g1, l2, l3, tr.opt.flat_p.clone()))
+    a1, ga, a2, a3, pa = res[0]
+    for b1, gb, b2, b3, pb in res[1:]:
+        for k in a1:
+            assert abs(a1[k] - b1[k]) <= 1e-6 * abs(a1[k]) + 1e-9, (k, a1[k], b1[k])
+            assert abs(a2[k] - b2[k]) <= 1e-5 * abs(a2[k]) + 1e-9, (k, a2[k], b2[k])
+            assert abs(a3[k] - b3[k]) <= 2e-5 * abs(a3[k]) + 1e-9, (k, a3[k], b3[k])
+        if deterministic:
+            assert a1 == b1 and a2 == b2 and a3 == b3 and torch.equal(ga, gb) and torch.equal(pa, pb)
+            continue
+        # feature-warp backward scatters with float atomics (like the reference's grid_sample): not bit-reproducible
+        assert float((ga - gb).norm() / ga.norm()) < 1e-4
+        assert float((pa - pb).abs().max()) <= 3 * 2.001e-4
+
+
+def test_pipelined_step_sees_weights_changed_from_outside():
+    """The per-network form keeps the weight images of the previous step's refresh; a torch in-place write to the parameters between
+    two steps (load_state_dict, a manual edit) must be picked up -- under hipGraph replay too, where the captured step contains no
+    start-of-step refresh."""
+    dev = torch.device("cuda")
+    bc = syn.sample(2, 128, 192, seed=1)
+    batch = (bc[0].to(dev), [r.to(dev) for r in bc[1]], bc[2].to(dev), bc[3].to(dev))
+    out = []
+    for use_graph in (False, True):
+        nets = T.build_nets(dev, init=False)
+        for n in nets:
+            n.load_state_dict(syn.seeded_state_dict(n, 0))
+        tr = T.CCTrainer(nets, T.StepConfig(), use_graph=use_graph)
+        assert tr.pipeline == "per_network"
+        la = float(tr.step(batch)["loss"])
+        for n in nets:
+            n.load_state_dict(syn.seeded_state_dict(n, 5))          # other weights, written in place into the bucket
+        lb = float(tr.step(batch)["loss"])
+        nets2 = T.build_nets(dev, init=False)
+        for n in nets2:
+            n.load_state_dict(syn.seeded_state_dict(n, 5))
+        tr2 = T.CCTrainer(nets2, T.StepConfig(), use_graph=False, pipeline="post")
+        want = float(tr2.step(batch)["loss"])
+        assert abs(lb - want) <= 1e-5 * abs(want), (use_graph, lb, want, la)
+        out.append(lb)
+    assert abs(out[0] - out[1]) <= 1e-5 * abs(out[0])
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
@@ -193,20 +226,21 @@ def test_step_is_bit_reproducible_in_deterministic_mode(use_graph, monkeypatch):
 
 
 def test_step_with_rccl_process_group_of_one(monkeypatch):
-    """The multi-GPU code path on the one GPU a test box has: a 1-rank RCCL (backend 'nccl') process group with
-    config.debug.force_comm -- parameter broadcast, the two hipGraphs with the asynchronous segment all-reduce between the replays,
-    the second all-reduce, Adam -- must reproduce the plain single-process step."""
+    """The multi-GPU code paths on the one GPU a test box has: a 1-rank RCCL (backend 'nccl') process group with
+    config.debug.force_comm.  per_network (the default): parameter broadcast, the trainer's own RCCL communicator, every network's
+    ncclAllReduce captured on its stream as a node of the ONE graph, Adam segments, weight images; post / staged: the process
+    group's asynchronous all-reduces behind / between the graphs.  All must reproduce the plain single-process step."""
     import socket
     import torch.distributed as dist
     dev = torch.device("cuda")
     bc = syn.sample(2, 128, 192, seed=1)
     batch = (bc[0].to(dev), [r.to(dev) for r in bc[1]], bc[2].to(dev), bc[3].to(dev))
 
-    def run():
+    def run(form=None):
         nets = T.build_nets(dev, init=False)
         for n in nets:
             n.load_state_dict(syn.seeded_state_dict(n, 0))
-        tr = T.CCTrainer(nets, T.StepConfig(), use_graph=True, comm_debug={"events": True})
+        tr = T.CCTrainer(nets, T.StepConfig(), use_graph=True, comm_debug={"events": True}, pipeline=form)
         l1 = {k: float(v) for k, v in tr.step(batch).items()}
         l2 = {k: float(v) for k, v in tr.step(batch).items()}
         l3 = {k: float(v) for k, v in tr.step(batch).items()}
@@ -221,22 +255,36 @@ def test_step_with_rccl_process_group_of_one(monkeypatch):
     from cc_amd import config as _cfg
     monkeypatch.setattr(_cfg.debug, "force_comm", True)
     dist.init_process_group("nccl", rank=0, world_size=1)
+    results = []
     try:
         tr, b1, b2, b3 = run()
-        # (per-network streams, the default: one graph, both all-reduces behind it; config.net_streams = False: the staged form)
-        assert tr.split_graphs == (not tr.net_streams) and (tr.graph_b is not None) == tr.split_graphs
-        # the record the N > 1 bench line carries: exposed time of each segment's all-reduce (events around work.wait()),
-        # each segment alone on an idle device, their difference
+        results.append((b1, b2, b3))
+        assert tr.pipeline == "per_network" and tr.graph_b is None and tr.opt._rccl is not None
+        n = tr.opt.flat_g.numel()
+        segs = [tr.opt.segment(i) for i in range(4)]
+        assert [(lo, hi) for _, lo, hi in tr.segment_calls] == [segs[1], segs[2], segs[0], segs[3]]     # pose, mask, disp, flow
         alone = tr.calibrate_comm(reps=2)
         st = tr.comm_stats()
-        assert len(alone) == 2 and all(a > 0 for a in alone)
-        assert st["steps_sampled"] == 3 and len(st["exposed_ms"]) == 2 and len(st["segments_mb"]) == 2
-        assert abs(sum(st["segments_mb"]) - 4e-6 * tr.opt.flat_g.numel()) < 0.2 and st["overlapped_ms"] >= 0
+        assert len(alone) == 4 and all(a > 0 for a in alone)
+        assert st["issue_order"] == ["pose", "mask", "disp", "flow"] and len(st["standalone_ms"]) == 4
+        assert abs(sum(st["segments_mb"]) - 4e-6 * n) < 0.3 and "ncclAllReduce" in st["collective"]
+        for form in ("post", "staged"):
+            tr, b1, b2, b3 = run(form)
+            results.append((b1, b2, b3))
+            assert tr.pipeline == form and (tr.graph_b is not None) == (form == "staged")
+            # the record the legacy N > 1 bench line carries: exposed time of each segment's all-reduce (events around work.wait()),
+            # each segment alone on an idle device, their difference
+            alone = tr.calibrate_comm(reps=2)
+            st = tr.comm_stats()
+            assert len(alone) == 2 and all(a > 0 for a in alone)
+            assert st["steps_sampled"] == 3 and len(st["exposed_ms"]) == 2 and len(st["segments_mb"]) == 2
+            assert abs(sum(st["segments_mb"]) - 4e-6 * n) < 0.2 and st["overlapped_ms"] >= 0
     finally:
         dist.destroy_process_group()
-    for a, b in ((a1, b1), (a2, b2), (a3, b3)):
-        for k in a:
-            assert abs(a[k] - b[k]) <= 2e-5 * abs(a[k]) + 1e-9, (k, a[k], b[k])
+    for b1, b2, b3 in results:
+        for a, b in ((a1, b1), (a2, b2), (a3, b3)):
+            for k in a:
+                assert abs(a[k] - b[k]) <= 2e-5 * abs(a[k]) + 1e-9, (k, a[k], b[k])
 
 
 def test_checkpoint_resume_on_device(tmp_path):

@@ -36,7 +36,7 @@ def test_full_cc_step_matches_oracle():
         # the fused-Adam update against torch.optim.Adam's on the oracle nets (first step: |update| = lr for every
         # parameter whose gradient is not ~0, where the sign of a 1e-12 gradient decides) -- parameter order is the same
         po = torch.cat([p.detach().reshape(-1) for n in onets for p in n.parameters()])
-        d = (tr.opt.flat_p[:po.numel()] - po).abs()
+        d = (tr.opt.gather(tr.opt.flat_p) - po).abs()
         assert float((d > 1e-6).float().mean()) < 1e-3 and float(d.max()) <= 2.001e-4, (float((d > 1e-6).float().mean()), float(d.max()))
         # module buffers after the step: BatchNorm running statistics and num_batches_tracked (the trainer keeps the counters of
         # all layers in one buffer and bumps them with one add) -- same keys, same values as the reference modules'
@@ -128,57 +128,86 @@ def test_data_parallel_two_ranks_gloo():
     assert float((ret[0][:flat.numel()] - flat).abs().max()) < 1e-6
 
 
-def _cc_dp_worker(rank, world, port, ret):
-    """One rank of the REAL data-parallel CC step (CCTrainer.step: four nets, all losses, staged backward with the
-    DispResNet6 + PoseNetB6 gradient segment reduced while MaskNet6 + Back2Future run backward, fused Adam)."""
+def _cc_dp_worker_one_step(rank, world, port, ret, pipeline):
+    """as above, one step only: returns the exchanged gradient and the updated parameters of THAT step"""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["OMP_NUM_THREADS"] = "4"
     torch.set_num_threads(4)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    B, H, W = 2, 64, 128
-    batch = syn.sample(B, H, W, seed=1 + rank)               # rank-specific shard, as bench.py draws it
+    batch = syn.sample(2, 64, 128, seed=1 + rank)
     with emulated_engine():
         nets = T.build_nets("cpu", init=False)
         for n in nets:
             n.load_state_dict(syn.seeded_state_dict(n, 0))
-            if rank == 1:                                   # the start-up broadcast must bring rank 1 back to rank 0's weights ...
+            if rank == 1:
                 for p in n.parameters():
                     p.data.mul_(1.01)
-                for b in n.buffers():                       # ... and buffers (BatchNorm running statistics / counters: a resume
-                    if b.dtype.is_floating_point:           # that only rank 0 read from disk)
+                for b in n.buffers():
+                    if b.dtype.is_floating_point:
                         b.data.add_(0.5)
                     else:
                         b.data.add_(7)
-        tr = T.CCTrainer(nets, T.StepConfig(), use_graph=False)
-        assert tr.split_graphs and 0 < tr.n_dp < tr.opt.n
+        tr = T.CCTrainer(nets, T.StepConfig(), use_graph=False, pipeline=pipeline)
+        assert tr.pipeline == pipeline and tr.split_graphs == (pipeline == "staged") and 0 < tr.n_dp < tr.opt.flat_p.numel()
         p0 = tr.opt.flat_p.clone()
         buf0 = torch.cat([b.detach().double().reshape(-1) for n in nets for b in n.buffers()])
         local = torch.zeros_like(tr.opt.flat_g)
-        calls = []
-        orig = tr.opt.all_reduce
+        calls, events = [], []
+        orig, orig_here, orig_seg = tr.opt.all_reduce, tr.opt.all_reduce_here, tr.opt.step_segment
 
         def spy(lo=0, hi=None, async_op=False):
             hi = tr.opt.flat_g.numel() if hi is None else hi
             local[lo:hi] = tr.opt.flat_g[lo:hi]             # this rank's own gradient segment, complete at issue time
             calls.append((lo, hi, async_op))
             return orig(lo, hi, async_op)
-        tr.opt.all_reduce = spy
+
+        def spy_here(lo, hi):
+            local[lo:hi] = tr.opt.flat_g[lo:hi]
+            calls.append((lo, hi, False))
+            events.append(("reduce", lo, hi))
+            return orig_here(lo, hi)
+
+        def spy_seg(lo, hi, tick, grad_scale=1.0):
+            events.append(("adam", lo, hi, bool(tick), grad_scale))
+            return orig_seg(lo, hi, tick, grad_scale)
+        tr.opt.all_reduce, tr.opt.all_reduce_here, tr.opt.step_segment = spy, spy_here, spy_seg
         losses = tr.step(batch)
-        ret[rank] = dict(p0=p0, buf0=buf0, local=local, reduced=tr.opt.flat_g.clone(), p1=tr.opt.flat_p.clone(), calls=calls,
-                         n_dp=tr.n_dp, loss=float(losses["loss"]))
+        from cc_amd import ops
+        images_fresh = all(e["ok"] for e in ops.packs.entries.values() if e)
+        # (clones, and ONE assignment at the end: tensors handed to the manager live in shared memory, and a nested update of a
+        # managed dict is lost)
+        out = dict(p0=p0, buf0=buf0, local=local.clone(), reduced=tr.opt.flat_g.clone(), p1=tr.opt.flat_p.clone(), calls=list(calls),
+                   events=list(events), n_dp=tr.n_dp, segs=[tr.opt.segment(i) for i in range(4)], loss=float(losses["loss"]),
+                   step=float(tr.opt.step_dev), images_fresh=images_fresh, n_images=sum(1 for e in ops.packs.entries.values() if e))
+        if pipeline == "per_network":
+            # the weight images the per-network refreshes left behind ARE the images of the updated weights: a full rebuild gives
+            # the same bytes, and the second step runs from them without a start-of-step launch
+            before = [e["buf"].clone() for e in ops.packs.entries.values() if e]
+            ops.packs.mark_stale()
+            ops.packs.prepack_all()
+            after = [e["buf"] for e in ops.packs.entries.values() if e]
+            out["images_equal"] = all(torch.equal(a, b) for a, b in zip(before, after))
+            ops.packs.end_step()
+            losses2 = tr.step(batch)
+            out["loss2"] = float(losses2["loss"])
+            out["step2"] = float(tr.opt.step_dev)
+        ret[rank] = out
     dist.destroy_process_group()
 
 
 @pytest.mark.slow
-def test_cc_step_data_parallel_two_ranks_gloo():
+@pytest.mark.parametrize("pipeline", ["per_network", "staged"])
+def test_cc_step_data_parallel_two_ranks_gloo(pipeline):
     """world_size-2 gloo run of CCTrainer.step (train.py:300-303's DataParallel as one process per GPU): ranks agree bit for
-    bit, the exchanged gradient is the sum of the two ranks' own gradients, the update equals Adam on their mean, and the
-    exchange is issued as two segments with the first one started before the second backward stage."""
+    bit, the exchanged gradient is the sum of the two ranks' own gradients, the update equals Adam on their mean.
+    per_network (the default form): the exchange is issued as the four networks' segments in the order their backward passes
+    finish (pose, mask, disp, flow), each followed by ITS Adam segment with the step counter advanced once at the start, and the
+    weight images left behind equal a full rebuild.  staged: two segments, the first one started before the second backward stage."""
     world, port = 2, _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_cc_dp_worker, args=(world, port, ret), nprocs=world, join=True)
+    mp.spawn(_cc_dp_worker_one_step, args=(world, port, ret, pipeline), nprocs=world, join=True)
     r0, r1 = ret[0], ret[1]
     assert torch.equal(r0["p0"], r1["p0"]), "broadcast from rank 0 did not equalise the start weights"
     assert r0["buf0"].numel() > 0 and torch.equal(r0["buf0"], r1["buf0"]), "broadcast from rank 0 did not equalise the module buffers"
@@ -186,7 +215,22 @@ def test_cc_step_data_parallel_two_ranks_gloo():
     assert torch.equal(r0["reduced"], r0["local"] + r1["local"])
     assert float(r0["local"].abs().sum()) > 0 and not torch.equal(r0["local"], r1["local"])
     n_dp, n = r0["n_dp"], r0["p0"].numel()
-    assert [(lo, hi) for lo, hi, _ in r0["calls"]] == [(0, n_dp), (n_dp, n)] and all(a for _, _, a in r0["calls"])
+    if pipeline == "staged":
+        assert [(lo, hi) for lo, hi, _ in r0["calls"]] == [(0, n_dp), (n_dp, n)] and all(a for _, _, a in r0["calls"])
+    else:
+        segs = r0["segs"]                               # disp, pose, mask, flow
+        assert all(s is not None for s in segs) and segs[0][0] == 0 and segs[3][1] == n and segs[2][0] == n_dp
+        assert all(a[1] == b[0] for a, b in zip(segs, segs[1:])) and all(lo % 64 == 0 for lo, _ in segs)     # they tile the bucket
+        want = [segs[1], segs[2], segs[0], segs[3]]     # issue order: pose, mask, disp, flow (shortest backward first)
+        assert [(lo, hi) for lo, hi, _ in r0["calls"]] == want == [(lo, hi) for lo, hi, _ in r1["calls"]]
+        # every segment: its all-reduce, then ITS Adam segment (no tick: the counter was advanced once at the start of the step)
+        ev = r0["events"]
+        assert len(ev) == 8
+        for k, (lo, hi) in enumerate(want):
+            assert ev[2 * k] == ("reduce", lo, hi) and ev[2 * k + 1] == ("adam", lo, hi, False, 0.5), (k, ev[2 * k], ev[2 * k + 1])
+        assert r0["step"] == 1.0 and r0["step2"] == 2.0
+        assert r0["images_fresh"] and r0["n_images"] > 100 and r0["images_equal"]
+        assert abs(r0["loss2"]) < 1e3 and r0["loss2"] != r0["loss"]
     # single-process reference: torch.optim.Adam on the mean gradient
     p = r0["p0"].clone().requires_grad_(True)
     opt = torch.optim.Adam([p], lr=1e-4, betas=(0.9, 0.999))

@@ -83,13 +83,24 @@ for STEP in "$@"; do
     F=$(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find /tmp/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
     python tools/pmc_traffic.py "$F" "$W" $O/pmc_traffic.json "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace -- python bench.py --no-graph --steps 1 --warmup 1" > $O/pmc_traffic_$TAG.txt; tail -6 $O/pmc_traffic_$TAG.txt
     cp $O/pmc_traffic.json profiles/pmc_traffic.json ;;
+  calib)
+    # FETCH_SIZE / WRITE_SIZE per access pattern on a known byte count (tools/fetch_calib.hip) -> profiles/fetch_calib.json
+    [ -x tools/_bin/fetch_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/fetch_calib.hip -o tools/_bin/fetch_calib
+    for C in FETCH_SIZE WRITE_SIZE; do
+      rm -rf /tmp/cal_$C
+      ( cd /tmp && timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/cal_$C -o run -- $R/tools/_bin/fetch_calib ) > $O/calib_$C.log 2>&1; echo "calib $C rc=$?"
+    done
+    F=$(find /tmp/cal_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find /tmp/cal_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+    python tools/fetch_calib.py "$F" "$W" $O/calib_FETCH_SIZE.log $O/fetch_calib.json | tee $O/fetch_calib_$TAG.txt
+    cp $O/fetch_calib.json profiles/fetch_calib.json ;;
   sq)
     rm -rf /tmp/pmc_sq
     ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d /tmp/pmc_sq -o run -- env CC_NET_STREAMS=0 python $R/bench.py --no-graph --steps 1 --warmup 1 $NOCPU ) > $O/pmc_sq_$TAG.log 2>&1; echo "pmc sq rc=$?"
     F=$(find /tmp/pmc_sq -name "*counter_collection.csv" | head -1)
     PMC_ROWS=${PMC_ROWS:-400} python tools/pmc_sq.py "$F" > $O/pmc_sq_$TAG.txt 2>&1; grep -E "^kernel|ssim|warp_|pose2flow" $O/pmc_sq_$TAG.txt | cut -c1-200 ;;
   layers)
-    ( CC_TIMING_DETAIL=1 CC_TIMING_DUMP=$O/layers_$TAG.tsv timeout 400 python bench.py --steps 5 --warmup 3 --no-cpu-baseline )      # (the table comes from bench.py's isolated pass: side streams off) > $O/bench_${TAG}_layers.log 2> $O/bench_${TAG}_layers.err
+    # (the table comes from bench.py's isolated pass: side streams off)
+    ( CC_TIMING_DETAIL=1 CC_TIMING_DUMP=$O/layers_$TAG.tsv timeout 400 python bench.py --steps 5 --warmup 3 --no-cpu-baseline ) > $O/bench_${TAG}_layers.log 2> $O/bench_${TAG}_layers.err
     python tools/layer_rates.py $O/layers_$TAG.tsv > $O/layer_rates_$TAG.txt; head -${LAYER_ROWS:-40} $O/layer_rates_$TAG.txt | cut -c1-170 ;;
   ab)
     export CC_LIB_PATH=${CC_LIB_PATH:-$TOOLS_LIB}
