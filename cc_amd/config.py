@@ -25,6 +25,15 @@ deterministic = False
 net_streams = True
 
 
+# True: in the per-network pipeline a network that marks points of its forward pass (DispResNet6: GRAD_CHUNKS) hands the parameters
+# behind a mark to its gradient tail (all-reduce -> Adam -> weight images, on the step's origin stream, idle by then) as soon as its
+# backward pass has come back to that mark, instead of the whole segment at the end.  DispResNet6 finishes its backward pass LAST, so
+# its tail (0.47 ms on one GPU; data-parallel also its 219 MB exchange) is the one part of the optimizer nothing else covers.  OFF by
+# default: on one GPU the two extra cross-stream dependencies cost the replayed graph more than the hidden tail saves (18.25 vs 16.69
+# ms; on a fourth stream 19.15; profiles/r06_ab_round6.txt) -- a data-parallel run should measure both.
+grad_chunks = False
+
+
 class _Debug:
     """A/B and diagnosis switches of the host glue.  The product reads nothing from the process environment: these are plain attributes that
     tools/ab_env.py (bench.py, the A/B scripts, tests/conftest.py) sets from CC_* variables explicitly.  All False / None = the
@@ -38,6 +47,7 @@ class _Debug:
     force_comm = False           # issue the gradient collectives on a one-rank process group too (tests, tools)
     capture_mode = "thread_local"    # hipGraph capture error mode of CCTrainer
     net_stream_priority = (0, 0, 0)  # HIP stream priorities of the networks' side streams (0 normal, -1 high)
+    chunk_inline = False         # measurement: the gradient chunks' tails on the network's own stream instead of its tail stream
     pipe_skip_tail = ()          # per-network pipeline, measurement only: names of the networks whose Adam segment + weight-image refresh are skipped
     reduce_trace = None          # a list: every weight-gradient reduce descriptor of the step is appended to it (tools/reduce_bytes.py)
     library_path = None          # another build of libccengine.so (the tools build): picked up by _lib.engine() on first use

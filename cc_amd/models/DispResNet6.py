@@ -35,6 +35,12 @@ class DispResNet6(nn.Module):
     def init_weights(self):
         xavier_zero_bias(self)
 
+    # Gradient chunks for a trainer that exchanges / updates a network's parameters while its backward pass still runs
+    # (cc_amd/trainer.py, per-network pipeline): tag of a tape.mark() in _body -> the first parameter (registration order = the order
+    # of the optimizer's bucket) whose gradient is complete when the backward pass reaches that mark; everything from there to the
+    # previously completed part is final.  The backward pass walks the decoder first, then conv7 ... conv1.
+    GRAD_CHUNKS = (("decoder", "upconv7.0.weight"), ("conv5", "conv5.0.conv1.weight"))
+
     def _body(self, tape, x):
         """The forward pass on the tape: every decoder concatenation (upconv, skip[, disp_up]) is one buffer whose slices the
         up-convolution, the encoder stage and the disparity up-sampling write directly."""
@@ -49,9 +55,12 @@ class DispResNet6(nn.Module):
         c1a = tape.conv(x, self.conv1[0].weight, self.conv1[0].bias, 2, 3, "relu")
         c = [x, tape.conv(c1a, self.conv1[2].weight, self.conv1[2].bias, 1, 3, "relu", out=cats[2].slot(1))]
         for i in range(2, 8):
+            if i == 5:
+                tape.mark("conv5")         # backward: conv5 .. conv7 (27.5 M of the 54.6 M parameters) are done here
             stage = getattr(self, "conv%d" % i)
             y = basic_block(tape, stage[0], c[-1])
             c.append(basic_block(tape, stage[1], y, out=cats[i + 1].slot(1) if i < 7 else None))
+        tape.mark("decoder")               # backward: the whole decoder (24.3 M parameters) is done here
         out, disps, prev = c[7], {}, None
         for lvl in range(7, 0, -1):
             cb = cats[lvl]

@@ -196,6 +196,19 @@ class _WgradQueue:
         if len(q) >= self.GROUP:
             self._launch(key)
 
+    def _take_items(self):
+        items = []
+        for key in list(self.pending):
+            q = self.pending.pop(key, None)
+            if not q:
+                continue
+            B, M, AH, AW, Cin, IH, IW, R, S, si, pad, o_sm, o_sc, a_bs, x_bs = key
+            for g0 in range(0, len(q), self.GROUP):
+                qq = q[g0:g0 + self.GROUP]
+                items.append(([t[0] for t in qq], [t[1] for t in qq], [t[2] for t in qq],
+                              (B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc)))
+        return items
+
     def _launch(self, key):
         q = self.pending.pop(key, None)
         if not q:
@@ -207,16 +220,7 @@ class _WgradQueue:
     def flush(self):
         # what is still parked at the end of the stage (single layers of unique shapes, incomplete groups) goes out as ONE list call:
         # the groups that take the generic weight-gradient kernel share launches (cc_conv2d_wgrad_list)
-        items = []
-        for key in list(self.pending):
-            q = self.pending.pop(key, None)
-            if not q:
-                continue
-            B, M, AH, AW, Cin, IH, IW, R, S, si, pad, o_sm, o_sc, a_bs, x_bs = key
-            for g0 in range(0, len(q), self.GROUP):
-                qq = q[g0:g0 + self.GROUP]
-                items.append(([t[0] for t in qq], [t[1] for t in qq], [t[2] for t in qq],
-                              (B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc)))
+        items = self._take_items()
         if items:
             _wgrad_list(items)
         wgrad_reduces._cur().flush()          # (this stream's reductions: the proxy runs every stream's queue on its own stream)

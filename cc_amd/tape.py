@@ -88,6 +88,10 @@ BN_COUNTERS = None
 # pass (inside its autograd node, i.e. on the network's stream, behind its last gradient launch) -- the trainer then runs the
 # network's gradient exchange, Adam segment and weight-image refresh right there instead of behind the whole backward pass.
 NET_DONE = None
+# ... and with (module, tag) when the backward pass comes back to a point the network's forward marked (Tape.mark): every parameter
+# used AFTER that point has its complete gradient (parked weight-gradient launches aside: the callee flushes them), so the trainer
+# can start exchanging / updating that part of the network's bucket segment while the rest of its backward pass still runs.
+NET_MARK = None
 
 class TT:
     """A tensor on the tape + the state of its gradient during the backward pass."""
@@ -216,6 +220,7 @@ class Tape:
         self.nodes = []           # backward closures in forward order
         self.tts = []
         self.param_grads = {}     # id(param) -> (param, gradient) for parameters without a flat-bucket sink
+        self.owner = None         # the network module (for NET_MARK)
         self.E = engine()
 
     # ------------------------------------------------------------------ bookkeeping
@@ -252,6 +257,17 @@ class Tape:
 
     def concat(self, B, chans, H, W, ref):
         return ConcatBuffer(self, B, chans, H, W, ref)
+
+    def mark(self, tag):
+        """A point of the forward pass: in the backward pass NET_MARK(owner module, tag) is called once everything recorded after
+        this point has been differentiated (see NET_MARK)."""
+        if self.record:
+            owner = self.owner
+
+            def bwd():
+                if NET_MARK is not None:
+                    NET_MARK(owner, tag)
+            self.nodes.append(bwd)
 
     def _cat(self, cb):
         assert all(p is not None for p in cb.parts)
@@ -740,6 +756,7 @@ class _NetFn(torch.autograd.Function):
     def forward(ctx, body, n_in, *tensors):
         need = ctx.needs_input_grad[2:]
         tape = Tape(record=any(need))
+        tape.owner = getattr(body, "__self__", None)
         ins = [tape.leaf(t, needs=need[i]) for i, t in enumerate(tensors[:n_in])]
         outs = body(tape, *ins)
         ctx.tape, ctx.ins, ctx.outs, ctx.n_in, ctx.body = tape, ins, outs, n_in, body

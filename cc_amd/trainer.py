@@ -15,6 +15,8 @@ MI355X-first structure around that body:
     passes.  Only the last finisher's exchange is exposed; on one GPU the optimizer and the weight-image refresh leave the
     critical path the same way.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -295,21 +297,24 @@ class FlatAdam:
         return None
 
     def rccl(self):
-        """the trainer's own RCCL communicator (cc_amd/rccl.py), created on first use OUTSIDE any stream capture: collectives that
-        are enqueued on the caller's stream; HIP devices with an RCCL process group only, None otherwise (gloo: all_reduce())"""
+        """the trainer's own RCCL communicators (cc_amd/rccl.py), created on first use OUTSIDE any stream capture: collectives that
+        are enqueued on the caller's stream; HIP devices with an RCCL process group only, None otherwise (gloo: all_reduce()).
+        TWO of them: one communicator executes its collectives in issue order, and DispResNet6's chunks (issued while its backward
+        pass runs) must not queue behind -- or hold up -- the other networks' segments."""
         if self._rccl is None and self.flat_g.is_cuda and self.comm_active() and dist.get_backend() == "nccl":
             from . import rccl
-            self._rccl = rccl.Communicator(self.flat_g.device)
+            self._rccl = (rccl.Communicator(self.flat_g.device), rccl.Communicator(self.flat_g.device))
         return self._rccl
 
-    def all_reduce_here(self, lo, hi):
+    def all_reduce_here(self, lo, hi, comm=0):
         """SUM-all-reduce flat_g[lo:hi] ORDERED ON THE CURRENT STREAM (what follows on this stream sees the sum; inside a capture it is
-        a node of the graph): ncclAllReduce on this stream on HIP devices, a blocking process-group call otherwise."""
+        a node of the graph): ncclAllReduce on this stream on HIP devices (communicator `comm`), a blocking process-group call
+        otherwise."""
         if not self.comm_active() or hi <= lo or self.comm_probe == "skip":
             return
-        comm = self.rccl()
-        if comm is not None:
-            comm.all_reduce_sum_(self.flat_g[lo:hi])
+        comms = self.rccl()
+        if comms is not None:
+            comms[comm].all_reduce_sum_(self.flat_g[lo:hi])
         else:
             dist.all_reduce(self.flat_g[lo:hi])
 
@@ -425,6 +430,25 @@ class CCTrainer:
         pri = tuple(config.debug.net_stream_priority) + (0, 0, 0)
         self.net_streams = tuple(torch.cuda.Stream(dev0, priority=pri[i]) for i in range(nst)) if (nst and dev0.type == "cuda") else None
         self._net_index = {id(n): i for i, n in enumerate(nets) if n is not None}
+        # gradient chunks (per_network): a network that marks points of its forward pass (module.GRAD_CHUNKS; DispResNet6, the last
+        # finisher of the backward pass) hands the parameters behind a mark over as soon as its backward pass has come back to it:
+        # (network index, tag) -> first element of the chunk in the bucket.  The chunks' tails run on the step's ORIGIN stream, which
+        # has only PoseNetB6 + MaskNet6 to do and is idle long before DispResNet6 reaches its first mark (a FOURTH stream for them
+        # costs the replayed graph +2.5 ms, profiles/r06_ab_round6.txt)
+        self._chunk_lo, self._open_hi, self._origin = {}, {}, None
+        if pipeline == "per_network" and config.grad_chunks:
+            for i, n in enumerate(nets):
+                if n is None or self.opt.net_ranges[i] is None or not getattr(n, "GRAD_CHUNKS", None):
+                    continue
+                off, at = self.opt.net_ranges[i][0], {}
+                for name, p in n.named_parameters():
+                    if p.requires_grad:
+                        at[name] = off
+                        off += p.numel()
+                for tag, first in n.GRAD_CHUNKS:
+                    if first in at and at[first] % 4 == 0:
+                        self._chunk_lo[(i, tag)] = at[first]
+
         self._done = set()
         self.segment_calls = []          # per_network, most recent step: [(network index, lo, hi)] in issue order (tests, bench)
         self._packed_version = None      # flat_p._version the weight images were built for (per_network)
@@ -476,6 +500,7 @@ class CCTrainer:
         the streams have been joined: they were allocated on this stream and are read on the others."""
         if not pairs:
             return
+        self._origin = torch.cuda.current_stream() if self.net_streams else None
         _fork(self.net_streams or ())
         if self.net_streams and not torch.cuda.is_current_stream_capturing():
             for _, gt in pairs:                                  # (eager mode: see cc_forward)
@@ -519,7 +544,7 @@ class CCTrainer:
 
     def _stage_end(self, failed=False):
         tape.BN_COUNTERS = None
-        tape.NET_DONE = None
+        tape.NET_DONE = tape.NET_MARK = None
         if failed:
             # a stage raised part-way: the parked launches' operands belong to the failed step and no fork / join is in place for
             # the side streams -- drop them instead of launching
@@ -556,36 +581,61 @@ class CCTrainer:
         if i is not None and i not in self._done:
             self._finish_network(i)
 
+    def _net_mark(self, module, tag):
+        """tape.NET_MARK: the backward pass of `module` has come back to the point its forward marked `tag` -- the parameters from the
+        chunk's first one up to the part already handed over are final (module.GRAD_CHUNKS).  Their tail starts now, on the
+        network's TAIL stream, while the network's own stream goes on with the backward pass."""
+        i = self._net_index.get(id(module))
+        lo = self._chunk_lo.get((i, tag)) if i is not None else None
+        if lo is None or i in self._done:
+            return
+        hi = self._open_hi.get(i, self.opt.segment(i)[1])
+        if not (self.opt.segment(i)[0] < lo < hi):
+            return
+        self._open_hi[i] = lo
+        cur, org = torch.cuda.current_stream() if self.net_streams else None, self._origin
+        other = org if (org is not None and cur is not None and org.cuda_stream != cur.cuda_stream and not config.debug.chunk_inline) else None
+        self._tail(i, lo, hi, other)
+
+    def _tail(self, i, lo, hi, stream=None):
+        """The tail of a gradient pipeline for elements [lo, hi) of network i's bucket segment: what the backward pass has parked on
+        the CURRENT stream so far (weight-gradient groups, reduce and bias tables), then -- on `stream` if given (the step's origin
+        stream, which waits for the current one; never the other way round: a side stream must not wait for a stream that waited
+        for it, tools/capture_join_probe.py), else on the current stream -- the all-reduce of that range, its Adam update, its
+        weight images."""
+        ops.wgrad_queue._cur().flush()          # (this stream's queue; it flushes this stream's reduce / bias tables behind it)
+        self.segment_calls.append((i, lo, hi))
+        if NET_NAMES[i] in config.debug.pipe_skip_tail:      # (measurement: what does this network's tail cost the step?)
+            return
+        if stream is not None:
+            stream.wait_stream(torch.cuda.current_stream())
+        with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+            self.opt.all_reduce_here(lo, hi, comm=1 if i == 0 else 0)
+            self.opt.step_segment(lo, hi, False, self.opt.grad_scale())
+            base = self.opt.flat_p.data_ptr()
+            ops.packs.repack_range(base + 4 * lo, base + 4 * hi)
+
     def _finish_network(self, i):
-        """The tail of network i's gradient pipeline on the CURRENT stream: what its backward left parked (weight-gradient groups,
-        reduce and bias tables), the all-reduce of its bucket segment, its Adam segment, its weight images.  The other networks'
-        streams keep running their backward passes meanwhile."""
+        """End of network i's backward pass (on its stream): the tail of what is left of its segment."""
         self._done.add(i)
         seg = self.opt.segment(i)
         if seg is None:
             return
-        ops.wgrad_queue._cur().flush()          # (this stream's queue; it flushes this stream's reduce / bias tables behind it)
-        lo, hi = seg
-        self.segment_calls.append((i, lo, hi))
-        if NET_NAMES[i] in config.debug.pipe_skip_tail:      # (measurement: what does this network's tail cost the step?)
-            return
-        self.opt.all_reduce_here(lo, hi)
-        self.opt.step_segment(lo, hi, False, self.opt.grad_scale())
-        base = self.opt.flat_p.data_ptr()
-        ops.packs.repack_range(base + 4 * lo, base + 4 * hi)
+        self._tail(i, seg[0], self._open_hi.get(i, seg[1]))
 
     def _step_pipelined(self, batch):
         """train.py:445-568 with every network's exchange + update behind ITS backward pass (see the class docstring)"""
         ok = False
         self._done = set()
+        self._open_hi = {}
         self.segment_calls = []
         try:
             self._begin(batch)
             losses, dp, mf = self._loss_grads(batch)
-            tape.NET_DONE = self._net_done
+            tape.NET_DONE, tape.NET_MARK = self._net_done, (self._net_mark if self._chunk_lo else None)
             both = dp + mf
             self._backward(both)
-            tape.NET_DONE = None
+            tape.NET_DONE = tape.NET_MARK = None
             self._sync_streams(bool(both))
             for i in range(len(self.nets)):     # networks that are not on the tape (alternative architectures) or received no gradient
                 if i not in self._done:
@@ -703,6 +753,8 @@ class CCTrainer:
         [DispResNet6 | PoseNetB6] [MaskNet6 | Back2Future] (post / staged)"""
         n = self.opt.flat_g.numel()
         if self.pipeline == "per_network":
+            if self.segment_calls:              # as the most recent (captured) step issued them: chunks of DispResNet6's segment included
+                return [(lo, hi) for _, lo, hi in self.segment_calls]
             return [s for s in (self.opt.segment(i) for i in range(len(self.nets))) if s is not None]
         return [(0, self.n_dp), (self.n_dp, n)] if 0 < self.n_dp < n else [(0, n)]
 
@@ -747,17 +799,19 @@ class CCTrainer:
             if not self.opt.comm_active():
                 return None
             order = [NET_NAMES[i] for i, _, _ in self.segment_calls]
-            segs = {NET_NAMES[i]: (lo, hi) for i, lo, hi in self.segment_calls}
             r = {"design": ("per-network gradient pipelines inside ONE graph: at the end of a network's backward pass its own stream "
                             "issues ncclAllReduce on its segment of the flat bucket (a node of that graph branch), then its Adam segment, "
-                            "then its weight images; issue order = order the backward passes are enqueued (shortest first); only the "
-                            "last finisher's exchange is not covered by another network's backward"),
-                 "issue_order": order, "segments_mb": [round(4e-6 * (segs[k][1] - segs[k][0]), 1) for k in order],
-                 "collective": "ncclAllReduce on the network's stream (cc_amd/rccl.py)" if self.opt._rccl is not None
+                            "then its weight images; issue order = order the backward passes are enqueued (shortest first); DispResNet6 "
+                            "(the last finisher, on a communicator of its own) " +
+                            ("hands its segment over in chunks (decoder, conv5-7, rest) while its backward pass still runs, their tails "
+                             "on the step's origin stream" if self._chunk_lo else
+                             "exchanges its segment at the end of its backward pass: the one exchange no other network's backward covers "
+                             "(config.grad_chunks would start it earlier; off: it costs the one-GPU graph +1.5 ms)")),
+                 "issue_order": order, "segments_mb": [round(4e-6 * (hi - lo), 1) for _, lo, hi in self.segment_calls],
+                 "collective": "ncclAllReduce on the issuing stream (cc_amd/rccl.py), two communicators" if self.opt._rccl is not None
                  else "torch.distributed.all_reduce (blocking)"}
-            if self.comm_standalone_ms:
-                by_seg = dict(zip(self.segments(), self.comm_standalone_ms))
-                r["standalone_ms"] = [round(by_seg.get(segs[k], float("nan")), 3) for k in order]
+            if self.comm_standalone_ms and len(self.comm_standalone_ms) == len(order):
+                r["standalone_ms"] = [round(v, 3) for v in self.comm_standalone_ms]
             return r
         if not self.comm_events:
             return None

@@ -267,6 +267,15 @@ def test_step_with_rccl_process_group_of_one(monkeypatch):
         st = tr.comm_stats()
         assert len(alone) == 4 and all(a > 0 for a in alone)
         assert st["issue_order"] == ["pose", "mask", "disp", "flow"] and len(st["standalone_ms"]) == 4
+        # config.grad_chunks: DispResNet6 hands its segment over in three chunks while its backward pass runs (on the origin stream,
+        # its own communicator); same results to the summation order of the weight gradients parked at the marks
+        monkeypatch.setattr(_cfg, "grad_chunks", True)
+        trc, c1, c2, c3 = run()
+        c5, dec = sorted(v for k, v in trc._chunk_lo.items() if k[0] == 0)
+        assert [(lo, hi) for _, lo, hi in trc.segment_calls] == [segs[1], segs[2], (dec, segs[0][1]), (c5, dec), (segs[0][0], c5), segs[3]]
+        assert trc.comm_stats()["issue_order"] == ["pose", "mask", "disp", "disp", "disp", "flow"]
+        results.append((c1, c2, c3))
+        monkeypatch.setattr(_cfg, "grad_chunks", False)
         assert abs(sum(st["segments_mb"]) - 4e-6 * n) < 0.3 and "ncclAllReduce" in st["collective"]
         for form in ("post", "staged"):
             tr, b1, b2, b3 = run(form)

@@ -148,6 +148,8 @@ def _cc_dp_worker_one_step(rank, world, port, ret, pipeline):
                         b.data.add_(0.5)
                     else:
                         b.data.add_(7)
+        from cc_amd import config as _cfg
+        _cfg.grad_chunks = True             # (off by default; the chunked hand-over of DispResNet6's segment is the superset of the logic)
         tr = T.CCTrainer(nets, T.StepConfig(), use_graph=False, pipeline=pipeline)
         assert tr.pipeline == pipeline and tr.split_graphs == (pipeline == "staged") and 0 < tr.n_dp < tr.opt.flat_p.numel()
         p0 = tr.opt.flat_p.clone()
@@ -162,11 +164,11 @@ def _cc_dp_worker_one_step(rank, world, port, ret, pipeline):
             calls.append((lo, hi, async_op))
             return orig(lo, hi, async_op)
 
-        def spy_here(lo, hi):
+        def spy_here(lo, hi, comm=0):
             local[lo:hi] = tr.opt.flat_g[lo:hi]
             calls.append((lo, hi, False))
             events.append(("reduce", lo, hi))
-            return orig_here(lo, hi)
+            return orig_here(lo, hi, comm)
 
         def spy_seg(lo, hi, tick, grad_scale=1.0):
             events.append(("adam", lo, hi, bool(tick), grad_scale))
@@ -179,6 +181,7 @@ def _cc_dp_worker_one_step(rank, world, port, ret, pipeline):
         # managed dict is lost)
         out = dict(p0=p0, buf0=buf0, local=local.clone(), reduced=tr.opt.flat_g.clone(), p1=tr.opt.flat_p.clone(), calls=list(calls),
                    events=list(events), n_dp=tr.n_dp, segs=[tr.opt.segment(i) for i in range(4)], loss=float(losses["loss"]),
+                   chunks=sorted(v for k, v in tr._chunk_lo.items() if k[0] == 0),
                    step=float(tr.opt.step_dev), images_fresh=images_fresh, n_images=sum(1 for e in ops.packs.entries.values() if e))
         if pipeline == "per_network":
             # the weight images the per-network refreshes left behind ARE the images of the updated weights: a full rebuild gives
@@ -201,9 +204,9 @@ def _cc_dp_worker_one_step(rank, world, port, ret, pipeline):
 def test_cc_step_data_parallel_two_ranks_gloo(pipeline):
     """world_size-2 gloo run of CCTrainer.step (train.py:300-303's DataParallel as one process per GPU): ranks agree bit for
     bit, the exchanged gradient is the sum of the two ranks' own gradients, the update equals Adam on their mean.
-    per_network (the default form): the exchange is issued as the four networks' segments in the order their backward passes
-    finish (pose, mask, disp, flow), each followed by ITS Adam segment with the step counter advanced once at the start, and the
-    weight images left behind equal a full rebuild.  staged: two segments, the first one started before the second backward stage."""
+    per_network (the default form): the exchange is issued as the networks' segments in the order their backward passes are
+    enqueued (pose, mask, disp -- in three chunks, as its backward pass passes its marks --, flow), each followed by ITS Adam
+    segment with the step counter advanced once at the start, and the weight images left behind equal a full rebuild.  staged: two segments, the first one started before the second backward stage."""
     world, port = 2, _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
@@ -221,11 +224,15 @@ def test_cc_step_data_parallel_two_ranks_gloo(pipeline):
         segs = r0["segs"]                               # disp, pose, mask, flow
         assert all(s is not None for s in segs) and segs[0][0] == 0 and segs[3][1] == n and segs[2][0] == n_dp
         assert all(a[1] == b[0] for a, b in zip(segs, segs[1:])) and all(lo % 64 == 0 for lo, _ in segs)     # they tile the bucket
-        want = [segs[1], segs[2], segs[0], segs[3]]     # issue order: pose, mask, disp, flow (shortest backward first)
+        # issue order: pose, mask, disp, flow (shortest backward first); DispResNet6 -- the last finisher -- hands its segment over in
+        # chunks while its backward pass still runs: the decoder's parameters, then conv5..conv7, then the rest
+        c5, dec = r0["chunks"]
+        assert segs[0][0] < c5 < dec < segs[0][1] and c5 % 4 == 0 and dec % 4 == 0
+        want = [segs[1], segs[2], (dec, segs[0][1]), (c5, dec), (segs[0][0], c5), segs[3]]
         assert [(lo, hi) for lo, hi, _ in r0["calls"]] == want == [(lo, hi) for lo, hi, _ in r1["calls"]]
         # every segment: its all-reduce, then ITS Adam segment (no tick: the counter was advanced once at the start of the step)
         ev = r0["events"]
-        assert len(ev) == 8
+        assert len(ev) == 12
         for k, (lo, hi) in enumerate(want):
             assert ev[2 * k] == ("reduce", lo, hi) and ev[2 * k + 1] == ("adam", lo, hi, False, 0.5), (k, ev[2 * k], ev[2 * k + 1])
         assert r0["step"] == 1.0 and r0["step2"] == 2.0

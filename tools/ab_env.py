@@ -27,6 +27,10 @@ def apply(env=None):
         config.net_streams = got["net_streams"] = int(env["CC_NET_STREAMS"])           # 0 / 1 (= 2 side streams) / 3
     if env.get("CC_NET_STREAM_PRIORITY"):              # e.g. "0,-1": Back2Future's stream high
         config.debug.net_stream_priority = got["net_stream_priority"] = tuple(int(v) for v in env["CC_NET_STREAM_PRIORITY"].replace(":", ",").split(","))
+    if env.get("CC_GRAD_CHUNKS") is not None:          # product switch cc_amd.config.grad_chunks
+        config.grad_chunks = got["grad_chunks"] = bool(int(env["CC_GRAD_CHUNKS"]))
+    if env.get("CC_CHUNK_INLINE", "0") == "1":
+        config.debug.chunk_inline = got["chunk_inline"] = True
     if env.get("CC_PIPE_SKIP_TAIL"):                   # measurement: networks (disp,pose,mask,flow) whose Adam segment + weight images are skipped
         config.debug.pipe_skip_tail = got["pipe_skip_tail"] = tuple(env["CC_PIPE_SKIP_TAIL"].replace(":", ",").split(","))
     if env.get("CC_PIPELINE"):                         # bench.py --pipeline default override for the `ab` step of tools/gpu.sh
