@@ -793,14 +793,34 @@ def main():
                                                        truth64=cpu_first.get("grads64"), cond=cpu_first.get("cond"))
                     rows_ = par["gradient_pin"]["by_net_given_reference_output_gradients"]
                     par["gradient_l2_given_ref_output_grads"] = [r_["l2_rel"] for r_ in rows_]
-                    # Gate per network: the engine may differ from the reference by what the reference's own fp32 evaluation differs
-                    # from the exact (float64) gradient of the same weights, times 3 -- 1e-4 where that is smaller.  (DispResNet6's
-                    # gradient is ill-conditioned: BatchNorm batch statistics over 16 - 208 values at its deep levels; 1e-7 of input
-                    # noise moves the reference's own gradient by 2e-3.  The other three networks sit at 1e-5 - 1e-4.)
-                    if all("reference_vs_fp64" in r_ for r_ in rows_):
-                        bars_ = [max(1e-4, 3.0 * r_["reference_vs_fp64"]) for r_ in rows_]
-                        par["gradient_pin"]["bars"] = [float("%.3e" % b_) for b_ in bars_]
-                        par["gradient_pin"]["ok"] = bool(all(r_["l2_rel"] <= b_ for r_, b_ in zip(rows_, bars_)))
+                    # Gate (round 6, fixed numbers): every network's parameter gradient against the EXACT (float64) gradient of the same
+                    # weights and output gradients.  PoseNetB6 / MaskNet6 / Back2Future: <= 1e-4.  DispResNet6 (ReLU + BatchNorm over
+                    # 16 - 208 values): its figure is made of single ReLU decisions at pre-activations within rounding of zero
+                    # (profiles/r06_grad_pin.txt: two of 425 984 elements, |z| < 3e-6 against activations of 6; one of them carries 98.8 %
+                    # of the squared error of its tensor), so it is gated where that can be separated: at the block boundaries with no
+                    # flipped decision at or above them the engine's d loss / d (pre-activation) is held to 2.5 x the reference's own
+                    # distance to float64, every flipped decision must sit at |pre-activation| <= 1e-5 of the layer's largest
+                    # activation, at most 8 of them, and the whole-network figure to 2e-3.
+                    if all("engine_vs_fp64" in r_ for r_ in rows_):
+                        ok_small = all(r_["engine_vs_fp64"] <= 1e-4 for r_ in rows_[1:])
+                        bd = grad_pin.boundaries(init_sd, batch_cpu, cpu_first["out_grads"], dev)
+                        par["gradient_pin"]["dispresnet6_boundaries"] = bd["boundaries"]
+                        flips = [f_ for b_ in bd["boundaries"] for f_ in b_["flips"]]
+                        nflip = sum(b_["relu_flips_engine"] for b_ in bd["boundaries"])
+                        clean, seen_flip = [], False
+                        for b_ in reversed(bd["boundaries"]):           # deepest boundary first = the order of the backward pass
+                            seen_flip = seen_flip or b_["relu_flips_engine"] > 0
+                            if not seen_flip:
+                                clean.append(b_)
+                        ok_clean = bool(clean) and all(b_["engine_vs_fp64"] <= 2.5 * b_["reference_vs_fp64"] for b_ in clean)
+                        ok_flips = nflip <= 8 and all(abs(f_["preactivation_fp64"]) <= 1e-5 * f_["max_abs_Y_fp64"] for f_ in flips
+                                                      if f_.get("preactivation_fp64") is not None)
+                        par["gradient_pin"]["gate"] = {
+                            "pose_mask_flow_engine_vs_fp64_le_1e-4": bool(ok_small),
+                            "disp_flip_free_boundaries_le_2.5x_reference": bool(ok_clean), "flip_free_boundaries": [b_["boundary"] for b_ in clean],
+                            "disp_relu_flips": nflip, "disp_flips_within_rounding_of_zero": bool(ok_flips),
+                            "disp_engine_vs_fp64_le_2e-3": bool(rows_[0]["engine_vs_fp64"] <= 2e-3)}
+                        par["gradient_pin"]["ok"] = bool(ok_small and ok_clean and ok_flips and rows_[0]["engine_vs_fp64"] <= 2e-3)
                         par["ok"] = bool(par["ok"] and par["gradient_pin"]["ok"])
                 except Exception as e:                          # noqa: BLE001 -- a diagnosis must not cost the bench line
                     par["gradient_pin"] = {"error": repr(e)}

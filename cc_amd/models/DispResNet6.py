@@ -58,8 +58,8 @@ class DispResNet6(nn.Module):
             if i == 5:
                 tape.mark("conv5")         # backward: conv5 .. conv7 (27.5 M of the 54.6 M parameters) are done here
             stage = getattr(self, "conv%d" % i)
-            y = basic_block(tape, stage[0], c[-1])
-            c.append(basic_block(tape, stage[1], y, out=cats[i + 1].slot(1) if i < 7 else None))
+            y = tape.tap(basic_block(tape, stage[0], c[-1]), "conv%d.0" % i)
+            c.append(tape.tap(basic_block(tape, stage[1], y, out=cats[i + 1].slot(1) if i < 7 else None), "conv%d.1" % i))
         tape.mark("decoder")               # backward: the whole decoder (24.3 M parameters) is done here
         out, disps, prev = c[7], {}, None
         for lvl in range(7, 0, -1):

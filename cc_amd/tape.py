@@ -92,10 +92,13 @@ NET_DONE = None
 # used AFTER that point has its complete gradient (parked weight-gradient launches aside: the callee flushes them), so the trainer
 # can start exchanging / updating that part of the network's bucket segment while the rest of its backward pass still runs.
 NET_MARK = None
+# diagnosis (tools/grad_pin.py): a dict -> every tensor a network's forward tagged with Tape.tap() leaves its accumulated gradient
+# there when its producer picks it up in the backward pass: name -> (gradient clone or None, already-pre-activation flag)
+TAPS = None
 
 class TT:
     """A tensor on the tape + the state of its gradient during the backward pass."""
-    __slots__ = ("t", "act", "act_a", "act_b", "uses", "remaining", "grad", "pend", "pre", "needs")
+    __slots__ = ("t", "act", "act_a", "act_b", "uses", "remaining", "grad", "pend", "pre", "needs", "tapname")
 
     def __init__(self, t, needs=True, act=0, act_a=1.0, act_b=0.0):
         assert t.dtype == torch.float32 and (t.dim() != 4 or _dense(t)), (tuple(t.shape), t.stride())
@@ -107,6 +110,7 @@ class TT:
         self.pend = []           # other tensors that are additive parts of the gradient (not summed yet)
         self.pre = False         # grad is already w.r.t. the producer's PRE-activation
         self.needs = needs       # gradient wanted at all
+        self.tapname = None      # diagnosis: see TAPS
 
     # ---- contributions (called by the consumers' backward, in reverse forward order)
     def skip(self):
@@ -178,6 +182,12 @@ class TT:
 
     def final(self):
         """-> (gradient or None, already-pre-activation flag); called by the producer's backward."""
+        g, pre = self._final()
+        if self.tapname is not None and TAPS is not None:
+            TAPS[self.tapname] = (g.detach().clone() if g is not None else None, pre)
+        return g, pre
+
+    def _final(self):
         if not self.needs:
             return None, False
         if self.grad is None:
@@ -257,6 +267,12 @@ class Tape:
 
     def concat(self, B, chans, H, W, ref):
         return ConcatBuffer(self, B, chans, H, W, ref)
+
+    def tap(self, tt, name):
+        """diagnosis: leave tt's accumulated gradient in TAPS[name] during the backward pass (no-op unless TAPS is a dict)"""
+        if TAPS is not None:
+            tt.tapname = name
+        return tt
 
     def mark(self, tag):
         """A point of the forward pass: in the backward pass NET_MARK(owner module, tag) is called once everything recorded after

@@ -170,6 +170,135 @@ def conditioning(init_sd, batch, og, eps=1e-7):
     return res
 
 
+BOUNDARIES = ("conv4.1", "conv5.0", "conv5.1", "conv6.0", "conv6.1", "conv7.0", "conv7.1")
+
+
+def _oracle_boundaries(init_sd, batch, og, dtype):
+    """DispResNet6 (oracle module = the reference's arithmetic) forward + backward in `dtype`, driven by the output gradients og[0:6]:
+    -> {boundary: (block output Y, d loss / d Y)} at the BasicBlock outputs of BOUNDARIES, and the parameter gradients by name."""
+    from oracle import step as S
+    torch.set_default_dtype(dtype)
+    try:
+        m = S.build_nets("oracle", flow=False, mask=False)[0]
+    finally:
+        torch.set_default_dtype(torch.float32)
+    m.to(dtype)
+    m.load_state_dict({a: (b.to(dtype) if b.is_floating_point() else b) for a, b in init_sd[0].items()})
+    m.train()
+    keep = {}
+
+    def hook(name):
+        def f(mod, inp, out):
+            out.retain_grad()
+            keep[name] = out
+        return f
+    hs = []
+    pre = {}
+
+    def hook_pre(name):
+        # the block's PRE-activation: conv2(...) + shortcut (models/DispResNet6.py:31-43) -- the number whose sign is the ReLU decision
+        def f(mod, inp, out):
+            pre[name] = (pre.get(name + "/res"), out.detach())
+        return f
+
+    def hook_in(name, blk):
+        def f(mod, inp):
+            x = inp[0].detach()
+            pre[name + "/res"] = x if blk.downsample is None else blk.downsample(inp[0]).detach()
+        return f
+    for name in BOUNDARIES:
+        stage, blk = name.split(".")
+        b_ = getattr(m, stage)[int(blk)]
+        hs.append(b_.register_forward_hook(hook(name)))
+        hs.append(b_.register_forward_pre_hook(hook_in(name, b_)))
+        hs.append(b_.conv2.register_forward_hook(hook_pre(name)))
+    outs = list(m(batch[0].to(dtype)))
+    pr = [(t, g_.to(dtype)) for t, g_ in zip(outs, og[0:6]) if g_ is not None]
+    torch.autograd.backward([t for t, _ in pr], [g_ for _, g_ in pr])
+    for h in hs:
+        h.remove()
+    return ({k: (v.detach(), v.grad.detach(), (pre[k][1] + pre[k][0]) if (k in pre and pre[k][0] is not None) else None)
+             for k, v in keep.items()},
+            {k: p_.grad.detach() for k, p_ in m.named_parameters() if p_.grad is not None})
+
+
+def boundaries(init_sd, batch_cpu, og, dev):
+    """WHERE inside DispResNet6's backward does the engine's gradient leave the float64 one?  At the outputs Y of
+    the BasicBlocks conv4.1 ... conv7.1: the gradient w.r.t. the block's PRE-activation, dL/dZ = dL/dY * 1[Y > 0] (what the tape
+    hands the block's last convolution), engine / reference-fp32 against float64, and how many ReLU decisions 1[Y > 0] each fp32
+    side takes differently from float64 (a flipped decision switches a whole gradient path on or off)."""
+    from cc_amd import trainer as T, ops, tape
+    t64, p64 = _oracle_boundaries(init_sd, batch_cpu, og, torch.float64)
+    t32, p32 = _oracle_boundaries(init_sd, batch_cpu, og, torch.float32)
+    nets = T.build_nets(dev, flow=False, mask=False)
+    net = nets[0]
+    net.load_state_dict(init_sd[0])
+    net.train()
+    ops.packs.reset()
+    tape.TAPS = {}
+    try:
+        outs = list(net(batch_cpu[0].to(dev)))
+        for p_ in net.parameters():
+            p_.grad = None
+        pr = [(t, g_.to(dev)) for t, g_ in zip(outs, og[0:6]) if g_ is not None]
+        torch.autograd.backward([t for t, _ in pr], [g_ for _, g_ in pr])
+        torch.cuda.synchronize()
+        taps = dict(tape.TAPS)
+    finally:
+        tape.TAPS = None
+    # the engine's block outputs: a second forward pass with hooks on the module outputs is not available on the tape, so the
+    # ReLU decisions of the engine are read off its gradient (dL/dZ is exactly 0 where the engine took Y <= 0) together with the
+    # float64 activations: an element counts as an engine flip when float64 says active (Y64 > 0, dL/dZ64 != 0) and the engine's
+    # dL/dZ is exactly 0, or the other way round
+    rows = []
+    for name in BOUNDARIES:
+        if name not in taps or taps[name][0] is None:
+            continue
+        g_e, pre = taps[name]
+        g_e = g_e.cpu().double()
+        y64, gy64, zpre64 = t64[name]
+        y32, gy32, zpre32 = t32[name]
+        z64 = gy64 * (y64 > 0)
+        z32 = (gy32 * (y32 > 0)).double()
+        a64 = y64 > 0
+        if not pre:                     # (the tape had not applied relu' yet: apply the float64 decision, flips then show as 0)
+            g_e = g_e * a64
+        flips_ref = int(((y32 > 0) != a64).sum())
+        act_e = g_e != 0
+        flips_eng = int(((act_e != (z64 != 0)) & (gy64 != 0)).sum()) if pre else 0
+        # the part of each side's error that sits on elements where the ReLU decisions agree with float64
+        agree_e = (act_e == (z64 != 0))
+        agree_r = ((y32 > 0) == a64)
+        flip_detail = []
+        if pre and flips_eng:
+            idx = ((act_e != (z64 != 0)) & (gy64 != 0)).nonzero()
+            e2 = float(((g_e - z64) ** 2).sum())
+            for ix in idx[:4]:
+                ix = tuple(int(v) for v in ix)
+                flip_detail.append({"index": list(ix), "Y_fp64": float("%.3e" % float(y64[ix])), "Y_ref_fp32": float("%.3e" % float(y32[ix])),
+                                    "preactivation_fp64": float("%.3e" % float(zpre64[ix])) if zpre64 is not None else None,
+                                    "preactivation_ref_fp32": float("%.3e" % float(zpre32[ix])) if zpre32 is not None else None,
+                                    "elements_with_abs_preactivation_fp64_below_2e-6": int((zpre64.abs() < 2e-6).sum()) if zpre64 is not None else None,
+                                    "dLdY_fp64": float("%.3e" % float(gy64[ix])), "engine_dLdZ": float("%.3e" % float(g_e[ix])),
+                                    "rms_dLdZ_fp64": float("%.3e" % float(z64.pow(2).mean().sqrt())),
+                                    "max_abs_Y_fp64": float("%.3e" % float(y64.abs().max())),
+                                    "share_of_squared_error": float("%.3f" % (float((g_e[ix] - z64[ix]) ** 2) / max(e2, 1e-300)))})
+        rows.append({"boundary": name, "shape": list(y64.shape), "pre_applied_by_tape": bool(pre), "flips": flip_detail,
+                     "engine_vs_fp64": float("%.3e" % _l2(g_e, z64)), "reference_vs_fp64": float("%.3e" % _l2(z32, z64)),
+                     "relu_flips_engine": flips_eng, "relu_flips_reference": flips_ref,
+                     "engine_vs_fp64_where_relu_agrees": float("%.3e" % _l2(torch.where(agree_e, g_e, z64), z64)),
+                     "reference_vs_fp64_where_relu_agrees": float("%.3e" % _l2(torch.where(agree_r, z32, z64), z64))})
+    # the parameter gradients of the same run, per tensor of conv5 / conv6
+    par = []
+    ge = {k: p_.grad.detach().cpu().double() for k, p_ in net.named_parameters() if p_.grad is not None}
+    for k in ("conv4.1.conv2.weight", "conv5.0.conv1.weight", "conv5.0.conv2.weight", "conv5.1.conv1.weight", "conv5.1.conv2.weight",
+              "conv6.0.conv1.weight", "conv6.0.conv2.weight", "conv6.1.conv1.weight", "conv6.1.conv2.weight"):
+        if k in ge and k in p64:
+            par.append([k, float("%.2e" % _l2(ge[k], p64[k])), float("%.2e" % _l2(p32[k].double(), p64[k]))])
+    ops.packs.reset()
+    return {"boundaries": rows, "weights (name, engine vs fp64, reference vs fp64)": par}
+
+
 def cpu_child(inp, outp):
     """the reference (or, without oracle/_ref, the oracle) step on the host cores, in a process that sees no GPU"""
     from oracle import step as S, ref_import
@@ -212,6 +341,14 @@ def main():
     res = run(init_sd, batch_cpu, r["og"], r["pg"], dev, truth64=r.get("pg64"), cond=r.get("cond"))
     res["cpu_side"] = r["kind"]
     print(json.dumps(res, indent=1))
+    if os.environ.get("GRAD_PIN_BOUNDARIES", "1") == "1":
+        torch.set_num_threads(min(32, os.cpu_count() or 8))
+        b = boundaries(init_sd, batch_cpu, r["og"], dev)
+        print("== DispResNet6 block boundaries: d loss / d (pre-activation) against float64 (reference's output gradients on all sides)")
+        for row in b["boundaries"]:
+            print(json.dumps(row))
+        for row in b["weights (name, engine vs fp64, reference vs fp64)"]:
+            print("  %-24s engine vs fp64 %.2e   reference vs fp64 %.2e" % tuple(row))
     if os.environ.get("GRAD_PIN_VARIANTS"):
         # the same comparison under kernel-selection switches of the TOOLS build: "VAR=VAL,VAR=VAL;VAR=VAL;..." -- does the figure
         # move with the algorithm a layer runs on?
