@@ -19,6 +19,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wno-unused-result", "-I", os.path.join(os.path.dirname(HERE), "include")]
 
 
+# per-file flags.  ssim.hip: no SLP vectorisation -- it packs the separable filters' FMAs into v_pk_fma_f32 / v_pk_add_f32, which cost
+# more on gfx950 than the scalar instructions they replace (profiles/r04_ab_round4.txt: the packed forward filter ran 47 % slower),
+# and narrows half-used 16-byte LDS reads into ds_read2_b32 pairs
+FILE_FLAGS = {"ssim.hip": ["-fno-slp-vectorize"]}
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
@@ -71,7 +77,8 @@ def _build(verbose, force, OUT, OBJ, extra):
         objs.append(obj)
         is_ver = os.path.basename(src) == "version.hip"
         if force or _stale(obj, [src] + headers) or (is_ver and hash_changed):
-            jobs.append([HIPCC] + FLAGS + extra + (["-DCC_SRC_HASH=%du" % sh] if is_ver else []) + ["-c", src, "-o", obj])
+            jobs.append([HIPCC] + FLAGS + extra + FILE_FLAGS.get(os.path.basename(src), []) +
+                        (["-DCC_SRC_HASH=%du" % sh] if is_ver else []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

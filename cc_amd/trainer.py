@@ -85,7 +85,7 @@ def _tensors(x):
             yield from _tensors(y)
 
 
-def cc_forward(nets, batch, cfg, keep=False, cut=None, streams=None):
+def cc_forward(nets, batch, cfg, keep=False, cut=None, streams=None, after_fork=None):
     """train.py:454-509.  batch = (tgt, [4 refs], K, Kinv).
     cut: optional dict; when given, the losses are computed on detached copies of the network outputs and
     cut['dp'] / cut['mf'] receive the (output, detached copy) pairs of DispResNet6 + PoseNetB6 / MaskNet6 + Back2Future, so
@@ -106,8 +106,6 @@ def cc_forward(nets, batch, cfg, keep=False, cut=None, streams=None):
                 outs.append(t)
         return outs
 
-    LF.pyramid_cache.prefetch([tgt] + list(refs))        # the frames' scale pyramids (every loss pools them): one launch for all five
-
     forked = []
 
     def _on(st, fn):
@@ -127,6 +125,11 @@ def cc_forward(nets, batch, cfg, keep=False, cut=None, streams=None):
     # issue order, and Back2Future, the longest backward, must not hold up DispResNet6's segment)
     flow_out = _on(s_flow, lambda: flow_net(tgt, refs[1:3])) if full else None         # :463
     disp_out = _on(s_disp, lambda: list(disp_net(tgt)))                                # :454
+    # (behind the side streams' launches, on the step's stream: nothing of it is needed before the losses / the backward pass, and
+    # in front of the forks it would hold up DispResNet6, whose chain is the step's critical path)
+    if after_fork is not None:
+        after_fork()
+    LF.pyramid_cache.prefetch([tgt] + list(refs))        # the frames' scale pyramids (every loss pools them): one launch for all five
     mask_out = _on(s_mask, lambda: list(mask_net(tgt, refs))) if full else None        # :460
     pose_out = pose_net(tgt, refs)                                                     # :459
     _join(forked)
@@ -471,7 +474,8 @@ class CCTrainer:
             self.opt.tick()                # the networks' Adam segments of this step all read the advanced counter
         else:
             ops.packs.prepack_all()        # every conv layer's [tap][c][m] weight images, one launch (weights changed in Adam)
-        self.opt.zero_grad()                                                # :566
+        if not self.net_streams:
+            self.opt.zero_grad()                                            # :566  (with side streams: behind their forks, cc_forward)
         ops.grad_sinks = self.opt.sinks
         LF.scalar_pool.begin(batch[0].device)
 
@@ -480,7 +484,8 @@ class CCTrainer:
         cut = {}
         LF.head_grads.begin()              # the loss terms' gradients of a shared network output meet in one accumulator
         try:
-            out = cc_forward(self.nets, batch, self.cfg, cut=cut, streams=self.net_streams)
+            out = cc_forward(self.nets, batch, self.cfg, cut=cut, streams=self.net_streams,
+                             after_fork=self.opt.zero_grad if self.net_streams else None)
             self.bn_counters.commit()
             pairs = cut.get("dp", []) + cut.get("mf", [])
             g = torch.autograd.grad(out["loss"], [d for _, d in pairs], allow_unused=True) if pairs else ()   # :567, losses only

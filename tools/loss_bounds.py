@@ -1,12 +1,17 @@
 #!/usr/bin/env python
 """Which bound does each warp / loss kernel sit on?  (north_star: ">= 50 % HBM roofline on the warp + loss kernels")
 
-Joins three committed artefacts of ONE build: the rocprofv3 kernel stats of the bench (average duration per launch), the PMC
-traffic pass (HBM bytes per launch, (2 x FETCH_SIZE + WRITE_SIZE) KiB: MI355X_MICROARCH.md's gfx950 correction) and the SQ counter
-pass (wave time split: SQ_WAIT_ANY = parked at s_waitcnt / barriers, SQ_WAIT_INST_ANY = issue stalls, SQ_ACTIVE_INST_ANY =
-issuing; VALU share = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES -- all in quad-cycles, disjoint, summing to SQ_WAVE_CYCLES).
+Joins four artefacts of ONE build: the rocprofv3 kernel stats of the bench (average duration per launch), bench.py's JSON line (the
+ALGORITHMIC bytes of each job-table call: SURVEY.md 8d's per-pixel figures x the pixels of the jobs), the PMC traffic pass (bytes
+moved per launch, counters calibrated per access pattern: tools/pmc_traffic.py) and the SQ counter pass (wave time split: SQ_WAIT_ANY
+= parked at s_waitcnt / barriers, SQ_WAIT_INST_ANY = issue stalls, SQ_ACTIVE_INST_ANY = issuing; VALU share = SQ_ACTIVE_INST_VALU /
+SQ_WAVE_CYCLES -- all in quad-cycles, disjoint, summing to SQ_WAVE_CYCLES).
 
-    python tools/loss_bounds.py profiles/r05_rocprof_kernel_stats_fin.csv profiles/pmc_traffic.json profiles/r05_pmc_sq_fin.txt
+The roofline fraction is quoted on the ALGORITHMIC bytes / rocprofv3 duration (column `alg of 8`, SURVEY.md 8d's convention); bytes
+moved / duration stands beside it (`moved of 8`: what the memory system was asked for -- above the algorithmic figure where a
+kernel re-reads, e.g. the gathers' neighbouring rows fetched into several XCDs' L2s).
+
+    python tools/loss_bounds.py <kernel_stats.csv> profiles/pmc_traffic.json <pmc_sq.txt> <bench json log>
 """
 import csv
 import json
@@ -25,8 +30,24 @@ def norm(n):
     return n.split("(")[0].strip()
 
 
+ALG = {"k_inverse_warp_fwd_jobs": "cc_inverse_warp_fwd_jobs", "k_inverse_warp_bwd_jobs": "cc_inverse_warp_bwd_jobs",
+       "k_flow_warp_fwd_jobs": "cc_flow_warp_fwd_jobs", "k_flow_warp_bwd_jobs": "cc_flow_warp_bwd_jobs",
+       "k_pose2flow_fwd_jobs": "cc_pose2flow_fwd_jobs", "k_ssim_photo_jobs": "cc_ssim_photo_fwd_jobs",
+       "k_ssim_adjoint_jobs": "cc_ssim_photo_bwd_jobs", "k_ssim_err_jobs": "cc_ssim_err_fwd_jobs"}
+
+
 def main():
     stats, traffic, sq = sys.argv[1:4]
+    alg = {}
+    if len(sys.argv) > 4:
+        for ln in open(sys.argv[4]):
+            if ln.startswith("{"):
+                kk = json.loads(ln).get("kernels") or {}
+                for kn, cn in ALG.items():
+                    e = kk.get(cn)
+                    if e and e.get("calls"):
+                        alg[kn] = e["gbps"] * e["ms"] * 1e6 / e["calls"]        # bytes per call (GB/s x ms)
+    alg["k_adam"] = 28.0 * 74258164
     dur = {}
     for r in csv.DictReader(open(stats)):
         dur[norm(r["Name"])] = (float(r["AverageNs"]) / 1e3, int(r["Calls"]))
@@ -41,7 +62,7 @@ def main():
             vals = [float(v) for v in m.group(3).split()]
             if len(vals) == len(cols):
                 sqr[m.group(1).strip()] = dict(zip(cols, vals))
-    print("%-34s %8s %9s %8s %6s | %7s %7s %7s %6s | %s" % ("kernel", "us", "HBM MB", "TB/s", "of 8", "parked", "stalled", "issuing", "VALU", "bound"))
+    print("%-34s %8s %9s %8s | %9s %8s %6s | %7s %7s %7s %6s | %s" % ("kernel", "us", "alg MB", "alg of 8", "moved MB", "TB/s", "of 8", "parked", "stalled", "issuing", "VALU", "bound"))
     for k in KERNELS:
         dk = next((n for n in dur if n == k or n.startswith(k + "<")), None)
         tk = next((n for n in tr if n == k or n.startswith(k + "<")), None)
@@ -56,9 +77,13 @@ def main():
         parked, stalled, issuing = c.get("WAIT_ANY", 0) / wc, c.get("WAIT_INST_ANY", 0) / wc, c.get("ACTIVE_INST_AN", 0) / wc
         valu = c.get("ACTIVE_INST_VA", 0) / wc
         frac = tbs * 1e3 / PEAK
-        bound = "HBM" if frac >= 0.5 else ("latency (waves parked at waitcnt / barriers)" if parked >= 0.45 else
-                                           ("issue (VALU / address arithmetic)" if issuing + stalled >= 0.6 else "mixed: latency + issue"))
-        print("%-34s %8.1f %9.1f %8.2f %6.2f | %7.2f %7.2f %7.2f %6.2f | %s" % (dk[:34], us, mb, tbs, frac, parked, stalled, issuing, valu, bound))
+        amb = alg.get(k, float("nan")) / 1e6
+        afrac = amb / us * 1e3 / PEAK
+        bound = "HBM" if afrac >= 0.5 else ("latency (waves parked at waitcnt / barriers)" if parked >= 0.45 else
+                                            ("issue (VALU / address arithmetic)" if issuing + stalled >= 0.6 else "mixed: latency + issue"))
+        acc = tr[tk].get("access", "") if tk else ""
+        print("%-34s %8.1f %9.1f %8.2f | %9.1f %8.2f %6.2f | %7.2f %7.2f %7.2f %6.2f | %s%s" % (
+            dk[:34], us, amb, afrac, mb, tbs, frac, parked, stalled, issuing, valu, bound, "  [gather: moved > distinct]" if acc == "gather" else ""))
 
 
 if __name__ == "__main__":
