@@ -48,6 +48,7 @@ class _Debug:
     capture_mode = "thread_local"    # hipGraph capture error mode of CCTrainer
     net_stream_priority = (0, 0, 0)  # HIP stream priorities of the networks' side streams (0 normal, -1 high)
     chunk_inline = False         # measurement: the gradient chunks' tails on the network's own stream instead of its tail stream
+    pipe_extra = {}              # measurement: {network name: extra 256 MB fills (~50 us each) in its tail} -- how much slack has its stream?
     pipe_skip_tail = ()          # per-network pipeline, measurement only: names of the networks whose Adam segment + weight-image refresh are skipped
     reduce_trace = None          # a list: every weight-gradient reduce descriptor of the step is appended to it (tools/reduce_bytes.py)
     library_path = None          # another build of libccengine.so (the tools build): picked up by _lib.engine() on first use

@@ -929,6 +929,9 @@ WinoPlan wino_plan(int B, int Cin, int H, int W, int M, int mult) {
         if (t_best < best || small_mode == 2) { best = t_best; p.tile = t_tile; p.nsplit = t_ns; p.cps = t_cps; }
     }
     if (p.tile) { p.nqb = nqb_s; p.nmb = nmb_s; }
+    // layers with fewer than 48 output channels are admitted for the 32-row blocks only: on a 64 x 64 block half of the rows would be
+    // padding (the eligibility floor dropped from 33 to 32 channels when the 32 x 32 instances arrived, round 5)
+    if (!p.tile && M < 48 && cctools::env_int("CC_WINO_MINM", 32) >= 32) return WinoPlan{};
     p.part_floats = p.nsplit > 1 ? (size_t)p.nsplit * B * M * p.Hp * p.Wp : 0;
     return p;
 }

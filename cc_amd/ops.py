@@ -365,6 +365,20 @@ def _act_bwd_bias(gys, ys, geffs, gbs, ref, B, C, H, W, gy_bs, act, act_a, act_b
         E.call("cc_act_bwd_bias_group", *args, STREAM)
 
 
+_WS_BYTES = {}
+
+
+def _wgrad_ws_bytes(B, M, AH, AW, Cin, R, S, si):
+    """cc_conv2d_wgrad_ws_bytes, memoised per geometry (the library plans every group size for it: once per shape, not once per
+    weight-gradient call of an eager step)"""
+    E = engine()
+    key = (id(E), B, M, AH, AW, Cin, R, S, si)
+    v = _WS_BYTES.get(key)
+    if v is None:
+        v = _WS_BYTES[key] = E.call("cc_conv2d_wgrad_ws_bytes", B, M, AH, AW, Cin, R, S, si)
+    return v
+
+
 _ZEROS64 = {}
 
 
@@ -382,7 +396,7 @@ def _wgrad_group(a_list, x_list, gw_list, ref, B, M, AH, AW, a_bs, Cin, IH, IW, 
     import ctypes
     E = engine()
     G = len(a_list)
-    per = E.call("cc_conv2d_wgrad_ws_bytes", B, M, AH, AW, Cin, R, S, si)
+    per = _wgrad_ws_bytes(B, M, AH, AW, Cin, R, S, si)
     a1, a2, a3 = _parr(a_list), _parr(x_list), _parr(gw_list)
     if accumulate and wgrad_queue.enabled and not _dbg.no_wgrad_defer:
         ptrs = [t.data_ptr() for t in gw_list]
@@ -442,7 +456,7 @@ def _wgrad_list(items):
             continue
         wgrad_reduces.targets.update(ptrs)
         G = len(a_list)
-        ws = _ws(E.call("cc_conv2d_wgrad_ws_bytes", B, M, AH, AW, Cin, R, S, si) * G, a_list[0])
+        ws = _ws(_wgrad_ws_bytes(B, M, AH, AW, Cin, R, S, si) * G, a_list[0])
         pad4 = lambda ts: [t.data_ptr() for t in ts] + [0] * (4 - len(ts))
         desc.extend([G] + pad4(a_list) + pad4(x_list) + pad4(gw_list) +
                     [ws.data_ptr(), B, M, AH, AW, a_bs, Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, 1, 0, 0])

@@ -617,8 +617,15 @@ class CCTrainer:
         with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
             self.opt.all_reduce_here(lo, hi, comm=1 if i == 0 else 0)
             self.opt.step_segment(lo, hi, False, self.opt.grad_scale())
+            for _ in range(config.debug.pipe_extra.get(NET_NAMES[i], 0)):        # (measurement: how much slack does this stream have?)
+                engine().call("cc_fill", self._scratch(), self._scratch().numel(), 0.0, STREAM)
             base = self.opt.flat_p.data_ptr()
             ops.packs.repack_range(base + 4 * lo, base + 4 * hi)
+
+    def _scratch(self):
+        if getattr(self, "_scr", None) is None:
+            self._scr = torch.empty(64 << 20, device=self.opt.flat_p.device, dtype=torch.float32)      # 256 MB: ~50 us per fill
+        return self._scr
 
     def _finish_network(self, i):
         """End of network i's backward pass (on its stream): the tail of what is left of its segment."""

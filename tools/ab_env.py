@@ -31,6 +31,9 @@ def apply(env=None):
         config.grad_chunks = got["grad_chunks"] = bool(int(env["CC_GRAD_CHUNKS"]))
     if env.get("CC_CHUNK_INLINE", "0") == "1":
         config.debug.chunk_inline = got["chunk_inline"] = True
+    if env.get("CC_PIPE_EXTRA"):                       # e.g. "flow:10"
+        k, v = env["CC_PIPE_EXTRA"].split(":")
+        config.debug.pipe_extra = got["pipe_extra"] = {k: int(v)}
     if env.get("CC_PIPE_SKIP_TAIL"):                   # measurement: networks (disp,pose,mask,flow) whose Adam segment + weight images are skipped
         config.debug.pipe_skip_tail = got["pipe_skip_tail"] = tuple(env["CC_PIPE_SKIP_TAIL"].replace(":", ",").split(","))
     if env.get("CC_PIPELINE"):                         # bench.py --pipeline default override for the `ab` step of tools/gpu.sh

@@ -9,12 +9,21 @@ with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-adam = [i for i, r in enumerate(rows) if "k_adam" in r[2]]
-adam = [i for j, i in enumerate(adam) if j + 1 == len(adam) or adam[j + 1] != i + 1]     # the optimizer is 2 back-to-back launches
-assert len(adam) >= 2, "need two optimizer launches"
+# round 6 (per-network pipeline): the optimizer is one k_adam per network INSIDE the step, and the step begins with a stand-alone
+# k_adam_tick (cc_adam_tick) -- a step = the dispatches from one such tick up to the next.  Older traces: the dispatches between the
+# ends of two optimizer launches (k_adam_tick + k_adam back to back behind the step).
+ticks = [i for i, r in enumerate(rows) if "k_adam_tick" in r[2] and not (i + 1 < len(rows) and "k_adam(" in rows[i + 1][2].replace("k_adam_tick", ""))]
+if len(ticks) >= 3:
+    adam = [i - 1 for i in ticks]           # (last dispatch of the previous step)
+    cands = [rows[ticks[i - 1]: ticks[i]] for i in range(max(1, len(ticks) - 3), len(ticks))]
+else:
+    adam = [i for i, r in enumerate(rows) if "k_adam" in r[2]]
+    adam = [i for j, i in enumerate(adam) if j + 1 == len(adam) or adam[j + 1] != i + 1]     # the optimizer is 2 back-to-back launches
+    assert len(adam) >= 2, "need two optimizer launches"
+    cands = [rows[adam[i - 1] + 1: adam[i] + 1] for i in range(max(1, len(adam) - 3), len(adam))]
 # of the last (up to) three replayed steps, the one with the shortest wall time: the profiler's buffer flushes now and then stall
-# a step for milliseconds in the middle of the graph
-cands = [rows[adam[i - 1] + 1: adam[i] + 1] for i in range(max(1, len(adam) - 3), len(adam))]
+# a step for milliseconds in the middle of the graph.  (The host copies of the next batch that precede a replay are dropped.)
+cands = [[r for r in st if "copyBuffer" not in r[2] or r[0] > st[0][0] + 20000] for st in cands]
 step = min(cands, key=lambda st: st[-1][1] - st[0][0])
 # step period: end of the optimizer launch to the end of the next one (includes whatever idles BETWEEN two replays)
 ends = [rows[i][1] for i in adam]
@@ -47,3 +56,13 @@ print("one replayed step: %d kernels, wall %.3f ms, sum of kernel durations %.3f
 print("%-72s %6s %10s %9s %6s" % ("kernel", "calls", "total_us", "avg_us", "%"))
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-72s %6d %10.1f %9.2f %6.2f" % (n, c, t / 1e3, t / 1e3 / c, 100.0 * t / (t1 - t0)))
+
+if len(sys.argv) > 2 and sys.argv[2] == "--seq":
+    # the step as a sequence: start offset, duration, gap to the previous kernel's end, name (chains of one stream read top to bottom)
+    print("\nsequence (us from the step's first dispatch):")
+    prev = step[0][0]
+    for s_, e_, n in step:
+        n = re.sub(r"\(anonymous namespace\)::", "", n)
+        n = re.sub(r"^void ", "", n).split("(")[0][:60]
+        print("%9.1f %8.1f %7.1f  %s" % ((s_ - t0) / 1e3, (e_ - s_) / 1e3, (s_ - prev) / 1e3, n))
+        prev = max(prev, e_)
