@@ -68,12 +68,12 @@ for STEP in "$@"; do
   prof|prof0)
     # prof: the step as it runs (networks on their side streams: kernels overlap); prof0: CC_NET_STREAMS=0, kernels one after the other
     # (per-kernel durations that mean the kernel, the reference for roofline.avg_launch_us)
-    PE=""; [ "$K" = prof0 ] && PE="CC_NET_STREAMS=0"
-    ( cd /tmp && env $PE timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o $TAG -- python $R/bench.py --steps 5 --warmup 2 $NOCPU ) > $O/rocprof_$TAG.log 2>&1; echo "rocprof rc=$?"
-    S=$(find $O/prof_$TAG -name "*kernel_stats.csv" | head -1); T=$(find $O/prof_$TAG -name "*kernel_trace.csv" | head -1)
-    [ -n "$S" ] && cp "$S" $O/rocprof_kernel_stats_$TAG.csv
-    python tools/step_trace.py "$T" > $O/step_trace_$TAG.txt 2>&1; head -${TRACE_ROWS:-45} $O/step_trace_$TAG.txt
-    find $O/prof_$TAG -name "*kernel_trace.csv" -size +20M -delete ;;
+    PE=""; PT=$TAG; [ "$K" = prof0 ] && PE="CC_NET_STREAMS=0" && PT=${TAG}_serial
+    ( cd /tmp && env $PE timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$PT -o $PT -- python $R/bench.py --steps 5 --warmup 2 $NOCPU ) > $O/rocprof_$PT.log 2>&1; echo "rocprof rc=$?"
+    S=$(find $O/prof_$PT -name "*kernel_stats.csv" | head -1); T=$(find $O/prof_$PT -name "*kernel_trace.csv" | head -1)
+    [ -n "$S" ] && cp "$S" $O/rocprof_kernel_stats_$PT.csv
+    python tools/step_trace.py "$T" > $O/step_trace_$PT.txt 2>&1; head -${TRACE_ROWS:-45} $O/step_trace_$PT.txt
+    find $O/prof_$PT -name "*kernel_trace.csv" -size +20M -delete ;;
   pmc)
     CMD="env CC_NET_STREAMS=0 python $R/bench.py --no-graph --steps 1 --warmup 1 $NOCPU"      # (per-kernel counters: kernels one after the other)
     for C in FETCH_SIZE WRITE_SIZE; do
