@@ -372,6 +372,11 @@ def _wgrad_ws_bytes(B, M, AH, AW, Cin, R, S, si):
     """cc_conv2d_wgrad_ws_bytes, memoised per geometry (the library plans every group size for it: once per shape, not once per
     weight-gradient call of an eager step)"""
     E = engine()
+    tools = getattr(E, "_is_tools", None)
+    if tools is None:
+        tools = E._is_tools = bool(E.fn["cc_is_tools_build"]())
+    if tools:                     # (tools / emulation builds: the plan depends on the environment switches of the moment)
+        return E.call("cc_conv2d_wgrad_ws_bytes", B, M, AH, AW, Cin, R, S, si)
     key = (id(E), B, M, AH, AW, Cin, R, S, si)
     v = _WS_BYTES.get(key)
     if v is None:

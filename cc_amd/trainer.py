@@ -677,11 +677,12 @@ class CCTrainer:
             and K.shape == s_K.shape and Kinv.shape == s_Kinv.shape, \
             "batch shapes differ from the captured step's (%s vs %s): use a fixed batch size / drop_last" % (
                 tuple(tgt.shape), tuple(s_tgt.shape))
-        s_tgt.copy_(tgt)
-        for a, b in zip(s_refs, refs):
-            a.copy_(b)
-        s_K.copy_(K)
-        s_Kinv.copy_(Kinv)
+        dst, src = [s_tgt] + list(s_refs) + [s_K, s_Kinv], [tgt] + list(refs) + [K, Kinv]
+        if all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in src):
+            torch._foreach_copy_(dst, src)          # one multi-tensor launch instead of seven copies in front of every replay
+        else:
+            for a, b in zip(dst, src):
+                a.copy_(b)
 
     def capture(self, batch, warmup=2):
         """Warm up eagerly on a side stream, then capture forward+backward of one step into a hipGraph."""

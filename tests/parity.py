@@ -1136,7 +1136,7 @@ WGRAD_LIST_SHAPES_WINO = [(2, 48, 6, 16, 64, 3, 1, 1), (1, 20, 8, 24, 40, 3, 1, 
                           (2, 12, 9, 14, 20, 3, 2, 1), (1, 70, 9, 32, 130, 3, 1, 1)]
 
 
-def check_wgrad_list(dev, tol=2e-5, shapes=None):
+def check_wgrad_list(dev, tol=2e-5, shapes=None, groups=None):
     """cc_conv2d_wgrad_list (ops._wgrad_list: what a backward stage's weight-gradient queue flushes at its end): groups of different
     shapes in one call -- stride-2 / 1x1 / small-map layers on the generic kernel (k_wgrad_multi: several per launch), direct-mode
     problems (no split) next to split ones, a G = 2 group, a weight that occurs twice (its two accumulations must not share a
@@ -1157,7 +1157,7 @@ def check_wgrad_list(dev, tol=2e-5, shapes=None):
     shapes = list(shapes or WGRAD_LIST_SHAPES)
     items, want, bufs = [], [], []
     for si_, (B, Cin, H, W, Cout, k, st, pad) in enumerate(shapes):
-        G = 2 if si_ == 1 else 1
+        G = (groups or {1: 2}).get(si_, 1)          # problems per group (same-shaped layers of one launch): default a G = 2 group at index 1
         OH, OW = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
         a_l, x_l, gw_l = [], [], []
         for _ in range(G):

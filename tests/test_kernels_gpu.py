@@ -123,8 +123,11 @@ def test_weight_gradient_list_winograd(monkeypatch):
         parity.check_wgrad_list("cuda", shapes=parity.WGRAD_LIST_SHAPES_WINO)
     for k in ("CC_WW_MINQ", "CC_WW_MINM", "CC_WW_MINC", "CC_WWP_MINQ", "CC_WWP_MINM", "CC_WWP_MINC", "CC_WW_MINCHUNKS"):
         monkeypatch.delenv(k)
+    # the PRODUCT library at its own thresholds: k_wino_wgrad_multi with single problems, a G = 2 group (index 1) and a G = 3 group (index 3)
+    assert _lib.engine().fn["cc_is_tools_build"]() == 0
     parity.check_wgrad_list("cuda", shapes=[(4, 128, 8, 28, 128, 3, 1, 1), (4, 96, 16, 52, 96, 3, 1, 1), (4, 128, 8, 26, 96, 3, 1, 1),
-                                             (4, 64, 32, 104, 64, 3, 1, 1), (2, 12, 9, 14, 20, 3, 2, 1), (4, 192, 4, 16, 192, 3, 1, 1)])
+                                             (4, 64, 32, 104, 64, 3, 1, 1), (2, 12, 9, 14, 20, 3, 2, 1), (4, 192, 4, 16, 192, 3, 1, 1)],
+                            groups={1: 2, 3: 3})
 
 
 def test_convs_prepacked_weight_images():
