@@ -462,7 +462,21 @@ class CCTrainer:
         self.losses = None
         self.nan_flags = []
         if self.pipeline == "per_network" and self.opt.comm_active():
-            self.opt.rccl()              # the communicator must exist before any capture
+            try:
+                self.opt.rccl()          # the communicators must exist before any capture
+            except Exception as e:       # noqa: BLE001 -- librccl not bindable / communicator set-up refused: keep training, say so
+                self._fall_back("the direct RCCL communicators could not be created (%r)" % (e,))
+
+    def _fall_back(self, why):
+        """Data-parallel only: the per-network form needs ncclAllReduce on the networks' streams (cc_amd/rccl.py).  If that path is
+        not available on a machine, the step falls back -- LOUDLY -- to round 5's form (one graph, the process group's two
+        all-reduces behind it): slower, same results."""
+        import sys
+        print("[ccengine] WARNING: per-network gradient pipeline unavailable -- %s; falling back to pipeline='post' "
+              "(process-group all-reduces behind the graph)" % why, file=sys.stderr, flush=True)
+        self.pipeline, self.split_graphs = "post", False
+        self.graph = self.graph_b = None
+        self._chunk_lo = {}
 
     # ------------------------------------------------------------------------------------------------ the step's pieces
     def _begin(self, batch):
@@ -855,7 +869,14 @@ class CCTrainer:
                     ops.packs.end_step()
             if self.use_graph:
                 if self.graph is None:
-                    self.capture(batch)
+                    try:
+                        self.capture(batch)
+                    except RuntimeError as e:
+                        if not self.opt.comm_active():
+                            raise
+                        # a collective that cannot be captured on this stack: the legacy form issues them outside the graph
+                        self._fall_back("capturing the step with its collectives failed (%s)" % (str(e).splitlines()[0][:200],))
+                        return self._step_legacy(batch)
                 self._copy_in(batch)
                 self.graph.replay()
                 return self.losses

@@ -244,3 +244,25 @@ def test_cc_step_data_parallel_two_ranks_gloo(pipeline):
     p.grad = (r0["local"] + r1["local"]) * 0.5
     opt.step()
     assert float((p.detach() - r0["p1"]).abs().max()) < 1e-6
+
+
+def test_per_network_pipeline_falls_back_loudly_without_direct_rccl(monkeypatch, capsys):
+    """Data-parallel start-up on a machine where the direct RCCL binding cannot be used: the trainer says so on stderr and runs
+    round 5's form (process-group all-reduces behind the step) instead of failing."""
+    from cc_amd import config as _cfg
+    port = _free_port()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(port))
+    monkeypatch.setattr(_cfg.debug, "force_comm", True)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        def boom(self):
+            raise OSError("librccl.so: cannot open shared object file")
+        monkeypatch.setattr(T.FlatAdam, "rccl", boom)
+        with emulated_engine():
+            nets = T.build_nets("cpu", flow=False, mask=False, init=True)
+            tr = T.CCTrainer(nets, T.StepConfig(), use_graph=False)
+        assert tr.pipeline == "post" and not tr.split_graphs
+        assert "falling back to pipeline='post'" in capsys.readouterr().err
+    finally:
+        dist.destroy_process_group()
