@@ -7,7 +7,7 @@ import csv, sys, collections, re
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
 rows.sort()
 # round 6 (per-network pipeline): the optimizer is one k_adam per network INSIDE the step, and the step begins with a stand-alone
 # k_adam_tick (cc_adam_tick) -- a step = the dispatches from one such tick up to the next.  Older traces: the dispatches between the
@@ -31,10 +31,10 @@ periods = [(b - a) / 1e6 for a, b in zip(ends[:-1], ends[1:])][-4:]
 if periods:
     print("step period (optimizer end to optimizer end), last %d steps: %s ms" % (len(periods), " ".join("%.3f" % p for p in periods)))
 t0, t1 = step[0][0], step[-1][1]
-busy = sum(e - s for s, e, _ in step)
+busy = sum(e - s for s, e, *_ in step)
 # with the networks on streams of their own (round 5) kernels overlap: time covered by at least one kernel, and by two or more
 covered, two, cur_end, sec_end = 0, 0, None, None
-ev = sorted([(s_, 1) for s_, e_, _ in step] + [(e_, -1) for s_, e_, _ in step])
+ev = sorted([(s_, 1) for s_, e_, *_ in step] + [(e_, -1) for s_, e_, *_ in step])
 depth, last = 0, ev[0][0]
 for t_, d_ in ev:
     if depth >= 1:
@@ -45,7 +45,7 @@ for t_, d_ in ev:
     last = t_
 gaps = (step[-1][1] - step[0][0]) - covered
 agg = collections.defaultdict(lambda: [0, 0])
-for s, e, n in step:
+for s, e, n, _q in step:
     n = re.sub(r"\(anonymous namespace\)::", "", n)
     n = re.sub(r"^void ", "", n)
     n = n.split("(")[0][:70]
@@ -61,8 +61,20 @@ if len(sys.argv) > 2 and sys.argv[2] == "--seq":
     # the step as a sequence: start offset, duration, gap to the previous kernel's end, name (chains of one stream read top to bottom)
     print("\nsequence (us from the step's first dispatch):")
     prev = step[0][0]
-    for s_, e_, n in step:
+    for s_, e_, n, q_ in step:
         n = re.sub(r"\(anonymous namespace\)::", "", n)
         n = re.sub(r"^void ", "", n).split("(")[0][:60]
-        print("%9.1f %8.1f %7.1f  %s" % ((s_ - t0) / 1e3, (e_ - s_) / 1e3, (s_ - prev) / 1e3, n))
+        print("%9.1f %8.1f %7.1f  q%-3s %s" % ((s_ - t0) / 1e3, (e_ - s_) / 1e3, (s_ - prev) / 1e3, q_, n))
         prev = max(prev, e_)
+
+if len(sys.argv) > 2 and sys.argv[2] in ("--queues", "--seq"):
+    # per hardware queue (= branch of the replayed graph): kernels, busy time, first start / last end, the last three kernels --
+    # which chain finishes last (round 6: DispResNet6's, with its Adam segment and weight images at the very end)
+    print("\nper hardware queue of the replayed step (us from its first dispatch):")
+    byq = collections.defaultdict(list)
+    for s_, e_, n, q_ in step:
+        byq[q_].append((s_, e_, re.sub(r"^void ", "", re.sub(r"\(anonymous namespace\)::", "", n)).split("(")[0][:40]))
+    for q_, ks in sorted(byq.items(), key=lambda kv: kv[1][-1][1]):
+        print("queue %-3s %4d kernels  busy %8.1f  first %8.1f  last end %8.1f   ...%s" % (
+            q_, len(ks), sum(e_ - s_ for s_, e_, _ in ks) / 1e3, (ks[0][0] - t0) / 1e3, (max(e_ for _, e_, _ in ks) - t0) / 1e3,
+            " | ".join(n for _, _, n in ks[-3:])))
