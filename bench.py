@@ -62,10 +62,12 @@ def parse():
                          "forward, only DispResNet6 + PoseNetB6 are trained (227 MB gradient bucket); reported beside the metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--pipeline", choices=("per_network", "post", "staged"), default="per_network",
-                    help="per_network (default): every network's gradient all-reduce -> Adam segment -> weight images at the end of ITS "
+    ap.add_argument("--pipeline", choices=("auto", "per_network", "post", "staged"), default="auto",
+                    help="per_network: every network's gradient all-reduce -> Adam segment -> weight images at the end of ITS "
                          "backward pass, on its own stream inside the one hipGraph; post: round 5 (one graph, two process-group "
-                         "all-reduces behind it); staged: rounds 3-4 (two graphs, the first all-reduce between them)")
+                         "all-reduces behind it); staged: rounds 3-4 (two graphs, the first all-reduce between them); auto (default): "
+                         "per_network -- and at N > 1, where no form has ever been measured on more than one GPU, a few untimed steps of "
+                         "per_network and of post first, the faster one runs the timed region (recorded in comm.form_selection)")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU steps after one warm-up (median is reported)")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="0 = min(usable threads (affinity / cgroup quota), 64): with all 256 hardware threads of the GPU box the "
@@ -493,7 +495,8 @@ def main():
     if os.environ.get("CC_COMM_PROBE"):
         comm_debug["probe"] = os.environ["CC_COMM_PROBE"]
     ab_env.assert_applied()
-    tr = T.CCTrainer(nets, cfg, use_graph=not args.no_graph, pipeline=ab_switches.get("pipeline", args.pipeline), comm_debug=comm_debug)
+    pipe = ab_switches.get("pipeline", args.pipeline)
+    tr = T.CCTrainer(nets, cfg, use_graph=not args.no_graph, pipeline="per_network" if pipe == "auto" else pipe, comm_debug=comm_debug)
 
     def sync():
         torch.cuda.synchronize()
@@ -515,6 +518,35 @@ def main():
                 first_params = tr.opt.gather(tr.opt.flat_p).detach().cpu().clone()       # (chain order, without the bucket's padding)
                 first_grads = tr.opt.gather(tr.opt.flat_g).detach().cpu().clone()
             log("warm-up step %d done at %.1f s" % (i, time.perf_counter() - t_w))
+    form_selection = None
+    if pipe == "auto" and use_dist and (world > 1 or os.environ.get("CC_FORCE_FORM_SELECTION") == "1") and not args.no_graph \
+            and tr.pipeline == "per_network":
+        # No step form has been measured on more than one GPU (rounds 1-6: one GPU per gpurun call).  The per-network form has its
+        # collectives INSIDE the replayed graph; whether RCCL's captured all-reduces cost the graph anything on this machine is unknown
+        # (a mid-graph cross-stream edge costs 1-2.5 ms on one GPU, profiles/r06_ab_round6.txt), so both forms run a few untimed steps
+        # and the faster one -- max over ranks -- runs the timed region.
+        def _probe(n=6):
+            for _ in range(3):
+                tr.step(batch)
+            sync()
+            ta = time.perf_counter()
+            for _ in range(n):
+                tr.step(batch)
+            sync()
+            t_ = torch.tensor([(time.perf_counter() - ta) / n * 1e3], device=dev, dtype=torch.float64)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            return float(t_.item())
+        ms_pn = _probe()
+        tr.switch_pipeline("post")
+        ms_post = _probe()
+        chosen = "per_network" if ms_pn <= ms_post else "post"
+        if chosen != tr.pipeline:
+            tr.switch_pipeline(chosen)
+            for _ in range(3):
+                tr.step(batch)
+        form_selection = {"per_network_ms": round(ms_pn, 3), "post_ms": round(ms_post, 3), "chosen": chosen,
+                          "how": "6 replayed steps each after 3 untimed ones, max over ranks, before the timed region"}
+        log("form selection: per_network %.2f ms, post %.2f ms -> %s" % (ms_pn, ms_post, chosen))
     comm_cal = tr.calibrate_comm() if use_dist else None            # each segment's all-reduce alone (outside the timed region)
     sync()
     # per-step device time stamps: an event after every step on the compute stream (no host synchronisation inside the region)
@@ -533,6 +565,8 @@ def main():
     step_ms = {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": round(per_step[0], 3), "max": round(per_step[-1], 3),
                "source": "HIP events after every step on the compute stream; `ms_per_step` is the wall-clock mean of the region"}
     comm = tr.comm_stats() if use_dist else None
+    if comm is not None and form_selection is not None:
+        comm["form_selection"] = form_selection
     rank_losses = None
     if use_dist:
         lt = torch.tensor([float(losses["loss"]), step_ms["median"]], device=dev, dtype=torch.float64)

@@ -451,6 +451,7 @@ class CCTrainer:
                 for tag, first in n.GRAD_CHUNKS:
                     if first in at and at[first] % 4 == 0:
                         self._chunk_lo[(i, tag)] = at[first]
+        self._chunk_lo_all = dict(self._chunk_lo)
 
         self._done = set()
         self.segment_calls = []          # per_network, most recent step: [(network index, lo, hi)] in issue order (tests, bench)
@@ -466,6 +467,18 @@ class CCTrainer:
                 self.opt.rccl()          # the communicators must exist before any capture
             except Exception as e:       # noqa: BLE001 -- librccl not bindable / communicator set-up refused: keep training, say so
                 self._fall_back("the direct RCCL communicators could not be created (%r)" % (e,))
+
+    def switch_pipeline(self, pipeline):
+        """Change the step form of a live trainer (same bucket, same optimizer state): the captured graphs are dropped and the next
+        step captures the new form.  bench.py uses it at N > 1 to time the per-network form against round 5's on the machine at hand."""
+        assert pipeline in ("per_network", "post", "staged"), pipeline
+        if pipeline == "per_network" and self.opt.comm_active() and self.opt.flat_g.is_cuda:
+            self.opt.rccl()
+        self.pipeline, self.split_graphs = pipeline, pipeline == "staged"
+        self.graph = self.graph_b = None
+        self._chunk_lo = dict(self._chunk_lo_all) if pipeline == "per_network" else {}
+        self.comm_events, self.stage_b_events = [], []
+        ops.packs.mark_stale()
 
     def _fall_back(self, why):
         """Data-parallel only: the per-network form needs ncclAllReduce on the networks' streams (cc_amd/rccl.py).  If that path is
