@@ -225,6 +225,9 @@ class _WgradQueue:
             _wgrad_list(items)
         wgrad_reduces._cur().flush()          # (this stream's reductions: the proxy runs every stream's queue on its own stream)
 
+    def busy(self):
+        return any(self.pending.values())
+
     def drop(self):
         """error path: forget the parked launches (their operands die with the failed step)"""
         self.pending = {}
@@ -252,6 +255,9 @@ class _WgradReduces:
             arr = (ctypes.c_long * len(self.desc))(*self.desc)
             engine().call("cc_wgrad_reduce_table", ctypes.addressof(arr), len(self.desc) // 16, STREAM)
         self.desc, self.keep, self.targets, self.bias_jobs = [], [], set(), []
+
+    def busy(self):
+        return bool(self.desc or self.bias_jobs)
 
     def drop(self):
         self.desc, self.keep, self.targets, self.bias_jobs = [], [], set(), []
@@ -330,8 +336,10 @@ class _PerStream:
         self._inst.clear()
 
     def streams(self):
-        """the streams that have (had) parked work: the caller makes its stream wait for them after flush()"""
-        return [st for _, st in self._inst.values() if st is not None]
+        """the streams that HAVE parked work: the caller forks them before flush() and joins them after it.  (Streams whose queue a
+        network's own tail has emptied already are left alone: an empty fork / join pair is still a cross-stream edge of the
+        captured graph.)"""
+        return [st for inst, st in self._inst.values() if st is not None and inst.busy()]
 
 
 wgrad_queue = _PerStream(_WgradQueue)
