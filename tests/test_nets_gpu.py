@@ -174,6 +174,34 @@ def test_step_forms_agree(deterministic, monkeypatch):
         assert float((pa - pb).abs().max()) <= 3 * 2.001e-4
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_weight_images_left_by_the_pipelined_step_equal_a_full_rebuild(use_graph):
+    """Per-network form: every network's weight images are rebuilt right behind ITS Adam segment, on its own stream, and the next
+    step starts from them without a start-of-step refresh.  After two steps every image must be byte-identical to what one full
+    rebuild from the current weights gives (a stale or half-written image would poison every later step silently)."""
+    from cc_amd import ops
+    dev = torch.device("cuda")
+    bc = syn.sample(2, 128, 192, seed=1)
+    batch = (bc[0].to(dev), [r.to(dev) for r in bc[1]], bc[2].to(dev), bc[3].to(dev))
+    nets = T.build_nets(dev, init=False)
+    for n in nets:
+        n.load_state_dict(syn.seeded_state_dict(n, 0))
+    tr = T.CCTrainer(nets, T.StepConfig(), use_graph=use_graph)
+    assert tr.pipeline == "per_network"
+    tr.step(batch)
+    tr.step(batch)
+    torch.cuda.synchronize()
+    ents = [e for e in ops.packs.entries.values() if e]
+    assert len(ents) > 300 and all(e["ok"] for e in ents)
+    left = [e["buf"].clone() for e in ents]
+    ops.packs.mark_stale()
+    ops.packs.prepack_all()
+    torch.cuda.synchronize()
+    bad = [i for i, (a, e) in enumerate(zip(left, ents)) if not torch.equal(a, e["buf"])]
+    ops.packs.end_step()
+    assert not bad, (len(bad), len(ents))
+
+
 def test_pipelined_step_sees_weights_changed_from_outside():
     """The per-network form keeps the weight images of the previous step's refresh; a torch in-place write to the parameters between
     two steps (load_state_dict, a manual edit) must be picked up -- under hipGraph replay too, where the captured step contains no
