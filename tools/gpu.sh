@@ -11,6 +11,7 @@
 #   prof / prof0      rocprofv3 --kernel-trace --stats of the bench + step_trace table of ONE replayed step (prof0: CC_NET_STREAMS=0)
 #   pmc               FETCH_SIZE / WRITE_SIZE passes -> gpurun_out/pmc_traffic.json (+ copy to profiles/)
 #   sq                SQ counter pass (tools/pmc_sq.py)
+#   mfma              MFMA utilisation of the conv kernels (tools/pmc_mfma.py; run prof0 first for the durations)
 #   layers            per-layer-shape table (tools/layer_rates.py)
 #   ab:VAR=VAL[,VAR=VAL...]   same-box A/B against the default (tools build of the library; default run first and last)
 #   py:SCRIPT[:ARGS]  python tools/SCRIPT ARGS  (probes: wino_bench.py, conv_bench.py, ...)
@@ -98,6 +99,12 @@ for STEP in "$@"; do
     ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d /tmp/pmc_sq -o run -- env CC_NET_STREAMS=0 python $R/bench.py --no-graph --steps 1 --warmup 1 $NOCPU ) > $O/pmc_sq_$TAG.log 2>&1; echo "pmc sq rc=$?"
     F=$(find /tmp/pmc_sq -name "*counter_collection.csv" | head -1)
     PMC_ROWS=${PMC_ROWS:-400} python tools/pmc_sq.py "$F" > $O/pmc_sq_$TAG.txt 2>&1; grep -E "^kernel|ssim|warp_|pose2flow" $O/pmc_sq_$TAG.txt | cut -c1-200 ;;
+  mfma)
+    # MFMA utilisation of the conv kernels (tools/pmc_mfma.py); needs the serial profile's kernel stats for the TFLOP/s column
+    rm -rf /tmp/pmc_mfma
+    ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_F32 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_mfma -o run -- env CC_NET_STREAMS=0 python $R/bench.py --no-graph --steps 1 --warmup 1 $NOCPU ) > $O/pmc_mfma_$TAG.log 2>&1; echo "pmc mfma rc=$?"
+    F=$(find /tmp/pmc_mfma -name "*counter_collection.csv" | head -1)
+    python tools/pmc_mfma.py "$F" $O/rocprof_kernel_stats_${TAG}_serial.csv > $O/pmc_mfma_$TAG.txt 2>&1; head -26 $O/pmc_mfma_$TAG.txt | cut -c1-120 ;;
   layers)
     # (the table comes from bench.py's isolated pass: side streams off)
     ( CC_TIMING_DETAIL=1 CC_TIMING_DUMP=$O/layers_$TAG.tsv timeout 400 python bench.py --steps 5 --warmup 3 --no-cpu-baseline ) > $O/bench_${TAG}_layers.log 2> $O/bench_${TAG}_layers.err
