@@ -66,8 +66,10 @@ def parse():
                     help="per_network: every network's gradient all-reduce -> Adam segment -> weight images at the end of ITS "
                          "backward pass, on its own stream inside the one hipGraph; post: round 5 (one graph, two process-group "
                          "all-reduces behind it); staged: rounds 3-4 (two graphs, the first all-reduce between them); auto (default): "
-                         "per_network -- and at N > 1, where no form has ever been measured on more than one GPU, a few untimed steps of "
-                         "per_network and of post first, the faster one runs the timed region (recorded in comm.form_selection)")
+                         "per_network -- and at N > 1, where no form has ever been measured on more than one GPU: the region is timed in "
+                         "the post form first, then per_network runs a few untimed steps under a watchdog (CC_FORM_WATCHDOG_S, 240 s) and, "
+                         "if faster, the region again; recorded in comm.form_selection.  If those steps never come back the watchdog "
+                         "prints the post form's line and ends the run")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU steps after one warm-up (median is reported)")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="0 = min(usable threads (affinity / cgroup quota), 64): with all 256 hardware threads of the GPU box the "
@@ -496,7 +498,12 @@ def main():
         comm_debug["probe"] = os.environ["CC_COMM_PROBE"]
     ab_env.assert_applied()
     pipe = ab_switches.get("pipeline", args.pipeline)
-    tr = T.CCTrainer(nets, cfg, use_graph=not args.no_graph, pipeline="per_network" if pipe == "auto" else pipe, comm_debug=comm_debug)
+    # auto at N > 1: the step starts in round 5's "post" form (process-group all-reduce behind the graph: the conventional path), is
+    # timed in it, and only then tries the per-network form under a watchdog (select_form below) -- a captured-RCCL form that has never
+    # run on more than one GPU must not be able to cost the run its number
+    select = pipe == "auto" and use_dist and (world > 1 or os.environ.get("CC_FORCE_FORM_SELECTION") == "1") and not args.no_graph
+    tr = T.CCTrainer(nets, cfg, use_graph=not args.no_graph, comm_debug=comm_debug,
+                     pipeline=("post" if select else "per_network") if pipe == "auto" else pipe)
 
     def sync():
         torch.cuda.synchronize()
@@ -518,47 +525,105 @@ def main():
                 first_params = tr.opt.gather(tr.opt.flat_p).detach().cpu().clone()       # (chain order, without the bucket's padding)
                 first_grads = tr.opt.gather(tr.opt.flat_g).detach().cpu().clone()
             log("warm-up step %d done at %.1f s" % (i, time.perf_counter() - t_w))
-    form_selection = None
-    if pipe == "auto" and use_dist and (world > 1 or os.environ.get("CC_FORCE_FORM_SELECTION") == "1") and not args.no_graph \
-            and tr.pipeline == "per_network":
-        # No step form has been measured on more than one GPU (rounds 1-6: one GPU per gpurun call).  The per-network form has its
-        # collectives INSIDE the replayed graph; whether RCCL's captured all-reduces cost the graph anything on this machine is unknown
-        # (a mid-graph cross-stream edge costs 1-2.5 ms on one GPU, profiles/r06_ab_round6.txt), so both forms run a few untimed steps
-        # and the faster one -- max over ranks -- runs the timed region.
-        def _probe(n=6):
+    def timed_region():
+        """EXACTLY args.steps steps between barrier + synchronize; per-step device time stamps: an event after every step on the
+        compute stream (no host synchronisation inside the region).  -> (wall seconds of this rank, sorted per-step ms, last losses)"""
+        sync()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        t0_ = time.perf_counter()
+        marks[0].record()
+        for i in range(args.steps):
+            ls_ = tr.step(batch)
+            marks[i + 1].record()
+        sync()
+        dt_ = time.perf_counter() - t0_
+        return dt_, sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)), ls_
+
+    def max_over_ranks(x):
+        if not use_dist:
+            return float(x)
+        t_ = torch.tensor([x], device=dev, dtype=torch.float64)
+        dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+        return float(t_.item())
+
+    def contract_line(dt_max, loss_, pipeline, extra_comm):
+        """the driver's keys alone (the emergency line of the watchdog below; the full line is assembled at the end of main)"""
+        return {"metric": "train images/sec (%dx%d, 5-frame sample, 6-scale CC step)" % (W, H),
+                "value": round(B * world * args.steps / dt_max, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "full CC: DispResNet6+PoseNetB6+MaskNet6+Back2Future, all losses" if args.config == "c3"
+                           else "DispResNet6+PoseNetB6, photometric+smoothness", "per_gpu_batch": B, "global_batch": B * world,
+                           "height": H, "width": W, "scales": 6, "frames": 5, "parallelism": "dp%d" % world, "hipgraph": True,
+                           "loss": round(float(loss_), 6), "pipeline": pipeline},
+                "comm": extra_comm, "roofline": None}
+
+    form_selection, first_region = None, None
+    if select and tr.pipeline == "post":
+        # No step form has been measured on more than one GPU (rounds 1-6: one GPU per gpurun call).  The "post" form is timed FIRST,
+        # over the full region; then the per-network form (collectives INSIDE the replayed graph, cc_amd/rccl.py) runs a few untimed
+        # steps under a watchdog, and if it is the faster one -- max over ranks -- the region is timed again in it.  Should those steps
+        # not come back (captured collectives of three communicators on three graph branches: nothing says they cannot wedge on a
+        # machine this code has never seen), every rank's watchdog ends its process after rank 0 has printed the line of the "post"
+        # region -- the run keeps its number and says what happened.
+        import threading
+        dt_post, steps_post, losses_post = timed_region()
+        dt_post_max = max_over_ranks(dt_post)
+        ms_post = 1e3 * dt_post_max / args.steps
+        limit = float(os.environ.get("CC_FORM_WATCHDOG_S", "240"))
+        disarm = threading.Event()
+
+        def _watch():
+            if disarm.wait(limit):
+                return
+            if rank == 0:
+                sel = {"post_ms": round(ms_post, 3), "chosen": "post",
+                       "per_network": "its first steps did not finish within %.0f s: watchdog ended the run on the post form's line" % limit}
+                log("form selection: the per-network form did not come back within %.0f s -- printing the post form's line" % limit)
+                print(json.dumps(contract_line(dt_post_max, losses_post["loss"], "post", {"form_selection": sel})), flush=True)
+            else:
+                time.sleep(2.0)
+            os._exit(0)
+        threading.Thread(target=_watch, daemon=True).start()
+        ms_pn, why = None, None
+        try:
+            tr.switch_pipeline("per_network")
             for _ in range(3):
                 tr.step(batch)
             sync()
-            ta = time.perf_counter()
-            for _ in range(n):
-                tr.step(batch)
-            sync()
-            t_ = torch.tensor([(time.perf_counter() - ta) / n * 1e3], device=dev, dtype=torch.float64)
-            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
-            return float(t_.item())
-        ms_pn = _probe()
-        tr.switch_pipeline("post")
-        ms_post = _probe()
-        chosen = "per_network" if ms_pn <= ms_post else "post"
+            if tr.pipeline == "per_network":          # (the trainer falls back to "post" by itself when the capture is refused)
+                ta = time.perf_counter()
+                for _ in range(6):
+                    tr.step(batch)
+                sync()
+                ms_pn = max_over_ranks((time.perf_counter() - ta) / 6 * 1e3)
+            else:
+                why = "capture or communicator set-up refused (see stderr)"
+        except Exception as e:      # noqa: BLE001 -- an RCCL error code: stay on the form that works
+            why = repr(e)
+        # every rank must take the same branch: a rank that failed alone would leave the others in a collective
+        fl = torch.tensor([0.0 if ms_pn is not None else 1.0], device=dev, dtype=torch.float64)
+        dist.all_reduce(fl, op=dist.ReduceOp.MAX)
+        if float(fl.item()) > 0:
+            ms_pn = None
+        chosen = "per_network" if (ms_pn is not None and ms_pn <= ms_post) else "post"
         if chosen != tr.pipeline:
             tr.switch_pipeline(chosen)
-            for _ in range(3):
-                tr.step(batch)
-        form_selection = {"per_network_ms": round(ms_pn, 3), "post_ms": round(ms_post, 3), "chosen": chosen,
-                          "how": "6 replayed steps each after 3 untimed ones, max over ranks, before the timed region"}
-        log("form selection: per_network %.2f ms, post %.2f ms -> %s" % (ms_pn, ms_post, chosen))
+        for _ in range(3):
+            tr.step(batch)
+        sync()
+        form_selection = {"post_ms": round(ms_post, 3), "per_network_ms": round(ms_pn, 3) if ms_pn is not None else None,
+                          "chosen": chosen, "per_network_failed": why,
+                          "how": "post: the full timed region; per_network: 6 replayed steps after 3 untimed ones under a %.0f s watchdog, "
+                                 "max over ranks; the chosen form runs the reported region" % limit}
+        log("form selection: post %.2f ms, per_network %s -> %s" % (ms_post, ("%.2f ms" % ms_pn) if ms_pn is not None else "failed", chosen))
+        if chosen == "post":
+            disarm.set()
+            first_region = (dt_post, steps_post, losses_post)
     comm_cal = tr.calibrate_comm() if use_dist else None            # each segment's all-reduce alone (outside the timed region)
-    sync()
-    # per-step device time stamps: an event after every step on the compute stream (no host synchronisation inside the region)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        losses = tr.step(batch)
-        marks[i + 1].record()
-    sync()
-    dt = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    dt, per_step, losses = first_region if first_region is not None else timed_region()
+    if select and form_selection is not None and form_selection["chosen"] == "per_network":
+        disarm.set()
 
     def pct(q):
         return round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 3)

@@ -256,6 +256,7 @@ class FlatAdam:
         # the gradient exchange -- the ranks diverge.  Off unless a tools script sets it on the instance AND says so loudly.
         self.comm_probe = ""
         self._rccl = None
+        self.n_comms = 1            # RCCL communicators of the captured form: one per issuing stream (rccl())
 
     def zero_grad(self):
         engine().call("cc_fill", self.flat_g, self.flat_g.numel(), 0.0, STREAM)
@@ -302,11 +303,14 @@ class FlatAdam:
     def rccl(self):
         """the trainer's own RCCL communicators (cc_amd/rccl.py), created on first use OUTSIDE any stream capture: collectives that
         are enqueued on the caller's stream; HIP devices with an RCCL process group only, None otherwise (gloo: all_reduce()).
-        TWO of them: one communicator executes its collectives in issue order, and DispResNet6's chunks (issued while its backward
-        pass runs) must not queue behind -- or hold up -- the other networks' segments."""
+        ONE PER ISSUING STREAM (`n_comms`, set by CCTrainer: the step's own stream + its side streams): a communicator executes its
+        collectives in issue order and RCCL orders launches of one communicator that come from different streams with edges of its
+        own -- inside a capture those would be cross-stream edges in the middle of the graph (tools/capture_join_probe.py: 1-2.5 ms,
+        and a side stream must never wait for a stream that waited for it).  A communicator that only ever sees one stream adds
+        nothing to the graph but its kernel.  Every rank creates them in the same order."""
         if self._rccl is None and self.flat_g.is_cuda and self.comm_active() and dist.get_backend() == "nccl":
             from . import rccl
-            self._rccl = (rccl.Communicator(self.flat_g.device), rccl.Communicator(self.flat_g.device))
+            self._rccl = tuple(rccl.Communicator(self.flat_g.device) for _ in range(max(1, int(self.n_comms))))
         return self._rccl
 
     def all_reduce_here(self, lo, hi, comm=0):
@@ -462,6 +466,7 @@ class CCTrainer:
         self.static_batch = None
         self.losses = None
         self.nan_flags = []
+        self.opt.n_comms = 1 + (len(self.net_streams) if self.net_streams else 0)
         if self.pipeline == "per_network" and self.opt.comm_active():
             try:
                 self.opt.rccl()          # the communicators must exist before any capture
@@ -642,12 +647,23 @@ class CCTrainer:
         if stream is not None:
             stream.wait_stream(torch.cuda.current_stream())
         with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
-            self.opt.all_reduce_here(lo, hi, comm=1 if i == 0 else 0)
+            self.opt.all_reduce_here(lo, hi, comm=self._comm_index(stream))
             self.opt.step_segment(lo, hi, False, self.opt.grad_scale())
             for _ in range(config.debug.pipe_extra.get(NET_NAMES[i], 0)):        # (measurement: how much slack does this stream have?)
                 engine().call("cc_fill", self._scratch(), self._scratch().numel(), 0.0, STREAM)
             base = self.opt.flat_p.data_ptr()
             ops.packs.repack_range(base + 4 * lo, base + 4 * hi)
+
+    def _comm_index(self, stream=None):
+        """the communicator of the stream a collective is issued on (`stream`, else the current one): 0 = the step's own stream,
+        1 + k = side stream k -- the same on every rank, and never two streams on one communicator (FlatAdam.rccl)"""
+        if not self.net_streams:
+            return 0
+        h = (stream if stream is not None else torch.cuda.current_stream()).cuda_stream
+        for k, st in enumerate(self.net_streams):
+            if st.cuda_stream == h:
+                return 1 + k
+        return 0
 
     def _scratch(self):
         if getattr(self, "_scr", None) is None:
@@ -848,7 +864,7 @@ class CCTrainer:
                              "exchanges its segment at the end of its backward pass: the one exchange no other network's backward covers "
                              "(config.grad_chunks would start it earlier; off: it costs the one-GPU graph +1.5 ms)")),
                  "issue_order": order, "segments_mb": [round(4e-6 * (hi - lo), 1) for _, lo, hi in self.segment_calls],
-                 "collective": "ncclAllReduce on the issuing stream (cc_amd/rccl.py), two communicators" if self.opt._rccl is not None
+                 "collective": "ncclAllReduce on the issuing stream (cc_amd/rccl.py), one communicator per issuing stream (%d)" % len(self.opt._rccl) if self.opt._rccl is not None
                  else "torch.distributed.all_reduce (blocking)"}
             if self.comm_standalone_ms and len(self.comm_standalone_ms) == len(order):
                 r["standalone_ms"] = [round(v, 3) for v in self.comm_standalone_ms]
