@@ -858,7 +858,7 @@ class CCTrainer:
             r = {"design": ("per-network gradient pipelines inside ONE graph: at the end of a network's backward pass its own stream "
                             "issues ncclAllReduce on its segment of the flat bucket (a node of that graph branch), then its Adam segment, "
                             "then its weight images; issue order = order the backward passes are enqueued (shortest first); DispResNet6 "
-                            "(the last finisher, on a communicator of its own) " +
+                            "(the last finisher; every issuing stream has a communicator of its own) " +
                             ("hands its segment over in chunks (decoder, conv5-7, rest) while its backward pass still runs, their tails "
                              "on the step's origin stream" if self._chunk_lo else
                              "exchanges its segment at the end of its backward pass: the one exchange no other network's backward covers "
