@@ -33,6 +33,13 @@ net_streams = True
 # ms; on a fourth stream 19.15; profiles/r06_ab_round6.txt) -- a data-parallel run should measure both.
 grad_chunks = False
 
+# Pure bias-gradient sums (layers without an activation behind the bias) parked until the end of a backward stage and done by ONE
+# table launch (cc_bias_grad_table), instead of one partial-sum pass per layer right where the gradient appears (whose second stage
+# joins the stage's reduce table either way).  Built in round 3 for the single-stream step; with the networks on streams of their own
+# the table launches sit in the streams' tails, where nothing overlaps them: same-box A/B 16.30 / 16.33 / 16.26 ms without against
+# 16.42 / 16.40 / 16.35 / 16.38 with (profiles/r06_ab_round6.txt).  OFF.
+bias_table = False
+
 
 class _Debug:
     """A/B and diagnosis switches of the host glue.  The product reads nothing from the process environment: these are plain attributes that
@@ -41,7 +48,6 @@ class _Debug:
     no_slice_gy = False          # copy a concat gradient's channel slice instead of reading it in place
     no_wgrad_defer = False       # reduce every weight gradient right behind its kernel instead of once per backward stage
     no_sum_n = False             # pairwise adds for multi-consumer gradients instead of one n-ary sum
-    no_bias_table = False        # one bias-gradient pass per layer instead of the per-stage table launch
     no_wgrad_list = False        # the stage's last parked weight-gradient groups one by one
     no_wgrad_queue = False       # no parking of same-shaped weight gradients at all
     force_comm = False           # issue the gradient collectives on a one-rank process group too (tests, tools)

@@ -135,6 +135,21 @@ __device__ __forceinline__ void cc_buf_glds16(cc_buf_t rsrc, unsigned voff, unsi
 // s_waitcnt vmcnt(0) with expcnt/lgkmcnt left at their maxima (gfx9 encoding)
 #define CC_WAIT_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)
 
+// XCD-aware work order.  The workgroups of a launch are dealt round-robin to the 8 XCDs of the chip (private 4 MB L2 each): workgroups
+// b, b + 8, b + 16, ... share an L2.  cc_xcd_order(b, n) gives workgroup b of n the work item (b & 7) * (n / 8) + (b >> 3), so every XCD
+// works through ONE CONTIGUOUS run of items: neighbouring tiles (shared halo rows), the channel blocks of one tile (same input patch)
+// or the blocks of one reduction range (same operand slices) meet in one L2 instead of being fetched from HBM by up to eight.  A
+// bijection of [0, n) (the n % 8 items past the last whole group of 8 keep their index); results do not depend on it.
+// CC_XCD_MASK (A/B builds): bit 0 direct conv kernels, bit 1 Winograd weight gradient, bit 2 generic weight gradient, bit 3 the
+// job-table warp / smoothness kernels (the SSIM tiles and the Winograd forward kernel have orders of their own).
+#ifndef CC_XCD_MASK
+#define CC_XCD_MASK 15
+#endif
+__device__ __forceinline__ int cc_xcd_order(int b, int n) {
+    const int cnt = n >> 3;
+    return b < (cnt << 3) ? (b & 7) * cnt + (b >> 3) : b;
+}
+
 namespace cc {
 
 constexpr int kWave = 64;

@@ -746,11 +746,13 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
 #endif
 template <int BM, int CK, int TPS, int SPLIT>
 __global__ __launch_bounds__(256, CC_PATCH_LB) void k_conv_patch(CP g) {
-    conv_patch_body<BM, CK, TPS, SPLIT, 0>(g, (int)blockIdx.x);
+    // tiles in XCD order (cc_common.h): an XCD's L2 sees a contiguous run of tiles -- and, whenever gridDim.x is a multiple of 8,
+    // all channel blocks (blockIdx.y) and splits of a tile
+    conv_patch_body<BM, CK, TPS, SPLIT, 0>(g, (CC_XCD_MASK & 1) ? cc_xcd_order((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x);
 }
 template <int BM, int TPS, int SPLIT>          // stacked tiny maps (8-channel chunks only)
 __global__ __launch_bounds__(256, CC_PATCH_LB) void k_conv_patch_stk(CP g) {
-    conv_patch_body<BM, 8, TPS, SPLIT, 1>(g, (int)blockIdx.x);
+    conv_patch_body<BM, 8, TPS, SPLIT, 1>(g, (CC_XCD_MASK & 1) ? cc_xcd_order((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x);
 }
 
 // The (up to) four output-parity classes of a stride-2 data-gradient / transposed convolution in ONE launch:
@@ -778,12 +780,14 @@ struct CPM {
 // the class descriptor is read straight from the kernel-argument segment (scalar loads at a run-time offset): indexing the
 // by-value argument `a.c[k]` makes the compiler copy descriptors to scratch memory once the body is large
 #define CC_MULTI_BODY(BM_, CK_, TPS_, STK_)                                                                                   \
-    int k = 0, first = 0;                                                                                                     \
+    int k = 0, first = 0, end = a.bx_end[0];                                                                                  \
     _Pragma("unroll") for (int q = 0; q < MAXCLS - 1; q++)                                                                    \
-        if (q + 1 < a.n && (int)blockIdx.x >= a.bx_end[q]) { k = q + 1; first = a.bx_end[q]; }                                \
+        if (q + 1 < a.n && (int)blockIdx.x >= a.bx_end[q]) { k = q + 1; first = a.bx_end[q]; end = a.bx_end[q + 1]; }         \
     const CP& g = CC_MULTI_DESC(a, k);                                                                                        \
     if ((int)blockIdx.z >= g.nsplit || (int)blockIdx.y * BM_ >= g.Mpad) return;     /* grid.y / grid.z are the launch's maxima */ \
-    conv_patch_body<BM_, CK_, TPS_, 2, STK_>(g, (int)blockIdx.x - first);
+    /* the class's tiles in XCD order (cc_common.h) */                                                                        \
+    conv_patch_body<BM_, CK_, TPS_, 2, STK_>(g, (CC_XCD_MASK & 1) ? cc_xcd_order((int)blockIdx.x - first, end - first)        \
+                                                                  : (int)blockIdx.x - first);
 
 template <int BM, int CK, int TPS>
 __global__ __launch_bounds__(256, CC_PATCH_LB) void k_conv_patch_multi(CPM a) { CC_MULTI_BODY(BM, CK, TPS, 0) }
@@ -1248,7 +1252,18 @@ __device__ __forceinline__ void wgrad_body(const WG& g, const int bx_, const int
 }
 
 template <int BM>
-__global__ __launch_bounds__(256) void k_wgrad(WG g) { wgrad_body<BM>(g, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z); }
+__global__ __launch_bounds__(256) void k_wgrad(WG g) {
+    if constexpr (CC_XCD_MASK & 4) {
+        // XCD order (cc_common.h) over the flattened grid, x fastest: the tiles of one (problem, pixel range) -- which gather the same
+        // slices of dY and x -- run on one XCD
+        const int gx = (int)gridDim.x, gy = (int)gridDim.y;
+        const int b = cc_xcd_order((int)blockIdx.x + gx * ((int)blockIdx.y + gy * (int)blockIdx.z), gx * gy * (int)gridDim.z);
+        const int r = b / gx;
+        wgrad_body<BM>(g, b - r * gx, r % gy, r / gy);
+    } else {
+        wgrad_body<BM>(g, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+    }
+}
 
 // Problems of DIFFERENT shapes in one launch (the single-layer weight gradients a backward stage leaves parked until its end -- the
 // stride-2 / 1x1 / small-map layers: 15-40 us launches of 30-600 workgroups each, mostly ramp-up and drain; cc_conv2d_wgrad_list).
@@ -1257,16 +1272,16 @@ constexpr int MAXWCLS = 12;
 struct WGM { WG c[MAXWCLS]; int n; int bx_end[MAXWCLS]; int gx[MAXWCLS], gy[MAXWCLS]; };
 template <int BM>
 __global__ __launch_bounds__(256) void k_wgrad_multi(WGM a) {
-    int k = 0, first = 0;
+    int k = 0, first = 0, end = a.bx_end[0];
 #pragma unroll
     for (int q = 0; q < MAXWCLS - 1; q++)
-        if (q + 1 < a.n && (int)blockIdx.x >= a.bx_end[q]) { k = q + 1; first = a.bx_end[q]; }
+        if (q + 1 < a.n && (int)blockIdx.x >= a.bx_end[q]) { k = q + 1; first = a.bx_end[q]; end = a.bx_end[q + 1]; }
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(CC_HIPEMU)
     const WG& g = *(reinterpret_cast<const WG*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WGM, c)) + k);
 #else
     const WG& g = a.c[k];
 #endif
-    const int b = (int)blockIdx.x - first;
+    const int b = (CC_XCD_MASK & 4) ? cc_xcd_order((int)blockIdx.x - first, end - first) : (int)blockIdx.x - first;      // (as k_wgrad)
     const int gx = a.gx[k], gy = a.gy[k];
     const int bx = b % gx, r = b / gx;
     wgrad_body<BM>(g, bx, r % gy, r / gy);

@@ -48,6 +48,16 @@ __device__ __forceinline__ int find(const JobTab& t, int bx, int& first) {
     return j;
 }
 
+// ... -> (job, index of the block INSIDE the job in XCD order, cc_common.h): a job's blocks are consecutive pieces of its images, so
+// every XCD works through a contiguous band of rows -- the rows a bilinear gather or a stencil shares with the piece above / below
+// are then fetched into ONE L2 (the warp kernels moved 1.3-1.7x their distinct bytes with the blocks dealt round-robin)
+__device__ __forceinline__ int find_xcd(const JobTab& t, int bx, int& local) {
+    int first;
+    const int j = find(t, bx, first);
+    local = (CC_XCD_MASK & 8) ? cc_xcd_order(bx - first, t.blk_end[j] - first) : bx - first;
+    return j;
+}
+
 template <class T>
 __device__ __forceinline__ T* ptr(const JobTab& t, int j, int k) { return reinterpret_cast<T*>(t.slot[j][k]); }
 

@@ -469,10 +469,9 @@ __global__ __launch_bounds__(256) void k_edge_weights_jobs(JobTab t) {
 template <int PPT>
 __global__ __launch_bounds__(256) void k_edge_smooth_jobs(JobTab t, int C, float gscale) {
     __shared__ float red[4];
-    int first__;
-    const int j = ccjobs::find(t, (int)blockIdx.x, first__);
+    int local__;
+    const int j = ccjobs::find_xcd(t, (int)blockIdx.x, local__);
     const int HW = t.H[j] * t.W[j], nb1 = (HW + 255) >> 8, nb__ = (nb1 + PPT - 1) / PPT;
-    const int local__ = (int)blockIdx.x - first__;
     const int bc = local__ / nb__, blk = local__ - bc * nb__;
     const int Cj = C ? C : (int)t.slot[j][4];
     const int planes = C ? t.B : t.B * Cj;

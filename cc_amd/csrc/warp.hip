@@ -453,11 +453,10 @@ __global__ __launch_bounds__(256) void k_rigid_noocc_fused(const float* __restri
 // per-workgroup costs, and the pixels of a work-item are independent load chains (measured on the smoothness kernel: 99 -> 57 us).
 constexpr int WPPT = 4;
 #define CC_WARP_JOB_BLOCK(t, j, b, blk, H, W, HW, nb1)                                      \
-    int first__;                                                                            \
-    const int j = ccjobs::find(t, (int)blockIdx.x, first__);                                \
+    int local__;                                                                            \
+    const int j = ccjobs::find_xcd(t, (int)blockIdx.x, local__);                            \
     const int H = t.H[j], W = t.W[j], HW = H * W, nb1 = (HW + 255) >> 8;                    \
     const int nb4__ = (nb1 + WPPT - 1) / WPPT;                                              \
-    const int local__ = (int)blockIdx.x - first__;                                          \
     const int b = local__ / nb4__, blk = local__ - b * nb4__;
 
 // rigid fwd slots: 0 img [B,C,H,W], 1 depth [B,H,W], 2 P [B,12], 3 Kinv [B,9], 4 out
@@ -555,10 +554,9 @@ __global__ __launch_bounds__(256) void k_flow_warp_fwd_jobs(JobTab t, int C) {
 template <bool AC, bool BORDER>
 __global__ __launch_bounds__(256) void k_flow_warp_bwd_jobs(JobTab t, int C) {
     // (one pixel per work-item: with WPPT = 4 this kernel was slower, 26.0 vs 23.4 us -- no block reduction to amortise)
-    int first;
-    const int j = ccjobs::find(t, (int)blockIdx.x, first);
+    int local;
+    const int j = ccjobs::find_xcd(t, (int)blockIdx.x, local);
     const int H = t.H[j], W = t.W[j], HW = H * W, nb = (HW + 255) >> 8;
-    const int local = (int)blockIdx.x - first;
     const int b = local / nb, p = (local - b * nb) * 256 + (int)threadIdx.x;
     if (p >= HW) return;
     const float* __restrict__ gout = ccjobs::ptr<const float>(t, j, 0);

@@ -304,23 +304,32 @@ __device__ __forceinline__ void wino_wgrad_body(const D& g, const float* __restr
 
 template <int ABL>
 __global__ __launch_bounds__(WGT, 2) void k_wino_wgrad(WW g) {
-    wino_wgrad_body<ABL>(g, g.ga[blockIdx.y], g.gx[blockIdx.y], g.gws[blockIdx.y], (int)blockIdx.x, (int)blockIdx.z);
+    if constexpr (CC_XCD_MASK & 2) {
+        // XCD order (cc_common.h) over the flattened grid, x fastest: the 64 x 64 blocks of one (problem, chunk range) -- they
+        // transform the same slices of dY and x -- run on one XCD
+        const int gx = (int)gridDim.x, gy = (int)gridDim.y;
+        const int b = cc_xcd_order((int)blockIdx.x + gx * ((int)blockIdx.y + gy * (int)blockIdx.z), gx * gy * (int)gridDim.z);
+        const int r = b / gx, y = r % gy;
+        wino_wgrad_body<ABL>(g, g.ga[y], g.gx[y], g.gws[y], b - r * gx, r / gy);
+    } else {
+        wino_wgrad_body<ABL>(g, g.ga[blockIdx.y], g.gx[blockIdx.y], g.gws[blockIdx.y], (int)blockIdx.x, (int)blockIdx.z);
+    }
 }
 
 // Problems of DIFFERENT shapes in one launch (what a backward stage leaves parked until its end: the single layers and incomplete
 // groups of the small pyramid levels, 8-250 workgroups each -- a launch of its own is mostly ramp-up and drain for them;
 // cc_conv2d_wgrad_list).  blockIdx.x ranges over the problems' grids back to back, longest chains first.
 __global__ __launch_bounds__(WGT, 2) void k_wino_wgrad_multi(WWM a) {
-    int k = 0, first = 0;
+    int k = 0, first = 0, end = a.blk_end[0];
 #pragma unroll 1
     for (int q = 0; q + 1 < a.n; q++)
-        if ((int)blockIdx.x >= a.blk_end[q]) { k = q + 1; first = a.blk_end[q]; }
+        if ((int)blockIdx.x >= a.blk_end[q]) { k = q + 1; first = a.blk_end[q]; end = a.blk_end[q + 1]; }
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(CC_HIPEMU)
     const WW1& g = *(reinterpret_cast<const WW1*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WWM, p)) + k);
 #else
     const WW1& g = a.p[k];
 #endif
-    const int b = (int)blockIdx.x - first;
+    const int b = (CC_XCD_MASK & 2) ? cc_xcd_order((int)blockIdx.x - first, end - first) : (int)blockIdx.x - first;      // (as k_wino_wgrad)
     const int bz = b / g.nxy;
     wino_wgrad_body<0>(g, g.a, g.x, g.ws, b - bz * g.nxy, bz);
 }

@@ -323,7 +323,7 @@ class Tape:
                 return out
             gbs = [t for t, _ in tgt]
         geffs = [_new((B, C, H, W), ref) for _ in range(G)] if act != 0 else [None] * G
-        if act == 0 and acc and ops.wgrad_queue.enabled and not ops._dbg.no_wgrad_defer and not ops._dbg.no_bias_table:
+        if act == 0 and acc and config.bias_table and ops.wgrad_queue.enabled and not ops._dbg.no_wgrad_defer:
             # pure bias sums inside a trainer stage: parked, all layers of the stage in one launch (cc_bias_grad_table)
             for g, gb in zip(gs, gbs):
                 ops.wgrad_reduces.park_bias(g, gb, B, C, H, W, _bs(g))

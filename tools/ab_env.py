@@ -9,7 +9,7 @@ import os
 
 _FLAGS = {
     "CC_NO_SLICE_GY": "no_slice_gy", "CC_NO_WGRAD_DEFER": "no_wgrad_defer", "CC_NO_SUM_N": "no_sum_n",
-    "CC_NO_BIAS_TABLE": "no_bias_table", "CC_NO_WGRAD_LIST": "no_wgrad_list", "CC_NO_WGRAD_QUEUE": "no_wgrad_queue",
+    "CC_NO_WGRAD_LIST": "no_wgrad_list", "CC_NO_WGRAD_QUEUE": "no_wgrad_queue",
     "CC_FORCE_COMM": "force_comm",
 }
 
@@ -29,6 +29,8 @@ def apply(env=None):
         config.debug.net_stream_priority = got["net_stream_priority"] = tuple(int(v) for v in env["CC_NET_STREAM_PRIORITY"].replace(":", ",").split(","))
     if env.get("CC_GRAD_CHUNKS") is not None:          # product switch cc_amd.config.grad_chunks
         config.grad_chunks = got["grad_chunks"] = bool(int(env["CC_GRAD_CHUNKS"]))
+    if env.get("CC_BIAS_TABLE") is not None:           # product switch cc_amd.config.bias_table
+        config.bias_table = got["bias_table"] = bool(int(env["CC_BIAS_TABLE"]))
     if env.get("CC_CHUNK_INLINE", "0") == "1":
         config.debug.chunk_inline = got["chunk_inline"] = True
     if env.get("CC_PIPE_EXTRA"):                       # e.g. "flow:10"
