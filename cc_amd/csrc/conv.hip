@@ -271,6 +271,8 @@ struct CP {
     int res_mul;
     const float* add; long add_bs;
     int vec4;              // fused epilogue may use 16-byte accesses: unit lattice stride, rows 16-byte aligned in y / res / add
+    int wmajor;            // XCD order of the launch (conv_xcd_blocks): 0 = an XCD's run of work shares INPUT tiles, 1 = it shares WEIGHT
+                           // blocks (layers whose weights are the larger operand: the 8x26 ... 2x7 maps of the 256-1024 channel layers)
 };
 
 // wp[(t*Cpad + c)*Mpad + m] = w[w0 + m*w_sm + c*w_sc + i*w_ri + j*w_sj]  (0 beyond Cin / M), t = i*St + j
@@ -391,7 +393,7 @@ __device__ __forceinline__ float abl_fix(float v) { return v; }
 // STK: the tile stacks the rows of CP::ipt images (maps of <= 4 lattice rows); a separate instantiation -- the row mapping costs
 // scalar registers the common kernels do not have (they sit at the SGPR limit: +10 spills and -6 % measured with it compiled in)
 template <int BM, int CK, int TPS, int SPLIT, int STK>
-__device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
+__device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in, const int by_in, const int bz_in) {
     constexpr int WM = (BM >= 64) ? BM / 2 : 32;
     constexpr int TM = WM / 32;
     constexpr int TN = (BM >= 64) ? 2 : 1;           // lattice rows of the tile per wave
@@ -416,10 +418,10 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
     const int lr = g.tw16 ? (l31 >> 4) : 0, lc = g.tw16 ? (l31 & 15) : l31;     // this lane's row / column inside the group
     const int ty0 = tile_y * (g.tw16 ? 8 : TH), tx0 = tile_x * (g.tw16 ? 16 : TW);
     const int gy0 = g.si * ty0 + g.ymin, gx0 = g.si * tx0 + g.xmin;
-    const int m0 = blockIdx.y * BM;
+    const int m0 = by_in * BM;
     const int T = g.Rt * g.St;
     const int nchunk = g.Cpad / CK;
-    const int c_beg = blockIdx.z * g.cps;
+    const int c_beg = bz_in * g.cps;
     int c_end = c_beg + g.cps;
     if (c_end > nchunk) c_end = nchunk;
     const int x_cs = g.IH * g.IW;
@@ -622,7 +624,7 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
                 if (m >= g.M) continue;
                 if (SPLIT == 1 || (SPLIT == 2 && g.nsplit > 1)) {
                     const int Wp16 = g.tiles_x * (g.tw16 ? 16 : TW), Hp16 = g.tiles_y * (g.tw16 ? 8 : TH);      // padded slab rows
-                    g.part[(long)blockIdx.z * g.part_stride + (((long)n * g.M + m) * Hp16 + ty) * Wp16 + tx] = abl_fix(acc16[h][r]);
+                    g.part[(long)bz_in * g.part_stride + (((long)n * g.M + m) * Hp16 + ty) * Wp16 + tx] = abl_fix(acc16[h][r]);
                 } else {
                     float v = abl_fix(acc16[h][r]);
                     if (g.bias) v += g.bias[m];
@@ -666,7 +668,7 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
             // the slab is padded so that every store is aligned and in bounds, but the padding is never read: quads that start
             // outside the image are not written (the 2x7 / 4x13 layers would otherwise write 5-18x their partial sums)
             const bool live = rowok && ty < g.OHt && tx < g.OWt;
-            float* pb = g.part + (long)blockIdx.z * g.part_stride + (((long)(n + ej) * g.M + (m0 + wm * WM + a * 32 + rsub)) * Hp + ty) * Wp + tx;
+            float* pb = g.part + (long)bz_in * g.part_stride + (((long)(n + ej) * g.M + (m0 + wm * WM + a * 32 + rsub)) * Hp + ty) * Wp + tx;
             const long mstep = (long)8 * Hp * Wp;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -739,6 +741,27 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
     }
 }
 
+// Workgroup -> (tile, channel block, split) in XCD order (cc_common.h).  Input-major (wmajor 0): the tiles in XCD order, channel block
+// and split as dispatched -- an XCD's L2 sees a contiguous run of tiles (shared halos) and, whenever gridDim.x is a multiple of 8, all
+// channel blocks and splits of a tile (same input patch).  Weight-major (wmajor 1): the whole grid in XCD order, tiles fastest -- an
+// XCD works through ALL tiles of a contiguous range of (channel block, split) pairs, so a slice of the weight image is streamed from
+// HBM by one XCD instead of by all eight (512 -> 512 3x3 on 8x26: 9.4 MB of weights against 1.7 MB of input).
+__device__ __forceinline__ void conv_xcd_blocks(int wmajor, int& bx, int& by, int& bz) {
+    bx = (int)blockIdx.x; by = (int)blockIdx.y; bz = (int)blockIdx.z;
+    if constexpr (!(CC_XCD_MASK & 1)) return;
+    if (wmajor < 0) return;
+    if (wmajor) {
+        const int gx = (int)gridDim.x, gy = (int)gridDim.y;
+        const int w = cc_xcd_order(bx + gx * (by + gy * bz), gx * gy * (int)gridDim.z);
+        const int r = w / gx;
+        bx = w - r * gx;
+        bz = r / gy;
+        by = r - bz * gy;
+    } else {
+        bx = cc_xcd_order(bx, (int)gridDim.x);
+    }
+}
+
 // min 4 waves per SIMD (<= 128 registers): the accumulators then live in VGPRs (95-99 registers in total, no spill) instead of
 // 64 AGPRs + 72-85 VGPRs, and four 40 KB workgroups fit a CU (CC_PATCH_LB: A/B builds, tools/)
 #ifndef CC_PATCH_LB
@@ -746,13 +769,15 @@ __device__ __forceinline__ void conv_patch_body(const CP& g, const int bx_in) {
 #endif
 template <int BM, int CK, int TPS, int SPLIT>
 __global__ __launch_bounds__(256, CC_PATCH_LB) void k_conv_patch(CP g) {
-    // tiles in XCD order (cc_common.h): an XCD's L2 sees a contiguous run of tiles -- and, whenever gridDim.x is a multiple of 8,
-    // all channel blocks (blockIdx.y) and splits of a tile
-    conv_patch_body<BM, CK, TPS, SPLIT, 0>(g, (CC_XCD_MASK & 1) ? cc_xcd_order((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x);
+    int bx, by, bz;
+    conv_xcd_blocks(g.wmajor, bx, by, bz);
+    conv_patch_body<BM, CK, TPS, SPLIT, 0>(g, bx, by, bz);
 }
 template <int BM, int TPS, int SPLIT>          // stacked tiny maps (8-channel chunks only)
 __global__ __launch_bounds__(256, CC_PATCH_LB) void k_conv_patch_stk(CP g) {
-    conv_patch_body<BM, 8, TPS, SPLIT, 1>(g, (CC_XCD_MASK & 1) ? cc_xcd_order((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x);
+    int bx, by, bz;
+    conv_xcd_blocks(g.wmajor, bx, by, bz);
+    conv_patch_body<BM, 8, TPS, SPLIT, 1>(g, bx, by, bz);
 }
 
 // The (up to) four output-parity classes of a stride-2 data-gradient / transposed convolution in ONE launch:
@@ -768,6 +793,7 @@ struct CPM {
     CP c[MAXCLS];
     int n;
     int bx_end[MAXCLS];
+    int wmajor;            // as CP::wmajor, for the launch (the classes' weights against their inputs)
 };
 
 // (a macro, not a function taking the argument block by reference: the kernel reads its class descriptor from the kernel-argument
@@ -780,14 +806,16 @@ struct CPM {
 // the class descriptor is read straight from the kernel-argument segment (scalar loads at a run-time offset): indexing the
 // by-value argument `a.c[k]` makes the compiler copy descriptors to scratch memory once the body is large
 #define CC_MULTI_BODY(BM_, CK_, TPS_, STK_)                                                                                   \
+    int bx, by, bz;                                                                                                           \
+    conv_xcd_blocks(a.wmajor ? 1 : -1, bx, by, bz);      /* -1: as dispatched (the class's tiles are put in XCD order below) */  \
     int k = 0, first = 0, end = a.bx_end[0];                                                                                  \
     _Pragma("unroll") for (int q = 0; q < MAXCLS - 1; q++)                                                                    \
-        if (q + 1 < a.n && (int)blockIdx.x >= a.bx_end[q]) { k = q + 1; first = a.bx_end[q]; end = a.bx_end[q + 1]; }         \
+        if (q + 1 < a.n && bx >= a.bx_end[q]) { k = q + 1; first = a.bx_end[q]; end = a.bx_end[q + 1]; }                      \
     const CP& g = CC_MULTI_DESC(a, k);                                                                                        \
-    if ((int)blockIdx.z >= g.nsplit || (int)blockIdx.y * BM_ >= g.Mpad) return;     /* grid.y / grid.z are the launch's maxima */ \
-    /* the class's tiles in XCD order (cc_common.h) */                                                                        \
-    conv_patch_body<BM_, CK_, TPS_, 2, STK_>(g, (CC_XCD_MASK & 1) ? cc_xcd_order((int)blockIdx.x - first, end - first)        \
-                                                                  : (int)blockIdx.x - first);
+    if (bz >= g.nsplit || by * BM_ >= g.Mpad) return;     /* grid.y / grid.z are the launch's maxima */                        \
+    bx -= first;                                                                                                              \
+    if ((CC_XCD_MASK & 1) && !a.wmajor) bx = cc_xcd_order(bx, end - first);                                                   \
+    conv_patch_body<BM_, CK_, TPS_, 2, STK_>(g, bx, by, bz);
 
 template <int BM, int CK, int TPS>
 __global__ __launch_bounds__(256, CC_PATCH_LB) void k_conv_patch_multi(CPM a) { CC_MULTI_BODY(BM, CK, TPS, 0) }
@@ -1847,6 +1875,10 @@ inline CP make_cp(const GG& g, const ConvPlan& p, const float* zeros, const floa
     c.part_stride = (long)g.B * g.M * (p.tiles_y * (p.tw16 ? 8 : TH)) * (p.tiles_x * (p.tw16 ? 16 : TW));      // padded slabs
     c.act = g.act; c.act_a = g.act_a; c.act_b = g.act_b; c.res_mul = g.res_mul;
     c.add = g.add; c.add_bs = g.add_bs;
+#ifndef CC_CONV_WMAJOR
+#define CC_CONV_WMAJOR 1
+#endif
+    c.wmajor = (CC_CONV_WMAJOR && (long)g.M * g.Rt * g.St > (long)g.B * g.IH * g.IW) ? 1 : 0;      // weights M Cin T floats, input B Cin IH IW
     c.vec4 = (g.so == 1) && ((g.OW & 3) == 0) && ((g.ox0 & 3) == 0) && ((((uintptr_t)g.y) & 15) == 0) && ((g.y_bs & 3) == 0) &&
              (!g.res || ((((uintptr_t)g.res) & 15) == 0 && (g.res_bs & 3) == 0)) &&
              (!g.add || ((((uintptr_t)g.add) & 15) == 0 && (g.add_bs & 3) == 0));
@@ -2146,6 +2178,15 @@ inline bool launch_classes(const ClsIn* cs, int n, hipStream_t s, bool idle_taps
         gf += 2e-9 * g.B * g.OHt * g.OWt * (double)g.M * g.Cin * g.Rt * g.St;
     }
     a.n = nc;
+    {   // launch-wide XCD order: weight-major when the classes' weights outweigh their inputs
+        double wf = 0, xf = 0;
+        for (int k = 0; k < nc; k++) {
+            const CP& c = a.c[k];
+            wf += (double)c.M * c.Cin * c.Rt * c.St;
+            xf += (double)c.B * c.Cin * c.IH * c.IW;
+        }
+        a.wmajor = (CC_CONV_WMAJOR && wf > xf) ? 1 : 0;
+    }
     if (smem > 80 * 1024) return false;
     if (nc > 0) {
         dim3 grid((unsigned)bx, (unsigned)maxy, (unsigned)maxsplit);

@@ -52,6 +52,8 @@ struct WN {
     int act;
     float act_a, act_b;
     int res_mul, vec2;
+    int mb_major;      // work-item order inside a problem: 0 = tile block, then m block (an XCD's run shares INPUT tiles); 1 = m block, then
+                       // tile block (it shares WEIGHT blocks: the deep layers, whose weights are the larger operand) -- wino_launch
 };
 
 constexpr int VBLK = 16 * WCK * 64;       // floats of one V chunk (64 tiles)
@@ -92,7 +94,9 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_wino_f2x3(WN g) {
     if (w >= g.total) return;
     const int prob = w / g.per_prob;
     const int wr = w - prob * g.per_prob;
-    const int qb = wr / g.nmb, mb = wr - qb * g.nmb;
+    int qb, mb;
+    if (g.mb_major) { const int nqb = g.per_prob / g.nmb; mb = wr / nqb; qb = wr - mb * nqb; }
+    else { qb = wr / g.nmb; mb = wr - qb * g.nmb; }
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(CC_HIPEMU)
     // per-problem pointers straight from the kernel-argument segment (indexing the by-value struct copies it to scratch)
     const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -518,7 +522,9 @@ __global__ __launch_bounds__(256 * KS, 2) void k_wino_f2x3_s(WN g) {
     if (w >= g.total) return;
     const int prob = w / g.per_prob;
     const int wr = w - prob * g.per_prob;
-    const int qb = wr / g.nmb, mb = wr - qb * g.nmb;
+    int qb, mb;
+    if (g.mb_major) { const int nqb = g.per_prob / g.nmb; mb = wr / nqb; qb = wr - mb * nqb; }
+    else { qb = wr / g.nmb; mb = wr - qb * g.nmb; }
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(CC_HIPEMU)
     const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
     const ccint::WinoProb& P = *(reinterpret_cast<const ccint::WinoProb*>(ka + offsetof(WN, p)) + prob);
@@ -967,6 +973,14 @@ bool wino_launch(const WinoGeom& gg, const WinoPlan& p, const WinoProb* probs, i
     for (int k = 0; k < nprob; k++)
         v2 = v2 && ((((uintptr_t)probs[k].y) | (uintptr_t)probs[k].res | (uintptr_t)probs[k].add | (uintptr_t)probs[k].part) % 16 == 0);
     a.vec2 = v2 ? 1 : 0;
+    // XCD order (the kernels deal consecutive work items to one XCD): which operand should an XCD's run of items have in common?  The
+    // transformed weights of a problem are 16 M Cin floats, its input B Cin H W: on the 8x26 ... 2x7 maps of the 256-1024 channel layers
+    // the weights are 2-20x the input, and with tile-block-major order every XCD streamed ALL of them from HBM (M512 C512 8x26:
+    // 90 MB per launch for 17 MB of weights).
+#ifndef CC_WINO_MBMAJOR
+#define CC_WINO_MBMAJOR 1
+#endif
+    a.mb_major = (CC_WINO_MBMAJOR && 16l * gg.M > (long)gg.B * gg.H * gg.W) ? 1 : 0;
     if (cctools::env_flag("CC_WINO_TRACE"))
         fprintf(stderr, "wino: %dx[B%d M%d C%d %dx%d] tile %d nqb %d nmb %d nsplit %d cps %d act %d res_mul %d vec2 %d\n", nprob, gg.B, gg.M,
                 gg.Cin, gg.H, gg.W, p.tile, p.nqb, p.nmb, p.nsplit, p.cps, gg.act, gg.res_mul, a.vec2);
