@@ -40,6 +40,10 @@ grad_chunks = False
 # 16.42 / 16.40 / 16.35 / 16.38 with (profiles/r06_ab_round6.txt).  OFF.
 bias_table = False
 
+# The loss phase on two streams (cc_amd.trainer.cc_forward): consensus target + flow photometric loss on Back2Future's stream beside
+# the rigid photometric loss and the mask / smoothness terms on the step's own.  HIP devices with config.net_streams only.
+loss_stream = True
+
 
 class _Debug:
     """A/B and diagnosis switches of the host glue.  The product reads nothing from the process environment: these are plain attributes that

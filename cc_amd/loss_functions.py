@@ -279,6 +279,28 @@ class _HeadGrads:
 
 head_grads = _HeadGrads()
 
+# The stream the fused loss terms below issue their FORWARD launches on (None: the current one).  Set by cc_amd.trainer.cc_forward
+# around the calls it wants beside -- not behind -- the rigid photometric loss (warps, SSIM, adjoints: a fused term computes its
+# gradients in the forward call).  The switch sits INSIDE forward on purpose: the call returns on the caller's stream, so autograd binds
+# the node -- and with it the backward call, which adds into the step's shared gradient accumulators (_HeadGrads) in the engine's
+# execution order -- to the caller's stream; a `with torch.cuda.stream(..)` AROUND the call would move the backward call to the side
+# stream and race with the other terms' accumulations.  The caller forks the stream before and joins it after.
+forward_stream = None
+
+
+def _on_forward_stream(fwd):
+    def forward(ctx, *args):
+        st = forward_stream
+        if st is None:
+            return fwd(ctx, *args)
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(st):
+            out = fwd(ctx, *args)
+        if not torch.cuda.is_current_stream_capturing() and getattr(ctx, "arena", None) is not None:
+            ctx.arena.flat.record_stream(cur)        # (eager mode: the stash is read by backward on the caller's stream)
+        return out
+    return forward
+
 
 class _GradArena:
     """The gradients a fused loss stashes in forward live in ONE flat buffer (one view per differentiable input, same
@@ -837,10 +859,17 @@ def _photo_flow_jobs(ctx, cfg, tgt_img, refs, flows, masks, need, rest):
     return loss_acc.reshape(())
 
 
+# The stream _PhotoFlowFn.forward issues its launches on (None: the current one).  Set by cc_amd.trainer.cc_forward around ITS call of
+# photometric_flow_loss so that the flow loss (warps, SSIM, adjoints: all computed in the forward call) runs beside the rigid
+# photometric loss instead of behind it.  The switch sits INSIDE forward on purpose: the call returns on the caller's stream, so autograd
+# binds the node -- and with it the backward call, which adds into the step's shared gradient accumulators (_HeadGrads) in the
+# engine's execution order -- to the caller's stream; a `with torch.cuda.stream(..)` AROUND the call would move the backward call to the
+# side stream and race with the other terms' accumulations.  The caller forks the stream before and joins it after.
 class _PhotoFlowFn(torch.autograd.Function):
     """loss_functions.py:27-77 over all scales; flows = [flow list of ref 0, flow list of ref 1]."""
 
     @staticmethod
+    @_on_forward_stream
     def forward(ctx, cfg, tgt_img, *rest):
         R, S = cfg.n_refs, cfg.n_scales
         refs = rest[:R]
@@ -934,6 +963,7 @@ class _PerScaleFn(torch.autograd.Function):
     """Shared driver: sum over scales of a fused value+gradient kernel on one prediction list."""
 
     @staticmethod
+    @_on_forward_stream
     def forward(ctx, launch, *preds):
         need = ctx.needs_input_grad
         loss_acc = _zeros1(preds[0])
@@ -953,6 +983,7 @@ class _ScaleJobsFn(torch.autograd.Function):
     build(preds_detached, grad_views, partial_offsets_fn) -> issues the call; see the users below."""
 
     @staticmethod
+    @_on_forward_stream
     def forward(ctx, issue, *preds):
         need = ctx.needs_input_grad
         loss_acc = _zeros1(preds[0])

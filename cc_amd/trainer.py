@@ -158,22 +158,41 @@ def cc_forward(nets, batch, cfg, keep=False, cut=None, streams=None, after_fork=
     flow_fwd, flow_bwd, _ = flow_out
     flow_fwd, flow_bwd = _cut("mf", list(flow_fwd)), _cut("mf", list(flow_bwd))
     cam_fwd, cam_bwd = LF.rigid_flows_levels(depth, pose, (2, 1), K, Kinv)             # :470-471  pose2flow per scale
-    target = LF.consensus_exp_masks(cam_fwd, cam_bwd, flow_fwd, flow_bwd, tgt, refs[2], refs[1],
-                                    wssim=cfg.wssim, wrig=cfg.wrig, ws=cfg.w3)         # :473
-    rig_fwd = LF.abs_diff_levels(cam_fwd, flow_fwd)                                    # :475  (a - b).abs(), thresholded only
-    rig_bwd = LF.abs_diff_levels(cam_bwd, flow_bwd)                                    # :476
     flow_exp_mask = LF.complement_slice_levels(exp_mask, 1, 3)                         # :488  1 - m[:, 1:3]
+    # config.loss_stream: the loss phase is the one part of the step a single stream runs alone (every network's forward pass is done,
+    # no backward pass can start: 1.2 ms of latency-bound kernels, tools/branch_timeline.py).  Its two independent halves -- the
+    # consensus target + the flow photometric loss, and the rigid photometric loss + the mask / smoothness terms -- run side by side:
+    # Back2Future's stream (idle between the passes) is forked here and joined before the consensus loss, which needs the target.
+    # The order of the CALLS is unchanged, so the terms meet the shared gradient accumulators in the same order as on one stream.
+    side = s_flow if (config.loss_stream and s_flow is not None) else None
+    origin = torch.cuda.current_stream() if side is not None else None
+    if side is not None:
+        side.wait_stream(origin)
+    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):       # (no autograd node is created in here)
+        target = LF.consensus_exp_masks(cam_fwd, cam_bwd, flow_fwd, flow_bwd, tgt, refs[2], refs[1],
+                                        wssim=cfg.wssim, wrig=cfg.wrig, ws=cfg.w3)     # :473
+        rig_fwd = LF.abs_diff_levels(cam_fwd, flow_fwd)                                # :475  (a - b).abs(), thresholded only
+        rig_bwd = LF.abs_diff_levels(cam_bwd, flow_bwd)                                # :476
     l1 = LF.photometric_reconstruction_loss(tgt, refs, K, Kinv, depth, exp_mask, pose,
                                             lambda_oob=cfg.lambda_oob, qch=cfg.qch, wssim=cfg.wssim)   # :490
-    l2 = LF.explainability_loss(exp_mask) if cfg.w2 > 0 else 0                         # :492-495
-    if cfg.smoothness_type == "regular":                                               # :497-501
-        l3s = [LF.smooth_loss(depth), LF.smooth_loss(flow_fwd), LF.smooth_loss(flow_bwd), LF.smooth_loss(exp_mask)]
-    else:
-        l3s = [LF.edge_aware_smoothness_sum(tgt, [depth, flow_fwd, flow_bwd, exp_mask])]      # the four terms, one job table
+    LF.forward_stream = side         # (the forward launches of the terms below: on the side stream, behind the consensus target)
+    try:
+        l2 = LF.explainability_loss(exp_mask) if cfg.w2 > 0 else 0                     # :492-495
+        if cfg.smoothness_type == "regular":                                           # :497-501
+            l3s = [LF.smooth_loss(depth), LF.smooth_loss(flow_fwd), LF.smooth_loss(flow_bwd), LF.smooth_loss(exp_mask)]
+        else:
+            l3s = [LF.edge_aware_smoothness_sum(tgt, [depth, flow_fwd, flow_bwd, exp_mask])]  # the four terms, one job table
+        l4 = LF.photometric_flow_loss(tgt, refs[1:3], [flow_bwd, flow_fwd], flow_exp_mask,
+                                      lambda_oob=cfg.lambda_oob, qch=cfg.qch, wssim=cfg.wssim)         # :503
+    finally:
+        LF.forward_stream = None
+    if side is not None:
+        origin.wait_stream(side)
+        if not torch.cuda.is_current_stream_capturing():      # (eager mode: allocated on the side stream, read on this one)
+            for t in list(target) + list(rig_fwd) + list(rig_bwd) + [l4] + list(l3s) + ([l2] if torch.is_tensor(l2) else []):
+                t.record_stream(origin)
     with torch.no_grad():
         l3 = l3s[0].detach() if len(l3s) == 1 else torch.stack(l3s).sum()              # reported; the total below takes the terms
-    l4 = LF.photometric_flow_loss(tgt, refs[1:3], [flow_bwd, flow_fwd], flow_exp_mask,
-                                  lambda_oob=cfg.lambda_oob, qch=cfg.qch, wssim=cfg.wssim)             # :503
     l5 = LF.consensus_depth_flow_mask(exp_mask, rig_bwd, rig_fwd, target, target,
                                       THRESH=cfg.THRESH, wbce=cfg.wbce)                # :506
     terms = [(cfg.w1, l1)] + ([(cfg.w2, l2)] if cfg.w2 > 0 else []) + [(cfg.w3, t) for t in l3s] + [(cfg.w4, l4), (cfg.w5, l5)]

@@ -31,6 +31,8 @@ def apply(env=None):
         config.grad_chunks = got["grad_chunks"] = bool(int(env["CC_GRAD_CHUNKS"]))
     if env.get("CC_BIAS_TABLE") is not None:           # product switch cc_amd.config.bias_table
         config.bias_table = got["bias_table"] = bool(int(env["CC_BIAS_TABLE"]))
+    if env.get("CC_LOSS_STREAM") is not None:          # product switch cc_amd.config.loss_stream
+        config.loss_stream = got["loss_stream"] = bool(int(env["CC_LOSS_STREAM"]))
     if env.get("CC_CHUNK_INLINE", "0") == "1":
         config.debug.chunk_inline = got["chunk_inline"] = True
     if env.get("CC_PIPE_EXTRA"):                       # e.g. "flow:10"
