@@ -80,14 +80,21 @@ rows = []
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ms = []
+# Steady state: replays are launched back to back (as a training loop does -- the host submits step k + 1 while step k runs, so no
+# branch waits for its first packet); the stamps of the LAST replay of each burst are read.  "sync" as the second argument
+# synchronises after every replay instead (then each step starts on an empty queue: the branches start 0.9 / 1.5 ms apart).
+burst = 1 if (len(sys.argv) > 2 and sys.argv[2] == "sync") else 8
 for _ in range(n):
-    ev0.record()
-    tr.step(batch)
+    for k in range(burst):
+        if k == burst - 1:
+            ev0.record()
+        tr.step(batch)
     ev1.record()
     torch.cuda.synchronize()
     ms.append(ev0.elapsed_time(ev1))
     rows.append(buf.cpu().tolist())
-print("replayed step: median %.3f ms by HIP events (%d replays, %d stamp nodes in the graph)" % (statistics.median(ms), n, len(names)))
+print("replayed step: median %.3f ms by HIP events (%d bursts of %d replays, %d stamp nodes in the graph)"
+      % (statistics.median(ms), n, burst, len(names)))
 med = {i: statistics.median((r[i] - r[0]) / 100.0 for r in rows) for i in names}
 for i, t in sorted(med.items(), key=lambda kv: kv[1]):
     print("%10.1f us  %s" % (t, names[i]))
