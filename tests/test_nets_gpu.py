@@ -175,6 +175,33 @@ def test_step_forms_agree(deterministic, monkeypatch):
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
+def test_loss_phase_on_two_streams_changes_no_bit(use_graph, monkeypatch):
+    """config.loss_stream (round 6): the consensus target, the mask / smoothness terms and the flow photometric loss issue their forward
+    launches on Back2Future's stream beside the rigid photometric loss; the terms are CALLED in the same order and their backward
+    calls stay on the step's stream, so the shared gradient accumulators see the same sequence of '=' / '+=': with the scatter kernels
+    in their deterministic form every loss, gradient and updated parameter is bit-identical to the one-stream phase -- eagerly (the
+    caching allocator's cross-stream hand-overs) and as a captured graph."""
+    from cc_amd import config
+    monkeypatch.setattr(config, "deterministic", True)
+    dev = torch.device("cuda")
+    bc = syn.sample(2, 128, 192, seed=1)
+    batch = (bc[0].to(dev), [r.to(dev) for r in bc[1]], bc[2].to(dev), bc[3].to(dev))
+    res = []
+    for on in (False, True):
+        monkeypatch.setattr(config, "loss_stream", on)
+        nets = T.build_nets(dev, init=False)
+        for n in nets:
+            n.load_state_dict(syn.seeded_state_dict(n, 0))
+        tr = T.CCTrainer(nets, T.StepConfig(), use_graph=use_graph)
+        assert tr.net_streams, "the networks' side streams are the shipped configuration on HIP devices"
+        ls = [{k: float(v) for k, v in tr.step(batch).items()} for _ in range(3)]
+        res.append((ls, tr.opt.flat_g.clone(), tr.opt.flat_p.clone()))
+    (la, ga, pa), (lb, gb, pb) = res
+    assert la == lb
+    assert torch.equal(ga, gb) and torch.equal(pa, pb)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
 def test_weight_images_left_by_the_pipelined_step_equal_a_full_rebuild(use_graph):
     """Per-network form: every network's weight images are rebuilt right behind ITS Adam segment, on its own stream, and the next
     step starts from them without a start-of-step refresh.  After two steps every image must be byte-identical to what one full
