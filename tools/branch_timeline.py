@@ -70,6 +70,27 @@ def lg(bt):
 
 
 tr._loss_grads = lg
+# inside the loss phase (the only phase one stream runs alone): the rigid photometric loss (the step's stream; the side stream's chain
+# runs beside it), the join + consensus loss, the weighted total, then the backward pass of the loss terms
+from cc_amd import loss_functions as LF
+
+
+def _wrap(name, i, label_a, label_b):
+    f = getattr(LF, name)
+
+    def g(*a, **k):
+        if label_a:
+            stamp(i, label_a)
+        r = f(*a, **k)
+        stamp(i + 1, label_b)
+        return r
+    setattr(LF, name, g)
+
+
+_wrap("rigid_flows_levels", 32, "loss phase: rigid flows start", "  rigid flows issued")
+_wrap("photometric_reconstruction_loss", 34, "  rigid photometric loss starts", "  rigid photometric loss ends")
+_wrap("consensus_depth_flow_mask", 36, "  side stream joined, consensus loss starts", "  consensus loss ends")
+_wrap("weighted_total", 38, None, "  weighted total done (the terms' backward calls follow)")
 tr._sync_streams = lambda *a: (_sync(*a), stamp(31, "streams joined: step ends"))[0]
 
 for _ in range(4):
