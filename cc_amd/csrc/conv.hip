@@ -2946,7 +2946,7 @@ static int wgrad_group_impl(int G, const long* a, const long* x, const long* gw,
         // (recorded only when the thin path is taken: the name is empty otherwise; alignment can still turn a problem away, then
         // the record brackets nothing)
         cctiming::Scope tsc(nm[0] ? nm : "k_wgrad_thin<declined>", nm[0] ? 2e-9 * G * B * AH * AW * (double)M * Cin * R * S : 0.0,
-                            nm[0] ? s : nullptr, nm[0] != 0);
+                            nm[0] ? s : nullptr, nm[0] != 0 && !ccint::wgrad_thin_parking());
         for (int k = 0; k < G && thin; k++)
             thin = ccint::wgrad_thin_launch((const float*)a[k], (const float*)x[k], (float*)gw[k], ws + k * stride_f, B, M, AH, AW, a_bs,
                                             Cin, IH, IW, x_bs, R, S, si, pad, o_sm, o_sc, accumulate, s, sink);
@@ -3114,6 +3114,19 @@ int cc_conv2d_wgrad_list(int n, const long* desc_host, const float* zeros64_or_n
     wino_parked.n = 0;
     WgradCollector col = {parked, CAP, 0, cctools::env_flag("CC_NO_WINO_WGRAD_LIST") ? nullptr : &wino_parked};
     ccint::RedSink sink = {red_host, red_cap, 0};
+    // the thin weight gradients of the list share launches too (wgrad_thin.hip: per kernel instance); launched when this call ends
+    struct ThinPark {
+        hipStream_t s; bool was;
+        explicit ThinPark(hipStream_t st) : s(st), was(ccint::wgrad_thin_park(true)) {}
+        ~ThinPark() {
+            const double gf = ccint::wgrad_thin_parked_gflop();
+            if (gf > 0) {
+                cctiming::Scope tsc("k_wgrad_thin_multi", gf, s);
+                ccint::wgrad_thin_flush(s);
+            }
+            ccint::wgrad_thin_park(was);
+        }
+    } thin_park(s);
     for (int i = 0; i < n; i++) {
         const long* d = desc_host + 32l * i;
         const int G = (int)d[0];

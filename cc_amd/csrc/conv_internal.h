@@ -20,6 +20,14 @@ bool wgrad_thin_launch(const float* a, const float* x, float* gw, float* ws, int
                        int IH, int IW, long x_bs, int R, int S, int si, int pad, long o_sm, long o_sc, int accumulate, hipStream_t s,
                        RedSink* sink = nullptr);
 
+// Parking (cc_conv2d_wgrad_list): while on (per thread), wgrad_thin_launch stores its problem instead of launching it (the reduce
+// descriptor is emitted as usual) and wgrad_thin_flush launches what is stored -- problems of one kernel instance share launches
+// (k_wgrad_thin_multi).  wgrad_thin_park returns the previous state.
+bool wgrad_thin_park(bool on);
+bool wgrad_thin_parking();
+double wgrad_thin_parked_gflop();
+void wgrad_thin_flush(hipStream_t s);
+
 // name of the kernel wgrad_thin_launch would use ("" when not eligible)
 void wgrad_thin_name(int B, int M, int AH, int AW, int Cin, int IH, int IW, int R, int S, int si, int pad, char* out, int cap);
 

@@ -55,15 +55,15 @@ struct ThinCfg {
 
 // DBG (ablation builds of the 3x3/s1 kernel only, CC_WGRAD_THIN_DBG): 1 = no MFMAs (loads + masks), 2 = no loads after the
 // first unit (MFMAs + masks on stale registers); results are wrong by construction.
-template <int S, int SI, int PAD, int TR, int DBG = 0>
-__global__ __launch_bounds__(64 * THIN_NW) void k_wgrad_thin(WT g) {
+template <int S, int SI, int PAD, int TR, int DBG>
+__device__ __forceinline__ void wgrad_thin_body(const WT& g, const int bx_, const int by_) {
     typedef ThinCfg<S, SI, PAD, TR> C;
     constexpr int PQ = C::PQ, NQ = C::NQ, TS = C::TS;
     __shared__ float red[TS * 256];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, k = lane >> 4;
-    int combo = blockIdx.y;
+    int combo = by_;
     const int tg = combo % g.ngt;
     combo /= g.ngt;
     const int cg = combo % g.ngc, mg = combo / g.ngc;
@@ -81,8 +81,8 @@ __global__ __launch_bounds__(64 * THIN_NW) void k_wgrad_thin(WT g) {
 
     // XCD-aware range assignment: workgroups are dealt round-robin to the 8 XCDs (private L2 each); give XCD k the k-th
     // CONTIGUOUS eighth of the unit ranges so that the halo rows two neighbouring ranges share are fetched by ONE L2
-    // (npb is a multiple of 8; blockIdx.x % 8 is the XCD for every blockIdx.y)
-    const int pb = (g.swz ? ((int)(blockIdx.x & 7) * (g.npb >> 3) + (int)(blockIdx.x >> 3)) : (int)blockIdx.x);
+    // (npb is a multiple of 8; the range index bx_ % 8 is the XCD for every combination when the launch is this problem's alone)
+    const int pb = (g.swz ? ((bx_ & 7) * (g.npb >> 3) + (bx_ >> 3)) : bx_);
     const int u0 = pb * g.upb;
     const int u1 = (u0 + g.upb < g.units) ? (u0 + g.upb) : g.units;
 
@@ -217,11 +217,41 @@ __global__ __launch_bounds__(64 * THIN_NW) void k_wgrad_thin(WT g) {
         __syncthreads();
     }
     // slab [t][m16][c16]; D element (reg, lane) is m = 4*(lane>>4) + reg, c = lane & 15
-    float* __restrict__ slab = g.ws + ((long)blockIdx.y * g.npb + pb) * (TS * 256);
+    float* __restrict__ slab = g.ws + ((long)by_ * g.npb + pb) * (TS * 256);
     for (int e = threadIdx.x; e < TS * 256; e += 64 * THIN_NW) {
         const int t = e >> 8, mc = e & 255, mm = mc >> 4, cc_ = mc & 15;
         slab[e] = red[(t * 4 + (mm & 3)) * 64 + (mm >> 2) * 16 + cc_];
     }
+}
+
+
+template <int S, int SI, int PAD, int TR, int DBG = 0>
+__global__ __launch_bounds__(64 * THIN_NW) void k_wgrad_thin(WT g) {
+    wgrad_thin_body<S, SI, PAD, TR, DBG>(g, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// Problems of DIFFERENT shapes (one kernel instance: same tap geometry) in one launch: the thin weight gradients a backward stage
+// leaves parked until its end (cc_conv2d_wgrad_list).  A problem's own grid is 64-256 workgroups of four waves per 16 x 16 channel
+// combination -- ONE wave per SIMD for the 16 -> 16 layers -- and the kernel is bound by the latency of its load path (header): launched
+// one after the other the problems leave most of the chip's wave slots empty; side by side they fill them.  blockIdx.x ranges over the
+// problems' grids back to back (a problem's grid flattened range-fastest, so that the XCD order of its ranges survives whenever the
+// grids in front of it are multiples of 8 -- it is a bijection of the ranges either way).
+constexpr int THIN_MAXP = 24;
+struct WTM { WT p[THIN_MAXP]; int blk_end[THIN_MAXP]; int n; };
+template <int S, int SI, int PAD, int TR>
+__global__ __launch_bounds__(64 * THIN_NW) void k_wgrad_thin_multi(WTM a) {
+    int k = 0, first = 0;
+#pragma unroll 1
+    for (int q = 0; q + 1 < a.n; q++)
+        if ((int)blockIdx.x >= a.blk_end[q]) { k = q + 1; first = a.blk_end[q]; }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CC_HIPEMU)
+    const WT& g = *(reinterpret_cast<const WT*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WTM, p)) + k);
+#else
+    const WT& g = a.p[k];
+#endif
+    const int b = (int)blockIdx.x - first;
+    const int by = b / g.npb;
+    wgrad_thin_body<S, SI, PAD, TR, 0>(g, b - by * g.npb, by);
 }
 
 
@@ -277,9 +307,89 @@ void launch_thin(const WT& g, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad_thin<S, SI, PAD, TR>), grid, dim3(64 * THIN_NW), 0, s, g);
 }
 
+template <int S, int SI, int PAD, int TR>
+void launch_thin_multi(const WTM& m, unsigned blocks, hipStream_t s) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad_thin_multi<S, SI, PAD, TR>), dim3(blocks), dim3(64 * THIN_NW), 0, s, m);
+}
+
+// problems parked by wgrad_thin_launch while wgrad_thin_park(true) is in force (this thread), launched by wgrad_thin_flush
+constexpr int THIN_PARK_CAP = 96;
+struct ThinParkedOne { WT g; int kind, ncombo; double gflop; };
+struct ThinParked { bool on; int n; ThinParkedOne d[THIN_PARK_CAP]; };
+thread_local ThinParked g_thin_parked = {};
+
+void launch_thin_kind(int kind, const WT& g, dim3 grid, hipStream_t s) {
+    switch (kind) {
+        case K_3_1: launch_thin<3, 1, 1, 3>(g, grid, s); break;
+        case K_3_2: launch_thin<3, 2, 1, 3>(g, grid, s); break;
+        case K_7_2: launch_thin<7, 2, 3, 2>(g, grid, s); break;
+        case K_7_1: launch_thin<7, 1, 3, 2>(g, grid, s); break;
+        case K_1_1: launch_thin<1, 1, 0, 1>(g, grid, s); break;
+        case K_5_2: launch_thin<5, 2, 2, 3>(g, grid, s); break;
+        case K_1_2: launch_thin<1, 2, 0, 1>(g, grid, s); break;
+        default: launch_thin<4, 2, 1, 4>(g, grid, s); break;
+    }
+}
+
+void launch_thin_multi_kind(int kind, const WTM& m, unsigned blocks, hipStream_t s) {
+    switch (kind) {
+        case K_3_1: launch_thin_multi<3, 1, 1, 3>(m, blocks, s); break;
+        case K_3_2: launch_thin_multi<3, 2, 1, 3>(m, blocks, s); break;
+        case K_7_2: launch_thin_multi<7, 2, 3, 2>(m, blocks, s); break;
+        case K_7_1: launch_thin_multi<7, 1, 3, 2>(m, blocks, s); break;
+        case K_1_1: launch_thin_multi<1, 1, 0, 1>(m, blocks, s); break;
+        case K_5_2: launch_thin_multi<5, 2, 2, 3>(m, blocks, s); break;
+        case K_1_2: launch_thin_multi<1, 2, 0, 1>(m, blocks, s); break;
+        default: launch_thin_multi<4, 2, 1, 4>(m, blocks, s); break;
+    }
+}
+
 }  // namespace
 
 namespace ccint {
+
+bool wgrad_thin_park(bool on) {
+    const bool was = g_thin_parked.on;
+    g_thin_parked.on = on && !env_int("CC_NO_WGRAD_THIN_LIST", 0);
+    return was;
+}
+
+bool wgrad_thin_parking() { return g_thin_parked.on; }
+
+double wgrad_thin_parked_gflop() {
+    double gf = 0;
+    for (int i = 0; i < g_thin_parked.n; i++) gf += g_thin_parked.d[i].gflop;
+    return gf;
+}
+
+// launch what is parked: per kernel instance, the problems in the order they were parked, up to THIN_MAXP per launch (a single
+// problem goes to the plain kernel)
+void wgrad_thin_flush(hipStream_t s) {
+    ThinParked& P = g_thin_parked;
+    for (int kind = 0; kind < K_NONE && P.n > 0; kind++) {
+        int i = 0;
+        while (i < P.n) {
+            WTM m = {};
+            long blk = 0;
+            int last = -1;
+            for (; i < P.n && m.n < THIN_MAXP; i++) {
+                if (P.d[i].kind != kind) continue;
+                const long nb = (long)P.d[i].g.npb * P.d[i].ncombo;
+                if (m.n && blk + nb >= (1l << 31)) break;
+                m.p[m.n] = P.d[i].g;
+                blk += nb;
+                m.blk_end[m.n] = (int)blk;
+                m.n++;
+                last = i;
+            }
+            if (!m.n) break;
+            if (env_int("CC_WGRAD_THIN_TRACE", 0)) fprintf(stderr, "[wgrad_thin_multi] kind %d: %d problems, %ld workgroups\n", kind, m.n, blk);
+            if (m.n == 1) launch_thin_kind(kind, P.d[last].g, dim3((unsigned)P.d[last].g.npb, (unsigned)P.d[last].ncombo), s);
+            else launch_thin_multi_kind(kind, m, (unsigned)blk, s);
+        }
+    }
+    P.n = 0;
+}
 
 size_t wgrad_thin_ws_floats(int B, int M, int AH, int AW, int Cin, int R, int S, int si) {
     const ThinPlan p = plan_thin(B, M, AH, AW, Cin, R, S, si);
@@ -304,6 +414,14 @@ bool wgrad_thin_launch(const float* a, const float* x, float* gw, float* ws, int
         fprintf(stderr, "[wgrad_thin] kind %d M %d Cin %d A %dx%d X %dx%d npb %d upb %d combos %d\n", p.kind, M, Cin, AH, AW, IH, IW,
                 p.npb, p.upb, ncombo);
     dim3 grid((unsigned)p.npb, (unsigned)ncombo);
+    if (g_thin_parked.on && g_thin_parked.n < THIN_PARK_CAP) {
+        ThinParkedOne& d = g_thin_parked.d[g_thin_parked.n++];
+        d.g = g; d.kind = p.kind; d.ncombo = ncombo;
+        d.gflop = 2e-9 * B * AH * AW * (double)M * Cin * R * S;
+        const long rdp[RD_LONGS] = {2, (long)ws, (long)gw, p.npb, accumulate, o_sm, o_sc, p.TS, S, p.TR, p.ngc, p.ngt, M, Cin, R, ncombo};
+        (void)wgrad_reduce_emit(sink, rdp, 1, s);
+        return true;
+    }
     switch (p.kind) {
         case K_3_1: {
             const int dbg = env_int("CC_WGRAD_THIN_DBG", 0);
