@@ -1136,6 +1136,14 @@ WGRAD_LIST_SHAPES_WINO = [(2, 48, 6, 16, 64, 3, 1, 1), (1, 20, 8, 24, 40, 3, 1, 
                           (2, 12, 9, 14, 20, 3, 2, 1), (1, 70, 9, 32, 130, 3, 1, 1)]
 
 
+# thin layers (<= 32 channels a side, >= 8192 output pixels, width a multiple of 4: wgrad_thin.hip) inside a list: problems of one kernel
+# instance share launches (k_wgrad_thin_multi) -- three 3x3 / stride-1 problems of different channel counts plus a G = 3 group, two
+# 3x3 / stride-2, two 1x1, a 7x7 / stride-2 on its own (the plain kernel), next to a generic-kernel problem
+WGRAD_LIST_SHAPES_THIN = [(2, 16, 64, 128, 16, 3, 1, 1), (2, 32, 64, 128, 16, 3, 1, 1), (2, 12, 9, 14, 20, 3, 2, 1), (2, 16, 64, 128, 8, 3, 1, 1),
+                          (2, 16, 128, 128, 32, 3, 2, 1), (2, 8, 128, 128, 16, 3, 2, 1), (2, 32, 64, 128, 16, 1, 1, 0), (2, 16, 64, 128, 24, 1, 1, 0),
+                          (2, 8, 128, 128, 16, 7, 2, 3), (1, 17, 128, 128, 16, 3, 1, 1)]
+
+
 def check_wgrad_list(dev, tol=2e-5, shapes=None, groups=None):
     """cc_conv2d_wgrad_list (ops._wgrad_list: what a backward stage's weight-gradient queue flushes at its end): groups of different
     shapes in one call -- stride-2 / 1x1 / small-map layers on the generic kernel (k_wgrad_multi: several per launch), direct-mode

@@ -129,6 +129,11 @@ def test_weight_gradient_list():
     parity.check_wgrad_list("cpu")
 
 
+def test_weight_gradient_list_thin():
+    # thin layers inside a list share launches per kernel instance (k_wgrad_thin_multi)
+    parity.check_wgrad_list("cpu", shapes=parity.WGRAD_LIST_SHAPES_THIN, groups={3: 3})
+
+
 def test_weight_gradient_list_winograd(monkeypatch):
     for k in ("CC_WW_MINQ", "CC_WW_MINM", "CC_WW_MINC", "CC_WWP_MINQ", "CC_WWP_MINM", "CC_WWP_MINC"):
         monkeypatch.setenv(k, "1")

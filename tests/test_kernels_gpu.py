@@ -111,6 +111,11 @@ def test_weight_gradient_list():
     parity.check_wgrad_list("cuda")
 
 
+def test_weight_gradient_list_thin():
+    # ... with thin layers in the list: the problems of one kernel instance share launches (k_wgrad_thin_multi)
+    parity.check_wgrad_list("cuda", shapes=parity.WGRAD_LIST_SHAPES_THIN, groups={3: 3})
+
+
 def test_weight_gradient_list_winograd(monkeypatch):
     # ... with 3x3 / stride-1 layers on the Winograd weight-gradient kernel in the list: they share multi-geometry launches
     # (k_wino_wgrad_multi); small shapes steered there through the tools build's switches, product-size shapes at product thresholds
