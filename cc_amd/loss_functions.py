@@ -859,12 +859,6 @@ def _photo_flow_jobs(ctx, cfg, tgt_img, refs, flows, masks, need, rest):
     return loss_acc.reshape(())
 
 
-# The stream _PhotoFlowFn.forward issues its launches on (None: the current one).  Set by cc_amd.trainer.cc_forward around ITS call of
-# photometric_flow_loss so that the flow loss (warps, SSIM, adjoints: all computed in the forward call) runs beside the rigid
-# photometric loss instead of behind it.  The switch sits INSIDE forward on purpose: the call returns on the caller's stream, so autograd
-# binds the node -- and with it the backward call, which adds into the step's shared gradient accumulators (_HeadGrads) in the
-# engine's execution order -- to the caller's stream; a `with torch.cuda.stream(..)` AROUND the call would move the backward call to the
-# side stream and race with the other terms' accumulations.  The caller forks the stream before and joins it after.
 class _PhotoFlowFn(torch.autograd.Function):
     """loss_functions.py:27-77 over all scales; flows = [flow list of ref 0, flow list of ref 1]."""
 
