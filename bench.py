@@ -606,23 +606,49 @@ def main():
         dist.all_reduce(fl, op=dist.ReduceOp.MAX)
         if float(fl.item()) > 0:
             ms_pn = None
-        chosen = "per_network" if (ms_pn is not None and ms_pn <= ms_post) else "post"
-        if chosen != tr.pipeline:
-            tr.switch_pipeline(chosen)
+        # ... and the per-network form with DispResNet6's segment handed over in chunks while its backward pass still runs
+        # (config.grad_chunks: slower on one GPU, where it hides nothing; data-parallel it starts the one exchange that no other
+        # network's backward pass covers early) -- a third candidate, under the same watchdog
+        ms_ch = None
+        if ms_pn is not None:
+            try:
+                tr.set_grad_chunks(True)
+                for _ in range(3):
+                    tr.step(batch)
+                sync()
+                ta = time.perf_counter()
+                for _ in range(6):
+                    tr.step(batch)
+                sync()
+                ms_ch = max_over_ranks((time.perf_counter() - ta) / 6 * 1e3)
+            except Exception as e:      # noqa: BLE001
+                why = "with gradient chunks: " + repr(e)
+            fl = torch.tensor([0.0 if ms_ch is not None else 1.0], device=dev, dtype=torch.float64)
+            dist.all_reduce(fl, op=dist.ReduceOp.MAX)
+            if float(fl.item()) > 0:
+                ms_ch = None
+        cands = [("post", ms_post)] + ([("per_network", ms_pn)] if ms_pn is not None else []) + \
+                ([("per_network+grad_chunks", ms_ch)] if ms_ch is not None else [])
+        chosen_full = min(cands, key=lambda kv: kv[1])[0]
+        chosen = "post" if chosen_full == "post" else "per_network"
+        tr.grad_chunks = chosen_full == "per_network+grad_chunks"
+        tr.switch_pipeline(chosen)          # (drops the captured graph: the next step captures the chosen form)
         for _ in range(3):
             tr.step(batch)
         sync()
         form_selection = {"post_ms": round(ms_post, 3), "per_network_ms": round(ms_pn, 3) if ms_pn is not None else None,
-                          "chosen": chosen, "per_network_failed": why,
+                          "per_network_grad_chunks_ms": round(ms_ch, 3) if ms_ch is not None else None,
+                          "chosen": chosen_full, "per_network_failed": why,
                           "how": "post: the full timed region; per_network: 6 replayed steps after 3 untimed ones under a %.0f s watchdog, "
                                  "max over ranks; the chosen form runs the reported region" % limit}
-        log("form selection: post %.2f ms, per_network %s -> %s" % (ms_post, ("%.2f ms" % ms_pn) if ms_pn is not None else "failed", chosen))
+        log("form selection: post %.2f ms, per_network %s, with gradient chunks %s -> %s"
+            % (ms_post, ("%.2f ms" % ms_pn) if ms_pn is not None else "failed", ("%.2f ms" % ms_ch) if ms_ch is not None else "-", chosen_full))
         if chosen == "post":
             disarm.set()
             first_region = (dt_post, steps_post, losses_post)
     comm_cal = tr.calibrate_comm() if use_dist else None            # each segment's all-reduce alone (outside the timed region)
     dt, per_step, losses = first_region if first_region is not None else timed_region()
-    if select and form_selection is not None and form_selection["chosen"] == "per_network":
+    if select and form_selection is not None and form_selection["chosen"] != "post":
         disarm.set()
 
     def pct(q):
@@ -817,7 +843,8 @@ def main():
                        "rank_losses": rank_losses,
                        "hip_runtime": {"AMD_DIRECT_DISPATCH": os.environ.get("AMD_DIRECT_DISPATCH", "default (1)")},
                        "dead_occlusion_decoders_elided": bool(args.elide_occ), "ab_switches": ab_switches or None,
-                       "net_streams": (len(tr.net_streams) if tr.net_streams else 0), "pipeline": tr.pipeline},
+                       "net_streams": (len(tr.net_streams) if tr.net_streams else 0), "pipeline": tr.pipeline,
+                       "grad_chunks": bool(getattr(tr, "grad_chunks", False))},
             "step_ms": step_ms, "comm": comm,
             "roofline": roof, "kernels": kernels,
         }

@@ -461,20 +461,21 @@ class CCTrainer:
         # (network index, tag) -> first element of the chunk in the bucket.  The chunks' tails run on the step's ORIGIN stream, which
         # has only PoseNetB6 + MaskNet6 to do and is idle long before DispResNet6 reaches its first mark (a FOURTH stream for them
         # costs the replayed graph +2.5 ms, profiles/r06_ab_round6.txt)
-        self._chunk_lo, self._open_hi, self._origin = {}, {}, None
-        if pipeline == "per_network" and config.grad_chunks:
-            for i, n in enumerate(nets):
-                if n is None or self.opt.net_ranges[i] is None or not getattr(n, "GRAD_CHUNKS", None):
-                    continue
-                off, at = self.opt.net_ranges[i][0], {}
-                for name, p in n.named_parameters():
-                    if p.requires_grad:
-                        at[name] = off
-                        off += p.numel()
-                for tag, first in n.GRAD_CHUNKS:
-                    if first in at and at[first] % 4 == 0:
-                        self._chunk_lo[(i, tag)] = at[first]
-        self._chunk_lo_all = dict(self._chunk_lo)
+        self._chunk_lo, self._chunk_lo_all, self._open_hi, self._origin = {}, {}, {}, None
+        self.grad_chunks = bool(config.grad_chunks)
+        for i, n in enumerate(nets):        # (the table is built either way: set_grad_chunks switches the chunks on a live trainer)
+            if n is None or self.opt.net_ranges[i] is None or not getattr(n, "GRAD_CHUNKS", None):
+                continue
+            off, at = self.opt.net_ranges[i][0], {}
+            for name, p in n.named_parameters():
+                if p.requires_grad:
+                    at[name] = off
+                    off += p.numel()
+            for tag, first in n.GRAD_CHUNKS:
+                if first in at and at[first] % 4 == 0:
+                    self._chunk_lo_all[(i, tag)] = at[first]
+        if pipeline == "per_network" and self.grad_chunks:
+            self._chunk_lo = dict(self._chunk_lo_all)
 
         self._done = set()
         self.segment_calls = []          # per_network, most recent step: [(network index, lo, hi)] in issue order (tests, bench)
@@ -500,9 +501,15 @@ class CCTrainer:
             self.opt.rccl()
         self.pipeline, self.split_graphs = pipeline, pipeline == "staged"
         self.graph = self.graph_b = None
-        self._chunk_lo = dict(self._chunk_lo_all) if pipeline == "per_network" else {}
+        self._chunk_lo = dict(self._chunk_lo_all) if (pipeline == "per_network" and self.grad_chunks) else {}
         self.comm_events, self.stage_b_events = [], []
         ops.packs.mark_stale()
+
+    def set_grad_chunks(self, on):
+        """config.grad_chunks for a live trainer (per-network form; the captured graph is dropped): bench.py times the form with and
+        without the chunks at N > 1, where DispResNet6's exchange is what they start early."""
+        self.grad_chunks = bool(on)
+        self.switch_pipeline(self.pipeline)
 
     def _fall_back(self, why):
         """Data-parallel only: the per-network form needs ncclAllReduce on the networks' streams (cc_amd/rccl.py).  If that path is
