@@ -414,7 +414,8 @@ bool wgrad_thin_launch(const float* a, const float* x, float* gw, float* ws, int
         fprintf(stderr, "[wgrad_thin] kind %d M %d Cin %d A %dx%d X %dx%d npb %d upb %d combos %d\n", p.kind, M, Cin, AH, AW, IH, IW,
                 p.npb, p.upb, ncombo);
     dim3 grid((unsigned)p.npb, (unsigned)ncombo);
-    if (g_thin_parked.on && g_thin_parked.n < THIN_PARK_CAP) {
+    // (parking needs a DEFERRED reduce sink: an immediate one would launch the reduction in front of the parked kernel)
+    if (g_thin_parked.on && sink && g_thin_parked.n < THIN_PARK_CAP) {
         ThinParkedOne& d = g_thin_parked.d[g_thin_parked.n++];
         d.g = g; d.kind = p.kind; d.ncombo = ncombo;
         d.gflop = 2e-9 * B * AH * AW * (double)M * Cin * R * S;
